@@ -1,0 +1,142 @@
+/*
+ * batch.c — ORACLE-side CPU baseline with the reference's threading shape.  TEST/BENCH INFRASTRUCTURE.
+ *
+ * Restates the compute phase of `slow5tools view -t T -K B` for SLOW5->BLOW5 (zlib + svb-zd):
+ *   - batch loop of B records (src/view.c:254-300; default B = 4096, src/cmd.h:8)
+ *   - work_db: static block partition over T pthreads + single-item work stealing
+ *     (src/thread.c:19-37 steal_work, :40-67 pthread_single, :69-111 pthread_db), threads created and
+ *     joined per batch (src/thread.c:100-110), serial when T == 1 (src/thread.c:116-121)
+ *   - per record (src/view.c:35-57): codec state allocated and freed per record, one malloc'd
+ *     output buffer per record, freed after the ordered "write" (src/view.c:296-299)
+ * What is timed is the work_db analogue only (time_depress_parse, src/view.c:293,319): the serial
+ * read/write phases are excluded, which favours the CPU.  The decode half of the callback
+ * (slow5_rec_depress_parse of an ASCII/BLOW5 input) is also excluded: input is int16 in memory.
+ */
+#define _GNU_SOURCE
+#include "s5oracle.h"
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef struct {
+    const int16_t *sig;
+    uint64_t n_samples, first_idx, base;
+    int rec_method, sig_method;
+    int64_t n_batch;
+    uint8_t **out;
+    size_t *out_len;
+} batch_t;
+
+typedef struct worker {
+    batch_t *db;
+    volatile int32_t starti;
+    int32_t endi;
+    struct worker *all;
+    int32_t n_threads;
+} worker_t;
+
+static void encode_one(batch_t *db, int32_t i) {
+    s5o_rec_t r;
+    char id[37];
+    uint64_t ridx = db->first_idx + db->base + (uint64_t)i;
+    s5o_synth_read_id(ridx, id);
+    r.read_id_len = 36;
+    r.read_id = id;
+    r.read_group = 0;
+    r.digitisation = 8192.0;
+    r.offset = 23.0;
+    r.range = 1467.61;
+    r.sampling_rate = 4000.0;
+    r.len_raw_signal = db->n_samples;
+    r.raw_signal = db->sig + (db->base + (uint64_t)i) * db->n_samples;
+    r.aux = NULL;
+    r.aux_len = 0;
+    uint8_t *scratch = (uint8_t *)malloc(s5o_payload_bound(&r, db->sig_method));
+    uint8_t *out = (uint8_t *)malloc(s5o_rec_to_mem_bound(&r, db->sig_method));
+    db->out_len[i] = s5o_rec_to_mem(&r, db->rec_method, db->sig_method, scratch, out);
+    db->out[i] = out;
+    free(scratch);
+}
+
+static int32_t steal(worker_t *all, int32_t n) {
+    int32_t c = -1;
+    for (int32_t t = 0; t < n; t++)
+        if (all[t].endi - all[t].starti > 1) { c = t; break; }
+    if (c < 0) return -1;
+    int32_t k = __sync_fetch_and_add(&all[c].starti, 1);
+    return k >= all[c].endi ? -1 : k;
+}
+
+static void *worker_main(void *arg) {
+    worker_t *w = (worker_t *)arg;
+    int32_t i;
+    for (;;) {
+        i = __sync_fetch_and_add(&w->starti, 1);
+        if (i >= w->endi) break;
+        encode_one(w->db, i);
+    }
+    while ((i = steal(w->all, w->n_threads)) >= 0) encode_one(w->db, i);
+    return NULL;
+}
+
+static void work_batch(batch_t *db, int n_threads) {
+    if (n_threads <= 1) {
+        for (int32_t i = 0; i < db->n_batch; i++) encode_one(db, i);
+        return;
+    }
+    pthread_t *tids = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    worker_t *ws = (worker_t *)malloc(sizeof(worker_t) * (size_t)n_threads);
+    int32_t step = (int32_t)((db->n_batch + n_threads - 1) / n_threads), i = 0;
+    for (int t = 0; t < n_threads; t++) {
+        ws[t].db = db;
+        ws[t].starti = i;
+        i += step;
+        ws[t].endi = i > db->n_batch ? (int32_t)db->n_batch : i;
+        if (ws[t].starti > ws[t].endi) ws[t].starti = ws[t].endi;
+        ws[t].all = ws;
+        ws[t].n_threads = n_threads;
+    }
+    for (int t = 0; t < n_threads; t++) pthread_create(&tids[t], NULL, worker_main, &ws[t]);
+    for (int t = 0; t < n_threads; t++) pthread_join(tids[t], NULL);
+    free(ws);
+    free(tids);
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+uint64_t s5o_encode_batch_mt(const int16_t *sig, uint64_t n_reads, uint64_t n_samples, uint64_t first_read_idx,
+                             int rec_method, int sig_method, int n_threads, int batch_size, double *secs,
+                             uint64_t *checksum) {
+    batch_t db;
+    db.sig = sig;
+    db.n_samples = n_samples;
+    db.first_idx = first_read_idx;
+    db.rec_method = rec_method;
+    db.sig_method = sig_method;
+    db.out = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)batch_size);
+    db.out_len = (size_t *)malloc(sizeof(size_t) * (size_t)batch_size);
+    uint64_t total = 0, ck = 0;
+    double t = 0;
+    for (uint64_t base = 0; base < n_reads; base += (uint64_t)batch_size) {
+        db.base = base;
+        db.n_batch = (int64_t)(n_reads - base < (uint64_t)batch_size ? n_reads - base : (uint64_t)batch_size);
+        double t0 = now_s();
+        work_batch(&db, n_threads);
+        t += now_s() - t0;
+        for (int64_t i = 0; i < db.n_batch; i++) { /* the ordered fwrite analogue (untimed) */
+            total += db.out_len[i];
+            ck = ck * 1000003ull + s5o_adler32(db.out[i], db.out_len[i]);
+            free(db.out[i]);
+        }
+    }
+    free(db.out);
+    free(db.out_len);
+    if (secs) *secs = t;
+    if (checksum) *checksum = ck;
+    return total;
+}

@@ -1,0 +1,87 @@
+/*
+ * s5oracle.h — CPU ORACLE for the BLOW5 per-read press path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the algorithm that slow5tools reaches through
+ * slow5lib (an un-vendored submodule: /root/reference/.gitmodules:1-3, slow5lib/ is empty, so
+ * the reference's own implementation cannot be compiled here).  Third-party code restated:
+ *   - hasindu2008/slow5lib >= v1.3.0 (src/slow5.c, src/slow5_press.c) — record layout + press API
+ *   - its thirdparty/streamvbyte (namespaced streamvbyte_slow5) — 32-bit StreamVByte + zigzag delta
+ *   - system zlib 1.2.11 (used as-is through libz, not restated)
+ * Call sites that define the contract: src/view.c:35-57, src/merge.c:43-70, src/get.c:37-66;
+ * the uncompressed layout is stated literally by the reference in test/misc/make_blow5.c:11-101.
+ *
+ * PARITY STATUS: pinned.  tests/test_oracle_golden.py checks every function here against the
+ * reference's own golden .blow5 fixtures (tests/golden/, copied from /root/reference/test/data,
+ * see SURVEY.md Appendix B): every svb-zd blob re-encodes bit-for-bit, every zlib record
+ * re-compresses byte-for-byte, and decoded signals equal the ASCII twin exp_1_lossless.slow5.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
+ * The product (slow5tools_amd/, include/) never links or calls it.
+ */
+#ifndef S5ORACLE_H
+#define S5ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* on-disk method codes (names from src/misc.c:253-263) */
+enum { S5O_REC_NONE = 0, S5O_REC_ZLIB = 1 };
+enum { S5O_SIG_NONE = 0, S5O_SIG_SVB_ZD = 1 };
+
+/* ---- a5 / a8: svb-zd signal codec (StreamVByte 32-bit, 2-bit keys, zigzag delta) ---- */
+size_t s5o_svbzd_bound(uint64_t n);                       /* 4 + ceil(n/4) + 4n            */
+size_t s5o_svbzd_encode(const int16_t *x, uint64_t n, uint8_t *out);      /* returns bytes */
+/* returns 0 on success; *n_out = sample count; out must hold n samples (query with out=NULL) */
+int s5o_svbzd_decode(const uint8_t *in, size_t in_len, int16_t *out, uint64_t *n_out);
+
+/* ---- a6 / a9: zlib record codec (system libz; level 6, wbits 15, memLevel 8) ---- */
+size_t s5o_zlib_bound(size_t n);
+/* per-record deflateInit2/deflate/deflateEnd, as slow5_press_init per record (src/view.c:43-54) */
+int s5o_zlib_compress(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len);
+int s5o_zlib_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len /* in: cap */);
+uint32_t s5o_adler32(const uint8_t *p, size_t n);
+
+/* ---- a1 / a4 / a7: the in-memory read and its BLOW5 record ---- */
+typedef struct {
+    uint16_t read_id_len;
+    const char *read_id;
+    uint32_t read_group;
+    double digitisation, offset, range, sampling_rate;
+    uint64_t len_raw_signal;          /* samples */
+    const int16_t *raw_signal;
+    const uint8_t *aux;               /* already-serialised aux fields (may be NULL) */
+    size_t aux_len;
+} s5o_rec_t;
+
+size_t s5o_payload_bound(const s5o_rec_t *r, int sig_method);
+/* packs the uncompressed record payload (Appendix A.3); returns its length */
+size_t s5o_rec_pack(const s5o_rec_t *r, int sig_method, uint8_t *out);
+size_t s5o_rec_to_mem_bound(const s5o_rec_t *r, int sig_method);
+/* slow5_rec_to_mem (src/view.c:49): [u64 size][press_record(payload)]; returns total length, 0 on error.
+ * scratch must hold s5o_payload_bound() bytes. */
+size_t s5o_rec_to_mem(const s5o_rec_t *r, int rec_method, int sig_method, uint8_t *scratch, uint8_t *out);
+
+/* parse an uncompressed payload: fills r (pointers into payload / into sig_out). sig_out must hold
+ * the samples (call once with sig_out=NULL to learn len_raw_signal). returns 0 ok. */
+int s5o_rec_parse(const uint8_t *payload, size_t len, int sig_method, s5o_rec_t *r, int16_t *sig_out);
+
+/* ---- synthetic reads (SURVEY.md §8(d) generator, integer-only so CPU == GPU bit-for-bit) ---- */
+void s5o_synth_read(uint64_t seed, uint64_t read_idx, uint64_t n, int16_t *out);
+void s5o_synth_read_id(uint64_t read_idx, char out[37]);
+
+/* ---- a12-a14: reference-shaped CPU batch encode (the cpu_baseline) ----
+ * pthread static split + 1-item work stealing as src/thread.c:19-111; per record:
+ * svb-zd encode -> pack -> deflateInit2/deflate/deflateEnd -> malloc'd buffer (src/view.c:35-57).
+ * sig: n_reads signals of n_samples each, contiguous. Returns total output bytes; *secs = compute wall time. */
+uint64_t s5o_encode_batch_mt(const int16_t *sig, uint64_t n_reads, uint64_t n_samples, uint64_t first_read_idx,
+                             int rec_method, int sig_method, int n_threads, int batch_size, double *secs,
+                             uint64_t *checksum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

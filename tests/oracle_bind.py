@@ -1,0 +1,205 @@
+"""ctypes binding of the CPU oracle (oracle/libs5oracle.so) — test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+REC_NONE, REC_ZLIB = 0, 1
+SIG_NONE, SIG_SVB_ZD = 0, 1
+
+
+class Rec(C.Structure):
+    _fields_ = [
+        ("read_id_len", C.c_uint16),
+        ("read_id", C.c_char_p),
+        ("read_group", C.c_uint32),
+        ("digitisation", C.c_double),
+        ("offset", C.c_double),
+        ("range", C.c_double),
+        ("sampling_rate", C.c_double),
+        ("len_raw_signal", C.c_uint64),
+        ("raw_signal", C.c_void_p),
+        ("aux", C.c_void_p),
+        ("aux_len", C.c_size_t),
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(ORACLE_DIR, "libs5oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    L = C.CDLL(so)
+    L.s5o_svbzd_bound.restype = C.c_size_t
+    L.s5o_svbzd_bound.argtypes = [C.c_uint64]
+    L.s5o_svbzd_encode.restype = C.c_size_t
+    L.s5o_svbzd_encode.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.s5o_svbzd_decode.restype = C.c_int
+    L.s5o_svbzd_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.s5o_zlib_bound.restype = C.c_size_t
+    L.s5o_zlib_bound.argtypes = [C.c_size_t]
+    L.s5o_zlib_compress.restype = C.c_int
+    L.s5o_zlib_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.s5o_zlib_decompress.restype = C.c_int
+    L.s5o_zlib_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.s5o_adler32.restype = C.c_uint32
+    L.s5o_adler32.argtypes = [C.c_void_p, C.c_size_t]
+    L.s5o_payload_bound.restype = C.c_size_t
+    L.s5o_payload_bound.argtypes = [C.POINTER(Rec), C.c_int]
+    L.s5o_rec_pack.restype = C.c_size_t
+    L.s5o_rec_pack.argtypes = [C.POINTER(Rec), C.c_int, C.c_void_p]
+    L.s5o_rec_to_mem_bound.restype = C.c_size_t
+    L.s5o_rec_to_mem_bound.argtypes = [C.POINTER(Rec), C.c_int]
+    L.s5o_rec_to_mem.restype = C.c_size_t
+    L.s5o_rec_to_mem.argtypes = [C.POINTER(Rec), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.s5o_rec_parse.restype = C.c_int
+    L.s5o_rec_parse.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Rec), C.c_void_p]
+    L.s5o_synth_read.restype = None
+    L.s5o_synth_read.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.s5o_synth_read_id.restype = None
+    L.s5o_synth_read_id.argtypes = [C.c_uint64, C.c_char_p]
+    L.s5o_encode_batch_mt.restype = C.c_uint64
+    L.s5o_encode_batch_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def svbzd_encode(x):
+    x = np.ascontiguousarray(x, dtype=np.int16)
+    out = np.empty(lib().s5o_svbzd_bound(len(x)), dtype=np.uint8)
+    n = lib().s5o_svbzd_encode(_ptr(x), len(x), _ptr(out))
+    return out[:n].tobytes()
+
+
+def svbzd_decode(blob):
+    b = np.frombuffer(blob, dtype=np.uint8)
+    n = C.c_uint64()
+    rc = lib().s5o_svbzd_decode(_ptr(b), len(b), None, C.byref(n))
+    if rc != 0:
+        raise ValueError("svbzd header rc=%d" % rc)
+    out = np.empty(n.value, dtype=np.int16)
+    rc = lib().s5o_svbzd_decode(_ptr(b), len(b), _ptr(out), C.byref(n))
+    if rc != 0:
+        raise ValueError("svbzd decode rc=%d" % rc)
+    return out
+
+
+def zlib_compress(data):
+    b = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(lib().s5o_zlib_bound(len(b)), dtype=np.uint8)
+    n = C.c_size_t(len(out))
+    rc = lib().s5o_zlib_compress(_ptr(b), len(b), _ptr(out), C.byref(n))
+    assert rc == 0, rc
+    return out[: n.value].tobytes()
+
+
+def zlib_decompress(data, cap):
+    b = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    n = C.c_size_t(cap)
+    rc = lib().s5o_zlib_decompress(_ptr(b), len(b), _ptr(out), C.byref(n))
+    if rc != 0:
+        raise ValueError("inflate rc=%d" % rc)
+    return out[: n.value].tobytes()
+
+
+def adler32(data):
+    b = np.frombuffer(data, dtype=np.uint8)
+    return lib().s5o_adler32(_ptr(b), len(b))
+
+
+def make_rec(read_id, read_group, digitisation, offset, rng, sampling_rate, signal, aux=b""):
+    """returns (Rec, keepalive) — keepalive holds the buffers the struct points to."""
+    rid = read_id if isinstance(read_id, bytes) else read_id.encode()
+    sig = np.ascontiguousarray(signal, dtype=np.int16)
+    auxb = np.frombuffer(aux, dtype=np.uint8) if aux else None
+    r = Rec()
+    r.read_id_len = len(rid)
+    r.read_id = rid
+    r.read_group = read_group
+    r.digitisation, r.offset, r.range, r.sampling_rate = digitisation, offset, rng, sampling_rate
+    r.len_raw_signal = len(sig)
+    r.raw_signal = sig.ctypes.data
+    r.aux = auxb.ctypes.data if auxb is not None else None
+    r.aux_len = len(aux)
+    return r, (rid, sig, auxb)
+
+
+def rec_pack(rec, sig_method):
+    out = np.empty(lib().s5o_payload_bound(C.byref(rec), sig_method), dtype=np.uint8)
+    n = lib().s5o_rec_pack(C.byref(rec), sig_method, _ptr(out))
+    return out[:n].tobytes()
+
+
+def rec_to_mem(rec, rec_method, sig_method):
+    scratch = np.empty(lib().s5o_payload_bound(C.byref(rec), sig_method), dtype=np.uint8)
+    out = np.empty(lib().s5o_rec_to_mem_bound(C.byref(rec), sig_method), dtype=np.uint8)
+    n = lib().s5o_rec_to_mem(C.byref(rec), rec_method, sig_method, _ptr(scratch), _ptr(out))
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def rec_parse(payload, sig_method):
+    """returns dict of primary fields + signal + aux bytes"""
+    b = np.frombuffer(payload, dtype=np.uint8)
+    r = Rec()
+    rc = lib().s5o_rec_parse(_ptr(b), len(b), sig_method, C.byref(r), None)
+    if rc != 0:
+        raise ValueError("rec_parse rc=%d" % rc)
+    sig = np.empty(r.len_raw_signal, dtype=np.int16)
+    rc = lib().s5o_rec_parse(_ptr(b), len(b), sig_method, C.byref(r), _ptr(sig))
+    if rc != 0:
+        raise ValueError("rec_parse rc=%d" % rc)
+    base = b.ctypes.data
+    id_off = 2
+    aux_off = r.aux - base
+    return dict(
+        read_id=payload[id_off : id_off + r.read_id_len],
+        read_group=r.read_group,
+        digitisation=r.digitisation,
+        offset=r.offset,
+        range=r.range,
+        sampling_rate=r.sampling_rate,
+        signal=sig,
+        aux=payload[aux_off : aux_off + r.aux_len],
+    )
+
+
+def synth_read(seed, read_idx, n):
+    out = np.empty(n, dtype=np.int16)
+    lib().s5o_synth_read(seed, read_idx, n, _ptr(out))
+    return out
+
+
+def synth_reads(seed, first, count, n):
+    out = np.empty((count, n), dtype=np.int16)
+    for i in range(count):
+        lib().s5o_synth_read(seed, first + i, n, out[i].ctypes.data_as(C.c_void_p))
+    return out
+
+
+def synth_read_id(read_idx):
+    buf = C.create_string_buffer(37)
+    lib().s5o_synth_read_id(read_idx, buf)
+    return buf.value
+
+
+def encode_batch_mt(sig2d, first_idx, n_threads, batch_size=4096, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD):
+    sig2d = np.ascontiguousarray(sig2d, dtype=np.int16)
+    secs = C.c_double()
+    ck = C.c_uint64()
+    total = lib().s5o_encode_batch_mt(_ptr(sig2d), sig2d.shape[0], sig2d.shape[1], first_idx, rec_method, sig_method,
+                                      n_threads, batch_size, C.byref(secs), C.byref(ck))
+    return total, secs.value, ck.value

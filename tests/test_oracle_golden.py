@@ -1,0 +1,175 @@
+"""Pins the CPU oracle against the reference's own golden fixtures.
+
+Mirrors the byte-identical diffs of the reference's shell tests:
+  test/test_view.sh:90-165 (all codec combos, both directions), test/test_merge.sh:131-140,
+  test/test_index.sh cases 3-4 (record offsets/sizes).
+"""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+from blow5_fixture import (Blow5, NONE_NONE_FIXTURES, ZLIB_NONE_FIXTURES, ZLIB_SVB_FIXTURES, golden,
+                           read_slow5_ascii)
+
+
+def _payload(f, rec):
+    if f.rec_method == 1:
+        return ob.zlib_decompress(rec, 8 * len(rec) + 4096)
+    return rec
+
+
+@pytest.mark.parametrize("name", ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES)
+def test_zlib_records_recompress_byte_identical(name):
+    f = Blow5(golden(name))
+    assert f.rec_method == 1
+    for rec in f.records:
+        pl = _payload(f, rec)
+        assert zlib.decompress(rec) == pl
+        assert ob.zlib_compress(pl) == rec  # oracle zlib == reference bytes
+        assert ob.adler32(pl) == struct.unpack(">I", rec[-4:])[0]
+
+
+@pytest.mark.parametrize("name", ZLIB_SVB_FIXTURES)
+def test_svbzd_blobs_reencode_bit_identical(name):
+    f = Blow5(golden(name))
+    assert f.sig_method == 1
+    for rec in f.records:
+        pl = _payload(f, rec)
+        d = ob.rec_parse(pl, ob.SIG_SVB_ZD)
+        idl = struct.unpack_from("<H", pl, 0)[0]
+        L = struct.unpack_from("<Q", pl, 2 + idl + 4 + 32)[0]
+        blob = pl[2 + idl + 4 + 32 + 8 :][:L]
+        assert struct.unpack_from("<I", blob, 0)[0] == len(d["signal"])
+        assert ob.svbzd_encode(d["signal"]) == blob
+        assert np.array_equal(ob.svbzd_decode(blob), d["signal"])
+
+
+@pytest.mark.parametrize("name", ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES + NONE_NONE_FIXTURES)
+def test_rec_to_mem_reproduces_fixture_records(name):
+    f = Blow5(golden(name))
+    for rec in f.records:
+        pl = _payload(f, rec)
+        d = ob.rec_parse(pl, f.sig_method)
+        r, keep = ob.make_rec(d["read_id"], d["read_group"], d["digitisation"], d["offset"], d["range"],
+                              d["sampling_rate"], d["signal"], d["aux"])
+        assert ob.rec_pack(r, f.sig_method) == pl
+        mem = ob.rec_to_mem(r, f.rec_method, f.sig_method)
+        assert mem == struct.pack("<Q", len(rec)) + rec
+
+
+def test_decode_matches_ascii_twin():
+    truth = read_slow5_ascii(golden("exp_1_lossless.slow5"))
+    assert len(truth) == 1
+    t = truth[0]
+    for name in ["exp_1_lossless.blow5", "exp_1_lossless_zlib.blow5", "exp_1_lossless_zlib_svb_v0.2.0.blow5"]:
+        f = Blow5(golden(name))
+        d = ob.rec_parse(_payload(f, f.records[0]), f.sig_method)
+        assert d["read_id"] == t["read_id"]
+        assert d["read_group"] == t["read_group"]
+        for k in ("digitisation", "offset", "range", "sampling_rate"):
+            assert d[k] == t[k]
+        assert np.array_equal(d["signal"], t["signal"])
+        assert len(d["signal"]) == 59676
+
+
+def test_first_key_byte_known_answer():
+    # N = 59676 -> 4 + 14919 + 60333 = 75256 B; first key byte 0x05
+    f = Blow5(golden("exp_1_lossless_zlib_svb_v0.2.0.blow5"))
+    pl = _payload(f, f.records[0])
+    d = ob.rec_parse(pl, 1)
+    blob = ob.svbzd_encode(d["signal"])
+    assert len(blob) == 75256
+    assert blob[4] == 0x05
+    assert list(d["signal"][:3]) == [1039, 588, 588]
+
+
+def test_index_offsets_match_idx_fixture():
+    f = Blow5(golden("example_multi_rg_v0.2.0.blow5"))
+    idx = open(golden("example_multi_rg_v0.2.0.blow5.idx.exp"), "rb").read()
+    assert idx[:9] == b"SLOW5IDX\x01"
+    off = 64
+    got = []
+    while idx[off : off + 8] != b"XDI5WOLS":
+        (l,) = struct.unpack_from("<H", idx, off)
+        rid = idx[off + 2 : off + 2 + l]
+        o, s = struct.unpack_from("<QQ", idx, off + 2 + l)
+        got.append((rid, o, s))
+        off += 2 + l + 16
+    assert len(got) == len(f.records)
+    for (rid, o, s), fo, rec in zip(got, f.offsets, f.records):
+        assert o == fo and s == 8 + len(rec)
+        assert _payload(f, rec)[2:38] == rid
+
+
+EDGE_SIGNALS = {
+    "empty": np.zeros(0, np.int16),
+    "one": np.array([-5], np.int16),
+    "zeros": np.zeros(1000, np.int16),
+    "const": np.full(777, 1234, np.int16),
+    "alt_extremes": np.tile(np.array([32767, -32768], np.int16), 500),
+    "ramp": np.arange(-3000, 3000, dtype=np.int16),
+}
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 4000, 4095, 4096, 4097, 65535, 65536])
+def test_svbzd_roundtrip_lengths(n):
+    rng = np.random.default_rng(n)
+    x = rng.integers(-32768, 32768, n, dtype=np.int16)
+    blob = ob.svbzd_encode(x)
+    assert struct.unpack_from("<I", blob, 0)[0] == n
+    assert np.array_equal(ob.svbzd_decode(blob), x)
+    y = (rng.normal(500, 30, n)).astype(np.int16)
+    assert np.array_equal(ob.svbzd_decode(ob.svbzd_encode(y)), y)
+
+
+@pytest.mark.parametrize("name", sorted(EDGE_SIGNALS))
+def test_svbzd_edge_signals(name):
+    x = EDGE_SIGNALS[name]
+    blob = ob.svbzd_encode(x)
+    assert np.array_equal(ob.svbzd_decode(blob), x)
+    if name == "alt_extremes":
+        # |delta| = 65535 -> zigzag 131069/131070 -> 3-byte codes (code 2) except the first (65534: 2 bytes)
+        keys = np.frombuffer(blob[4 : 4 + 250], dtype=np.uint8)
+        assert keys[0] == 0b10101001 and (keys[1:] == 0b10101010).all()
+    if name == "zeros":
+        assert len(blob) == 4 + 250 + 1000 and set(blob[4:]) == {0}
+
+
+def test_svbzd_decoder_accepts_4byte_codes_and_rejects_truncation():
+    # code 3 never occurs on encode with int16 input but a decoder must accept it
+    blob = struct.pack("<I", 1) + bytes([3]) + struct.pack("<I", 10)
+    assert list(ob.svbzd_decode(blob)) == [5]
+    good = ob.svbzd_encode(np.arange(100, dtype=np.int16))
+    with pytest.raises(ValueError):
+        ob.svbzd_decode(good[:-1])
+    with pytest.raises(ValueError):
+        ob.svbzd_decode(good + b"\x00")
+
+
+def test_synth_generator_statistics():
+    # svb ~1.265 B/sample, zlib-L6 ~0.87 B/sample at N=4000, P(2-byte code) ~1.4 %
+    sig = ob.synth_reads(0x5105, 0, 64, 4000)
+    svb = sum(len(ob.svbzd_encode(s)) for s in sig) / sig.size
+    d = np.diff(np.concatenate([np.zeros((64, 1), np.int32), sig.astype(np.int32)], axis=1), axis=1)
+    p2 = float((np.abs(d[:, 1:]) >= 128).mean())
+    r, keep = ob.make_rec(ob.synth_read_id(0), 0, 8192.0, 23.0, 1467.61, 4000.0, sig[0])
+    z = len(ob.rec_to_mem(r, 1, 1)) / 4000
+    assert 1.25 <= svb <= 1.28, svb
+    assert 0.008 <= p2 <= 0.02, p2
+    assert 0.80 <= z <= 0.92, z
+    assert sig.min() > 0 and sig.max() < 1400
+    assert ob.synth_read_id(0x1234abcd) == b"1234abcd-0000-4000-8000-00001234abcd"
+
+
+def test_batch_mt_matches_single_thread():
+    sig = ob.synth_reads(0x5105, 100, 96, 1000)
+    t1 = ob.encode_batch_mt(sig, 100, 1, batch_size=32)
+    t4 = ob.encode_batch_mt(sig, 100, 4, batch_size=32)
+    assert t1[0] == t4[0] and t1[2] == t4[2]
+    r, keep = ob.make_rec(ob.synth_read_id(100), 0, 8192.0, 23.0, 1467.61, 4000.0, sig[0])
+    total = sum(len(ob.rec_to_mem(ob.make_rec(ob.synth_read_id(100 + i), 0, 8192.0, 23.0, 1467.61, 4000.0, sig[i])[0],
+                                  1, 1)) for i in range(96))
+    assert total == t1[0]
