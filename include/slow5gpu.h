@@ -1,0 +1,152 @@
+/*
+ * slow5gpu.h — C ABI of the MI355X-native BLOW5 record press path (libslow5gpu.so).
+ *
+ * Plain C, plain pointers and sizes.  This is the drop-in boundary for the one data-parallel hot
+ * path of slow5tools: the per-record worker that `work_db` fans out over pthreads
+ *     /root/reference/src/view.c:35-57   depress_parse_rec_to_mem
+ *     /root/reference/src/merge.c:43-70  parallel_reads_model
+ *     /root/reference/src/get.c:37-66    work_per_single_read_get
+ * i.e. slow5_rec_to_mem() = svb-zd(raw_signal) -> pack -> zlib, and its inverse
+ * slow5_rec_depress_parse().  A whole batch (db_t, /root/reference/src/thread.h:50-66) is handed
+ * over in one call; results come back in the same per-record slots so the ordered fwrite loops
+ * (/root/reference/src/view.c:296-299) stay untouched.  See INTEGRATION.md for the patch.
+ *
+ * Two levels:
+ *   s5gpu_*_dev   : device-resident buffers + a HIP stream (what bench.py times; kernels only)
+ *   s5gpu_*_batch : host buffers in, malloc'd host buffers out (what slow5tools would call)
+ * The slow5lib-compatible per-record API (slow5_press_*, slow5_rec_to_mem, ...) is declared in
+ * slow5_compat.h and implemented on top of the batch calls.
+ */
+#ifndef SLOW5GPU_H
+#define SLOW5GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* on-disk method codes, identical to slow5lib's enum slow5_press_method values used by
+ * /root/reference/src/misc.c:253-263 (SLOW5_COMPRESS_NONE/ZLIB, SLOW5_COMPRESS_NONE/SVB_ZD) */
+enum { S5GPU_REC_NONE = 0, S5GPU_REC_ZLIB = 1 };
+enum { S5GPU_SIG_NONE = 0, S5GPU_SIG_SVB_ZD = 1 };
+
+enum {
+    S5GPU_OK = 0,
+    S5GPU_ERR_ARG = -1,       /* bad argument / unsupported method        */
+    S5GPU_ERR_HIP = -2,       /* HIP runtime error (s5gpu_last_error())   */
+    S5GPU_ERR_NOMEM = -3,
+    S5GPU_ERR_NODEV = -4,     /* no gfx950 device: the library never falls back to a CPU path */
+    S5GPU_ERR_DATA = -5       /* corrupt record (per-record status says which) */
+};
+
+/* One read of an encode batch.  All offsets index the batch-wide device buffers. */
+typedef struct s5gpu_read_desc {
+    uint64_t sig_off;    /* first sample of the read in `sig` (sample index, multiple of 8)          */
+    uint64_t hdr_off;    /* byte offset in `hdr` of the record bytes that precede the u64 length:    */
+                         /*   u16 read_id_len | read_id | u32 read_group | 4 x f64                   */
+    uint64_t aux_off;    /* byte offset in `aux` of the already-serialised aux fields                */
+    uint64_t out_off;    /* byte offset of this read's slot in `slots` (multiple of 16)              */
+    uint32_t n_samples;  /* len_raw_signal                                                          */
+    uint32_t hdr_len;    /* 2 + read_id_len + 4 + 32                                                 */
+    uint32_t aux_len;
+    uint32_t slot_cap;   /* bytes available at out_off, >= s5gpu_slot_bound()                        */
+} s5gpu_read_desc_t;
+
+/* Worst-case bytes one encoded record can occupy in its slot (incl. the u64 size prefix). */
+uint64_t s5gpu_slot_bound(uint32_t n_samples, uint32_t hdr_len, uint32_t aux_len, int rec_method, int sig_method);
+/* Uncompressed payload upper bound (what `max_payload` below must cover). */
+uint64_t s5gpu_payload_bound(uint32_t n_samples, uint32_t hdr_len, uint32_t aux_len, int sig_method);
+
+typedef struct s5gpu_encode_args {
+    uint32_t n_reads;
+    int32_t rec_method, sig_method;
+    const s5gpu_read_desc_t *desc;   /* device, n_reads entries                                      */
+    const int16_t *sig;              /* device, raw_signal of all reads                              */
+    const uint8_t *hdr;              /* device                                                       */
+    const uint8_t *aux;              /* device (may be NULL when every aux_len == 0)                 */
+    uint8_t *slots;                  /* device, out: [u64 size][record bytes] per read at out_off    */
+    uint32_t *out_len;               /* device, out: bytes written per read, incl. the 8-byte prefix */
+    uint32_t max_payload;            /* max over reads of s5gpu_payload_bound()                      */
+    uint8_t *scratch;                /* device, >= size of `slots`; used only for reads too long for */
+    uint64_t scratch_bytes;          /*   the LDS-resident path (may be NULL/0 otherwise)            */
+} s5gpu_encode_args_t;
+
+/* One record of a decode batch. */
+typedef struct s5gpu_rec_desc {
+    uint64_t in_off;     /* byte offset in `in` of the record bytes (without the u64 size prefix)    */
+    uint64_t pay_off;    /* byte offset of this record's payload slot in `payload` (multiple of 16)  */
+    uint64_t sig_off;    /* sample offset of this record's output in `sig_out` (multiple of 8)       */
+    uint32_t in_len;
+    uint32_t pay_cap;    /* bytes available at pay_off                                               */
+    uint32_t sig_cap;    /* samples available at sig_off                                             */
+    uint32_t reserved;
+} s5gpu_rec_desc_t;
+
+/* Parsed primary fields of one decoded record (slow5_rec_t minus the pointers). */
+typedef struct s5gpu_rec_fields {
+    int32_t status;        /* 0 ok; 1 bad zlib header; 2 corrupt data; 3 truncated; 4 adler mismatch;  */
+                           /* 5 payload slot too small (payload_len = needed); 6 signal slot too small */
+                           /* (n_samples = needed); 7 malformed record                                 */
+    uint32_t payload_len;  /* uncompressed record length                                               */
+    uint32_t n_samples;
+    uint32_t read_id_len;  /* read_id sits at payload + 2                                              */
+    uint32_t read_group;
+    uint32_t aux_off;      /* offset of the aux bytes within the payload                               */
+    uint32_t aux_len;
+    uint32_t reserved;
+    double digitisation, offset, range, sampling_rate;
+} s5gpu_rec_fields_t;
+
+typedef struct s5gpu_decode_args {
+    uint32_t n_recs;
+    int32_t rec_method, sig_method;
+    const s5gpu_rec_desc_t *desc;    /* device                                                       */
+    const uint8_t *in;               /* device, compressed records                                   */
+    uint8_t *payload;                /* device, out: uncompressed record per slot                    */
+    int16_t *sig_out;                /* device, out: raw_signal per record                           */
+    s5gpu_rec_fields_t *fields;      /* device, out                                                  */
+} s5gpu_decode_args_t;
+
+/* ---- lifetime ---- */
+int s5gpu_init(int device);              /* select device; S5GPU_ERR_NODEV if it is not a gfx950 GPU */
+void s5gpu_shutdown(void);
+const char *s5gpu_last_error(void);
+int s5gpu_device_count(void);
+
+/* ---- device-resident entry points (asynchronous on `hip_stream`, a hipStream_t; NULL = default) ---- */
+int s5gpu_encode_dev(const s5gpu_encode_args_t *args, void *hip_stream);
+int s5gpu_decode_dev(const s5gpu_decode_args_t *args, void *hip_stream);
+/* svb-zd only (BASELINE config 2): blob per read written at slots+out_off, out_len = blob bytes */
+int s5gpu_svbzd_encode_dev(const s5gpu_encode_args_t *args, void *hip_stream);
+/* Gather the slots into one contiguous BLOW5 record stream (what the ordered fwrite loop emits):
+ * rec_off[i] = byte offset of record i in `stream`, rec_off[n] = total bytes.  tmp: >= 8*(n/1024+2) bytes. */
+int s5gpu_compact_dev(uint32_t n_reads, const s5gpu_read_desc_t *desc, const uint8_t *slots, const uint32_t *out_len,
+                      uint64_t *rec_off, uint8_t *stream, uint64_t *tmp, void *hip_stream);
+/* synthetic reads on device (bench/test workload; bit-identical to oracle/synth.c) */
+int s5gpu_synth_dev(int16_t *sig, uint64_t n_reads, uint64_t n_samples, uint64_t stride_samples, uint64_t seed,
+                    uint64_t first_read_idx, void *hip_stream);
+/* hdr bytes for synthetic reads: 74 bytes per read (36-char id, read_group 0, 8192/23/1467.61/4000) */
+int s5gpu_synth_hdr_dev(uint8_t *hdr, uint64_t n_reads, uint64_t first_read_idx, void *hip_stream);
+
+/* timing hook: runs fn-equivalent `iters` times between two hipEvents on the stream, returns ms (bench.py) */
+int s5gpu_event_create(void **ev);
+int s5gpu_event_record(void *ev, void *hip_stream);
+int s5gpu_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms);   /* synchronises on ev_stop */
+int s5gpu_event_destroy(void *ev);
+
+/* ---- host-buffer batch entry points: the work_db replacement ---- */
+/* Encode n reads.  hdr[i]/aux[i] as in s5gpu_read_desc_t.  out[i] receives a malloc'd buffer the caller
+ * frees (ownership as slow5_rec_to_mem, /root/reference/src/view.c:49,298); out_len[i] its length. */
+int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                       const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                       int sig_method, void **out, size_t *out_len);
+/* Decode n records (bytes without the u64 prefix).  payload[i] and sig[i] receive malloc'd buffers. */
+int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int rec_method, int sig_method,
+                       void **payload, int16_t **sig, s5gpu_rec_fields_t *fields);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,64 @@
+"""Build libslow5gpu.so (HIP kernels + C ABI) in-tree for gfx950.  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libslow5gpu.so")
+
+HIP_SOURCES = ["kernels.hip", "host_api.hip"]
+C_SOURCES = ["slow5_compat.c"]
+DEPS = ["dev_common.h", "deflate_dev.h", "inflate_dev.h", "svb_dev.h", "slow5_compat_internal.h",
+        os.path.join(ROOT, "include", "slow5gpu.h"), os.path.join(ROOT, "include", "slow5_compat.h")]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in sources)
+
+
+def build(force=False, verbose=False):
+    deps = [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in DEPS]
+    objs = []
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if force or _newer(o, [s] + deps):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    for src in C_SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(CSRC, src.replace(".c", ".o"))
+        if force or _newer(o, [s] + deps):
+            cmd = ["gcc", "-O2", "-g", "-Wall", "-std=c11", "-fPIC", "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _newer(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,479 @@
+// deflate_dev.h — per-workgroup DEFLATE (RFC 1951) block encoder for gfx950, zlib (RFC 1950) framing.
+//
+// Replaces the record-press stage of slow5lib that slow5tools reaches through slow5_rec_to_mem
+// (/root/reference/src/view.c:49; zlib via -lz, /root/reference/Makefile:10).  Output is NOT
+// byte-identical to zlib's (no encoder is required to be); the contract is that stock zlib
+// inflates it to the identical payload (tests/test_gpu_parity.py).
+//
+// Design (SURVEY.md §0 finding 6): on svb-zd payloads LZ77 buys < 1 %, run-length + dynamic Huffman
+// does the work.  Per block (<= 16 KiB of payload held in LDS), one workgroup of 256 lanes:
+//   A  tokenise: lane t owns K = ceil(len/256) contiguous bytes; run boundaries via a 64-bit break
+//      mask per lane + one prefix-max and one suffix-min workgroup scan; tokens = literal |
+//      (length 3..258, distance 1); LDS-atomic histogram of the 286 lit/len symbols; Adler-32 partials
+//   B  code construction: rank-sort of the symbol frequencies (all lanes), two-queue Huffman merge
+//      (one lane, LDS), leaf depths by parallel parent walks, length limiting, canonical codes via
+//      wave ballots; code-length alphabet the same way
+//   C  cost compare dynamic / fixed / stored; per-lane bit totals -> workgroup prefix scan of bit
+//      offsets -> each lane packs its tokens into a 64-bit accumulator and ORs 32-bit words into LDS
+// then coalesced word copy LDS -> HBM.  No MFMA: there is no contraction anywhere in this path.
+#pragma once
+#include "dev_common.h"
+
+namespace s5 {
+
+constexpr int DEFL_BLK = NT * 64;    // max payload bytes per DEFLATE block (64 per lane: one break mask)
+constexpr int NLIT = 286;            // literal/length symbols in use
+constexpr int DOFF = 288;            // distance codes live at [DOFF, DOFF+32) in the shared tables
+
+struct DeflShared {
+    uint32_t freq[320];      // histogram: [0,288) lit/len, [288,320) dist
+    uint32_t code[320];      // bit-reversed code | nbits << 16
+    uint32_t lf[288];        // leaf frequencies, ascending
+    uint32_t nf[288];        // internal-node frequencies (creation order = ascending)
+    uint16_t lpar[288];      // leaf -> parent internal node
+    uint16_t npar[288];      // internal node -> parent
+    uint16_t rsym[288];      // rank -> symbol
+    uint16_t clseq[320];     // code-length sequence: sym | extra_value << 5
+    uint8_t lens[320];       // code lengths, same indexing as freq
+    uint32_t clfreq[20];
+    uint32_t clcode[20];
+    uint8_t cllens[20];
+    uint32_t blcount[16];
+    uint32_t ws[16];         // cross-wave scan scratch
+    uint32_t red[8];         // 0 matches, 1 extra bits, 2 adler A part, 3 adler B part, 4 dyn bits, 5 fixed bits, 6 cl bits
+    uint32_t ncl, hlit, hclen, ovf;
+};
+
+struct ZOut {                // replicated uniformly in every lane's registers
+    uint32_t bitpos;         // absolute bit position in the record slot (slot byte 0 = bit 0)
+    uint32_t flushed;        // 32-bit words already copied to HBM; obuf[0] holds word `flushed`
+};
+
+__device__ __forceinline__ void put_bits(uint32_t *obuf, const ZOut &z, uint32_t pos, uint32_t v, uint32_t nb) {
+    uint32_t w = (pos >> 5) - z.flushed, sh = pos & 31;
+    atomicOr(&obuf[w], v << sh);
+    if (sh + nb > 32) atomicOr(&obuf[w + 1], v >> (32 - sh));
+}
+
+// ---- length-limited Huffman code lengths for freq[0..n), n <= 2*NT ----
+__device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *freq, int n, int maxbits, uint8_t *lens) {
+    const int tid = threadIdx.x;
+    for (int s = tid; s < n; s += NT) lens[s] = 0;
+    if (tid < 16) S.blcount[tid] = 0;
+    if (tid == 0) S.ovf = 0;
+    const uint32_t f0 = tid < n ? freq[tid] : 0;
+    const uint32_t f1 = tid + NT < n ? freq[tid + NT] : 0;
+    int r0 = 0, r1 = 0, m = 0;
+    for (int j = 0; j < n; j++) {   // rank sort by (freq, symbol): LDS broadcast reads
+        const uint32_t fj = freq[j];
+        if (fj) {
+            m++;
+            r0 += (fj < f0) || (fj == f0 && j < tid);
+            r1 += (fj < f1) || (fj == f1 && j < tid + NT);
+        }
+    }
+    __syncthreads();
+    if (f0) { S.lf[r0] = f0; S.rsym[r0] = (uint16_t)tid; }
+    if (f1) { S.lf[r1] = f1; S.rsym[r1] = (uint16_t)(tid + NT); }
+    __syncthreads();
+    if (m <= 1) {   // degenerate: keep the code complete with two 1-bit codes
+        if (tid == 0) {
+            int sym = m ? S.rsym[0] : 0;
+            lens[sym] = 1;
+            lens[sym == 0 ? 1 : 0] = 1;
+            S.blcount[1] = 2;
+        }
+        __syncthreads();
+        return;
+    }
+    if (tid == 0) {   // two-queue merge: leaves ascending, internal nodes are created ascending
+        int i = 0, j = 0;
+        for (int k = 0; k < m - 1; k++) {
+            uint32_t a, b;
+            if (i < m && (j >= k || S.lf[i] <= S.nf[j])) { a = S.lf[i]; S.lpar[i] = (uint16_t)k; i++; }
+            else { a = S.nf[j]; S.npar[j] = (uint16_t)k; j++; }
+            if (i < m && (j >= k || S.lf[i] <= S.nf[j])) { b = S.lf[i]; S.lpar[i] = (uint16_t)k; i++; }
+            else { b = S.nf[j]; S.npar[j] = (uint16_t)k; j++; }
+            S.nf[k] = a + b;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < m; r += NT) {   // leaf depth = parent-chain length to the root (node m-2)
+        int d = 1, p = S.lpar[r];
+        while (p != m - 2) { p = S.npar[p]; d++; }
+        if (d > maxbits) { d = maxbits; S.ovf = 1; }
+        atomicAdd(&S.blcount[d], 1u);
+    }
+    __syncthreads();
+    if (S.ovf) {   // clamp happened: repair the Kraft sum on the per-length counts
+        if (tid == 0) {
+            uint32_t total = 0;
+            for (int i = maxbits; i >= 1; i--) total += S.blcount[i] << (maxbits - i);
+            while (total != (1u << maxbits)) {
+                S.blcount[maxbits]--;
+                for (int i = maxbits - 1; i > 0; i--)
+                    if (S.blcount[i]) { S.blcount[i]--; S.blcount[i + 1] += 2; break; }
+                total--;
+            }
+        }
+        __syncthreads();
+    }
+    for (int r = tid; r < m; r += NT) {   // rarest symbols get the longest codes
+        uint32_t cum = 0;
+        int L = maxbits;
+        for (; L > 1; L--) { cum += S.blcount[L]; if ((uint32_t)r < cum) break; }
+        lens[S.rsym[r]] = (uint8_t)L;
+    }
+    __syncthreads();
+}
+
+// ---- canonical codes from lengths (wave 0; S.blcount must match lens) ----
+__device__ __forceinline__ void assign_codes(DeflShared &S, const uint8_t *lens, int n, uint32_t *code_out) {
+    if (wave_id() == 0) {
+        uint32_t next[16];
+        uint32_t c = 0;
+        next[0] = 0;
+#pragma unroll
+        for (int b = 1; b < 16; b++) { c = (c + (b > 1 ? S.blcount[b - 1] : 0)) << 1; next[b] = c; }
+        const uint64_t lt = (1ull << lane_id()) - 1;
+        for (int base = 0; base < n; base += 64) {
+            const int s = base + lane_id();
+            const int l = s < n ? lens[s] : 0;
+            uint32_t mine = 0;
+#pragma unroll
+            for (int b = 1; b < 16; b++) {
+                const uint64_t mask = __ballot(l == b);
+                if (l == b) mine = next[b] + __popcll(mask & lt);
+                next[b] += __popcll(mask);
+            }
+            if (s < n) code_out[s] = l ? ((__brev(mine) >> (32 - l)) | ((uint32_t)l << 16)) : 0u;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int fixed_len(int s) { return s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8; }
+__device__ __forceinline__ uint32_t fixed_code(int s) {
+    uint32_t c, l;
+    if (s < 144) { c = 0x30 + s; l = 8; }
+    else if (s < 256) { c = 0x190 + (s - 144); l = 9; }
+    else if (s < 280) { c = s - 256; l = 7; }
+    else { c = 0xC0 + (s - 280); l = 8; }
+    return (__brev(c) >> (32 - l)) | (l << 16);
+}
+
+struct Tok { int sym; uint32_t eb, ev; };   // sym < 0: position covered by a match
+
+// token at position base+j of the block for the lane that owns it
+__device__ __forceinline__ Tok token_at(const uint8_t *buf, int base, int j, uint64_t brk, int lastb, int nextb) {
+    const uint64_t lo = brk & ((2ull << j) - 1);
+    const int s = lo ? base + 63 - __clzll((long long)lo) : lastb;
+    const uint64_t hi = j < 63 ? (brk >> (j + 1)) : 0ull;
+    const int e = hi ? base + j + __ffsll((long long)hi) : nextb;
+    const int rel = base + j - s, M = e - s - 1;
+    Tok t;
+    t.sym = buf[base + j];
+    t.eb = 0;
+    t.ev = 0;
+    if (rel > 0 && M >= 3) {
+        const int m = rel - 1, c = m / 258, off = m - c * 258;
+        const int Lc = min(258, M - c * 258);
+        if (Lc >= 3) {
+            if (off != 0) { t.sym = -1; return t; }
+            const int l = Lc - 3;
+            if (Lc == 258) t.sym = 285;
+            else if (l < 8) t.sym = 257 + l;
+            else {
+                const int nb = 29 - __clz(l);
+                t.sym = 261 + 4 * nb + ((l >> nb) & 3);
+                t.eb = nb;
+                t.ev = l & ((1 << nb) - 1);
+            }
+        }
+    }
+    return t;
+}
+
+// Copy completed words obuf -> HBM slot and slide the partial word to obuf[0].
+// final_all: copy everything including the last partial word, no slide.
+__device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOut &z, bool final_all) {
+    const int tid = threadIdx.x;
+    const uint32_t full = final_all ? (z.bitpos + 31) >> 5 : z.bitpos >> 5;
+    const uint32_t n = full - z.flushed;
+    for (uint32_t i = tid; i < n; i += NT) {
+        const uint32_t w = z.flushed + i;
+        if (w >= 2) out32[w] = obuf[i];   // words 0,1 = u64 size prefix, written last by lane 0
+    }
+    if (final_all) return;
+    __syncthreads();
+    const uint32_t partial = obuf[n];
+    __syncthreads();
+    for (uint32_t i = tid; i <= n; i += NT) obuf[i] = i == 0 ? partial : 0u;
+    __syncthreads();
+    z.flushed = full;
+}
+
+// Encode one DEFLATE block of `len` bytes at LDS `buf` into the LDS bit buffer `obuf`.
+// All NT lanes call with uniform arguments.  adA/adB: running Adler-32 halves (uniform).
+__device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, const uint8_t *buf, int len, bool final,
+                                           ZOut &z, uint32_t &adA, uint32_t &adB) {
+    const int tid = threadIdx.x;
+    if (len == 0) {   // empty stream: fixed block holding only end-of-block
+        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 10);
+        z.bitpos += 10;
+        __syncthreads();
+        return;
+    }
+    const int K = (len + NT - 1) / NT;
+    const int base = tid * K;
+    const int kk = max(0, min(K, len - base));
+
+    for (int i = tid; i < 320; i += NT) S.freq[i] = 0;
+    if (tid < 8) S.red[tid] = 0;
+    if (tid < 20) S.clfreq[tid] = 0;
+
+    // ---- A: break mask, Adler partials ----
+    uint64_t brk = 0;
+    uint32_t a_sum = 0, b_sum = 0;
+    {
+        int prev = -1;
+        if (base > 0 && kk > 0) prev = buf[base - 1];
+        for (int j = 0; j < kk; j++) {
+            const int b = buf[base + j];
+            if (b != prev) brk |= 1ull << j;
+            prev = b;
+            a_sum += b;
+            b_sum += (uint32_t)(len - (base + j)) * b;
+        }
+    }
+    const int local_last = brk ? base + 63 - __clzll((long long)brk) : -1;
+    const int local_first = brk ? base + __ffsll((long long)brk) - 1 : len;
+    const int lastb = block_excl_max(local_last, -1, S.ws);
+    const int nextb = block_suffix_excl_min(local_first, len, S.ws);
+
+    uint32_t nmatch = 0, nextra = 0;
+    for (int j = 0; j < kk; j++) {
+        const Tok t = token_at(buf, base, j, brk, lastb, nextb);
+        if (t.sym >= 0) {
+            atomicAdd(&S.freq[t.sym], 1u);
+            if (t.sym > 256) { nmatch++; nextra += t.eb; }
+        }
+    }
+    nmatch = wave_sum(nmatch);
+    nextra = wave_sum(nextra);
+    a_sum = wave_sum(a_sum);
+    b_sum = wave_sum(b_sum % 65521u);
+    if (lane_id() == 0) {
+        atomicAdd(&S.red[0], nmatch);
+        atomicAdd(&S.red[1], nextra);
+        atomicAdd(&S.red[2], a_sum);
+        atomicAdd(&S.red[3], b_sum);
+    }
+    if (tid == 0) atomicAdd(&S.freq[256], 1u);
+    __syncthreads();
+
+    // ---- B: codes ----
+    build_lengths(S, S.freq, NLIT, 15, S.lens);
+    assign_codes(S, S.lens, NLIT, S.code);
+    if (tid == 0) {
+        // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
+        S.lens[DOFF] = 1; S.lens[DOFF + 1] = 1;
+        S.code[DOFF] = 0u | (1u << 16); S.code[DOFF + 1] = 1u | (1u << 16);
+        int hlit = NLIT;
+        while (hlit > 257 && S.lens[hlit - 1] == 0) hlit--;
+        S.hlit = hlit;
+        // run-length code the hlit + 2 code lengths (RFC 1951 3.2.7: symbols 16/17/18)
+        const int n = hlit + 2;
+        int ncl = 0, p = 0;
+        while (p < n) {
+            const int v = p < hlit ? S.lens[p] : S.lens[DOFF + p - hlit];
+            int run = 1;
+            while (p + run < n && (p + run < hlit ? S.lens[p + run] : S.lens[DOFF + p + run - hlit]) == v) run++;
+            int r = run;
+            if (v == 0) {
+                while (r >= 11) { const int t = min(r, 138); S.clseq[ncl++] = (uint16_t)(18 | ((t - 11) << 5)); S.clfreq[18]++; r -= t; }
+                if (r >= 3) { S.clseq[ncl++] = (uint16_t)(17 | ((r - 3) << 5)); S.clfreq[17]++; r = 0; }
+                while (r > 0) { S.clseq[ncl++] = 0; S.clfreq[0]++; r--; }
+            } else {
+                S.clseq[ncl++] = (uint16_t)v; S.clfreq[v]++; r--;
+                while (r >= 3) { const int t = min(r, 6); S.clseq[ncl++] = (uint16_t)(16 | ((t - 3) << 5)); S.clfreq[16]++; r -= t; }
+                while (r > 0) { S.clseq[ncl++] = (uint16_t)v; S.clfreq[v]++; r--; }
+            }
+            p += run;
+        }
+        S.ncl = ncl;
+    }
+    __syncthreads();
+    build_lengths(S, S.clfreq, 19, 7, S.cllens);
+    assign_codes(S, S.cllens, 19, S.clcode);
+
+    // ---- C: cost of the three block types ----
+    {
+        uint32_t dynb = 0, fixb = 0, clb = 0;
+        for (int s = tid; s < NLIT; s += NT) {
+            const uint32_t f = S.freq[s];
+            dynb += f * S.lens[s];
+            fixb += f * fixed_len(s);
+        }
+        const int ncl = S.ncl;
+        for (int e = tid; e < ncl; e += NT) {
+            const int sym = S.clseq[e] & 31;
+            clb += S.cllens[sym] + (sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0);
+        }
+        dynb = wave_sum(dynb);
+        fixb = wave_sum(fixb);
+        clb = wave_sum(clb);
+        if (lane_id() == 0) { atomicAdd(&S.red[4], dynb); atomicAdd(&S.red[5], fixb); atomicAdd(&S.red[6], clb); }
+        if (tid == 0) {
+            const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            int h = 19;
+            while (h > 4 && S.cllens[order[h - 1]] == 0) h--;
+            S.hclen = h;
+        }
+    }
+    __syncthreads();
+    const uint32_t matches = S.red[0], extra = S.red[1];
+    const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
+    const uint32_t dyn_total = hdr_dyn + S.red[4] + extra + matches * 1;
+    const uint32_t fix_total = 3 + S.red[5] + extra + matches * 5;
+    const uint32_t sto_total = 3 + ((0u - (z.bitpos + 3)) & 7) + 32 + 8u * (uint32_t)len;
+    // Adler-32 running update (RFC 1950): B' = B + len*A + sum (len - i) x_i
+    {
+        const uint32_t nb = (uint32_t)(((uint64_t)adB + (uint64_t)len * adA + S.red[3]) % 65521u);
+        adA = (adA + S.red[2]) % 65521u;
+        adB = nb;
+    }
+
+    if (sto_total <= dyn_total && sto_total <= fix_total) {
+        // ---- stored block ----
+        const uint32_t bytepos = (z.bitpos + 3 + 7) >> 3;
+        uint8_t *ob8 = reinterpret_cast<uint8_t *>(obuf) + (bytepos - z.flushed * 4);
+        if (tid == 0) {
+            put_bits(obuf, z, z.bitpos, final ? 1u : 0u, 3);
+            put_bits(obuf, z, bytepos * 8, (uint32_t)len | ((~(uint32_t)len) << 16), 32);
+        }
+        __syncthreads();
+        for (int i = tid; i < len; i += NT) ob8[4 + i] = buf[i];
+        z.bitpos = (bytepos + 4 + (uint32_t)len) * 8;
+        __syncthreads();
+        return;
+    }
+
+    const bool use_fixed = fix_total < dyn_total;
+    uint32_t pos0;   // bit position of the first token
+    uint32_t dist_bits, dist_code = 0;
+    if (use_fixed) {
+        for (int s = tid; s < 288; s += NT) S.code[s] = fixed_code(s);
+        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
+        pos0 = z.bitpos + 3;
+        dist_bits = 5;
+        __syncthreads();
+    } else {
+        if (tid == 0) {
+            const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint32_t p = z.bitpos;
+            put_bits(obuf, z, p, (final ? 1u : 0u) | (2u << 1), 3);
+            put_bits(obuf, z, p + 3, S.hlit - 257, 5);
+            put_bits(obuf, z, p + 8, 1, 5);            // HDIST = 2 codes
+            put_bits(obuf, z, p + 13, S.hclen - 4, 4);
+            p += 17;
+            for (uint32_t i = 0; i < S.hclen; i++, p += 3) put_bits(obuf, z, p, S.cllens[order[i]], 3);
+        }
+        // code-length sequence: lane t owns entries 2t, 2t+1
+        const int ncl = S.ncl;
+        uint32_t v[2], nb[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int e = 2 * tid + q;
+            v[q] = 0; nb[q] = 0;
+            if (e < ncl) {
+                const uint32_t ent = S.clseq[e];
+                const uint32_t sym = ent & 31, cc = S.clcode[sym], cl = cc >> 16;
+                const uint32_t eb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+                v[q] = (cc & 0xFFFF) | ((ent >> 5) << cl);
+                nb[q] = cl + eb;
+            }
+        }
+        uint32_t tot;
+        uint32_t off = block_excl_add(nb[0] + nb[1], S.ws, tot);
+        const uint32_t p = z.bitpos + 17 + 3 * S.hclen + off;
+        if (nb[0]) put_bits(obuf, z, p, v[0], nb[0]);
+        if (nb[1]) put_bits(obuf, z, p + nb[0], v[1], nb[1]);
+        pos0 = z.bitpos + hdr_dyn;
+        dist_bits = 1;
+    }
+
+    // ---- tokens: per-lane bit totals -> prefix scan -> pack ----
+    uint32_t mybits = 0;
+    for (int j = 0; j < kk; j++) {
+        const Tok t = token_at(buf, base, j, brk, lastb, nextb);
+        if (t.sym >= 0) mybits += (S.code[t.sym] >> 16) + t.eb + (t.sym > 256 ? dist_bits : 0);
+    }
+    uint32_t total_bits;
+    const uint32_t start = pos0 + block_excl_add(mybits, S.ws, total_bits);
+    {
+        uint32_t widx = (start >> 5) - z.flushed;
+        uint32_t accbits = start & 31;
+        uint64_t acc = 0;
+        for (int j = 0; j < kk; j++) {
+            const Tok t = token_at(buf, base, j, brk, lastb, nextb);
+            if (t.sym < 0) continue;
+            const uint32_t cc = S.code[t.sym];
+            uint32_t nb = cc >> 16;
+            uint32_t v = cc & 0xFFFF;
+            if (t.sym > 256) {
+                v |= t.ev << nb;
+                nb += t.eb;
+                v |= dist_code << nb;
+                nb += dist_bits;
+            }
+            acc |= (uint64_t)v << accbits;
+            accbits += nb;
+            if (accbits >= 32) {
+                atomicOr(&obuf[widx++], (uint32_t)acc);
+                acc >>= 32;
+                accbits -= 32;
+            }
+        }
+        if (accbits && acc) atomicOr(&obuf[widx], (uint32_t)acc);
+    }
+    const uint32_t eob = S.code[256];
+    if (tid == 0) put_bits(obuf, z, pos0 + total_bits, eob & 0xFFFF, eob >> 16);
+    z.bitpos = pos0 + total_bits + (eob >> 16);
+    __syncthreads();
+}
+
+// zlib-frame a payload that sits in LDS (`pay`, `plen` bytes) into HBM slot `out` (16-B aligned).
+// Slot layout: [u64 size][78 9c][deflate blocks][adler32 BE]; returns total bytes incl. the prefix.
+// obuf: LDS, >= min(plen, DEFL_BLK)/4 + 16 words, zeroed on entry by this function.
+__device__ __forceinline__ uint32_t zlib_compress_lds(DeflShared &S, uint32_t *obuf, uint32_t obuf_words,
+                                                      const uint8_t *pay, uint32_t plen, uint8_t *out) {
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
+    __syncthreads();
+    ZOut z;
+    z.bitpos = 64;
+    z.flushed = 0;
+    if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);   // CMF/FLG 78 9c (deflate, 32K window, default level)
+    z.bitpos = 80;
+    uint32_t adA = 1, adB = 0;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    uint32_t done = 0;
+    do {
+        const uint32_t blen = min(plen - done, (uint32_t)DEFL_BLK);
+        const bool final = done + blen == plen;
+        deflate_block(S, obuf, pay + done, (int)blen, final, z, adA, adB);
+        done += blen;
+        if (!final) flush_words(obuf, out32, z, false);
+    } while (done < plen);
+    z.bitpos = (z.bitpos + 7) & ~7u;
+    if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
+    z.bitpos += 32;
+    __syncthreads();
+    flush_words(obuf, out32, z, true);
+    const uint32_t total = z.bitpos >> 3;
+    if (tid == 0) *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
+    return total;
+}
+
+}  // namespace s5

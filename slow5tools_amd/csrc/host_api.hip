@@ -1,0 +1,309 @@
+// host_api.hip — host side of libslow5gpu.so: lifetime, error reporting, events, and the
+// host-buffer batch calls that stand where slow5tools' work_db() stands
+// (/root/reference/src/thread.c:114, called at src/view.c:292, src/merge.c:440, src/get.c:364).
+//
+// No CPU fallback exists on purpose: without a gfx950 device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/slow5gpu.h"
+
+static thread_local char g_err[512] = "";
+static int g_device = -1;
+static std::mutex g_mu;
+
+extern "C" void s5gpu_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *s5gpu_last_error(void) { return g_err; }
+
+#define HIP_TRY(x)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) {                                                                      \
+            s5gpu_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return S5GPU_ERR_HIP;                                                                    \
+        }                                                                                            \
+    } while (0)
+
+extern "C" int s5gpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int s5gpu_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        s5gpu_set_error("s5gpu_init: no HIP device visible (this library has no CPU path)");
+        return S5GPU_ERR_NODEV;
+    }
+    if (device < 0 || device >= n) {
+        s5gpu_set_error("s5gpu_init: device %d out of range (0..%d)", device, n - 1);
+        return S5GPU_ERR_ARG;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        s5gpu_set_error("s5gpu_init: device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
+        return S5GPU_ERR_NODEV;
+    }
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    return S5GPU_OK;
+}
+
+// ---- grow-only device / pinned workspaces for the host-buffer batch calls ----
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    int reserve(size_t n) {
+        if (n <= cap) return S5GPU_OK;
+        if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 4 + 4096;
+        hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (e != hipSuccess) { s5gpu_set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); p = nullptr; return S5GPU_ERR_NOMEM; }
+        cap = want;
+        return S5GPU_OK;
+    }
+    void release() { if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
+};
+struct Ctx {
+    Buf d_sig, d_hdr, d_aux, d_desc, d_slots, d_len, d_scratch, d_in, d_pay, d_fields;
+    Buf h_in, h_out;   // pinned staging
+    hipStream_t st = nullptr;
+    Ctx() { h_in.pinned = true; h_out.pinned = true; }
+};
+static Ctx *g_ctx = nullptr;
+
+static int ctx_get(Ctx **out) {
+    if (g_device < 0) {
+        int rc = s5gpu_init(0);
+        if (rc) return rc;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ctx) {
+        g_ctx = new Ctx();
+        if (hipStreamCreateWithFlags(&g_ctx->st, hipStreamNonBlocking) != hipSuccess) {
+            delete g_ctx; g_ctx = nullptr;
+            s5gpu_set_error("hipStreamCreate failed");
+            return S5GPU_ERR_HIP;
+        }
+    }
+    *out = g_ctx;
+    return S5GPU_OK;
+}
+
+extern "C" void s5gpu_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ctx) {
+        Buf *bs[] = {&g_ctx->d_sig, &g_ctx->d_hdr, &g_ctx->d_aux, &g_ctx->d_desc, &g_ctx->d_slots, &g_ctx->d_len,
+                     &g_ctx->d_scratch, &g_ctx->d_in, &g_ctx->d_pay, &g_ctx->d_fields, &g_ctx->h_in, &g_ctx->h_out};
+        for (Buf *b : bs) b->release();
+        if (g_ctx->st) (void)hipStreamDestroy(g_ctx->st);
+        delete g_ctx;
+        g_ctx = nullptr;
+    }
+    g_device = -1;
+}
+
+// ---- events (bench.py times the kernels on the stream they run on) ----
+extern "C" int s5gpu_event_create(void **ev) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = (void *)e;
+    return S5GPU_OK;
+}
+extern "C" int s5gpu_event_record(void *ev, void *stream) {
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return S5GPU_OK;
+}
+extern "C" int s5gpu_event_elapsed_ms(void *a, void *b, float *ms) {
+    HIP_TRY(hipEventSynchronize((hipEvent_t)b));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return S5GPU_OK;
+}
+extern "C" int s5gpu_event_destroy(void *ev) {
+    HIP_TRY(hipEventDestroy((hipEvent_t)ev));
+    return S5GPU_OK;
+}
+
+static inline uint64_t up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// The whole batch in one call: H2D of signals/headers, one launch, D2H of the slots, one malloc per
+// record (the ownership contract of slow5_rec_to_mem: caller frees each buffer, src/view.c:298).
+extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                                  const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                                  int sig_method, void **out, size_t *out_len) {
+    if (n == 0) return S5GPU_OK;
+    if (!sig || !n_samples || !hdr || !hdr_len || !out || !out_len) { s5gpu_set_error("s5gpu_encode_batch: NULL argument"); return S5GPU_ERR_ARG; }
+    Ctx *c;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<s5gpu_read_desc_t> desc(n);
+    uint64_t so = 0, ho = 0, ao = 0, oo = 0;
+    uint32_t max_payload = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (n_samples[i] > 0xFFFFFFF0ull) { s5gpu_set_error("read %u: %llu samples exceed the u32 svb-zd count", i, (unsigned long long)n_samples[i]); return S5GPU_ERR_ARG; }
+        s5gpu_read_desc_t &d = desc[i];
+        d.sig_off = so; d.hdr_off = ho; d.aux_off = ao; d.out_off = oo;
+        d.n_samples = (uint32_t)n_samples[i];
+        d.hdr_len = hdr_len[i];
+        d.aux_len = (aux && aux_len) ? aux_len[i] : 0;
+        const uint64_t pb = s5gpu_payload_bound(d.n_samples, d.hdr_len, d.aux_len, sig_method);
+        const uint64_t sb = s5gpu_slot_bound(d.n_samples, d.hdr_len, d.aux_len, rec_method, sig_method);
+        if (pb > 0xFFFFFF00ull) { s5gpu_set_error("read %u: record larger than 4 GiB", i); return S5GPU_ERR_ARG; }
+        d.slot_cap = (uint32_t)sb;
+        if (pb > max_payload) max_payload = (uint32_t)pb;
+        so += up(d.n_samples, 8);
+        ho += d.hdr_len;
+        ao += d.aux_len;
+        oo += sb;
+    }
+    const size_t sig_bytes = (size_t)so * 2 + 64, in_bytes = up(sig_bytes, 64) + up(ho + 64, 64) + up(ao + 64, 64) + sizeof(s5gpu_read_desc_t) * n;
+    if ((rc = c->h_in.reserve(in_bytes)) || (rc = c->d_sig.reserve(sig_bytes)) || (rc = c->d_hdr.reserve(ho + 64)) ||
+        (rc = c->d_aux.reserve(ao + 64)) || (rc = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * n)) ||
+        (rc = c->d_slots.reserve(oo + 64)) || (rc = c->d_len.reserve(4ull * n)) || (rc = c->h_out.reserve(oo + 64 + 4ull * n)))
+        return rc;
+    const bool staged = rec_method == S5GPU_REC_ZLIB && max_payload > 48u * 1024u;
+    if (staged && (rc = c->d_scratch.reserve(oo + 64))) return rc;
+    // pack into pinned staging
+    uint8_t *hs = (uint8_t *)c->h_in.p;
+    uint8_t *hh = hs + up(sig_bytes, 64), *ha = hh + up(ho + 64, 64), *hd = ha + up(ao + 64, 64);
+    for (uint32_t i = 0; i < n; i++) {
+        const s5gpu_read_desc_t &d = desc[i];
+        if (d.n_samples) memcpy(hs + 2 * d.sig_off, sig[i], 2ull * d.n_samples);
+        memcpy(hh + d.hdr_off, hdr[i], d.hdr_len);
+        if (d.aux_len) memcpy(ha + d.aux_off, aux[i], d.aux_len);
+    }
+    memcpy(hd, desc.data(), sizeof(s5gpu_read_desc_t) * n);
+    HIP_TRY(hipMemcpyAsync(c->d_sig.p, hs, (size_t)so * 2, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipMemcpyAsync(c->d_hdr.p, hh, ho, hipMemcpyHostToDevice, c->st));
+    if (ao) HIP_TRY(hipMemcpyAsync(c->d_aux.p, ha, ao, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_read_desc_t) * n, hipMemcpyHostToDevice, c->st));
+    s5gpu_encode_args_t a;
+    memset(&a, 0, sizeof a);
+    a.n_reads = n; a.rec_method = rec_method; a.sig_method = sig_method;
+    a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
+    a.sig = (const int16_t *)c->d_sig.p; a.hdr = (const uint8_t *)c->d_hdr.p; a.aux = (const uint8_t *)c->d_aux.p;
+    a.slots = (uint8_t *)c->d_slots.p; a.out_len = (uint32_t *)c->d_len.p;
+    a.max_payload = max_payload;
+    a.scratch = staged ? (uint8_t *)c->d_scratch.p : nullptr;
+    a.scratch_bytes = staged ? c->d_scratch.cap : 0;
+    if ((rc = s5gpu_encode_dev(&a, c->st))) return rc;
+    uint8_t *ho_len = (uint8_t *)c->h_out.p;
+    uint8_t *ho_slots = ho_len + up(4ull * n, 64);
+    HIP_TRY(hipMemcpyAsync(ho_len, c->d_len.p, 4ull * n, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    const uint32_t *lens = (const uint32_t *)ho_len;
+    // D2H only the bytes that were produced: one copy per run of slots would need a compaction on device;
+    // slots are worst-case sized, so copy each record's prefix individually when that is much smaller.
+    uint64_t produced = 0;
+    for (uint32_t i = 0; i < n; i++) produced += lens[i];
+    if (c->h_out.cap < up(4ull * n, 64) + oo + 64) return S5GPU_ERR_NOMEM;
+    if (produced * 3 < oo && n <= 65536) {
+        for (uint32_t i = 0; i < n; i++)
+            HIP_TRY(hipMemcpyAsync(ho_slots + desc[i].out_off, (uint8_t *)c->d_slots.p + desc[i].out_off, lens[i], hipMemcpyDeviceToHost, c->st));
+    } else {
+        HIP_TRY(hipMemcpyAsync(ho_slots, c->d_slots.p, oo, hipMemcpyDeviceToHost, c->st));
+    }
+    HIP_TRY(hipStreamSynchronize(c->st));
+    for (uint32_t i = 0; i < n; i++) {
+        if (lens[i] < 8 || lens[i] > desc[i].slot_cap) { s5gpu_set_error("read %u: device produced an impossible length %u", i, lens[i]); return S5GPU_ERR_HIP; }
+        void *b = malloc(lens[i]);
+        if (!b) { for (uint32_t j = 0; j < i; j++) { free(out[j]); out[j] = NULL; } return S5GPU_ERR_NOMEM; }
+        memcpy(b, ho_slots + desc[i].out_off, lens[i]);
+        out[i] = b;
+        out_len[i] = lens[i];
+    }
+    return S5GPU_OK;
+}
+
+extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int rec_method, int sig_method,
+                                  void **payload, int16_t **sig, s5gpu_rec_fields_t *fields) {
+    if (n == 0) return S5GPU_OK;
+    if (!rec || !rec_len || !payload || !sig || !fields) { s5gpu_set_error("s5gpu_decode_batch: NULL argument"); return S5GPU_ERR_ARG; }
+    Ctx *c;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<s5gpu_rec_desc_t> desc(n);
+    std::vector<uint8_t> done(n, 0);
+    for (uint32_t i = 0; i < n; i++) { payload[i] = NULL; sig[i] = NULL; }
+    // capacity guesses; records that overflow report the size they need and are retried once
+    std::vector<uint32_t> pcap(n), scap(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (rec_len[i] > 0xFFFFFF00ull) { s5gpu_set_error("record %u larger than 4 GiB", i); return S5GPU_ERR_ARG; }
+        const uint64_t g = rec_method == S5GPU_REC_ZLIB ? 4ull * rec_len[i] + 4096 : rec_len[i];
+        pcap[i] = (uint32_t)(g > 0xFFFFFF00ull ? 0xFFFFFF00ull : g);
+        scap[i] = pcap[i];   // >= 1 byte per sample in either signal format... refined below
+    }
+    int overall = S5GPU_OK;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        std::vector<uint32_t> idx;
+        for (uint32_t i = 0; i < n; i++) if (!done[i]) idx.push_back(i);
+        if (idx.empty()) break;
+        const uint32_t m = (uint32_t)idx.size();
+        uint64_t io = 0, po = 0, so = 0;
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t i = idx[k];
+            s5gpu_rec_desc_t &d = desc[k];
+            d.in_off = io; d.pay_off = po; d.sig_off = so;
+            d.in_len = (uint32_t)rec_len[i]; d.pay_cap = pcap[i]; d.sig_cap = scap[i]; d.reserved = 0;
+            io += up(rec_len[i], 16); po += up((uint64_t)pcap[i] + 16, 16); so += up((uint64_t)scap[i] + 8, 8);
+        }
+        const size_t hin = up(io + 64, 64) + sizeof(s5gpu_rec_desc_t) * m;
+        const size_t hout = up(po + 64, 64) + up(so * 2 + 64, 64) + sizeof(s5gpu_rec_fields_t) * m;
+        if ((rc = c->h_in.reserve(hin)) || (rc = c->d_in.reserve(io + 64)) || (rc = c->d_desc.reserve(sizeof(s5gpu_rec_desc_t) * m)) ||
+            (rc = c->d_pay.reserve(po + 64)) || (rc = c->d_sig.reserve(so * 2 + 64)) || (rc = c->d_fields.reserve(sizeof(s5gpu_rec_fields_t) * m)) ||
+            (rc = c->h_out.reserve(hout)))
+            return rc;
+        uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + up(io + 64, 64);
+        for (uint32_t k = 0; k < m; k++) memcpy(hi + desc[k].in_off, rec[idx[k]], rec_len[idx[k]]);
+        memcpy(hd, desc.data(), sizeof(s5gpu_rec_desc_t) * m);
+        HIP_TRY(hipMemcpyAsync(c->d_in.p, hi, io, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_rec_desc_t) * m, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemsetAsync(c->d_fields.p, 0, sizeof(s5gpu_rec_fields_t) * m, c->st));
+        s5gpu_decode_args_t a;
+        memset(&a, 0, sizeof a);
+        a.n_recs = m; a.rec_method = rec_method; a.sig_method = sig_method;
+        a.desc = (const s5gpu_rec_desc_t *)c->d_desc.p; a.in = (const uint8_t *)c->d_in.p;
+        a.payload = (uint8_t *)c->d_pay.p; a.sig_out = (int16_t *)c->d_sig.p; a.fields = (s5gpu_rec_fields_t *)c->d_fields.p;
+        if ((rc = s5gpu_decode_dev(&a, c->st))) return rc;
+        uint8_t *hp = (uint8_t *)c->h_out.p, *hsg = hp + up(po + 64, 64), *hf = hsg + up(so * 2 + 64, 64);
+        HIP_TRY(hipMemcpyAsync(hf, c->d_fields.p, sizeof(s5gpu_rec_fields_t) * m, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipMemcpyAsync(hp, c->d_pay.p, po, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipMemcpyAsync(hsg, c->d_sig.p, so * 2, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        const s5gpu_rec_fields_t *ff = (const s5gpu_rec_fields_t *)hf;
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t i = idx[k];
+            const s5gpu_rec_fields_t &f = ff[k];
+            if (f.status == 5 && attempt < 2) { pcap[i] = f.payload_len; if (scap[i] < f.payload_len) scap[i] = f.payload_len; continue; }
+            if (f.status == 6 && attempt < 2) { scap[i] = f.n_samples; continue; }
+            fields[i] = f;
+            done[i] = 1;
+            if (f.status != 0) { overall = S5GPU_ERR_DATA; continue; }
+            payload[i] = malloc(f.payload_len ? f.payload_len : 1);
+            sig[i] = (int16_t *)malloc(f.n_samples ? 2ull * f.n_samples : 2);
+            if (!payload[i] || !sig[i]) return S5GPU_ERR_NOMEM;
+            memcpy(payload[i], hp + desc[k].pay_off, f.payload_len);
+            memcpy(sig[i], hsg + 2 * desc[k].sig_off, 2ull * f.n_samples);
+        }
+    }
+    if (overall) s5gpu_set_error("s5gpu_decode_batch: at least one record is corrupt (see fields[i].status)");
+    return overall;
+}

@@ -1,0 +1,534 @@
+// kernels.hip — gfx950 (CDNA4) kernels of the BLOW5 record press path + their launchers.
+// One read per workgroup (4 x wave64); all intermediates of a read live in LDS; HBM sees the int16
+// samples once (coalesced 16-B loads) and the finished record once (coalesced word stores).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/slow5gpu.h"
+#include "deflate_dev.h"
+#include "inflate_dev.h"
+#include "svb_dev.h"
+
+using namespace s5;
+
+extern "C" void s5gpu_set_error(const char *fmt, ...);
+
+#define HIP_TRY(x)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) {                                                                      \
+            s5gpu_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return S5GPU_ERR_HIP;                                                                    \
+        }                                                                                            \
+    } while (0)
+
+extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+constexpr uint32_t S_BYTES = (sizeof(DeflShared) + 15u) & ~15u;
+// Largest payload the LDS-resident (fused) kernel takes; longer reads go through the HBM-staged path.
+constexpr uint32_t FUSED_MAX_PAYLOAD = 48u * 1024u;
+
+struct EncParams {
+    s5gpu_encode_args_t a;
+    uint32_t obuf_words;   // LDS words of the bit buffer
+    uint32_t pay_cap;      // LDS bytes of the payload buffer (fused) / staging buffer (staged)
+};
+
+// ------------------------------------------------------------------------------------------------
+// payload = hdr | u64 L | signal bytes | aux   (slow5_rec_to_mem's uncompressed record, a4 in SURVEY §8)
+// dst may be LDS (fused kernel) or HBM (staged path / no record compression)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, const s5gpu_read_desc_t &d,
+                                                  uint8_t *pay, uint32_t *ws) {
+    const int tid = threadIdx.x;
+    const uint8_t *hdr = a.hdr + d.hdr_off;
+    for (uint32_t i = tid; i < d.hdr_len; i += NT) pay[i] = hdr[i];
+    uint8_t *lenp = pay + d.hdr_len;
+    uint8_t *sigp = lenp + 8;
+    const int16_t *sig = a.sig + d.sig_off;
+    const uint32_t n = d.n_samples;
+    uint64_t L;
+    uint32_t sig_bytes;
+    if (a.sig_method == S5GPU_SIG_SVB_ZD) {
+        const uint32_t nk = (n + 3) >> 2;
+        uint8_t *keys = sigp + 4;
+        uint8_t *data = keys + nk;
+        uint32_t total = 0;
+        for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) total += svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws);
+        L = 4ull + nk + total;
+        sig_bytes = (uint32_t)L;
+        if (tid < 4) sigp[tid] = (uint8_t)(n >> (8 * tid));
+    } else {
+        L = n;
+        sig_bytes = 2 * n;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(sig);
+        for (uint32_t i = tid; i < sig_bytes; i += NT) sigp[i] = src[i];
+    }
+    if (tid < 8) lenp[tid] = (uint8_t)(L >> (8 * tid));
+    if (d.aux_len) {
+        const uint8_t *aux = a.aux + d.aux_off;
+        uint8_t *ap = sigp + sig_bytes;
+        for (uint32_t i = tid; i < d.aux_len; i += NT) ap[i] = aux[i];
+    }
+    return d.hdr_len + 8 + sig_bytes + d.aux_len;
+}
+
+// K1+K5+K3+K6 fused: svb-zd -> pack -> DEFLATE -> zlib frame, one read per workgroup, payload in LDS.
+__global__ __launch_bounds__(NT) void k_encode_fused(EncParams p) {
+    const uint32_t r = blockIdx.x;
+    DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
+    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
+    uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
+    const s5gpu_read_desc_t d = p.a.desc[r];
+    const uint32_t plen = build_payload(p.a, d, pay, S.ws);
+    __syncthreads();
+    uint8_t *out = p.a.slots + d.out_off;
+    const uint32_t total = zlib_compress_lds(S, obuf, p.obuf_words, pay, plen, out);
+    if (threadIdx.x == 0) p.a.out_len[r] = total;
+}
+
+// Staged path, step 1: payload straight to HBM.  with_prefix: record compression "none" — the
+// payload IS the record, write [u64 size][payload] into the slot.
+__global__ __launch_bounds__(NT) void k_pack(EncParams p, int with_prefix) {
+    __shared__ uint32_t ws[16];
+    const uint32_t r = blockIdx.x;
+    const s5gpu_read_desc_t d = p.a.desc[r];
+    uint8_t *dst = with_prefix ? p.a.slots + d.out_off + 8 : p.a.scratch + d.out_off;
+    const uint32_t plen = build_payload(p.a, d, dst, ws);
+    if (threadIdx.x == 0) {
+        if (with_prefix) {
+            *reinterpret_cast<uint64_t *>(p.a.slots + d.out_off) = plen;
+            p.a.out_len[r] = plen + 8;
+        } else {
+            p.a.out_len[r] = plen;   // payload length, consumed by k_deflate_staged
+        }
+    }
+}
+
+// Staged path, step 2: DEFLATE a payload that sits in HBM, 16 KiB block at a time through LDS.
+__global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p) {
+    const uint32_t r = blockIdx.x;
+    DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
+    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
+    uint8_t *stage = smem + S_BYTES + 4u * p.obuf_words;
+    const s5gpu_read_desc_t d = p.a.desc[r];
+    const uint8_t *src = p.a.scratch + d.out_off;
+    const uint32_t plen = p.a.out_len[r];
+    uint8_t *out = p.a.slots + d.out_off;
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < p.obuf_words; i += NT) obuf[i] = 0;
+    __syncthreads();
+    ZOut z;
+    z.bitpos = 64;
+    z.flushed = 0;
+    if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);
+    z.bitpos = 80;
+    uint32_t adA = 1, adB = 0, done = 0;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    do {
+        const uint32_t blen = min(plen - done, (uint32_t)DEFL_BLK);
+        const bool final = done + blen == plen;
+        {   // HBM -> LDS, 16 B per lane (scratch slot and block offsets are 16-B aligned)
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
+            uint4 *d4 = reinterpret_cast<uint4 *>(stage);
+            for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
+        }
+        __syncthreads();
+        deflate_block(S, obuf, stage, (int)blen, final, z, adA, adB);
+        done += blen;
+        if (!final) flush_words(obuf, out32, z, false);
+    } while (done < plen);
+    z.bitpos = (z.bitpos + 7) & ~7u;
+    if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
+    z.bitpos += 32;
+    __syncthreads();
+    flush_words(obuf, out32, z, true);
+    const uint32_t total = z.bitpos >> 3;
+    __syncthreads();
+    if (tid == 0) {
+        *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
+        p.a.out_len[r] = total;
+    }
+}
+
+// K1 alone (BASELINE config 2): svb-zd blob of each read at slots + out_off.
+__global__ __launch_bounds__(NT) void k_svbzd_encode(EncParams p) {
+    __shared__ uint32_t ws[16];
+    const uint32_t r = blockIdx.x;
+    const s5gpu_read_desc_t d = p.a.desc[r];
+    const int16_t *sig = p.a.sig + d.sig_off;
+    uint8_t *blob = p.a.slots + d.out_off;
+    const uint32_t n = d.n_samples, nk = (n + 3) >> 2;
+    uint8_t *keys = blob + 4, *data = keys + nk;
+    uint32_t total = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) total += svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws);
+    if (threadIdx.x == 0) {
+        *reinterpret_cast<uint32_t *>(blob) = n;
+        p.a.out_len[r] = 4 + nk + total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ld_le(const uint8_t *p, int nbytes) {
+    uint64_t v = 0;
+    for (int i = 0; i < nbytes; i++) v |= (uint64_t)p[i] << (8 * i);
+    return v;
+}
+
+// K4: one record per wave64 (workgroup = 1 wave).  zlib stream -> payload slot; Adler-32 verified.
+__global__ __launch_bounds__(64) void k_inflate(s5gpu_decode_args_t a) {
+    __shared__ InflShared T;
+    const uint32_t r = blockIdx.x;
+    const s5gpu_rec_desc_t d = a.desc[r];
+    const uint8_t *in = a.in + d.in_off;
+    uint8_t *out = a.payload + d.pay_off;
+    const int lane = lane_id();
+    uint32_t olen = 0;
+    int status;
+    if (a.rec_method == S5GPU_REC_NONE) {
+        status = d.in_len > d.pay_cap ? INF_ERR_OVERFLOW : INF_OK;
+        olen = d.in_len;
+        if (status == INF_OK)
+            for (uint32_t i = lane; i < d.in_len; i += 64) out[i] = in[i];
+    } else {
+        status = zlib_inflate_wave(T, in, d.in_len, out, d.pay_cap, &olen);
+        if (status == INF_OK) {   // Adler-32 of what was written vs the big-endian trailer
+            uint64_t sa = 0, sb = 0;
+            for (uint32_t i = lane; i < olen; i += 64) {
+                const uint32_t x = out[i];
+                sa += x;
+                sb += (uint64_t)(olen - i) * x;
+            }
+            for (int dd = 32; dd >= 1; dd >>= 1) {
+                sa += __shfl_xor(sa, dd);
+                sb += __shfl_xor(sb, dd);
+            }
+            const uint32_t A = (uint32_t)((1 + sa) % 65521u);
+            const uint32_t B = (uint32_t)((sb + olen) % 65521u);
+            const uint8_t *t = in + d.in_len - 4;
+            const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+            if (((B << 16) | A) != want) status = INF_ERR_ADLER;
+        }
+    }
+    if (lane == 0) {
+        a.fields[r].status = status;
+        a.fields[r].payload_len = olen;
+    }
+}
+
+// K2 + field parse: payload -> primary fields + int16 raw_signal (slow5_rec_depress_parse, a7/a8)
+__global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
+    __shared__ uint32_t ws[16];
+    __shared__ int s_err;
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    s5gpu_rec_fields_t &f = a.fields[r];
+    if (f.status != 0) return;
+    const s5gpu_rec_desc_t d = a.desc[r];
+    const uint8_t *pay = a.payload + d.pay_off;
+    const uint32_t plen = f.payload_len;
+    if (tid == 0) s_err = 0;
+    __syncthreads();
+    int bad = 0;
+    uint32_t idl = 0, hl = 0;
+    if (plen < 2) bad = 1;
+    if (!bad) {
+        idl = (uint32_t)ld_le(pay, 2);
+        hl = 2 + idl + 4 + 32;
+        if ((uint64_t)hl + 8 > plen) bad = 1;
+    }
+    if (bad) { if (tid == 0) f.status = 7; return; }
+    const uint64_t L = ld_le(pay + hl, 8);
+    const uint8_t *sigp = pay + hl + 8;
+    const uint32_t avail = plen - hl - 8;
+    uint32_t n, sig_bytes;
+    int16_t *out = a.sig_out + d.sig_off;
+    if (a.sig_method == S5GPU_SIG_SVB_ZD) {
+        if (L > avail || L < 4) { if (tid == 0) f.status = 7; return; }
+        n = (uint32_t)ld_le(sigp, 4);
+        const uint32_t nk = (n + 3) >> 2;
+        if ((uint64_t)4 + nk > L) { if (tid == 0) f.status = 7; return; }
+        sig_bytes = (uint32_t)L;
+        if (n > d.sig_cap) { if (tid == 0) { f.status = 6; f.n_samples = n; } return; }
+        const uint8_t *keys = sigp + 4, *data = keys + nk, *dend = sigp + L;
+        uint32_t total = 0;
+        int carry = 0, err = 0;
+        for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE)
+            total += svb_decode_tile(keys + (t0 >> 2), data + total, dend, n, t0, out, carry, err, ws);
+        if (err) s_err = 1;
+        __syncthreads();
+        if (s_err || 4 + nk + total != L) { if (tid == 0) f.status = 7; return; }
+    } else {
+        if (L > avail / 2) { if (tid == 0) f.status = 7; return; }
+        n = (uint32_t)L;
+        sig_bytes = 2 * n;
+        if (n > d.sig_cap) { if (tid == 0) { f.status = 6; f.n_samples = n; } return; }
+        uint8_t *o8 = reinterpret_cast<uint8_t *>(out);
+        for (uint32_t i = tid; i < sig_bytes; i += NT) o8[i] = sigp[i];
+    }
+    if (tid == 0) {
+        f.n_samples = n;
+        f.read_id_len = idl;
+        f.read_group = (uint32_t)ld_le(pay + 2 + idl, 4);
+        uint64_t v[4];
+        for (int q = 0; q < 4; q++) v[q] = ld_le(pay + 2 + idl + 4 + 8 * q, 8);
+        f.digitisation = __longlong_as_double((long long)v[0]);
+        f.offset = __longlong_as_double((long long)v[1]);
+        f.range = __longlong_as_double((long long)v[2]);
+        f.sampling_rate = __longlong_as_double((long long)v[3]);
+        f.aux_off = hl + 8 + sig_bytes;
+        f.aux_len = plen - (hl + 8 + sig_bytes);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// compaction: slots -> contiguous record stream (the ordered fwrite of src/view.c:296-299)
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_CH = NT * 4;
+__device__ __forceinline__ uint64_t block_excl_add64(uint64_t v, uint64_t *ws, uint64_t &total) {
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t t = __shfl_up(incl, d);
+        if (lane_id() >= d) incl += t;
+    }
+    if (lane_id() == 63) ws[wave_id()] = incl;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint64_t x = ws[w];
+        if (w < wave_id()) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+__global__ __launch_bounds__(NT) void k_scan_partial(const uint32_t *len, uint32_t n, uint64_t *partial) {
+    __shared__ uint64_t ws[NW];
+    const uint32_t b0 = blockIdx.x * SCAN_CH + threadIdx.x * 4;
+    uint64_t s = 0;
+    for (int q = 0; q < 4; q++) if (b0 + q < n) s += len[b0 + q];
+    uint64_t tot;
+    block_excl_add64(s, ws, tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(NT) void k_scan_top(uint64_t *partial, uint32_t nb) {
+    __shared__ uint64_t ws[NW];
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += NT) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < nb ? partial[i] : 0;
+        uint64_t tot;
+        const uint64_t ex = block_excl_add64(v, ws, tot);
+        if (i < nb) partial[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) partial[nb] = carry;
+}
+__global__ __launch_bounds__(NT) void k_scan_final(const uint32_t *len, uint32_t n, const uint64_t *partial, uint64_t *off) {
+    __shared__ uint64_t ws[NW];
+    const uint32_t b0 = blockIdx.x * SCAN_CH + threadIdx.x * 4;
+    uint32_t l[4];
+    uint64_t s = 0;
+    for (int q = 0; q < 4; q++) { l[q] = b0 + q < n ? len[b0 + q] : 0; s += l[q]; }
+    uint64_t tot;
+    uint64_t ex = partial[blockIdx.x] + block_excl_add64(s, ws, tot);
+    for (int q = 0; q < 4; q++) {
+        if (b0 + q < n) off[b0 + q] = ex;
+        ex += l[q];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) off[n] = partial[gridDim.x];
+}
+__global__ __launch_bounds__(NT) void k_compact(const s5gpu_read_desc_t *desc, const uint8_t *slots, const uint32_t *len,
+                                                const uint64_t *off, uint8_t *stream) {
+    const uint32_t r = blockIdx.x;
+    const uint8_t *src = slots + desc[r].out_off;
+    uint8_t *dst = stream + off[r];
+    const uint32_t n = len[r];
+    // dst is only byte-aligned (BLOW5 framing has no padding): head bytes, aligned dwords, tail bytes
+    const uint32_t head = min(n, (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3));
+    if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+    const uint32_t nw = (n - head) >> 2;
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);   // slot is 16-B aligned
+    const uint32_t sh = head * 8;
+    for (uint32_t i = threadIdx.x; i < nw; i += NT) {
+        const uint32_t lo = s32[i], hi = s32[i + 1];   // slot_cap leaves >= 4 spare bytes
+        d32[i] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    }
+    const uint32_t tail0 = head + 4 * nw;
+    if (threadIdx.x < n - tail0) dst[tail0 + threadIdx.x] = src[tail0 + threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic workload (bit-identical to oracle/synth.c)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t ih4(uint64_t h) {
+    return (int64_t)((h & 0xFFFF) + ((h >> 16) & 0xFFFF) + ((h >> 32) & 0xFFFF) + (h >> 48)) - 131070;
+}
+__global__ __launch_bounds__(NT) void k_synth(int16_t *sig, uint64_t n_reads, uint64_t n, uint64_t stride, uint64_t seed,
+                                              uint64_t first) {
+    const uint64_t gid = (uint64_t)blockIdx.x * NT + threadIdx.x;
+    if (gid >= n_reads * n) return;
+    const uint64_t r = gid / n, i = gid - r * n;
+    const uint64_t key = mix64(seed + (first + r) * 0xD1342543DE82EF95ull);
+    uint64_t j = i;   // walk back to the event boundary (forced at multiples of 128)
+    for (;;) {
+        if ((j & 127) == 0) break;
+        const uint64_t h = mix64(key ^ (j * 4 + 1));
+        if ((((h >> 32) * 10ull) >> 32) == 0) break;
+        j--;
+    }
+    int64_t L = 520 + ((ih4(mix64(key ^ (j * 4 + 2))) * 1663) >> 20);
+    L = L < 200 ? 200 : L > 1100 ? 1100 : L;
+    const int64_t v = L + ((ih4(mix64(key ^ (i * 4 + 0))) * 277) >> 20);
+    sig[r * stride + i] = (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+}
+__global__ __launch_bounds__(NT) void k_synth_hdr(uint8_t *hdr, uint64_t n_reads, uint64_t first) {
+    const uint64_t r = (uint64_t)blockIdx.x * NT + threadIdx.x;
+    if (r >= n_reads) return;
+    uint8_t *h = hdr + r * 74;
+    const uint64_t idx = first + r;
+    const char *hex = "0123456789abcdef";
+    h[0] = 36; h[1] = 0;
+    uint8_t *id = h + 2;
+    for (int k = 0; k < 8; k++) id[k] = hex[(idx >> (4 * (7 - k))) & 15];
+    const char *mid = "-0000-4000-8000-";
+    for (int k = 0; k < 16; k++) id[8 + k] = mid[k];
+    for (int k = 0; k < 12; k++) id[24 + k] = hex[(idx >> (4 * (11 - k))) & 15];
+    uint8_t *q = h + 38;
+    for (int k = 0; k < 4; k++) q[k] = 0;   // read_group 0
+    const double vals[4] = {8192.0, 23.0, 1467.61, 4000.0};
+    for (int k = 0; k < 4; k++) {
+        const uint64_t bits = (uint64_t)__double_as_longlong(vals[k]);
+        for (int b = 0; b < 8; b++) q[4 + 8 * k + b] = (uint8_t)(bits >> (8 * b));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (C ABI)
+// ------------------------------------------------------------------------------------------------
+extern "C" uint64_t s5gpu_payload_bound(uint32_t n, uint32_t hdr_len, uint32_t aux_len, int sig_method) {
+    const uint64_t sig = sig_method == S5GPU_SIG_SVB_ZD ? 4ull + (n + 3ull) / 4 + 3ull * n : 2ull * n;
+    return hdr_len + 8ull + sig + aux_len;
+}
+extern "C" uint64_t s5gpu_slot_bound(uint32_t n, uint32_t hdr_len, uint32_t aux_len, int rec_method, int sig_method) {
+    const uint64_t p = s5gpu_payload_bound(n, hdr_len, aux_len, sig_method);
+    // stored blocks: 5 bytes + <1 byte of alignment per 16 KiB block; 8 prefix + 2 header + 4 adler; word slack
+    const uint64_t z = rec_method == S5GPU_REC_ZLIB ? p + 6 * (p / DEFL_BLK + 1) + 14 : p + 8;
+    return (z + 16 + 15) & ~15ull;
+}
+
+static int enc_check(const s5gpu_encode_args_t *a) {
+    if (!a || (a->n_reads && (!a->desc || !a->sig || !a->hdr || !a->slots || !a->out_len))) return S5GPU_ERR_ARG;
+    if (a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB) return S5GPU_ERR_ARG;
+    if (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD) return S5GPU_ERR_ARG;
+    return S5GPU_OK;
+}
+
+static bool g_attr_done = false;
+static int set_lds_attrs() {
+    if (g_attr_done) return S5GPU_OK;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    g_attr_done = true;
+    return S5GPU_OK;
+}
+
+extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
+    int rc = enc_check(a);
+    if (rc) { s5gpu_set_error("s5gpu_encode_dev: bad arguments"); return rc; }
+    if (a->n_reads == 0) return S5GPU_OK;
+    if ((rc = set_lds_attrs())) return rc;
+    hipStream_t st = (hipStream_t)stream_;
+    EncParams p;
+    p.a = *a;
+    if (a->rec_method == S5GPU_REC_NONE) {
+        p.obuf_words = 0; p.pay_cap = 0;
+        hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 1);
+    } else if (a->max_payload <= FUSED_MAX_PAYLOAD) {
+        const uint32_t blk = a->max_payload < (uint32_t)DEFL_BLK ? a->max_payload : (uint32_t)DEFL_BLK;
+        p.obuf_words = (blk + 64) / 4;
+        p.pay_cap = (a->max_payload + 15u) & ~15u;
+        const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
+        hipLaunchKernelGGL(k_encode_fused, dim3(a->n_reads), dim3(NT), lds, st, p);
+    } else {
+        if (!a->scratch) { s5gpu_set_error("s5gpu_encode_dev: reads longer than the LDS path need args.scratch"); return S5GPU_ERR_ARG; }
+        p.obuf_words = (DEFL_BLK + 64) / 4;
+        p.pay_cap = DEFL_BLK;
+        hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
+        const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
+        hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, st, p);
+    }
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
+extern "C" int s5gpu_svbzd_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
+    int rc = enc_check(a);
+    if (rc) { s5gpu_set_error("s5gpu_svbzd_encode_dev: bad arguments"); return rc; }
+    if (a->n_reads == 0) return S5GPU_OK;
+    EncParams p;
+    p.a = *a;
+    p.obuf_words = 0; p.pay_cap = 0;
+    hipLaunchKernelGGL(k_svbzd_encode, dim3(a->n_reads), dim3(NT), 0, (hipStream_t)stream_, p);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
+extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
+    if (!a || (a->n_recs && (!a->desc || !a->in || !a->payload || !a->sig_out || !a->fields))) {
+        s5gpu_set_error("s5gpu_decode_dev: bad arguments");
+        return S5GPU_ERR_ARG;
+    }
+    if ((a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB) ||
+        (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD)) {
+        s5gpu_set_error("s5gpu_decode_dev: unsupported method");
+        return S5GPU_ERR_ARG;
+    }
+    if (a->n_recs == 0) return S5GPU_OK;
+    hipStream_t st = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
+    hipLaunchKernelGGL(k_unpack, dim3(a->n_recs), dim3(NT), 0, st, *a);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
+extern "C" int s5gpu_compact_dev(uint32_t n, const s5gpu_read_desc_t *desc, const uint8_t *slots, const uint32_t *out_len,
+                                 uint64_t *rec_off, uint8_t *stream, uint64_t *tmp, void *stream_) {
+    if (n == 0) return S5GPU_OK;
+    if (!desc || !slots || !out_len || !rec_off || !stream || !tmp) return S5GPU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    const uint32_t nb = (n + SCAN_CH - 1) / SCAN_CH;
+    hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(NT), 0, st, out_len, n, tmp);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(NT), 0, st, tmp, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(NT), 0, st, out_len, n, tmp, rec_off);
+    hipLaunchKernelGGL(k_compact, dim3(n), dim3(NT), 0, st, desc, slots, out_len, rec_off, stream);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
+extern "C" int s5gpu_synth_dev(int16_t *sig, uint64_t n_reads, uint64_t n, uint64_t stride, uint64_t seed, uint64_t first,
+                               void *stream_) {
+    if (!sig || stride < n) return S5GPU_ERR_ARG;
+    const uint64_t tot = n_reads * n;
+    if (tot == 0) return S5GPU_OK;
+    const uint64_t nb = (tot + NT - 1) / NT;
+    if (nb > 0x7FFFFFFFull) return S5GPU_ERR_ARG;
+    hipLaunchKernelGGL(k_synth, dim3((uint32_t)nb), dim3(NT), 0, (hipStream_t)stream_, sig, n_reads, n, stride, seed, first);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+extern "C" int s5gpu_synth_hdr_dev(uint8_t *hdr, uint64_t n_reads, uint64_t first, void *stream_) {
+    if (!hdr) return S5GPU_ERR_ARG;
+    if (n_reads == 0) return S5GPU_OK;
+    hipLaunchKernelGGL(k_synth_hdr, dim3((uint32_t)((n_reads + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream_, hdr, n_reads, first);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}

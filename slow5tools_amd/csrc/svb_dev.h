@@ -1,0 +1,137 @@
+// svb_dev.h — svb-zd (StreamVByte-32 + zigzag delta) encode / decode tiles for one workgroup.
+//
+// Replaces slow5lib's signal press (thirdparty/streamvbyte, absent submodule) as reached from
+// slow5_rec_to_mem / slow5_rec_depress_parse (/root/reference/src/view.c:38,49).  Bit layout:
+// SURVEY.md Appendix A.3 — u32 N | ceil(N/4) key bytes (2 b/value, LSB first) | 1..4 LE bytes/value
+// of z = zigzag32(x[i] - x[i-1]), x[-1] = 0.
+//
+// One read per workgroup, tiles of 4096 samples: lane t owns 16 consecutive samples = two 16-byte
+// coalesced loads = exactly 4 key bytes; data offsets by wave prefix scan + 4-entry cross-wave scan.
+#pragma once
+#include "dev_common.h"
+
+namespace s5 {
+
+constexpr int SVB_TILE = NT * 16;   // samples per tile
+
+// Encode samples [t0, min(t0+SVB_TILE, n)) of one read.  sig: read base (16-B aligned).
+// keys: destination of this tile's key bytes (= key area + t0/4); data: destination of this tile's
+// first data byte.  Destinations may be LDS or HBM.  Returns the tile's data byte count (uniform).
+__device__ __forceinline__ uint32_t svb_encode_tile(const int16_t *__restrict__ sig, uint32_t n, uint32_t t0,
+                                                    uint8_t *keys, uint8_t *data, uint32_t *ws) {
+    const int tid = threadIdx.x;
+    const uint32_t i0 = t0 + 16u * tid;
+    const int valid = i0 >= n ? 0 : (int)min(16u, n - i0);
+    int x[16];
+    int prev = 0;
+    if (valid == 16) {
+        const int4 a = *reinterpret_cast<const int4 *>(sig + i0);
+        const int4 b = *reinterpret_cast<const int4 *>(sig + i0 + 8);
+        const int w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            x[2 * q] = (int)(short)(w[q] & 0xFFFF);
+            x[2 * q + 1] = w[q] >> 16;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) x[q] = q < valid ? (int)sig[i0 + q] : 0;
+    }
+    if (valid > 0 && i0 > 0) prev = sig[i0 - 1];
+    uint32_t key = 0, nbytes = 0;
+    uint32_t z[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int d = x[q] - prev;
+        prev = x[q];
+        z[q] = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
+        const uint32_t code = (z[q] > 0xFFu) + (z[q] > 0xFFFFu);   // int16 input: z <= 131070, code <= 2
+        if (q < valid) {
+            key |= code << (2 * q);
+            nbytes += code + 1;
+        }
+    }
+    uint32_t total;
+    uint32_t off = block_excl_add(nbytes, ws, total);
+    uint8_t *dp = data + off;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        if (q < valid) {
+            *dp++ = (uint8_t)z[q];
+            if (z[q] > 0xFFu) *dp++ = (uint8_t)(z[q] >> 8);
+            if (z[q] > 0xFFFFu) *dp++ = (uint8_t)(z[q] >> 16);
+        }
+    }
+    const int nk = (valid + 3) >> 2;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q < nk) keys[4 * tid + q] = (uint8_t)(key >> (8 * q));
+    return total;
+}
+
+// Decode values [t0, min(t0+SVB_TILE, n)) of one svb-zd blob.  keys: key area base + t0/4;
+// data: first data byte of this tile; data_end: end of blob.  `carry` = x[t0-1] (0 for the first tile).
+// Writes int16 samples to out[t0..].  Returns the tile's data byte count; updates carry (uniform).
+// err is set (not cleared) if a value would read past data_end.
+__device__ __forceinline__ uint32_t svb_decode_tile(const uint8_t *keys, const uint8_t *data, const uint8_t *data_end,
+                                                    uint32_t n, uint32_t t0, int16_t *__restrict__ out, int &carry,
+                                                    int &err, uint32_t *ws) {
+    const int tid = threadIdx.x;
+    const uint32_t i0 = t0 + 16u * tid;
+    const int valid = i0 >= n ? 0 : (int)min(16u, n - i0);
+    const int nk = (valid + 3) >> 2;
+    uint32_t key = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q < nk) key |= (uint32_t)keys[4 * tid + q] << (8 * q);
+    uint32_t nbytes = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+        if (q < valid) nbytes += ((key >> (2 * q)) & 3) + 1;
+    uint32_t total;
+    const uint32_t off = block_excl_add(nbytes, ws, total);
+    const uint8_t *dp = data + off;
+    if (valid > 0 && dp + nbytes > data_end) { err = 1; }
+    int d[16];
+    int sum = 0;
+    const bool ok = !(valid > 0 && dp + nbytes > data_end);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        d[q] = 0;
+        if (q < valid && ok) {
+            const uint32_t code = (key >> (2 * q)) & 3;
+            uint32_t zz = dp[0];
+            if (code > 0) zz |= (uint32_t)dp[1] << 8;
+            if (code > 1) zz |= (uint32_t)dp[2] << 16;
+            if (code > 2) zz |= (uint32_t)dp[3] << 24;
+            dp += code + 1;
+            d[q] = (int)(zz >> 1) ^ -(int)(zz & 1);
+        }
+        sum += d[q];
+    }
+    // prefix sum of deltas across the workgroup (wrapping int32 arithmetic, as the CPU decoder)
+    uint32_t tsum;
+    const uint32_t before = block_excl_add((uint32_t)sum, ws, tsum);
+    int acc = carry + (int)before;
+    if (valid == 16) {
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            acc += d[2 * q];
+            const uint32_t lo = (uint32_t)acc & 0xFFFFu;
+            acc += d[2 * q + 1];
+            w[q] = lo | ((uint32_t)acc << 16);
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(out + i0);
+        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (q < valid) { acc += d[q]; out[i0 + q] = (int16_t)acc; }
+    }
+    carry += (int)tsum;
+    return total;
+}
+
+}  // namespace s5

@@ -1,0 +1,232 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bars (north_star): svb-zd stage bit-exact vs the oracle; the DEFLATE stage must be a valid zlib stream
+that STOCK zlib inflates to the byte-identical record payload; decode returns the identical signal.
+Mirrors the reference's byte-identical diffs in test/test_view.sh:90-165 (encode and decode, all
+codec combinations) and test/test_view_integrity.sh:62-68 (round trip).
+"""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+from blow5_fixture import Blow5, NONE_NONE_FIXTURES, ZLIB_NONE_FIXTURES, ZLIB_SVB_FIXTURES, golden
+
+pytestmark = pytest.mark.gpu
+
+HDR_ARGS = (0, 8192.0, 23.0, 1467.61, 4000.0)
+
+
+@pytest.fixture(scope="module")
+def press():
+    from slow5tools_amd import _lib, press as p
+
+    _lib.check(_lib.lib().s5gpu_init(0), "s5gpu_init")
+    return p
+
+
+def _hdr(press, i):
+    return press.pack_hdr(ob.synth_read_id(i), *HDR_ARGS)
+
+
+def _oracle_payload(hdr, signal, aux, sig_method):
+    idl = struct.unpack_from("<H", hdr, 0)[0]
+    rg, dg, of, rn, sr = struct.unpack_from("<Idddd", hdr, 2 + idl)
+    r, keep = ob.make_rec(hdr[2:2 + idl], rg, dg, of, rn, sr, signal, aux)
+    return ob.rec_pack(r, sig_method), ob.rec_to_mem(r, ob.REC_ZLIB, sig_method)
+
+
+def _check_records(press, signals, hdrs, auxs, recs, rec_method, sig_method):
+    """every record: [u64 size] prefix right, stock zlib inflates to the oracle's payload"""
+    tot_gpu = tot_ref = 0
+    for i, rec in enumerate(recs):
+        aux = auxs[i] if auxs is not None else b""
+        payload, ref_mem = _oracle_payload(hdrs[i], signals[i], aux, sig_method)
+        (sz,) = struct.unpack_from("<Q", rec, 0)
+        assert sz == len(rec) - 8, (i, sz, len(rec))
+        body = rec[8:]
+        if rec_method == press.REC_ZLIB:
+            assert body[:2] == b"\x78\x9c"
+            got = zlib.decompress(body)                      # Python's stock zlib
+            assert got == payload, "record %d: inflate mismatch" % i
+            assert ob.zlib_decompress(body, len(payload) + 16) == payload   # system libz via the oracle
+            tot_gpu += len(rec)
+            tot_ref += len(ref_mem)
+        else:
+            assert body == payload
+    return tot_gpu, tot_ref
+
+
+# ---------------------------------------------------------------- svb-zd stage: bit-exact
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 255, 256, 257, 4000, 4095, 4096, 4097, 12289, 65536])
+def test_svbzd_encode_bit_exact_lengths(press, n):
+    rng = np.random.default_rng(n + 1)
+    sigs = [rng.integers(-32768, 32768, n, dtype=np.int16), (rng.normal(500, 40, n)).astype(np.int16),
+            np.zeros(n, np.int16), np.full(n, -7, np.int16)]
+    b = press.DeviceBatch([n] * len(sigs), with_stream_out=False)
+    b.upload(sigs, [_hdr(press, i) for i in range(len(sigs))])
+    b.svbzd_encode()
+    for s, blob in zip(sigs, b.records()):
+        assert blob == ob.svbzd_encode(s)
+
+
+def test_svbzd_encode_synthetic_4000_bit_exact(press):
+    n_reads, n = 512, 4000
+    b = press.DeviceBatch([n] * n_reads, with_stream_out=False)
+    b.synth(seed=0x5105, first=1000)
+    sig_dev = b.sig[: n_reads * n].cpu().numpy().reshape(n_reads, n)
+    sig_cpu = ob.synth_reads(0x5105, 1000, n_reads, n)
+    assert np.array_equal(sig_dev, sig_cpu)                 # device generator == oracle generator
+    hdr_dev = b.hdr[: 74 * n_reads].cpu().numpy().tobytes()
+    assert hdr_dev[:74] == _hdr(press, 1000) and hdr_dev[-74:] == _hdr(press, 1000 + n_reads - 1)
+    b.svbzd_encode()
+    for s, blob in zip(sig_cpu, b.records()):
+        assert blob == ob.svbzd_encode(s)
+
+
+def test_svbzd_encode_adversarial(press):
+    sigs = [np.tile(np.array([32767, -32768], np.int16), 2500), np.arange(-3000, 3000, dtype=np.int16),
+            np.random.default_rng(7).integers(-32768, 32768, 100000, dtype=np.int16)]
+    b = press.DeviceBatch([len(s) for s in sigs], with_stream_out=False)
+    b.upload(sigs, [_hdr(press, i) for i in range(len(sigs))])
+    b.svbzd_encode()
+    for s, blob in zip(sigs, b.records()):
+        assert blob == ob.svbzd_encode(s)
+
+
+# ---------------------------------------------------------------- full encode: valid zlib, identical payload
+def test_full_encode_synthetic_4000(press):
+    n_reads, n = 1024, 4000
+    b = press.DeviceBatch([n] * n_reads)
+    b.synth(seed=0x5105, first=0)
+    b.encode()
+    b.compact()
+    recs = b.records()
+    sig = ob.synth_reads(0x5105, 0, n_reads, n)
+    hdrs = [_hdr(press, i) for i in range(n_reads)]
+    tg, tr = _check_records(press, sig, hdrs, None, recs, press.REC_ZLIB, press.SIG_SVB_ZD)
+    assert tg <= 1.02 * tr, "GPU records %.4f x zlib-L6 size" % (tg / tr)
+    stream, off = b.stream_bytes()
+    assert stream == b"".join(recs)
+    assert list(off[: n_reads + 1]) == list(np.concatenate([[0], np.cumsum([len(r) for r in recs])]))
+
+
+@pytest.mark.parametrize("rec_method,sig_method", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_encode_all_method_combinations_ragged(press, rec_method, sig_method):
+    rng = np.random.default_rng(11)
+    lens = [0, 1, 2, 3, 5, 16, 100, 1000, 4000, 4096, 4097, 9999, 20000]
+    sigs = []
+    for k, n in enumerate(lens):
+        base = (500 + 30 * rng.standard_normal(n)).astype(np.int16)
+        if k % 3 == 1:
+            base[: n // 2] = 77        # long constant run
+        sigs.append(base)
+    hdrs = [press.pack_hdr(("read-%d" % k) * (1 + k % 3), k, 8192.0, 3.0 + k, 1467.61, 4000.0) for k in range(len(lens))]
+    auxs = [bytes(rng.integers(0, 256, (7 * k) % 53, dtype=np.uint8)) for k in range(len(lens))]
+    recs = press.encode_records(sigs, hdrs, auxs, rec_method, sig_method)
+    _check_records(press, sigs, hdrs, auxs, recs, rec_method, sig_method)
+
+
+def test_encode_incompressible_and_constant(press):
+    rng = np.random.default_rng(5)
+    sigs = [rng.integers(-32768, 32768, 4000, dtype=np.int16),      # ~all 3-byte codes, stored-block territory
+            np.zeros(4000, np.int16), np.full(50000, 1234, np.int16),  # pure runs
+            np.tile(np.array([32767, -32768], np.int16), 3000)]
+    hdrs = [_hdr(press, i) for i in range(len(sigs))]
+    recs = press.encode_records(sigs, hdrs)
+    tg, tr = _check_records(press, sigs, hdrs, None, recs, 1, 1)
+    # random data must not blow up: stored fallback keeps it within a few bytes of the payload
+    assert len(recs[0]) <= len(_oracle_payload(hdrs[0], sigs[0], b"", 1)[0]) + 8 + 2 + 4 + 6
+
+
+def test_encode_long_reads_staged_path(press):
+    sig = ob.synth_reads(0x5105, 5, 3, 100000)
+    sigs = [sig[0], sig[1][:65537], sig[2][:30000]]
+    hdrs = [_hdr(press, i) for i in range(3)]
+    recs = press.encode_records(sigs, hdrs)
+    tg, tr = _check_records(press, sigs, hdrs, None, recs, 1, 1)
+    assert tg <= 1.02 * tr
+
+
+@pytest.mark.parametrize("name", ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES + NONE_NONE_FIXTURES)
+def test_reencode_fixture_records(press, name):
+    """decode with the oracle, re-encode on the GPU, inflate with stock zlib -> the fixture's payload"""
+    f = Blow5(golden(name))
+    sigs, hdrs, auxs, pays = [], [], [], []
+    for rec in f.records:
+        pl = zlib.decompress(rec) if f.rec_method == 1 else rec
+        d = ob.rec_parse(pl, f.sig_method)
+        sigs.append(d["signal"])
+        hdrs.append(press.pack_hdr(d["read_id"], d["read_group"], d["digitisation"], d["offset"], d["range"], d["sampling_rate"]))
+        auxs.append(d["aux"])
+        pays.append(pl)
+    recs = press.encode_records(sigs, hdrs, auxs, f.rec_method, f.sig_method)
+    tg = tr = 0
+    for rec, pl, ref in zip(recs, pays, f.records):
+        body = rec[8:]
+        assert struct.unpack_from("<Q", rec, 0)[0] == len(body)
+        assert (zlib.decompress(body) if f.rec_method == 1 else body) == pl
+        tg += len(body)
+        tr += len(ref)
+    if f.rec_method == 1 and f.sig_method == 1:
+        assert tg <= 1.02 * tr, (tg, tr)
+
+
+# ---------------------------------------------------------------- decode
+@pytest.mark.parametrize("name", ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES + NONE_NONE_FIXTURES)
+def test_decode_fixture_records(press, name):
+    """records written by the reference (stock zlib, arbitrary LZ77 distances) decode to the oracle's answer"""
+    f = Blow5(golden(name))
+    got = press.decode_records(f.records, f.rec_method, f.sig_method)
+    for g, rec in zip(got, f.records):
+        pl = zlib.decompress(rec) if f.rec_method == 1 else rec
+        d = ob.rec_parse(pl, f.sig_method)
+        assert g["status"] == 0
+        assert g["payload"] == pl
+        assert np.array_equal(g["signal"], d["signal"])
+        for k in ("read_id", "read_group", "digitisation", "offset", "range", "sampling_rate", "aux"):
+            assert g[k] == d[k], k
+
+
+def test_roundtrip_own_streams(press):
+    n_reads, n = 300, 4000
+    sig = ob.synth_reads(0x5105, 77, n_reads, n)
+    hdrs = [_hdr(press, 77 + i) for i in range(n_reads)]
+    recs = press.encode_records(list(sig), hdrs)
+    got = press.decode_records([r[8:] for r in recs])
+    for i, g in enumerate(got):
+        assert g["status"] == 0 and np.array_equal(g["signal"], sig[i]) and g["read_id"] == ob.synth_read_id(77 + i)
+
+
+def test_decode_rejects_corrupt_records(press):
+    sig = ob.synth_reads(0x5105, 0, 4, 4000)
+    hdrs = [_hdr(press, i) for i in range(4)]
+    recs = [r[8:] for r in press.encode_records(list(sig), hdrs)]
+    bad_adler = recs[0][:-1] + bytes([recs[0][-1] ^ 1])
+    trunc = recs[1][: len(recs[1]) // 2]
+    bad_hdr = b"\x00\x00" + recs[2][2:]
+    got = press.decode_records([bad_adler, trunc, bad_hdr, recs[3]], raise_on_error=False)
+    assert got[0]["status"] == 4 and got[1]["status"] in (2, 3) and got[2]["status"] == 1
+    assert got[3]["status"] == 0 and np.array_equal(got[3]["signal"], sig[3])
+    with pytest.raises(press.S5GpuError):
+        press.decode_records([trunc])
+
+
+def test_decode_stored_and_fixed_blocks(press):
+    """streams from other encoders: zlib level 0 (stored), Z_FIXED, and a 32 KiB-distance match"""
+    rng = np.random.default_rng(3)
+    sig = (500 + 30 * rng.standard_normal(70000)).astype(np.int16)
+    hdr = _hdr(press, 1)
+    payload, _ = _oracle_payload(hdr, sig, b"", 1)
+    streams = [zlib.compress(payload, 0), zlib.compress(payload, 9)]
+    c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+    streams.append(c.compress(payload) + c.flush())
+    for g in press.decode_records(streams):
+        assert g["status"] == 0 and np.array_equal(g["signal"], sig)
+    # raw int16 record with a far repeat (distance ~32 KiB) exercises window copies
+    sig2 = np.concatenate([sig[:16000], sig[:16000]])
+    payload2, _ = _oracle_payload(hdr, sig2, b"", 0)
+    g = press.decode_records([zlib.compress(payload2, 9)], 1, 0)[0]
+    assert g["status"] == 0 and np.array_equal(g["signal"], sig2)
