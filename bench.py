@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — BLOW5 encode throughput (svb-zd + DEFLATE, BASELINE.json config 3) on N MI355X.
+
+A step = one pass of the hot path over one resident batch of synthetic reads:
+    k_encode_fused  (svb-zd -> pack -> DEFLATE -> zlib frame, one read per workgroup)
+  + s5gpu_compact   (slots -> contiguous BLOW5 record stream, what the ordered fwrite emits)
+Inputs (int16 signals, 74-byte record heads) are already in HBM when the timed region starts.
+Reads shard across ranks with no collective (weak scaling: every rank encodes its own batch).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--samples", type=int, default=4000, help="int16 samples per read")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
+    ap.add_argument("--svb-only", action="store_true", help="config 2: svb-zd stage alone")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    from slow5tools_amd import _lib, press
+
+    L = _lib.lib()
+    _lib.check(L.s5gpu_init(local_rank), "s5gpu_init")
+
+    n_reads, n = args.reads, args.samples
+    first = rank * n_reads                      # each rank encodes its own shard of the read index space
+    b = press.DeviceBatch(np.full(n_reads, n, dtype=np.uint64), device=dev)
+    b.synth(seed=0x5105, first=first)
+    torch.cuda.synchronize()
+
+    step = b.svbzd_encode if args.svb_only else b.encode
+    st = b._stream()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+        b.compact()
+    torch.cuda.synchronize()
+
+    K = args.steps
+    evs = []
+    for _ in range(3 * K):
+        e = C.c_void_p()
+        _lib.check(L.s5gpu_event_create(C.byref(e)))
+        evs.append(e)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        L.s5gpu_event_record(evs[3 * k], st)
+        step()
+        L.s5gpu_event_record(evs[3 * k + 1], st)
+        b.compact()
+        L.s5gpu_event_record(evs[3 * k + 2], st)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    enc_ms, cmp_ms = [], []
+    ms = C.c_float()
+    for k in range(K):
+        _lib.check(L.s5gpu_event_elapsed_ms(evs[3 * k], evs[3 * k + 1], C.byref(ms)))
+        enc_ms.append(ms.value)
+        _lib.check(L.s5gpu_event_elapsed_ms(evs[3 * k + 1], evs[3 * k + 2], C.byref(ms)))
+        cmp_ms.append(ms.value)
+    for e in evs:
+        L.s5gpu_event_destroy(e)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- results, rank 0 ----
+    out_len = b.out_len[:n_reads].cpu().numpy().astype(np.int64)
+    z_bytes = int(out_len.sum())
+    raw_bytes = 2 * n * n_reads
+    total_reads = n_reads * world
+    reads_per_s = total_reads * K / dt
+    value = reads_per_s * 2 * n / 1e9
+    # algorithmic HBM bytes of the dominant kernel per launch:
+    #   full encode: 2N + H (74-byte head) + Z (record incl. 8-byte prefix), per read; svb only: 2N + S
+    alg_bytes = raw_bytes + (0 if args.svb_only else 74 * n_reads) + z_bytes
+    kern_s = float(np.mean(enc_ms)) / 1e3
+    achieved = alg_bytes / kern_s / 1e9
+    peak = 8000.0
+
+    # parity spot check of this very run (outside the timed region)
+    import zlib
+
+    import oracle_bind as ob
+
+    idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
+    recs = b.records(idx)
+    parity = True
+    for i, rec in zip(idx, recs):
+        sig = ob.synth_read(0x5105, first + i, n)
+        if args.svb_only:
+            parity &= rec == ob.svbzd_encode(sig)
+        else:
+            r, keep = ob.make_rec(ob.synth_read_id(first + i), 0, 8192.0, 23.0, 1467.61, 4000.0, sig)
+            parity &= zlib.decompress(rec[8:]) == ob.rec_pack(r, ob.SIG_SVB_ZD)
+
+    # ---- CPU baseline: the oracle's reference-shaped pthread batch encode on this box's host cores ----
+    cpu = None
+    if args.cpu_seconds > 0 and not args.svb_only:
+        cores = os.cpu_count() or 1
+        stride = (n + 7) // 8 * 8
+        probe_reads = min(n_reads, 256 * cores)
+        sig_probe = b.sig[: probe_reads * stride].cpu().numpy().reshape(probe_reads, stride)[:, :n]
+        _, secs, _ = ob.encode_batch_mt(sig_probe, first, cores, 4096)
+        rate = probe_reads / max(secs, 1e-6)
+        m = int(min(n_reads, max(probe_reads, rate * args.cpu_seconds)))
+        sig_cpu = b.sig[: m * stride].cpu().numpy().reshape(m, stride)[:, :n]
+        tot, secs, _ = ob.encode_batch_mt(sig_cpu, first, cores, 4096)
+        cpu = {"value": round(m * 2 * n / secs / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
+               "reads_per_s": round(m / secs, 1), "bytes_per_sample": round(tot / (m * n), 4),
+               "sample": "first %d reads of the same batch (%d samples each), compute phase of view -t %d -K 4096 "
+                         "(svb-zd + zlib-1.2.11 level 6, per-record deflateInit), %.1f s" % (m, n, cores, secs)}
+
+    line = {
+        "metric": "blow5_encode_raw_signal_throughput" if not args.svb_only else "svbzd_encode_raw_signal_throughput",
+        "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int16->u8", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[%d]: %s, %d reads x %d int16 samples per GPU"
+                               % (1 if args.svb_only else 2, "svb-zd only" if args.svb_only else "full BLOW5 encode (svb-zd + DEFLATE, zlib framing)", n_reads, n),
+                   "reads_per_gpu": n_reads, "samples_per_read": n, "record_press": "none" if args.svb_only else "zlib",
+                   "signal_press": "svb-zd", "parallelism": "reads sharded over %d GPU(s), no collective" % world},
+        "reads_per_s": round(reads_per_s, 1),
+        "bytes_per_sample": round(z_bytes / (n_reads * n), 4),
+        "parity_spot_check": bool(parity),
+        "kernel_ms": {"encode": round(float(np.mean(enc_ms)), 3), "compact": round(float(np.mean(cmp_ms)), 3)},
+        "roofline": {"bound": "hbm", "kernel": "k_svbzd_encode" if args.svb_only else "k_encode_fused",
+                     "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
+                     "frac": round(achieved / peak, 5), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes},
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

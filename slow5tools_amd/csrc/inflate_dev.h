@@ -158,8 +158,9 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
     while (!last && status == INF_OK) {
         // ---- block header (lane 0 reads, broadcast) ----
         uint32_t hdr = 0;
-        if (lane == 0) { bi_refill(b); hdr = bi_get(b, 3); }
+        if (lane == 0) { bi_refill(b); hdr = bi_get(b, 3); if (b.over > 8) hdr = 8; }
         hdr = __shfl(hdr, 0);
+        if (hdr == 8) { status = INF_ERR_TRUNC; break; }   // ran off the end of the input
         last = hdr & 1;
         const int type = hdr >> 1;
         if (type == 3) { status = INF_ERR_DATA; break; }
@@ -250,10 +251,11 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
         // ---- symbols: lane 0 decodes, the wave replicates matches ----
         for (;;) {
             // lane 0 decodes up to the next match or end of block, writing literals itself
-            uint32_t mlen = 0, mdist = 0, st = 0;   // st: 0 match, 1 end of block, 2 error
+            uint32_t mlen = 0, mdist = 0, st = 0;   // st: 0 match, 1 end of block, 2 error, 3 truncated
             if (lane == 0) {
                 for (;;) {
                     bi_refill(b);
+                    if (b.over > 8) { st = 3; break; }   // zero-fill past the end must not decode forever
                     int sym;
                     const uint32_t e = T.llut[b.buf & ((1 << INF_LBITS) - 1)];
                     if (e >> 9) { sym = e & 511; bi_get(b, e >> 9); } else sym = infl_slow(b, T.lcount, T.lsym);
@@ -275,7 +277,7 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
             }
             st = __shfl(st, 0);
             o = __shfl(o, 0);
-            if (st == 2) { status = INF_ERR_DATA; break; }
+            if (st >= 2) { status = st == 2 ? INF_ERR_DATA : INF_ERR_TRUNC; break; }
             if (st == 1) break;
             mlen = __shfl(mlen, 0);
             mdist = __shfl(mdist, 0);
