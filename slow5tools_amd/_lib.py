@@ -51,7 +51,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB
+    path = os.environ.get("S5GPU_LIB") or _build.LIB   # S5GPU_LIB: e.g. the -DS5_PROFILE build (tools/phase_profile.py)
     if not os.path.exists(path):
         _build.build()
     L = C.CDLL(path)

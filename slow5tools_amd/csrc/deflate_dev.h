@@ -21,27 +21,46 @@
 
 namespace s5 {
 
+// Optional per-phase cycle accounting (build with -DS5_PROFILE; never in the product library).
+#ifdef S5_PROFILE
+__device__ unsigned long long g_prof[32];
+#define PROF_DECL unsigned long long prof_t_ = clock64();
+#define PROF_MARK(k)                                                                  \
+    do {                                                                              \
+        if (threadIdx.x == 0) {                                                       \
+            const unsigned long long now_ = clock64();                                \
+            atomicAdd(&g_prof[k], now_ - prof_t_);                                    \
+            prof_t_ = now_;                                                           \
+        }                                                                             \
+    } while (0)
+#define PROF_RESET prof_t_ = clock64();
+#else
+#define PROF_DECL
+#define PROF_MARK(k)
+#define PROF_RESET
+#endif
+
 constexpr int DEFL_BLK = NT * 64;    // max payload bytes per DEFLATE block (64 per lane: one break mask)
 constexpr int NLIT = 286;            // literal/length symbols in use
 constexpr int DOFF = 288;            // distance codes live at [DOFF, DOFF+32) in the shared tables
 
 struct DeflShared {
-    uint32_t freq[320];      // histogram: [0,288) lit/len, [288,320) dist
+    alignas(16) uint32_t freq[320];   // histogram: [0,288) lit/len, [288,320) dist
+    alignas(16) uint32_t clfreq[20];
     uint32_t code[320];      // bit-reversed code | nbits << 16
     uint32_t lf[288];        // leaf frequencies, ascending
-    uint32_t nf[288];        // internal-node frequencies (creation order = ascending)
-    uint16_t lpar[288];      // leaf -> parent internal node
+    alignas(16) uint32_t nf[288];   // internal-node frequencies (creation order = ascending); sort keys before the merge
     uint16_t npar[288];      // internal node -> parent
     uint16_t rsym[288];      // rank -> symbol
     uint16_t clseq[320];     // code-length sequence: sym | extra_value << 5
     uint8_t lens[320];       // code lengths, same indexing as freq
-    uint32_t clfreq[20];
     uint32_t clcode[20];
     uint8_t cllens[20];
     uint32_t blcount[16];
+    uint32_t icount[16];     // internal nodes per depth
     uint32_t ws[16];         // cross-wave scan scratch
     uint32_t red[8];         // 0 matches, 1 extra bits, 2 adler A part, 3 adler B part, 4 dyn bits, 5 fixed bits, 6 cl bits
-    uint32_t ncl, hlit, hclen, ovf;
+    uint32_t ncl, hlit, hclen;
 };
 
 struct ZOut {                // replicated uniformly in every lane's registers
@@ -55,27 +74,47 @@ __device__ __forceinline__ void put_bits(uint32_t *obuf, const ZOut &z, uint32_t
     if (sh + nb > 32) atomicOr(&obuf[w + 1], v >> (32 - sh));
 }
 
-// ---- length-limited Huffman code lengths for freq[0..n), n <= 2*NT ----
+// ---- length-limited Huffman code lengths for freq[0..n4), n <= 2*NT ----
+// freq must be 16-B aligned, readable (and zero) up to the next multiple of 4 entries.
 __device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *freq, int n, int maxbits, uint8_t *lens) {
     const int tid = threadIdx.x;
+    PROF_DECL
     for (int s = tid; s < n; s += NT) lens[s] = 0;
-    if (tid < 16) S.blcount[tid] = 0;
-    if (tid == 0) S.ovf = 0;
+    if (tid < 16) { S.blcount[tid] = 0; S.icount[tid] = 0; }
+    // Rank sort on unique keys (freq << 9 | symbol; unused symbols = ~0): rank = number of smaller keys.
+    // Keys go to LDS once (S.nf is free until the merge), then one compare + add per element, read as
+    // 16-B LDS broadcasts.  Symbols >= 256 (at most 30 of them) are ranked by wave 0 only.
     const uint32_t f0 = tid < n ? freq[tid] : 0;
     const uint32_t f1 = tid + NT < n ? freq[tid + NT] : 0;
+    const uint32_t key0 = f0 ? (f0 << 9) | (uint32_t)tid : 0xFFFFFFFFu;
+    const uint32_t key1 = f1 ? (f1 << 9) | (uint32_t)(tid + NT) : 0xFFFFFFFFu;
+    const int n4 = (n + 3) >> 2;
+    S.nf[tid] = key0;
+    if (tid + NT < 4 * n4) S.nf[tid + NT] = key1;
+    __syncthreads();
     int r0 = 0, r1 = 0, m = 0;
-    for (int j = 0; j < n; j++) {   // rank sort by (freq, symbol): LDS broadcast reads
-        const uint32_t fj = freq[j];
-        if (fj) {
-            m++;
-            r0 += (fj < f0) || (fj == f0 && j < tid);
-            r1 += (fj < f1) || (fj == f1 && j < tid + NT);
+    {
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(S.nf);
+#pragma unroll 8
+        for (int q = 0; q < n4; q++) {
+            const uint4 v = k4[q];
+            r0 += (v.x < key0) + (v.y < key0) + (v.z < key0) + (v.w < key0);
         }
+        if (wave_id() == 0 && n > NT) {
+#pragma unroll 8
+            for (int q = 0; q < n4; q++) {
+                const uint4 v = k4[q];
+                r1 += (v.x < key1) + (v.y < key1) + (v.z < key1) + (v.w < key1);
+            }
+        }
+        for (int b = 0; b < 4 * n4; b += 64)
+            m += __popcll(__ballot(b + lane_id() < 4 * n4 && S.nf[b + lane_id()] != 0xFFFFFFFFu));
     }
     __syncthreads();
     if (f0) { S.lf[r0] = f0; S.rsym[r0] = (uint16_t)tid; }
     if (f1) { S.lf[r1] = f1; S.rsym[r1] = (uint16_t)(tid + NT); }
     __syncthreads();
+    PROF_MARK(n > 19 ? 3 : 8);
     if (m <= 1) {   // degenerate: keep the code complete with two 1-bit codes
         if (tid == 0) {
             int sym = m ? S.rsym[0] : 0;
@@ -86,38 +125,88 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *fre
         __syncthreads();
         return;
     }
-    if (tid == 0) {   // two-queue merge: leaves ascending, internal nodes are created ascending
-        int i = 0, j = 0;
-        for (int k = 0; k < m - 1; k++) {
-            uint32_t a, b;
-            if (i < m && (j >= k || S.lf[i] <= S.nf[j])) { a = S.lf[i]; S.lpar[i] = (uint16_t)k; i++; }
-            else { a = S.nf[j]; S.npar[j] = (uint16_t)k; j++; }
-            if (i < m && (j >= k || S.lf[i] <= S.nf[j])) { b = S.lf[i]; S.lpar[i] = (uint16_t)k; i++; }
-            else { b = S.nf[j]; S.npar[j] = (uint16_t)k; j++; }
-            S.nf[k] = a + b;
+    if (wave_id() == 0) {
+        // Huffman tree by ROUNDS instead of one merge per step (the serial two-queue loop costs ~400
+        // cycles per merge on a GPU).  Leaves ascending in S.lf, internal nodes are produced ascending
+        // into S.nf.  Per round, one wave64: take the next 64 leaves and the next 64 nodes, bitonic-merge
+        // the 128 keys in two registers, and pair up EVERY item not larger than T = X0 + X1 at once —
+        // no node created in this round can be smaller than T, so the pairs are exactly the ones the
+        // serial algorithm would form.  The smallest remaining weight at least doubles per round:
+        // ~13 rounds for a 240-symbol alphabet (m-1 rounds only for Fibonacci-like weights).
+        const int lane = lane_id();
+        const uint32_t INF = 0xFFFFFFFFu;
+        int i = 0, j = 0, k = 0;
+        while (k < m - 1) {
+            // key = weight << 8 | is_node << 6 | window index; weights < 2^24
+            const uint32_t lv = i + lane < m ? S.lf[i + lane] : INF;
+            const int qn = 63 - lane;   // node window is loaded descending: [leaves asc | nodes desc] is bitonic
+            const uint32_t nv = j + qn < k ? S.nf[j + qn] : INF;
+            uint32_t a = lv == INF ? INF : (lv << 8) | (uint32_t)lane;
+            uint32_t b = nv == INF ? INF : (nv << 8) | 64u | (uint32_t)qn;
+            {   // bitonic merge of 128 keys: stride 64 across the two registers, then 32..1 inside each
+                const uint32_t lo = min(a, b), hi = max(a, b);
+                a = lo; b = hi;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const uint32_t pa = __shfl_xor(a, d), pb = __shfl_xor(b, d);
+                    const bool up = (lane & d) != 0;
+                    a = up ? max(a, pa) : min(a, pa);
+                    b = up ? max(b, pb) : min(b, pb);
+                }
+            }
+            // a[lane] = X[lane], b[lane] = X[64 + lane] in ascending order
+            const uint32_t x0 = __builtin_amdgcn_readlane(a, 0), x1 = __builtin_amdgcn_readlane(a, 1);
+            uint32_t T = (x0 >> 8) + (x1 >> 8);
+            if (i + 64 < m) T = min(T, __builtin_amdgcn_readlane(lv, 63));      // leaves beyond the window
+            if (j + 64 < k) T = min(T, __builtin_amdgcn_readlane(nv, 0));       // nodes beyond the window
+            const uint32_t va = a >> 8, vb = b >> 8;
+            int c = __popcll(__ballot(a != INF && va <= T)) + __popcll(__ballot(b != INF && vb <= T));
+            c &= ~1;
+            c = max(c, 2);
+            c = min(c, 2 * (m - 1 - k));
+            // pairs (X[2p], X[2p+1]) -> node k + p
+            const uint32_t sa = va + __shfl_xor(va, 1), sb = vb + __shfl_xor(vb, 1);
+            if (!(lane & 1) && lane < c) S.nf[k + (lane >> 1)] = sa;
+            if (!(lane & 1) && 64 + lane < c) S.nf[k + 32 + (lane >> 1)] = sb;
+            const bool ina = lane < c, inb = 64 + lane < c;
+            if (ina && (a & 64u)) S.npar[j + (a & 63u)] = (uint16_t)(k + (lane >> 1));
+            if (inb && (b & 64u)) S.npar[j + (b & 63u)] = (uint16_t)(k + 32 + (lane >> 1));
+            const int nn = __popcll(__ballot(ina && (a & 64u))) + __popcll(__ballot(inb && (b & 64u)));
+            i += c - nn;
+            j += nn;
+            k += c >> 1;
         }
     }
     __syncthreads();
-    for (int r = tid; r < m; r += NT) {   // leaf depth = parent-chain length to the root (node m-2)
-        int d = 1, p = S.lpar[r];
+    PROF_MARK(n > 19 ? 4 : 8);
+    // Depth of every internal node by a parallel parent walk (root = node m-2, depth 0).  Leaves at
+    // depth L = 2 * I[L-1] - I[L]; sorted order makes depth monotone in rank, so counts are enough.
+    for (int q = tid; q < m - 1; q += NT) {
+        int d = 0, p = q;
         while (p != m - 2) { p = S.npar[p]; d++; }
-        if (d > maxbits) { d = maxbits; S.ovf = 1; }
-        atomicAdd(&S.blcount[d], 1u);
+        atomicAdd(&S.icount[min(d, maxbits)], 1u);
     }
     __syncthreads();
-    if (S.ovf) {   // clamp happened: repair the Kraft sum on the per-length counts
-        if (tid == 0) {
+    if (tid == 0) {
+        uint32_t used = 0;
+        for (int L = 1; L < maxbits; L++) {
+            const uint32_t c = 2 * S.icount[L - 1] - S.icount[L];
+            S.blcount[L] = c;
+            used += c;
+        }
+        S.blcount[maxbits] = (uint32_t)m - used;   // every leaf at depth >= maxbits, clamped
+        if (S.icount[maxbits]) {   // some leaf was deeper than maxbits: repair the Kraft sum on the counts
             uint32_t total = 0;
-            for (int i = maxbits; i >= 1; i--) total += S.blcount[i] << (maxbits - i);
+            for (int b = maxbits; b >= 1; b--) total += S.blcount[b] << (maxbits - b);
             while (total != (1u << maxbits)) {
                 S.blcount[maxbits]--;
-                for (int i = maxbits - 1; i > 0; i--)
-                    if (S.blcount[i]) { S.blcount[i]--; S.blcount[i + 1] += 2; break; }
+                for (int b = maxbits - 1; b > 0; b--)
+                    if (S.blcount[b]) { S.blcount[b]--; S.blcount[b + 1] += 2; break; }
                 total--;
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     for (int r = tid; r < m; r += NT) {   // rarest symbols get the longest codes
         uint32_t cum = 0;
         int L = maxbits;
@@ -125,6 +214,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *fre
         lens[S.rsym[r]] = (uint8_t)L;
     }
     __syncthreads();
+    PROF_MARK(n > 19 ? 5 : 8);
 }
 
 // ---- canonical codes from lengths (wave 0; S.blcount must match lens) ----
@@ -224,6 +314,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
         __syncthreads();
         return;
     }
+    PROF_DECL
     const int K = (len + NT - 1) / NT;
     const int base = tid * K;
     const int kk = max(0, min(K, len - base));
@@ -250,6 +341,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
     const int local_first = brk ? base + __ffsll((long long)brk) - 1 : len;
     const int lastb = block_excl_max(local_last, -1, S.ws);
     const int nextb = block_suffix_excl_min(local_first, len, S.ws);
+    PROF_MARK(1);
 
     uint32_t nmatch = 0, nextra = 0;
     for (int j = 0; j < kk; j++) {
@@ -271,41 +363,78 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
     }
     if (tid == 0) atomicAdd(&S.freq[256], 1u);
     __syncthreads();
+    PROF_MARK(2);
 
     // ---- B: codes ----
     build_lengths(S, S.freq, NLIT, 15, S.lens);
+    PROF_RESET
     assign_codes(S, S.lens, NLIT, S.code);
+    PROF_MARK(6);
+    // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
     if (tid == 0) {
-        // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
         S.lens[DOFF] = 1; S.lens[DOFF + 1] = 1;
         S.code[DOFF] = 0u | (1u << 16); S.code[DOFF + 1] = 1u | (1u << 16);
-        int hlit = NLIT;
-        while (hlit > 257 && S.lens[hlit - 1] == 0) hlit--;
-        S.hlit = hlit;
-        // run-length code the hlit + 2 code lengths (RFC 1951 3.2.7: symbols 16/17/18)
-        const int n = hlit + 2;
-        int ncl = 0, p = 0;
-        while (p < n) {
-            const int v = p < hlit ? S.lens[p] : S.lens[DOFF + p - hlit];
-            int run = 1;
-            while (p + run < n && (p + run < hlit ? S.lens[p + run] : S.lens[DOFF + p + run - hlit]) == v) run++;
-            int r = run;
-            if (v == 0) {
-                while (r >= 11) { const int t = min(r, 138); S.clseq[ncl++] = (uint16_t)(18 | ((t - 11) << 5)); S.clfreq[18]++; r -= t; }
-                if (r >= 3) { S.clseq[ncl++] = (uint16_t)(17 | ((r - 3) << 5)); S.clfreq[17]++; r = 0; }
-                while (r > 0) { S.clseq[ncl++] = 0; S.clfreq[0]++; r--; }
-            } else {
-                S.clseq[ncl++] = (uint16_t)v; S.clfreq[v]++; r--;
-                while (r >= 3) { const int t = min(r, 6); S.clseq[ncl++] = (uint16_t)(16 | ((t - 3) << 5)); S.clfreq[16]++; r -= t; }
-                while (r > 0) { S.clseq[ncl++] = (uint16_t)v; S.clfreq[v]++; r--; }
-            }
-            p += run;
-        }
-        S.ncl = ncl;
+        S.hlit = 257;
     }
     __syncthreads();
+    if (tid < 29 && S.lens[257 + tid]) atomicMax(&S.hlit, 258u + tid);
+    __syncthreads();
+    {
+        // Run-length code the hlit + 2 code lengths (RFC 1951 3.2.7, symbols 16/17/18), in parallel:
+        // lane t owns positions 2t, 2t+1; run bounds from one prefix-max and one suffix-min scan; every
+        // position decides alone whether it emits an entry; a prefix sum compacts the entries.
+        const int hlit = (int)S.hlit, n = hlit + 2;
+        const int p0 = 2 * tid;
+        int v[2], prevv = -1;
+        if (p0 - 1 >= 0 && p0 - 1 < n) prevv = p0 - 1 < hlit ? S.lens[p0 - 1] : S.lens[DOFF + p0 - 1 - hlit];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int p = p0 + q;
+            v[q] = p < n ? (p < hlit ? S.lens[p] : S.lens[DOFF + p - hlit]) : -2 - q;   // past the end: never equal
+        }
+        const bool brk0 = p0 < n && v[0] != prevv, brk1 = p0 + 1 < n && v[1] != v[0];
+        const int local_last = brk1 ? p0 + 1 : brk0 ? p0 : -1;
+        const int local_first = brk0 ? p0 : brk1 ? p0 + 1 : n;
+        const int lastb = block_excl_max(local_last, -1, S.ws);
+        const int nextb = block_suffix_excl_min(local_first, n, S.ws);
+        uint32_t ent[2], nent = 0;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int p = p0 + q;
+            ent[q] = 0xFFFFFFFFu;
+            if (p >= n) continue;
+            const int s = q == 0 ? (brk0 ? p0 : lastb) : (brk1 ? p0 + 1 : brk0 ? p0 : lastb);
+            const int e = q == 0 ? (brk1 ? p0 + 1 : nextb) : nextb;
+            const int R = e - s, rel = p - s;
+            if (v[q] == 0) {
+                const int c = rel / 138, off = rel - c * 138, Lc = min(138, R - c * 138);
+                if (Lc >= 11) { if (off == 0) ent[q] = 18u | ((uint32_t)(Lc - 11) << 5); }
+                else if (Lc >= 3) { if (off == 0) ent[q] = 17u | ((uint32_t)(Lc - 3) << 5); }
+                else ent[q] = 0;
+            } else if (rel == 0) {
+                ent[q] = (uint32_t)v[q];
+            } else {
+                const int mm = rel - 1, c = mm / 6, off = mm - c * 6, Lc = min(6, R - 1 - c * 6);
+                if (Lc >= 3) { if (off == 0) ent[q] = 16u | ((uint32_t)(Lc - 3) << 5); }
+                else ent[q] = (uint32_t)v[q];
+            }
+            nent += ent[q] != 0xFFFFFFFFu;
+        }
+        uint32_t tot;
+        uint32_t at = block_excl_add(nent, S.ws, tot);
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            if (ent[q] != 0xFFFFFFFFu) {
+                S.clseq[at++] = (uint16_t)ent[q];
+                atomicAdd(&S.clfreq[ent[q] & 31], 1u);
+            }
+        if (tid == 0) S.ncl = tot;
+    }
+    __syncthreads();
+    PROF_MARK(7);
     build_lengths(S, S.clfreq, 19, 7, S.cllens);
     assign_codes(S, S.cllens, 19, S.clcode);
+    PROF_RESET
 
     // ---- C: cost of the three block types ----
     {
@@ -332,6 +461,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
         }
     }
     __syncthreads();
+    PROF_MARK(9);
     const uint32_t matches = S.red[0], extra = S.red[1];
     const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
     const uint32_t dyn_total = hdr_dyn + S.red[4] + extra + matches * 1;
@@ -403,6 +533,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
         dist_bits = 1;
     }
 
+    PROF_MARK(10);
     // ---- tokens: per-lane bit totals -> prefix scan -> pack ----
     uint32_t mybits = 0;
     for (int j = 0; j < kk; j++) {
@@ -411,6 +542,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
     }
     uint32_t total_bits;
     const uint32_t start = pos0 + block_excl_add(mybits, S.ws, total_bits);
+    PROF_MARK(11);
     {
         uint32_t widx = (start >> 5) - z.flushed;
         uint32_t accbits = start & 31;
@@ -441,6 +573,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
     if (tid == 0) put_bits(obuf, z, pos0 + total_bits, eob & 0xFFFF, eob >> 16);
     z.bitpos = pos0 + total_bits + (eob >> 16);
     __syncthreads();
+    PROF_MARK(12);
 }
 
 // zlib-frame a payload that sits in LDS (`pay`, `plen` bytes) into HBM slot `out` (16-B aligned).

@@ -82,11 +82,17 @@ __global__ __launch_bounds__(NT) void k_encode_fused(EncParams p) {
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
     const s5gpu_read_desc_t d = p.a.desc[r];
+    PROF_DECL
     const uint32_t plen = build_payload(p.a, d, pay, S.ws);
     __syncthreads();
+    PROF_MARK(0);
     uint8_t *out = p.a.slots + d.out_off;
     const uint32_t total = zlib_compress_lds(S, obuf, p.obuf_words, pay, plen, out);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
+    PROF_MARK(13);
+#ifdef S5_PROFILE
+    if (threadIdx.x == 0) atomicAdd(&g_prof[31], 1ull);
+#endif
 }
 
 // Staged path, step 1: payload straight to HBM.  with_prefix: record compression "none" — the
@@ -410,6 +416,17 @@ __global__ __launch_bounds__(NT) void k_synth_hdr(uint8_t *hdr, uint64_t n_reads
         for (int b = 0; b < 8; b++) q[4 + 8 * k + b] = (uint8_t)(bits >> (8 * b));
     }
 }
+
+#ifdef S5_PROFILE
+extern "C" int s5gpu_prof_read(unsigned long long *out, int reset) {
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32));
+    if (reset) {
+        unsigned long long z[32] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z));
+    }
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // launchers (C ABI)
