@@ -69,8 +69,10 @@ typedef struct s5gpu_encode_args {
     uint8_t *slots;                  /* device, out: [u64 size][record bytes] per read at out_off    */
     uint32_t *out_len;               /* device, out: bytes written per read, incl. the 8-byte prefix */
     uint32_t max_payload;            /* max over reads of s5gpu_payload_bound()                      */
-    uint8_t *scratch;                /* device, >= size of `slots`; used only for reads too long for */
-    uint64_t scratch_bytes;          /*   the LDS-resident path (may be NULL/0 otherwise)            */
+    uint32_t lds_payload_cap;        /* 0 = auto.  LDS bytes the one-workgroup-per-read kernel keeps */
+                                     /*   for a payload; reads that need more (long or incompressible*/
+                                     /*   signals) are re-run through the HBM-staged kernels          */
+    uint32_t *ovf;                   /* device, n_reads + 1 words of scratch (list of such reads)    */
 } s5gpu_encode_args_t;
 
 /* One record of a decode batch. */

@@ -30,7 +30,7 @@ class EncodeArgs(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("rec_method", C.c_int32), ("sig_method", C.c_int32),
                 ("desc", C.c_void_p), ("sig", C.c_void_p), ("hdr", C.c_void_p), ("aux", C.c_void_p),
                 ("slots", C.c_void_p), ("out_len", C.c_void_p), ("max_payload", C.c_uint32),
-                ("scratch", C.c_void_p), ("scratch_bytes", C.c_uint64)]
+                ("lds_payload_cap", C.c_uint32), ("ovf", C.c_void_p)]
 
 
 class DecodeArgs(C.Structure):

@@ -44,14 +44,21 @@ constexpr int DEFL_BLK = NT * 64;    // max payload bytes per DEFLATE block (64 
 constexpr int NLIT = 286;            // literal/length symbols in use
 constexpr int DOFF = 288;            // distance codes live at [DOFF, DOFF+32) in the shared tables
 
+// Scratch of one Huffman construction.  The 286-symbol instance (3.4 KiB) is only live between the
+// histogram and the code lengths, so the fused kernel overlays it on the (not yet used) bit buffer.
+template <int CAP>
+struct BuildScratchT {
+    alignas(16) uint32_t lf[CAP];   // leaf weights, ascending
+    alignas(16) uint32_t nf[CAP];   // sort keys, then internal-node weights (creation order = ascending)
+    uint16_t npar[CAP];             // internal node -> parent
+    uint16_t rsym[CAP];             // rank -> symbol
+};
+typedef BuildScratchT<288> BuildScratch;
+
 struct DeflShared {
     alignas(16) uint32_t freq[320];   // histogram: [0,288) lit/len, [288,320) dist
     alignas(16) uint32_t clfreq[20];
     uint32_t code[320];      // bit-reversed code | nbits << 16
-    uint32_t lf[288];        // leaf frequencies, ascending
-    alignas(16) uint32_t nf[288];   // internal-node frequencies (creation order = ascending); sort keys before the merge
-    uint16_t npar[288];      // internal node -> parent
-    uint16_t rsym[288];      // rank -> symbol
     uint16_t clseq[320];     // code-length sequence: sym | extra_value << 5
     uint8_t lens[320];       // code lengths, same indexing as freq
     uint32_t clcode[20];
@@ -61,6 +68,7 @@ struct DeflShared {
     uint32_t ws[16];         // cross-wave scan scratch
     uint32_t red[8];         // 0 matches, 1 extra bits, 2 adler A part, 3 adler B part, 4 dyn bits, 5 fixed bits, 6 cl bits
     uint32_t ncl, hlit, hclen;
+    BuildScratchT<32> clb;   // scratch of the 19-symbol code-length code
 };
 
 struct ZOut {                // replicated uniformly in every lane's registers
@@ -76,7 +84,9 @@ __device__ __forceinline__ void put_bits(uint32_t *obuf, const ZOut &z, uint32_t
 
 // ---- length-limited Huffman code lengths for freq[0..n4), n <= 2*NT ----
 // freq must be 16-B aligned, readable (and zero) up to the next multiple of 4 entries.
-__device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *freq, int n, int maxbits, uint8_t *lens) {
+template <int CAP>
+__device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> &B, const uint32_t *freq, int n, int maxbits,
+                                              uint8_t *lens) {
     const int tid = threadIdx.x;
     PROF_DECL
     for (int s = tid; s < n; s += NT) lens[s] = 0;
@@ -89,12 +99,12 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *fre
     const uint32_t key0 = f0 ? (f0 << 9) | (uint32_t)tid : 0xFFFFFFFFu;
     const uint32_t key1 = f1 ? (f1 << 9) | (uint32_t)(tid + NT) : 0xFFFFFFFFu;
     const int n4 = (n + 3) >> 2;
-    S.nf[tid] = key0;
-    if (tid + NT < 4 * n4) S.nf[tid + NT] = key1;
+    if (tid < 4 * n4) B.nf[tid] = key0;
+    if (tid + NT < 4 * n4) B.nf[tid + NT] = key1;
     __syncthreads();
     int r0 = 0, r1 = 0, m = 0;
     {
-        const uint4 *k4 = reinterpret_cast<const uint4 *>(S.nf);
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(B.nf);
 #pragma unroll 8
         for (int q = 0; q < n4; q++) {
             const uint4 v = k4[q];
@@ -108,16 +118,16 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *fre
             }
         }
         for (int b = 0; b < 4 * n4; b += 64)
-            m += __popcll(__ballot(b + lane_id() < 4 * n4 && S.nf[b + lane_id()] != 0xFFFFFFFFu));
+            m += __popcll(__ballot(b + lane_id() < 4 * n4 && B.nf[b + lane_id()] != 0xFFFFFFFFu));
     }
     __syncthreads();
-    if (f0) { S.lf[r0] = f0; S.rsym[r0] = (uint16_t)tid; }
-    if (f1) { S.lf[r1] = f1; S.rsym[r1] = (uint16_t)(tid + NT); }
+    if (f0) { B.lf[r0] = f0; B.rsym[r0] = (uint16_t)tid; }
+    if (f1) { B.lf[r1] = f1; B.rsym[r1] = (uint16_t)(tid + NT); }
     __syncthreads();
     PROF_MARK(n > 19 ? 3 : 8);
     if (m <= 1) {   // degenerate: keep the code complete with two 1-bit codes
         if (tid == 0) {
-            int sym = m ? S.rsym[0] : 0;
+            int sym = m ? B.rsym[0] : 0;
             lens[sym] = 1;
             lens[sym == 0 ? 1 : 0] = 1;
             S.blcount[1] = 2;
@@ -138,9 +148,9 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *fre
         int i = 0, j = 0, k = 0;
         while (k < m - 1) {
             // key = weight << 8 | is_node << 6 | window index; weights < 2^24
-            const uint32_t lv = i + lane < m ? S.lf[i + lane] : INF;
+            const uint32_t lv = i + lane < m ? B.lf[i + lane] : INF;
             const int qn = 63 - lane;   // node window is loaded descending: [leaves asc | nodes desc] is bitonic
-            const uint32_t nv = j + qn < k ? S.nf[j + qn] : INF;
+            const uint32_t nv = j + qn < k ? B.nf[j + qn] : INF;
             uint32_t a = lv == INF ? INF : (lv << 8) | (uint32_t)lane;
             uint32_t b = nv == INF ? INF : (nv << 8) | 64u | (uint32_t)qn;
             {   // bitonic merge of 128 keys: stride 64 across the two registers, then 32..1 inside each
@@ -166,11 +176,11 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *fre
             c = min(c, 2 * (m - 1 - k));
             // pairs (X[2p], X[2p+1]) -> node k + p
             const uint32_t sa = va + __shfl_xor(va, 1), sb = vb + __shfl_xor(vb, 1);
-            if (!(lane & 1) && lane < c) S.nf[k + (lane >> 1)] = sa;
-            if (!(lane & 1) && 64 + lane < c) S.nf[k + 32 + (lane >> 1)] = sb;
+            if (!(lane & 1) && lane < c) B.nf[k + (lane >> 1)] = sa;
+            if (!(lane & 1) && 64 + lane < c) B.nf[k + 32 + (lane >> 1)] = sb;
             const bool ina = lane < c, inb = 64 + lane < c;
-            if (ina && (a & 64u)) S.npar[j + (a & 63u)] = (uint16_t)(k + (lane >> 1));
-            if (inb && (b & 64u)) S.npar[j + (b & 63u)] = (uint16_t)(k + 32 + (lane >> 1));
+            if (ina && (a & 64u)) B.npar[j + (a & 63u)] = (uint16_t)(k + (lane >> 1));
+            if (inb && (b & 64u)) B.npar[j + (b & 63u)] = (uint16_t)(k + 32 + (lane >> 1));
             const int nn = __popcll(__ballot(ina && (a & 64u))) + __popcll(__ballot(inb && (b & 64u)));
             i += c - nn;
             j += nn;
@@ -183,7 +193,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *fre
     // depth L = 2 * I[L-1] - I[L]; sorted order makes depth monotone in rank, so counts are enough.
     for (int q = tid; q < m - 1; q += NT) {
         int d = 0, p = q;
-        while (p != m - 2) { p = S.npar[p]; d++; }
+        while (p != m - 2) { p = B.npar[p]; d++; }
         atomicAdd(&S.icount[min(d, maxbits)], 1u);
     }
     __syncthreads();
@@ -211,7 +221,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, const uint32_t *fre
         uint32_t cum = 0;
         int L = maxbits;
         for (; L > 1; L--) { cum += S.blcount[L]; if ((uint32_t)r < cum) break; }
-        lens[S.rsym[r]] = (uint8_t)L;
+        lens[B.rsym[r]] = (uint8_t)L;
     }
     __syncthreads();
     PROF_MARK(n > 19 ? 5 : 8);
@@ -305,10 +315,19 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
 
 // Encode one DEFLATE block of `len` bytes at LDS `buf` into the LDS bit buffer `obuf`.
 // All NT lanes call with uniform arguments.  adA/adB: running Adler-32 halves (uniform).
-__device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, const uint8_t *buf, int len, bool final,
-                                           ZOut &z, uint32_t &adA, uint32_t &adB) {
+// FUSED: single-block stream whose build scratch B overlays obuf; obuf is zeroed and the zlib header
+// written here once B is dead (caller passes z.bitpos = 80, z.flushed = 0, obuf_words = size to zero).
+template <bool FUSED>
+__device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words,
+                                              const uint8_t *buf, int len, bool final, ZOut &z, uint32_t &adA,
+                                              uint32_t &adB) {
     const int tid = threadIdx.x;
-    if (len == 0) {   // empty stream: fixed block holding only end-of-block
+    if (len == 0) {
+        if (FUSED) {
+            for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
+            __syncthreads();
+            if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);
+        }   // empty stream: fixed block holding only end-of-block
         if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 10);
         z.bitpos += 10;
         __syncthreads();
@@ -366,8 +385,13 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
     PROF_MARK(2);
 
     // ---- B: codes ----
-    build_lengths(S, S.freq, NLIT, 15, S.lens);
+    build_lengths(S, B, S.freq, NLIT, 15, S.lens);
     PROF_RESET
+    if (FUSED) {   // B is dead from here on: its storage becomes the bit buffer
+        for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
+        __syncthreads();
+        if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);   // CMF/FLG 78 9c (deflate, 32K window, default level)
+    }
     assign_codes(S, S.lens, NLIT, S.code);
     PROF_MARK(6);
     // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
@@ -432,7 +456,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
     }
     __syncthreads();
     PROF_MARK(7);
-    build_lengths(S, S.clfreq, 19, 7, S.cllens);
+    build_lengths(S, S.clb, S.clfreq, 19, 7, S.cllens);
     assign_codes(S, S.cllens, 19, S.clcode);
     PROF_RESET
 
@@ -576,34 +600,22 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, uint32_t *obuf, con
     PROF_MARK(12);
 }
 
-// zlib-frame a payload that sits in LDS (`pay`, `plen` bytes) into HBM slot `out` (16-B aligned).
-// Slot layout: [u64 size][78 9c][deflate blocks][adler32 BE]; returns total bytes incl. the prefix.
-// obuf: LDS, >= min(plen, DEFL_BLK)/4 + 16 words, zeroed on entry by this function.
-__device__ __forceinline__ uint32_t zlib_compress_lds(DeflShared &S, uint32_t *obuf, uint32_t obuf_words,
-                                                      const uint8_t *pay, uint32_t plen, uint8_t *out) {
+// Fused path: zlib-frame a payload of at most DEFL_BLK bytes that sits in LDS (`pay`) as ONE DEFLATE
+// block into HBM slot `out` (16-B aligned).  Slot layout: [u64 size][78 9c][block][adler32 BE].
+// obuf: LDS, obuf_words >= max(plen + 64, sizeof(BuildScratch)) / 4; returns total bytes incl. the prefix.
+__device__ __forceinline__ uint32_t zlib_compress_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words,
+                                                        const uint8_t *pay, uint32_t plen, uint8_t *out) {
     const int tid = threadIdx.x;
-    for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
-    __syncthreads();
     ZOut z;
-    z.bitpos = 64;
+    z.bitpos = 80;   // 64 bits of size prefix + 16 bits of zlib header, both written later
     z.flushed = 0;
-    if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);   // CMF/FLG 78 9c (deflate, 32K window, default level)
-    z.bitpos = 80;
     uint32_t adA = 1, adB = 0;
-    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
-    uint32_t done = 0;
-    do {
-        const uint32_t blen = min(plen - done, (uint32_t)DEFL_BLK);
-        const bool final = done + blen == plen;
-        deflate_block(S, obuf, pay + done, (int)blen, final, z, adA, adB);
-        done += blen;
-        if (!final) flush_words(obuf, out32, z, false);
-    } while (done < plen);
+    deflate_block<true>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB);
     z.bitpos = (z.bitpos + 7) & ~7u;
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
     z.bitpos += 32;
     __syncthreads();
-    flush_words(obuf, out32, z, true);
+    flush_words(obuf, reinterpret_cast<uint32_t *>(out), z, true);
     const uint32_t total = z.bitpos >> 3;
     if (tid == 0) *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
     return total;

@@ -81,7 +81,7 @@ struct Buf {
     void release() { if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
 };
 struct Ctx {
-    Buf d_sig, d_hdr, d_aux, d_desc, d_slots, d_len, d_scratch, d_in, d_pay, d_fields;
+    Buf d_sig, d_hdr, d_aux, d_desc, d_slots, d_len, d_ovf, d_in, d_pay, d_fields;
     Buf h_in, h_out;   // pinned staging
     hipStream_t st = nullptr;
     Ctx() { h_in.pinned = true; h_out.pinned = true; }
@@ -110,7 +110,7 @@ extern "C" void s5gpu_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_ctx) {
         Buf *bs[] = {&g_ctx->d_sig, &g_ctx->d_hdr, &g_ctx->d_aux, &g_ctx->d_desc, &g_ctx->d_slots, &g_ctx->d_len,
-                     &g_ctx->d_scratch, &g_ctx->d_in, &g_ctx->d_pay, &g_ctx->d_fields, &g_ctx->h_in, &g_ctx->h_out};
+                     &g_ctx->d_ovf, &g_ctx->d_in, &g_ctx->d_pay, &g_ctx->d_fields, &g_ctx->h_in, &g_ctx->h_out};
         for (Buf *b : bs) b->release();
         if (g_ctx->st) (void)hipStreamDestroy(g_ctx->st);
         delete g_ctx;
@@ -178,8 +178,7 @@ extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const u
         (rc = c->d_aux.reserve(ao + 64)) || (rc = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * n)) ||
         (rc = c->d_slots.reserve(oo + 64)) || (rc = c->d_len.reserve(4ull * n)) || (rc = c->h_out.reserve(oo + 64 + 4ull * n)))
         return rc;
-    const bool staged = rec_method == S5GPU_REC_ZLIB && max_payload > 48u * 1024u;
-    if (staged && (rc = c->d_scratch.reserve(oo + 64))) return rc;
+    if ((rc = c->d_ovf.reserve(4ull * n + 64))) return rc;
     // pack into pinned staging
     uint8_t *hs = (uint8_t *)c->h_in.p;
     uint8_t *hh = hs + up(sig_bytes, 64), *ha = hh + up(ho + 64, 64), *hd = ha + up(ao + 64, 64);
@@ -201,8 +200,8 @@ extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const u
     a.sig = (const int16_t *)c->d_sig.p; a.hdr = (const uint8_t *)c->d_hdr.p; a.aux = (const uint8_t *)c->d_aux.p;
     a.slots = (uint8_t *)c->d_slots.p; a.out_len = (uint32_t *)c->d_len.p;
     a.max_payload = max_payload;
-    a.scratch = staged ? (uint8_t *)c->d_scratch.p : nullptr;
-    a.scratch_bytes = staged ? c->d_scratch.cap : 0;
+    a.lds_payload_cap = 0;
+    a.ovf = (uint32_t *)c->d_ovf.p;
     if ((rc = s5gpu_encode_dev(&a, c->st))) return rc;
     uint8_t *ho_len = (uint8_t *)c->h_out.p;
     uint8_t *ho_slots = ho_len + up(4ull * n, 64);

@@ -27,8 +27,8 @@ extern "C" void s5gpu_set_error(const char *fmt, ...);
 extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
 constexpr uint32_t S_BYTES = (sizeof(DeflShared) + 15u) & ~15u;
-// Largest payload the LDS-resident (fused) kernel takes; longer reads go through the HBM-staged path.
-constexpr uint32_t FUSED_MAX_PAYLOAD = 48u * 1024u;
+constexpr uint32_t B_BYTES = (sizeof(BuildScratch) + 15u) & ~15u;
+constexpr uint32_t OVF = 0xFFFFFFFFu;
 
 struct EncParams {
     s5gpu_encode_args_t a;
@@ -36,27 +36,41 @@ struct EncParams {
     uint32_t pay_cap;      // LDS bytes of the payload buffer (fused) / staging buffer (staged)
 };
 
+__device__ __forceinline__ uint32_t payload_bound_dev(const s5gpu_read_desc_t &d, int sig_method) {
+    const uint32_t n = d.n_samples;
+    return d.hdr_len + 8 + (sig_method == S5GPU_SIG_SVB_ZD ? 4 + ((n + 3) >> 2) + 3 * n : 2 * n) + d.aux_len;
+}
+
 // ------------------------------------------------------------------------------------------------
 // payload = hdr | u64 L | signal bytes | aux   (slow5_rec_to_mem's uncompressed record, a4 in SURVEY §8)
-// dst may be LDS (fused kernel) or HBM (staged path / no record compression)
+// dst may be LDS (fused kernel) or HBM (staged path / no record compression).  cap = bytes dst can
+// take; returns OVF (uniform, nothing useful written) if the payload would not fit.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, const s5gpu_read_desc_t &d,
-                                                  uint8_t *pay, uint32_t *ws) {
+                                                  uint8_t *pay, uint32_t cap, uint32_t *ws) {
     const int tid = threadIdx.x;
+    const uint32_t n = d.n_samples;
+    const bool svb = a.sig_method == S5GPU_SIG_SVB_ZD;
+    const uint32_t nk = (n + 3) >> 2;
+    const uint32_t fixed = d.hdr_len + 8 + (svb ? 4 + nk : 0) + d.aux_len;   // everything but the data bytes
+    if (fixed > cap || (svb ? n : 2 * n) > cap - fixed) return OVF;             // cannot fit even at 1 byte/sample
     const uint8_t *hdr = a.hdr + d.hdr_off;
     for (uint32_t i = tid; i < d.hdr_len; i += NT) pay[i] = hdr[i];
     uint8_t *lenp = pay + d.hdr_len;
     uint8_t *sigp = lenp + 8;
     const int16_t *sig = a.sig + d.sig_off;
-    const uint32_t n = d.n_samples;
     uint64_t L;
     uint32_t sig_bytes;
-    if (a.sig_method == S5GPU_SIG_SVB_ZD) {
-        const uint32_t nk = (n + 3) >> 2;
+    if (svb) {
         uint8_t *keys = sigp + 4;
         uint8_t *data = keys + nk;
         uint32_t total = 0;
-        for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) total += svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws);
+        const uint32_t room = cap - fixed;
+        for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) {
+            const uint32_t t = svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws, room - total);
+            if (t > room - total) return OVF;
+            total += t;
+        }
         L = 4ull + nk + total;
         sig_bytes = (uint32_t)L;
         if (tid < 4) sigp[tid] = (uint8_t)(n >> (8 * tid));
@@ -75,7 +89,9 @@ __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, 
     return d.hdr_len + 8 + sig_bytes + d.aux_len;
 }
 
-// K1+K5+K3+K6 fused: svb-zd -> pack -> DEFLATE -> zlib frame, one read per workgroup, payload in LDS.
+// K1+K5+K3+K6 fused: svb-zd -> pack -> one DEFLATE block -> zlib frame.  One read per workgroup, every
+// intermediate in LDS.  A read whose payload does not fit the LDS budget (p.pay_cap: long read, or an
+// unusually incompressible signal) is appended to the overflow list and redone by the staged kernels.
 __global__ __launch_bounds__(NT) void k_encode_fused(EncParams p) {
     const uint32_t r = blockIdx.x;
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
@@ -83,11 +99,18 @@ __global__ __launch_bounds__(NT) void k_encode_fused(EncParams p) {
     uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
     const s5gpu_read_desc_t d = p.a.desc[r];
     PROF_DECL
-    const uint32_t plen = build_payload(p.a, d, pay, S.ws);
+    const uint32_t plen = build_payload(p.a, d, pay, p.pay_cap, S.ws);
+    if (plen == OVF) {
+        if (threadIdx.x == 0) {
+            const uint32_t at = atomicAdd(&p.a.ovf[0], 1u);
+            p.a.ovf[1 + at] = r;
+        }
+        return;
+    }
     __syncthreads();
     PROF_MARK(0);
     uint8_t *out = p.a.slots + d.out_off;
-    const uint32_t total = zlib_compress_lds(S, obuf, p.obuf_words, pay, plen, out);
+    const uint32_t total = zlib_compress_fused(S, obuf, p.obuf_words, pay, plen, out);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
     PROF_MARK(13);
 #ifdef S5_PROFILE
@@ -95,67 +118,85 @@ __global__ __launch_bounds__(NT) void k_encode_fused(EncParams p) {
 #endif
 }
 
-// Staged path, step 1: payload straight to HBM.  with_prefix: record compression "none" — the
-// payload IS the record, write [u64 size][payload] into the slot.
-__global__ __launch_bounds__(NT) void k_pack(EncParams p, int with_prefix) {
+// Staged path works IN PLACE in the read's slot: the payload is parked at the slot's tail
+// (offset slot_cap - payload_bound, 16-B aligned) and the zlib stream grows from the slot's head.  The
+// slot bound leaves more room than the worst-case (all-stored) framing overhead, and each 16 KiB block
+// is in LDS before its output is written, so the writer never catches the reader.
+__device__ __forceinline__ uint32_t park_offset(const s5gpu_read_desc_t &d, int sig_method) {
+    return (d.slot_cap - payload_bound_dev(d, sig_method)) & ~15u;
+}
+
+// Staged path, step 1: payload straight to HBM.  mode 0: all reads, parked for k_deflate_staged;
+// mode 1: record compression "none" — the payload IS the record: [u64 size][payload] at the slot head;
+// mode 2: like 0 but only the reads on the overflow list.
+__global__ __launch_bounds__(NT) void k_pack(EncParams p, int mode) {
     __shared__ uint32_t ws[16];
-    const uint32_t r = blockIdx.x;
-    const s5gpu_read_desc_t d = p.a.desc[r];
-    uint8_t *dst = with_prefix ? p.a.slots + d.out_off + 8 : p.a.scratch + d.out_off;
-    const uint32_t plen = build_payload(p.a, d, dst, ws);
-    if (threadIdx.x == 0) {
-        if (with_prefix) {
-            *reinterpret_cast<uint64_t *>(p.a.slots + d.out_off) = plen;
-            p.a.out_len[r] = plen + 8;
-        } else {
-            p.a.out_len[r] = plen;   // payload length, consumed by k_deflate_staged
+    const uint32_t count = mode == 2 ? p.a.ovf[0] : p.a.n_reads;
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const uint32_t r = mode == 2 ? p.a.ovf[1 + it] : it;
+        const s5gpu_read_desc_t d = p.a.desc[r];
+        uint8_t *dst = p.a.slots + d.out_off + (mode == 1 ? 8u : park_offset(d, p.a.sig_method));
+        const uint32_t plen = build_payload(p.a, d, dst, OVF - 1, ws);
+        if (threadIdx.x == 0) {
+            if (mode == 1) {
+                *reinterpret_cast<uint64_t *>(p.a.slots + d.out_off) = plen;
+                p.a.out_len[r] = plen + 8;
+            } else {
+                p.a.out_len[r] = plen;   // payload length, consumed by k_deflate_staged
+            }
         }
+        __syncthreads();
     }
 }
 
-// Staged path, step 2: DEFLATE a payload that sits in HBM, 16 KiB block at a time through LDS.
-__global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p) {
-    const uint32_t r = blockIdx.x;
+// Staged path, step 2: DEFLATE a parked payload, 16 KiB block at a time through LDS.
+__global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list) {
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
-    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
-    uint8_t *stage = smem + S_BYTES + 4u * p.obuf_words;
-    const s5gpu_read_desc_t d = p.a.desc[r];
-    const uint8_t *src = p.a.scratch + d.out_off;
-    const uint32_t plen = p.a.out_len[r];
-    uint8_t *out = p.a.slots + d.out_off;
+    BuildScratch &B = *reinterpret_cast<BuildScratch *>(smem + S_BYTES);
+    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES + B_BYTES);
+    uint8_t *stage = smem + S_BYTES + B_BYTES + 4u * p.obuf_words;
     const int tid = threadIdx.x;
-    for (uint32_t i = tid; i < p.obuf_words; i += NT) obuf[i] = 0;
-    __syncthreads();
-    ZOut z;
-    z.bitpos = 64;
-    z.flushed = 0;
-    if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);
-    z.bitpos = 80;
-    uint32_t adA = 1, adB = 0, done = 0;
-    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
-    do {
-        const uint32_t blen = min(plen - done, (uint32_t)DEFL_BLK);
-        const bool final = done + blen == plen;
-        {   // HBM -> LDS, 16 B per lane (scratch slot and block offsets are 16-B aligned)
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
-            uint4 *d4 = reinterpret_cast<uint4 *>(stage);
-            for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
-        }
+    const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const uint32_t r = use_list ? p.a.ovf[1 + it] : it;
+        const s5gpu_read_desc_t d = p.a.desc[r];
+        uint8_t *out = p.a.slots + d.out_off;
+        const uint8_t *src = out + park_offset(d, p.a.sig_method);
+        const uint32_t plen = p.a.out_len[r];
         __syncthreads();
-        deflate_block(S, obuf, stage, (int)blen, final, z, adA, adB);
-        done += blen;
-        if (!final) flush_words(obuf, out32, z, false);
-    } while (done < plen);
-    z.bitpos = (z.bitpos + 7) & ~7u;
-    if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
-    z.bitpos += 32;
-    __syncthreads();
-    flush_words(obuf, out32, z, true);
-    const uint32_t total = z.bitpos >> 3;
-    __syncthreads();
-    if (tid == 0) {
-        *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
-        p.a.out_len[r] = total;
+        for (uint32_t i = tid; i < p.obuf_words; i += NT) obuf[i] = 0;
+        __syncthreads();
+        ZOut z;
+        z.bitpos = 64;
+        z.flushed = 0;
+        if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);
+        z.bitpos = 80;
+        uint32_t adA = 1, adB = 0, done = 0;
+        uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+        do {
+            const uint32_t blen = min(plen - done, (uint32_t)DEFL_BLK);
+            const bool final = done + blen == plen;
+            {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
+                uint4 *d4 = reinterpret_cast<uint4 *>(stage);
+                for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
+            }
+            __syncthreads();
+            deflate_block<false>(S, B, obuf, 0, stage, (int)blen, final, z, adA, adB);
+            done += blen;
+            if (!final) flush_words(obuf, out32, z, false);
+        } while (done < plen);
+        z.bitpos = (z.bitpos + 7) & ~7u;
+        if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
+        z.bitpos += 32;
+        __syncthreads();
+        flush_words(obuf, out32, z, true);
+        const uint32_t total = z.bitpos >> 3;
+        __syncthreads();
+        if (tid == 0) {
+            *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
+            p.a.out_len[r] = total;
+        }
     }
 }
 
@@ -169,7 +210,7 @@ __global__ __launch_bounds__(NT) void k_svbzd_encode(EncParams p) {
     const uint32_t n = d.n_samples, nk = (n + 3) >> 2;
     uint8_t *keys = blob + 4, *data = keys + nk;
     uint32_t total = 0;
-    for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) total += svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws);
+    for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) total += svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws, OVF);
     if (threadIdx.x == 0) {
         *reinterpret_cast<uint32_t *>(blob) = n;
         p.a.out_len[r] = 4 + nk + total;
@@ -469,19 +510,42 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     if (a->rec_method == S5GPU_REC_NONE) {
         p.obuf_words = 0; p.pay_cap = 0;
         hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 1);
-    } else if (a->max_payload <= FUSED_MAX_PAYLOAD) {
-        const uint32_t blk = a->max_payload < (uint32_t)DEFL_BLK ? a->max_payload : (uint32_t)DEFL_BLK;
-        p.obuf_words = (blk + 64) / 4;
-        p.pay_cap = (a->max_payload + 15u) & ~15u;
+        HIP_TRY(hipGetLastError());
+        return S5GPU_OK;
+    }
+    if (!a->ovf) { s5gpu_set_error("s5gpu_encode_dev: args.ovf (n_reads + 1 words of device scratch) is required"); return S5GPU_ERR_ARG; }
+    // LDS budget of the fused kernel.  The payload bound assumes 3 bytes per sample; real signals take
+    // ~1.27 (P(2-byte code) ~1.5 %), so by default keep room for 1.55 bytes per sample: with
+    // ~4 KiB of tables that is ~17 KiB per 4000-sample read -> 8 workgroups per CU.  Anything that does
+    // not fit is redone by the staged kernels (correct for any input, slower).
+    uint32_t cap = a->lds_payload_cap;
+    if (cap == 0) {
+        const bool svb = a->sig_method == S5GPU_SIG_SVB_ZD;
+        cap = svb ? (uint32_t)((uint64_t)a->max_payload * 155 / 325) + 128 : a->max_payload;
+    }
+    if (cap > a->max_payload) cap = a->max_payload;
+    if (cap > (uint32_t)DEFL_BLK) cap = DEFL_BLK;
+    cap = (cap + 15u) & ~15u;
+    // every read certainly longer than the fused budget?  (min payload ~ 1.25 B/sample of a 3.25 B/sample bound)
+    const bool all_staged = a->sig_method == S5GPU_SIG_SVB_ZD ? (uint64_t)a->max_payload * 100 / 325 > 4ull * DEFL_BLK
+                                                              : a->max_payload > 4u * DEFL_BLK;
+    const uint32_t st_obuf = (DEFL_BLK + 64) / 4;
+    const size_t st_lds = S_BYTES + B_BYTES + 4ull * st_obuf + DEFL_BLK;
+    if (!all_staged) {
+        HIP_TRY(hipMemsetAsync(a->ovf, 0, 4, st));
+        p.pay_cap = cap;
+        p.obuf_words = (cap + 64 > B_BYTES ? cap + 64 : B_BYTES) / 4;
         const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
         hipLaunchKernelGGL(k_encode_fused, dim3(a->n_reads), dim3(NT), lds, st, p);
+        // overflow reads (usually none: the two launches below then exit at once)
+        p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
+        const uint32_t g = a->n_reads < 1024 ? a->n_reads : 1024;
+        hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2);
+        hipLaunchKernelGGL(k_deflate_staged, dim3(g), dim3(NT), st_lds, st, p, 1);
     } else {
-        if (!a->scratch) { s5gpu_set_error("s5gpu_encode_dev: reads longer than the LDS path need args.scratch"); return S5GPU_ERR_ARG; }
-        p.obuf_words = (DEFL_BLK + 64) / 4;
-        p.pay_cap = DEFL_BLK;
+        p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
         hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
-        const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
-        hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, st, p);
+        hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0);
     }
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;

@@ -17,8 +17,10 @@ constexpr int SVB_TILE = NT * 16;   // samples per tile
 // Encode samples [t0, min(t0+SVB_TILE, n)) of one read.  sig: read base (16-B aligned).
 // keys: destination of this tile's key bytes (= key area + t0/4); data: destination of this tile's
 // first data byte.  Destinations may be LDS or HBM.  Returns the tile's data byte count (uniform).
+// room: data bytes the destination can still take; if the tile needs more, nothing is written and the
+// (uniform) return value exceeds room — the caller routes the read to the HBM-staged path.
 __device__ __forceinline__ uint32_t svb_encode_tile(const int16_t *__restrict__ sig, uint32_t n, uint32_t t0,
-                                                    uint8_t *keys, uint8_t *data, uint32_t *ws) {
+                                                    uint8_t *keys, uint8_t *data, uint32_t *ws, uint32_t room) {
     const int tid = threadIdx.x;
     const uint32_t i0 = t0 + 16u * tid;
     const int valid = i0 >= n ? 0 : (int)min(16u, n - i0);
@@ -53,6 +55,7 @@ __device__ __forceinline__ uint32_t svb_encode_tile(const int16_t *__restrict__ 
     }
     uint32_t total;
     uint32_t off = block_excl_add(nbytes, ws, total);
+    if (total > room) return total;
     uint8_t *dp = data + off;
 #pragma unroll
     for (int q = 0; q < 16; q++) {

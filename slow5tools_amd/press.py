@@ -149,7 +149,7 @@ class DeviceBatch:
     """Device-resident encode batch.  torch is plumbing only: HBM allocations and the stream handle."""
 
     def __init__(self, n_samples, hdr_len=74, aux_len=0, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD, device="cuda:0",
-                 with_stream_out=True):
+                 with_stream_out=True, lds_payload_cap=0):
         import torch
 
         self.torch = torch
@@ -164,9 +164,7 @@ class DeviceBatch:
         self.aux = torch.zeros(self.tot["aux"] + 64, dtype=u8, device=self.dev)
         self.slots = torch.empty(self.tot["slots"] + 64, dtype=u8, device=self.dev)
         self.out_len = torch.zeros(self.n + 1, dtype=torch.int32, device=self.dev)
-        self.scratch = None
-        if rec_method == REC_ZLIB and self.tot["max_payload"] > 48 * 1024:
-            self.scratch = torch.empty(self.tot["slots"] + 64, dtype=u8, device=self.dev)
+        self.ovf = torch.zeros(self.n + 4, dtype=torch.int32, device=self.dev)
         self.rec_off = torch.zeros(self.n + 1, dtype=torch.int64, device=self.dev)
         self.tmp = torch.zeros(self.n // 1024 + 8, dtype=torch.int64, device=self.dev)
         self.stream_out = torch.empty(self.tot["slots"] + 64, dtype=u8, device=self.dev) if with_stream_out else None
@@ -175,8 +173,8 @@ class DeviceBatch:
         a.desc, a.sig, a.hdr, a.aux = self.desc.data_ptr(), self.sig.data_ptr(), self.hdr.data_ptr(), self.aux.data_ptr()
         a.slots, a.out_len = self.slots.data_ptr(), self.out_len.data_ptr()
         a.max_payload = self.tot["max_payload"]
-        a.scratch = self.scratch.data_ptr() if self.scratch is not None else None
-        a.scratch_bytes = self.scratch.numel() if self.scratch is not None else 0
+        a.lds_payload_cap = lds_payload_cap
+        a.ovf = self.ovf.data_ptr()
         self.args = a
 
     def _stream(self):

@@ -70,5 +70,5 @@ def test_no_cpu_fallback_without_gpu(lib):
 def test_struct_layouts_match_header():
     from slow5tools_amd import _lib
 
-    assert C.sizeof(_lib.EncodeArgs) == 88
+    assert C.sizeof(_lib.EncodeArgs) == 80
     assert C.sizeof(_lib.DecodeArgs) == 56

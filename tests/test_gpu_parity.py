@@ -150,6 +150,32 @@ def test_encode_long_reads_staged_path(press):
     assert tg <= 1.02 * tr
 
 
+@pytest.mark.parametrize("cap", [0, 2048, 5000, 5400])
+def test_lds_overflow_reads_take_the_staged_path(press, cap):
+    """reads whose payload exceeds the fused kernel's LDS budget (incompressible signal, or a forced
+    small budget) are redone by the HBM-staged kernels: same bytes out of stock zlib either way"""
+    rng = np.random.default_rng(17)
+    n_reads, n = 96, 4000
+    sig = ob.synth_reads(0x5105, 400, n_reads, n)
+    sig[5] = rng.integers(-32768, 32768, n, dtype=np.int16)       # ~3 bytes/sample: never fits the default budget
+    sig[40] = rng.integers(-2000, 2000, n, dtype=np.int16)        # ~2 bytes/sample
+    sig[41][:] = 0
+    hdrs = [_hdr(press, 400 + i) for i in range(n_reads)]
+    b = press.DeviceBatch([n] * n_reads, lds_payload_cap=cap)
+    b.upload(list(sig), hdrs)
+    b.encode()
+    b.compact()
+    recs = b.records()
+    n_ovf = int(b.ovf[0].item())
+    if cap == 2048:
+        assert n_ovf == n_reads
+    elif cap == 0:
+        assert 2 <= n_ovf <= 4
+    _check_records(press, sig, hdrs, None, recs, press.REC_ZLIB, press.SIG_SVB_ZD)
+    stream, off = b.stream_bytes()
+    assert stream == b"".join(recs)
+
+
 @pytest.mark.parametrize("name", ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES + NONE_NONE_FIXTURES)
 def test_reencode_fixture_records(press, name):
     """decode with the oracle, re-encode on the GPU, inflate with stock zlib -> the fixture's payload"""
