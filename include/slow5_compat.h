@@ -1,0 +1,122 @@
+/*
+ * slow5_compat.h — the slice of slow5lib's C API that sits on the record press path, implemented
+ * on the MI355X kernels (libslow5gpu.so).  Same names, argument meaning, ownership and error
+ * behaviour as the calls slow5tools makes:
+ *
+ *   slow5_press_init / slow5_press_free      /root/reference/src/view.c:43,54  merge.c:52,67  get.c:54,61
+ *   slow5_rec_to_mem                         /root/reference/src/view.c:49     merge.c:62     get.c:59
+ *   slow5_rec_depress_parse                  /root/reference/src/view.c:38     merge.c:46     split.c:84
+ *   slow5_rec_free                           /root/reference/src/view.c:56
+ *   slow5_ptr_compress_solo / _depress_solo  (slow5lib public press API named by BASELINE north_star;
+ *                                             no call site inside slow5tools — SURVEY.md §8b last row)
+ * plus the batch hooks that replace work_db() (src/thread.c:114) for view / merge / get.
+ *
+ * slow5lib itself is an absent submodule of the reference (/root/reference/.gitmodules:1-3), so the
+ * struct layouts below follow the field uses visible at the call sites, not
+ * slow5lib's private headers.  Two deliberate differences, both outside the press path:
+ *   - aux fields travel as their already-serialised BLOW5 bytes (aux_blob / aux_len) instead of
+ *     slow5lib's khash map: the aux/header attribute API is out of scope;
+ *   - only the binary format (BLOW5) is handled; SLOW5 ASCII parsing/formatting is SURVEY §8(f) row 2.
+ * A maintainer integrating into the real slow5lib keeps slow5lib's structs and calls the s5gpu_*
+ * functions from slow5lib's own slow5_rec_to_mem / slow5_rec_depress_parse — see INTEGRATION.md.
+ */
+#ifndef SLOW5_COMPAT_H
+#define SLOW5_COMPAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* names from /root/reference/src/misc.c:253-263; values = on-disk codes */
+enum slow5_press_method {
+    SLOW5_COMPRESS_NONE = 0,
+    SLOW5_COMPRESS_ZLIB = 1,
+    SLOW5_COMPRESS_SVB_ZD = 2,
+    SLOW5_COMPRESS_ZSTD = 3,   /* not implemented: SURVEY §8(f) row 4 */
+    SLOW5_COMPRESS_EX_ZD = 4   /* not implemented: SURVEY §8(f) row 4 */
+};
+typedef struct {
+    enum slow5_press_method record_method;   /* core->press_method.record_method, src/demux.c:1072 */
+    enum slow5_press_method signal_method;
+} slow5_press_method_t;
+
+struct __slow5_press { enum slow5_press_method method; void *stream; };
+struct slow5_press {                          /* fields read at src/stats.c:114,128; src/cat.c:227-228 */
+    struct __slow5_press *record_press;
+    struct __slow5_press *signal_press;
+};
+typedef struct slow5_press slow5_press_t;
+
+enum slow5_fmt { SLOW5_FORMAT_UNKNOWN = 0, SLOW5_FORMAT_ASCII = 1, SLOW5_FORMAT_BINARY = 2 };
+
+struct slow5_aux_meta;                        /* opaque: only tested against NULL (src/merge.c:58-62) */
+
+struct slow5_rec {                            /* field uses: src/read_fast5.c:665-666,736-763,1136-1138; src/merge.c:51 */
+    uint16_t read_id_len;
+    char *read_id;
+    uint32_t read_group;
+    double digitisation;
+    double offset;
+    double range;
+    double sampling_rate;
+    uint64_t len_raw_signal;
+    int16_t *raw_signal;
+    uint8_t *aux_blob;                        /* serialised aux fields (see header comment) */
+    uint64_t aux_len;
+};
+typedef struct slow5_rec slow5_rec_t;
+
+struct slow5_file {                           /* fields read at src/stats.c:98-114, src/quickcheck.c:88-89 */
+    FILE *fp;
+    enum slow5_fmt format;
+    struct slow5_press *compress;
+    void *header;
+    void *index;
+    struct { const char *pathname; } meta;
+};
+typedef struct slow5_file slow5_file_t;
+
+extern __thread int slow5_errno;              /* thread-local like slow5lib's (workers run concurrently) */
+enum { SLOW5_ERR_OK = 0, SLOW5_ERR_ARG = -2, SLOW5_ERR_MEM = -10, SLOW5_ERR_PRESS = -13, SLOW5_ERR_RECPARSE = -15,
+       SLOW5_ERR_OTH = -20 };
+
+struct slow5_press *slow5_press_init(slow5_press_method_t method);
+void slow5_press_free(struct slow5_press *comp);
+
+/* one-shot (de)compression of a byte range; returns a malloc'd buffer, NULL on error */
+void *slow5_ptr_compress_solo(enum slow5_press_method method, const void *ptr, size_t count, size_t *n);
+void *slow5_ptr_depress_solo(enum slow5_press_method method, const void *ptr, size_t count, size_t *n);
+
+/* BLOW5: returns malloc'd [u64 size][press_record(payload)], *n = total length; NULL on error.
+ * aux_meta == NULL drops the aux fields (lossy, src/merge.c:58-62). */
+void *slow5_rec_to_mem(struct slow5_rec *read, struct slow5_aux_meta *aux_meta, enum slow5_fmt format,
+                       struct slow5_press *compress, size_t *n);
+/* *mem = record bytes without the size prefix (as slow5_get_next_mem returns them); may replace *mem with
+ * the uncompressed record; allocates *read if NULL.  0 on success. */
+int slow5_rec_depress_parse(char **mem, size_t *bytes, const char *read_id, struct slow5_rec **read,
+                            struct slow5_file *s5p);
+struct slow5_rec *slow5_rec_init(void);
+void slow5_rec_free(struct slow5_rec *read);
+
+/* ---- batch hooks: one call per db_t batch instead of work_db(core, db, callback) ----
+ * view / merge worker (src/view.c:35-57, src/merge.c:43-70): decode n input records, optionally rewrite
+ * read_group (merge), re-encode with `to`.  mem[i] are freed like the reference's worker does; out[i] are
+ * malloc'd buffers for the ordered fwrite loop (src/view.c:296-299). new_read_group may be NULL. */
+int slow5_gpu_recompress_batch(int64_t n, char **mem, size_t *bytes, slow5_press_method_t from,
+                               slow5_press_method_t to, const uint32_t *new_read_group, int drop_aux, void **out,
+                               size_t *out_len);
+/* get worker (src/get.c:37-66) after the pread: decode n records into slow5_rec_t's */
+int slow5_gpu_depress_parse_batch(int64_t n, char **mem, size_t *bytes, slow5_press_method_t from,
+                                  struct slow5_rec **reads);
+/* encode n in-memory reads (f2s-style producers, src/read_fast5.c:176-181) */
+int slow5_gpu_rec_to_mem_batch(int64_t n, struct slow5_rec **reads, int drop_aux, slow5_press_method_t to, void **out,
+                               size_t *out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

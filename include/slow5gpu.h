@@ -122,6 +122,15 @@ int s5gpu_encode_dev(const s5gpu_encode_args_t *args, void *hip_stream);
 int s5gpu_decode_dev(const s5gpu_decode_args_t *args, void *hip_stream);
 /* svb-zd only (BASELINE config 2): blob per read written at slots+out_off, out_len = blob bytes */
 int s5gpu_svbzd_encode_dev(const s5gpu_encode_args_t *args, void *hip_stream);
+/* single stages, for the solo press calls (slow5_ptr_compress_solo / slow5_ptr_depress_solo):
+ *  deflate_parked: zlib-compress byte ranges already parked in their slots — read i's bytes sit at
+ *    slots + out_off + ((slot_cap - s5gpu_payload_bound(desc i)) & ~15), out_len[i] = their length on entry
+ *    and the framed length on return; works in place (see DESIGN.md "staged path").
+ *  inflate: zlib streams -> payload slots, fields[i].status / payload_len (Adler-32 verified)
+ *  svbzd_decode: svb-zd blobs (desc.in_off/in_len) -> sig_out, fields[i].status / n_samples */
+int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *args, void *hip_stream);
+int s5gpu_inflate_dev(const s5gpu_decode_args_t *args, void *hip_stream);
+int s5gpu_svbzd_decode_dev(const s5gpu_decode_args_t *args, void *hip_stream);
 /* Gather the slots into one contiguous BLOW5 record stream (what the ordered fwrite loop emits):
  * rec_off[i] = byte offset of record i in `stream`, rec_off[n] = total bytes.  tmp: >= 8*(n/1024+2) bytes. */
 int s5gpu_compact_dev(uint32_t n_reads, const s5gpu_read_desc_t *desc, const uint8_t *slots, const uint32_t *out_len,
@@ -147,6 +156,12 @@ int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_
 /* Decode n records (bytes without the u64 prefix).  payload[i] and sig[i] receive malloc'd buffers. */
 int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int rec_method, int sig_method,
                        void **payload, int16_t **sig, s5gpu_rec_fields_t *fields);
+
+/* ---- one-stage host-buffer calls behind slow5_ptr_compress_solo / slow5_ptr_depress_solo ----
+ * stage: 0 zlib compress, 1 zlib inflate, 2 svb-zd encode (in = int16 samples, in_len in bytes),
+ * 3 svb-zd decode.  out[i] malloc'd, caller frees.  status[i] per record (0 ok), may be NULL. */
+int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t *in_len, void **out, size_t *out_len,
+                     int32_t *status);
 
 #ifdef __cplusplus
 }

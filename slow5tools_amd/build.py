@@ -11,7 +11,7 @@ LIB = os.path.join(HERE, "libslow5gpu.so")
 
 HIP_SOURCES = ["kernels.hip", "host_api.hip"]
 C_SOURCES = ["slow5_compat.c"]
-DEPS = ["dev_common.h", "deflate_dev.h", "inflate_dev.h", "svb_dev.h", "slow5_compat_internal.h",
+DEPS = ["dev_common.h", "deflate_dev.h", "inflate_dev.h", "svb_dev.h",
         os.path.join(ROOT, "include", "slow5gpu.h"), os.path.join(ROOT, "include", "slow5_compat.h")]
 
 

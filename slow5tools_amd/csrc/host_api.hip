@@ -306,3 +306,152 @@ extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size
     if (overall) s5gpu_set_error("s5gpu_decode_batch: at least one record is corrupt (see fields[i].status)");
     return overall;
 }
+
+// ---- single-stage host-buffer batches (slow5_ptr_compress_solo / slow5_ptr_depress_solo) ----
+extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t *in_len, void **out, size_t *out_len,
+                                int32_t *status) {
+    if (n == 0) return S5GPU_OK;
+    if (!in || !in_len || !out || !out_len || stage < 0 || stage > 3) { s5gpu_set_error("s5gpu_solo_batch: bad argument"); return S5GPU_ERR_ARG; }
+    Ctx *c;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
+    for (uint32_t i = 0; i < n; i++)
+        if (in_len[i] > 0xFFFFFF00ull / 4) { s5gpu_set_error("item %u too large", i); return S5GPU_ERR_ARG; }
+    int overall = S5GPU_OK;
+    if (stage == 0 || stage == 2) {
+        // encode side: READ_DESC slots
+        std::vector<s5gpu_read_desc_t> desc(n);
+        std::vector<uint32_t> park(n, 0), lens(n);
+        uint64_t so = 0, oo = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            s5gpu_read_desc_t &d = desc[i];
+            memset(&d, 0, sizeof d);
+            d.out_off = oo;
+            if (stage == 0) {
+                const uint32_t len = (uint32_t)in_len[i];
+                d.hdr_len = (len > 8 ? len : 8) - 8;
+                d.slot_cap = (uint32_t)s5gpu_slot_bound(0, d.hdr_len, 0, S5GPU_REC_ZLIB, S5GPU_SIG_NONE);
+                park[i] = (d.slot_cap - (d.hdr_len + 8)) & ~15u;
+                lens[i] = len;
+            } else {
+                if (in_len[i] & 1) { s5gpu_set_error("svb-zd input %u is not a whole number of int16 samples", i); return S5GPU_ERR_ARG; }
+                d.n_samples = (uint32_t)(in_len[i] / 2);
+                d.sig_off = so;
+                so += up(d.n_samples, 8);
+                d.slot_cap = (uint32_t)up(4ull + (d.n_samples + 3ull) / 4 + 3ull * d.n_samples + 16, 16);
+            }
+            oo += d.slot_cap;
+        }
+        const size_t hin = up(stage == 0 ? oo : so * 2, 64) + 64 + sizeof(s5gpu_read_desc_t) * n + 4ull * n;
+        if ((rc = c->h_in.reserve(hin)) || (rc = c->d_slots.reserve(oo + 64)) || (rc = c->d_sig.reserve(so * 2 + 64)) ||
+            (rc = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * n)) || (rc = c->d_len.reserve(4ull * n)) ||
+            (rc = c->d_hdr.reserve(64)) || (rc = c->h_out.reserve(oo + 64 + 4ull * n)))
+            return rc;
+        uint8_t *h0 = (uint8_t *)c->h_in.p;
+        uint8_t *hd = h0 + up(stage == 0 ? oo : so * 2, 64) + 64, *hl = hd + sizeof(s5gpu_read_desc_t) * n;
+        for (uint32_t i = 0; i < n; i++) {
+            if (!in_len[i]) continue;
+            if (stage == 0) memcpy(h0 + desc[i].out_off + park[i], in[i], in_len[i]);
+            else memcpy(h0 + 2 * desc[i].sig_off, in[i], in_len[i]);
+        }
+        memcpy(hd, desc.data(), sizeof(s5gpu_read_desc_t) * n);
+        memcpy(hl, lens.data(), 4ull * n);
+        if (stage == 0) HIP_TRY(hipMemcpyAsync(c->d_slots.p, h0, oo, hipMemcpyHostToDevice, c->st));
+        else if (so) HIP_TRY(hipMemcpyAsync(c->d_sig.p, h0, so * 2, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_read_desc_t) * n, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->d_len.p, hl, 4ull * n, hipMemcpyHostToDevice, c->st));
+        s5gpu_encode_args_t a;
+        memset(&a, 0, sizeof a);
+        a.n_reads = n;
+        a.rec_method = stage == 0 ? S5GPU_REC_ZLIB : S5GPU_REC_NONE;
+        a.sig_method = stage == 0 ? S5GPU_SIG_NONE : S5GPU_SIG_SVB_ZD;
+        a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
+        a.sig = (const int16_t *)c->d_sig.p; a.hdr = (const uint8_t *)c->d_hdr.p;
+        a.slots = (uint8_t *)c->d_slots.p; a.out_len = (uint32_t *)c->d_len.p;
+        if ((rc = stage == 0 ? s5gpu_deflate_parked_dev(&a, c->st) : s5gpu_svbzd_encode_dev(&a, c->st))) return rc;
+        uint8_t *ho_len = (uint8_t *)c->h_out.p, *ho_slots = ho_len + up(4ull * n, 64);
+        if ((rc = c->h_out.reserve(up(4ull * n, 64) + oo + 64))) return rc;
+        ho_len = (uint8_t *)c->h_out.p; ho_slots = ho_len + up(4ull * n, 64);
+        HIP_TRY(hipMemcpyAsync(ho_len, c->d_len.p, 4ull * n, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipMemcpyAsync(ho_slots, c->d_slots.p, oo, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        const uint32_t *ol = (const uint32_t *)ho_len;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t skip = stage == 0 ? 8 : 0;   // the solo call returns the bare zlib stream, no u64 prefix
+            if (ol[i] < skip || ol[i] > desc[i].slot_cap) { s5gpu_set_error("item %u: impossible device length %u", i, ol[i]); return S5GPU_ERR_HIP; }
+            out_len[i] = ol[i] - skip;
+            out[i] = malloc(out_len[i] ? out_len[i] : 1);
+            if (!out[i]) return S5GPU_ERR_NOMEM;
+            memcpy(out[i], ho_slots + desc[i].out_off + skip, out_len[i]);
+        }
+        return S5GPU_OK;
+    }
+    // decode side: REC_DESC
+    std::vector<uint32_t> pcap(n), scap(n);
+    std::vector<uint8_t> done(n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        if (stage == 1) { pcap[i] = (uint32_t)(4 * in_len[i] + 4096); scap[i] = 0; }
+        else {
+            uint32_t ns = 0;
+            if (in_len[i] >= 4) memcpy(&ns, in[i], 4);
+            if ((uint64_t)ns > 4ull * in_len[i]) ns = 0;   // impossible count: let the kernel report it
+            scap[i] = ns; pcap[i] = 0;
+        }
+    }
+    for (int attempt = 0; attempt < 3; attempt++) {
+        std::vector<uint32_t> idx;
+        for (uint32_t i = 0; i < n; i++) if (!done[i]) idx.push_back(i);
+        if (idx.empty()) break;
+        const uint32_t m = (uint32_t)idx.size();
+        std::vector<s5gpu_rec_desc_t> desc(m);
+        uint64_t io = 0, po = 0, so = 0;
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t i = idx[k];
+            s5gpu_rec_desc_t &d = desc[k];
+            d.in_off = io; d.pay_off = po; d.sig_off = so;
+            d.in_len = (uint32_t)in_len[i]; d.pay_cap = pcap[i]; d.sig_cap = scap[i]; d.reserved = 0;
+            io += up(in_len[i] + 16, 16); po += up((uint64_t)pcap[i] + 16, 16); so += up((uint64_t)scap[i] + 8, 8);
+        }
+        const size_t hin = up(io + 64, 64) + sizeof(s5gpu_rec_desc_t) * m;
+        const size_t hout = up(po + 64, 64) + up(so * 2 + 64, 64) + sizeof(s5gpu_rec_fields_t) * m;
+        if ((rc = c->h_in.reserve(hin)) || (rc = c->d_in.reserve(io + 64)) || (rc = c->d_desc.reserve(sizeof(s5gpu_rec_desc_t) * m)) ||
+            (rc = c->d_pay.reserve(po + 64)) || (rc = c->d_sig.reserve(so * 2 + 64)) || (rc = c->d_fields.reserve(sizeof(s5gpu_rec_fields_t) * m)) ||
+            (rc = c->h_out.reserve(hout)))
+            return rc;
+        uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + up(io + 64, 64);
+        for (uint32_t k = 0; k < m; k++) if (in_len[idx[k]]) memcpy(hi + desc[k].in_off, in[idx[k]], in_len[idx[k]]);
+        memcpy(hd, desc.data(), sizeof(s5gpu_rec_desc_t) * m);
+        HIP_TRY(hipMemcpyAsync(c->d_in.p, hi, io, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_rec_desc_t) * m, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemsetAsync(c->d_fields.p, 0, sizeof(s5gpu_rec_fields_t) * m, c->st));
+        s5gpu_decode_args_t a;
+        memset(&a, 0, sizeof a);
+        a.n_recs = m; a.rec_method = S5GPU_REC_ZLIB; a.sig_method = S5GPU_SIG_SVB_ZD;
+        a.desc = (const s5gpu_rec_desc_t *)c->d_desc.p; a.in = (const uint8_t *)c->d_in.p;
+        a.payload = (uint8_t *)c->d_pay.p; a.sig_out = (int16_t *)c->d_sig.p; a.fields = (s5gpu_rec_fields_t *)c->d_fields.p;
+        if ((rc = stage == 1 ? s5gpu_inflate_dev(&a, c->st) : s5gpu_svbzd_decode_dev(&a, c->st))) return rc;
+        uint8_t *hp = (uint8_t *)c->h_out.p, *hsg = hp + up(po + 64, 64), *hf = hsg + up(so * 2 + 64, 64);
+        HIP_TRY(hipMemcpyAsync(hf, c->d_fields.p, sizeof(s5gpu_rec_fields_t) * m, hipMemcpyDeviceToHost, c->st));
+        if (stage == 1) HIP_TRY(hipMemcpyAsync(hp, c->d_pay.p, po, hipMemcpyDeviceToHost, c->st));
+        else HIP_TRY(hipMemcpyAsync(hsg, c->d_sig.p, so * 2, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        const s5gpu_rec_fields_t *ff = (const s5gpu_rec_fields_t *)hf;
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t i = idx[k];
+            const s5gpu_rec_fields_t &f = ff[k];
+            if (f.status == 5 && attempt < 2) { pcap[i] = f.payload_len; continue; }
+            if (f.status == 6 && attempt < 2) { scap[i] = f.n_samples; continue; }
+            done[i] = 1;
+            if (status) status[i] = f.status;
+            if (f.status != 0) { overall = S5GPU_ERR_DATA; continue; }
+            out_len[i] = stage == 1 ? f.payload_len : 2ull * f.n_samples;
+            out[i] = malloc(out_len[i] ? out_len[i] : 1);
+            if (!out[i]) return S5GPU_ERR_NOMEM;
+            memcpy(out[i], stage == 1 ? hp + desc[k].pay_off : hsg + 2 * desc[k].sig_off, out_len[i]);
+        }
+    }
+    if (overall) s5gpu_set_error("s5gpu_solo_batch: at least one input is corrupt (see status[i])");
+    return overall;
+}

@@ -332,6 +332,36 @@ __global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
     }
 }
 
+// K2 alone: svb-zd blob -> int16 (slow5_ptr_depress_solo(SVB_ZD)); in = blobs, fields.n_samples/status out
+__global__ __launch_bounds__(NT) void k_svbzd_decode(s5gpu_decode_args_t a) {
+    __shared__ uint32_t ws[16];
+    __shared__ int s_err;
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    s5gpu_rec_fields_t &f = a.fields[r];
+    const s5gpu_rec_desc_t d = a.desc[r];
+    const uint8_t *blob = a.in + d.in_off;
+    if (tid == 0) s_err = 0;
+    __syncthreads();
+    if (d.in_len < 4) { if (tid == 0) f.status = 7; return; }
+    const uint32_t n = (uint32_t)ld_le(blob, 4), nk = (n + 3) >> 2;
+    if ((uint64_t)4 + nk > d.in_len) { if (tid == 0) f.status = 7; return; }
+    if (n > d.sig_cap) { if (tid == 0) { f.status = 6; f.n_samples = n; } return; }
+    const uint8_t *keys = blob + 4, *data = keys + nk, *dend = blob + d.in_len;
+    int16_t *out = a.sig_out + d.sig_off;
+    uint32_t total = 0;
+    int carry = 0, err = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE)
+        total += svb_decode_tile(keys + (t0 >> 2), data + total, dend, n, t0, out, carry, err, ws);
+    if (err) s_err = 1;
+    __syncthreads();
+    if (tid == 0) {
+        f.status = (s_err || 4 + nk + total != d.in_len) ? 7 : 0;
+        f.n_samples = n;
+        f.payload_len = d.in_len;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // compaction: slots -> contiguous record stream (the ordered fwrite of src/view.c:296-299)
 // ------------------------------------------------------------------------------------------------
@@ -547,6 +577,40 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
         hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0);
     }
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
+extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stream_) {
+    int rc = enc_check(a);
+    if (rc) { s5gpu_set_error("s5gpu_deflate_parked_dev: bad arguments"); return rc; }
+    if (a->n_reads == 0) return S5GPU_OK;
+    if ((rc = set_lds_attrs())) return rc;
+    EncParams p;
+    p.a = *a;
+    p.obuf_words = (DEFL_BLK + 64) / 4;
+    p.pay_cap = DEFL_BLK;
+    const size_t lds = S_BYTES + B_BYTES + 4ull * p.obuf_words + DEFL_BLK;
+    hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
+static int dec_check(const s5gpu_decode_args_t *a, bool need_payload, bool need_sig) {
+    if (!a || (a->n_recs && (!a->desc || !a->in || !a->fields || (need_payload && !a->payload) || (need_sig && !a->sig_out)))) return S5GPU_ERR_ARG;
+    return S5GPU_OK;
+}
+extern "C" int s5gpu_inflate_dev(const s5gpu_decode_args_t *a, void *stream_) {
+    if (dec_check(a, true, false)) { s5gpu_set_error("s5gpu_inflate_dev: bad arguments"); return S5GPU_ERR_ARG; }
+    if (a->n_recs == 0) return S5GPU_OK;
+    hipLaunchKernelGGL(k_inflate, dim3(a->n_recs), dim3(64), 0, (hipStream_t)stream_, *a);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+extern "C" int s5gpu_svbzd_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
+    if (dec_check(a, false, true)) { s5gpu_set_error("s5gpu_svbzd_decode_dev: bad arguments"); return S5GPU_ERR_ARG; }
+    if (a->n_recs == 0) return S5GPU_OK;
+    hipLaunchKernelGGL(k_svbzd_decode, dim3(a->n_recs), dim3(NT), 0, (hipStream_t)stream_, *a);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }

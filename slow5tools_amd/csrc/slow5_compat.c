@@ -1,0 +1,225 @@
+/*
+ * slow5_compat.c — slow5lib's record-press entry points (include/slow5_compat.h) in plain C on top of
+ * the C ABI of the MI355X kernels (include/slow5gpu.h).  Host code stays C, as in the reference; nothing
+ * here computes a codec on the CPU — every call ends in s5gpu_*_batch and fails if there is no GPU.
+ *
+ * Mirrors the call contracts visible in slow5tools:
+ *   src/view.c:35-57   depress_parse -> press_init -> rec_to_mem -> press_free -> rec_free
+ *   src/merge.c:43-70  the same with read->read_group rewritten and aux dropped when lossy
+ *   src/get.c:37-66    slow5_get (depress+parse) then rec_to_mem
+ */
+#include "../../include/slow5_compat.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/slow5gpu.h"
+
+__thread int slow5_errno = 0;
+
+static int rec_code(enum slow5_press_method m) { return m == SLOW5_COMPRESS_NONE ? S5GPU_REC_NONE : m == SLOW5_COMPRESS_ZLIB ? S5GPU_REC_ZLIB : -1; }
+static int sig_code(enum slow5_press_method m) { return m == SLOW5_COMPRESS_NONE ? S5GPU_SIG_NONE : m == SLOW5_COMPRESS_SVB_ZD ? S5GPU_SIG_SVB_ZD : -1; }
+
+struct slow5_press *slow5_press_init(slow5_press_method_t method) {
+    if (rec_code(method.record_method) < 0 || sig_code(method.signal_method) < 0) {
+        slow5_errno = SLOW5_ERR_PRESS;   /* zstd / ex-zd: SURVEY §8(f) row 4 */
+        return NULL;
+    }
+    struct slow5_press *p = (struct slow5_press *)calloc(1, sizeof *p);
+    struct __slow5_press *r = (struct __slow5_press *)calloc(1, sizeof *r);
+    struct __slow5_press *s = (struct __slow5_press *)calloc(1, sizeof *s);
+    if (!p || !r || !s) { free(p); free(r); free(s); slow5_errno = SLOW5_ERR_MEM; return NULL; }
+    r->method = method.record_method;   /* codec state lives on the device side: nothing to allocate per record */
+    s->method = method.signal_method;
+    p->record_press = r;
+    p->signal_press = s;
+    return p;
+}
+
+void slow5_press_free(struct slow5_press *comp) {
+    if (!comp) return;
+    free(comp->record_press);
+    free(comp->signal_press);
+    free(comp);
+}
+
+void *slow5_ptr_compress_solo(enum slow5_press_method method, const void *ptr, size_t count, size_t *n) {
+    void *out = NULL;
+    size_t len = 0;
+    if (method == SLOW5_COMPRESS_NONE) {
+        out = malloc(count ? count : 1);
+        if (!out) { slow5_errno = SLOW5_ERR_MEM; return NULL; }
+        memcpy(out, ptr, count);
+        len = count;
+    } else {
+        const int stage = method == SLOW5_COMPRESS_ZLIB ? 0 : method == SLOW5_COMPRESS_SVB_ZD ? 2 : -1;
+        const void *in[1] = {ptr};
+        if (stage < 0 || s5gpu_solo_batch(stage, 1, in, &count, &out, &len, NULL) != S5GPU_OK) { slow5_errno = SLOW5_ERR_PRESS; return NULL; }
+    }
+    if (n) *n = len;
+    return out;
+}
+
+void *slow5_ptr_depress_solo(enum slow5_press_method method, const void *ptr, size_t count, size_t *n) {
+    void *out = NULL;
+    size_t len = 0;
+    if (method == SLOW5_COMPRESS_NONE) {
+        out = malloc(count ? count : 1);
+        if (!out) { slow5_errno = SLOW5_ERR_MEM; return NULL; }
+        memcpy(out, ptr, count);
+        len = count;
+    } else {
+        const int stage = method == SLOW5_COMPRESS_ZLIB ? 1 : method == SLOW5_COMPRESS_SVB_ZD ? 3 : -1;
+        const void *in[1] = {ptr};
+        if (stage < 0 || s5gpu_solo_batch(stage, 1, in, &count, &out, &len, NULL) != S5GPU_OK) { free(out); slow5_errno = SLOW5_ERR_PRESS; return NULL; }
+    }
+    if (n) *n = len;
+    return out;
+}
+
+struct slow5_rec *slow5_rec_init(void) { return (struct slow5_rec *)calloc(1, sizeof(struct slow5_rec)); }
+
+void slow5_rec_free(struct slow5_rec *read) {
+    if (!read) return;
+    free(read->read_id);
+    free(read->raw_signal);
+    free(read->aux_blob);
+    free(read);
+}
+
+/* record head = u16 id_len | id | u32 read_group | 4 x f64   */
+static uint8_t *pack_head(const struct slow5_rec *r, uint32_t *len) {
+    const uint32_t n = 2u + r->read_id_len + 4u + 32u;
+    uint8_t *h = (uint8_t *)malloc(n), *p = h;
+    if (!h) return NULL;
+    memcpy(p, &r->read_id_len, 2); p += 2;
+    memcpy(p, r->read_id, r->read_id_len); p += r->read_id_len;
+    memcpy(p, &r->read_group, 4); p += 4;
+    memcpy(p, &r->digitisation, 8); p += 8;
+    memcpy(p, &r->offset, 8); p += 8;
+    memcpy(p, &r->range, 8); p += 8;
+    memcpy(p, &r->sampling_rate, 8);
+    *len = n;
+    return h;
+}
+
+int slow5_gpu_rec_to_mem_batch(int64_t n, struct slow5_rec **reads, int drop_aux, slow5_press_method_t to, void **out,
+                               size_t *out_len) {
+    const int rc_m = rec_code(to.record_method), sg_m = sig_code(to.signal_method);
+    if (n < 0 || rc_m < 0 || sg_m < 0) { slow5_errno = SLOW5_ERR_PRESS; return -1; }
+    if (n == 0) return 0;
+    const int16_t **sig = (const int16_t **)malloc(sizeof(void *) * n);
+    uint64_t *ns = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    const void **hdr = (const void **)calloc(n, sizeof(void *));
+    uint32_t *hl = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    const void **aux = (const void **)malloc(sizeof(void *) * n);
+    uint32_t *al = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    int ret = -1;
+    if (!sig || !ns || !hdr || !hl || !aux || !al) { slow5_errno = SLOW5_ERR_MEM; goto done; }
+    for (int64_t i = 0; i < n; i++) {
+        const struct slow5_rec *r = reads[i];
+        sig[i] = r->raw_signal;
+        ns[i] = r->len_raw_signal;
+        hdr[i] = pack_head(r, &hl[i]);
+        if (!hdr[i]) { slow5_errno = SLOW5_ERR_MEM; goto done; }
+        aux[i] = drop_aux ? NULL : r->aux_blob;
+        al[i] = drop_aux ? 0u : (uint32_t)r->aux_len;
+    }
+    if (s5gpu_encode_batch((uint32_t)n, sig, ns, hdr, hl, aux, al, rc_m, sg_m, out, out_len) != S5GPU_OK) { slow5_errno = SLOW5_ERR_PRESS; goto done; }
+    ret = 0;
+done:
+    if (hdr) for (int64_t i = 0; i < n; i++) free((void *)hdr[i]);
+    free(sig); free(ns); free(hdr); free(hl); free(aux); free(al);
+    return ret;
+}
+
+void *slow5_rec_to_mem(struct slow5_rec *read, struct slow5_aux_meta *aux_meta, enum slow5_fmt format,
+                       struct slow5_press *compress, size_t *n) {
+    if (!read || format != SLOW5_FORMAT_BINARY) { slow5_errno = SLOW5_ERR_ARG; return NULL; }   /* ASCII: SURVEY §8(f) row 2 */
+    slow5_press_method_t m = {SLOW5_COMPRESS_NONE, SLOW5_COMPRESS_NONE};
+    if (compress) { m.record_method = compress->record_press->method; m.signal_method = compress->signal_press->method; }
+    void *out = NULL;
+    size_t len = 0;
+    if (slow5_gpu_rec_to_mem_batch(1, &read, aux_meta == NULL, m, &out, &len) != 0) return NULL;
+    if (n) *n = len;
+    return out;
+}
+
+static int fill_rec(struct slow5_rec **pr, const s5gpu_rec_fields_t *f, const uint8_t *payload, int16_t *sig) {
+    struct slow5_rec *r = *pr;
+    if (!r) { r = slow5_rec_init(); if (!r) return -1; *pr = r; }
+    else { free(r->read_id); free(r->raw_signal); free(r->aux_blob); r->read_id = NULL; r->raw_signal = NULL; r->aux_blob = NULL; }
+    r->read_id_len = (uint16_t)f->read_id_len;
+    r->read_id = (char *)malloc((size_t)f->read_id_len + 1);
+    if (!r->read_id) return -1;
+    memcpy(r->read_id, payload + 2, f->read_id_len);
+    r->read_id[f->read_id_len] = '\0';
+    r->read_group = f->read_group;
+    r->digitisation = f->digitisation;
+    r->offset = f->offset;
+    r->range = f->range;
+    r->sampling_rate = f->sampling_rate;
+    r->len_raw_signal = f->n_samples;
+    r->raw_signal = sig;   /* ownership moves to the record */
+    r->aux_len = f->aux_len;
+    if (f->aux_len) {
+        r->aux_blob = (uint8_t *)malloc(f->aux_len);
+        if (!r->aux_blob) return -1;
+        memcpy(r->aux_blob, payload + f->aux_off, f->aux_len);
+    }
+    return 0;
+}
+
+int slow5_gpu_depress_parse_batch(int64_t n, char **mem, size_t *bytes, slow5_press_method_t from, struct slow5_rec **reads) {
+    const int rc_m = rec_code(from.record_method), sg_m = sig_code(from.signal_method);
+    if (n < 0 || rc_m < 0 || sg_m < 0) { slow5_errno = SLOW5_ERR_PRESS; return -1; }
+    if (n == 0) return 0;
+    void **pay = (void **)calloc(n, sizeof(void *));
+    int16_t **sig = (int16_t **)calloc(n, sizeof(void *));
+    s5gpu_rec_fields_t *f = (s5gpu_rec_fields_t *)calloc(n, sizeof *f);
+    int ret = -1;
+    if (!pay || !sig || !f) { slow5_errno = SLOW5_ERR_MEM; goto done; }
+    if (s5gpu_decode_batch((uint32_t)n, (const void *const *)mem, bytes, rc_m, sg_m, pay, sig, f) != S5GPU_OK) { slow5_errno = SLOW5_ERR_RECPARSE; goto done; }
+    for (int64_t i = 0; i < n; i++) {
+        if (fill_rec(&reads[i], &f[i], (const uint8_t *)pay[i], sig[i]) != 0) { slow5_errno = SLOW5_ERR_MEM; goto done; }
+        sig[i] = NULL;
+        /* like slow5lib: *mem now holds the uncompressed record, the caller still frees it (src/view.c:41) */
+        free(mem[i]);
+        mem[i] = (char *)pay[i];
+        bytes[i] = f[i].payload_len;
+        pay[i] = NULL;
+    }
+    ret = 0;
+done:
+    if (pay) for (int64_t i = 0; i < n; i++) free(pay[i]);
+    if (sig) for (int64_t i = 0; i < n; i++) free(sig[i]);
+    free(pay); free(sig); free(f);
+    return ret;
+}
+
+int slow5_rec_depress_parse(char **mem, size_t *bytes, const char *read_id, struct slow5_rec **read, struct slow5_file *s5p) {
+    (void)read_id;
+    if (!mem || !*mem || !bytes || !read || !s5p || s5p->format != SLOW5_FORMAT_BINARY) { slow5_errno = SLOW5_ERR_ARG; return -1; }
+    slow5_press_method_t m = {SLOW5_COMPRESS_NONE, SLOW5_COMPRESS_NONE};
+    if (s5p->compress) { m.record_method = s5p->compress->record_press->method; m.signal_method = s5p->compress->signal_press->method; }
+    return slow5_gpu_depress_parse_batch(1, mem, bytes, m, read);
+}
+
+int slow5_gpu_recompress_batch(int64_t n, char **mem, size_t *bytes, slow5_press_method_t from, slow5_press_method_t to,
+                               const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len) {
+    if (n <= 0) return n == 0 ? 0 : -1;
+    struct slow5_rec **reads = (struct slow5_rec **)calloc(n, sizeof(void *));
+    if (!reads) { slow5_errno = SLOW5_ERR_MEM; return -1; }
+    int ret = slow5_gpu_depress_parse_batch(n, mem, bytes, from, reads);
+    if (ret == 0) {
+        for (int64_t i = 0; i < n; i++) {
+            free(mem[i]);   /* the reference's worker frees the input record after parsing (src/view.c:41) */
+            mem[i] = NULL;
+            if (new_read_group) reads[i]->read_group = new_read_group[i];   /* src/merge.c:51 */
+        }
+        ret = slow5_gpu_rec_to_mem_batch(n, reads, drop_aux, to, out, out_len);
+    }
+    for (int64_t i = 0; i < n; i++) slow5_rec_free(reads[i]);
+    free(reads);
+    return ret;
+}
