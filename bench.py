@@ -45,7 +45,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
-    from slow5tools_amd import _lib, press
+    from slow5tools_amd import _lib, press, shard
 
     L = _lib.lib()
     _lib.check(L.s5gpu_init(local_rank), "s5gpu_init")
@@ -59,9 +59,7 @@ def main():
     step = b.svbzd_encode if args.svb_only else b.encode
     st = b._stream()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = shard.barrier
 
     for _ in range(args.warmup):
         step()
@@ -86,10 +84,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(dt, device=dev)
 
     enc_ms, cmp_ms = [], []
     ms = C.c_float()
