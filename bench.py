@@ -114,6 +114,15 @@ def main():
     kern_s = float(np.mean(enc_ms)) / 1e3
     achieved = alg_bytes / kern_s / 1e9
     peak = 8000.0
+    # HBM traffic per launch from the committed PMC pass (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc.sh); only valid
+    # for the kernel/config it was collected on
+    traffic = None
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if not args.svb_only and t.get("samples_per_read") == n:
+            traffic = int(t["hbm_bytes_per_read"] * n_reads)
+    except Exception:
+        pass
 
     # parity spot check of this very run (outside the timed region)
     import zlib
@@ -163,7 +172,7 @@ def main():
         "kernel_ms": {"encode": round(float(np.mean(enc_ms)), 3), "compact": round(float(np.mean(cmp_ms)), 3)},
         "roofline": {"bound": "hbm", "kernel": "k_svbzd_encode" if args.svb_only else "k_encode_fused",
                      "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
-                     "frac": round(achieved / peak, 5), "traffic": None,
+                     "frac": round(achieved / peak, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes},
         "cpu_baseline": cpu,
     }

@@ -23,13 +23,15 @@ namespace s5 {
 
 // Optional per-phase cycle accounting (build with -DS5_PROFILE; never in the product library).
 #ifdef S5_PROFILE
+// lane 0 accumulates per-phase cycles in LDS (S.prof) and the kernel adds them to g_prof once at its end,
+// so the accounting itself stays out of the measured phases
 __device__ unsigned long long g_prof[32];
 #define PROF_DECL unsigned long long prof_t_ = clock64();
 #define PROF_MARK(k)                                                                  \
     do {                                                                              \
         if (threadIdx.x == 0) {                                                       \
             const unsigned long long now_ = clock64();                                \
-            atomicAdd(&g_prof[k], now_ - prof_t_);                                    \
+            S.prof[k] += now_ - prof_t_;                                              \
             prof_t_ = now_;                                                           \
         }                                                                             \
     } while (0)
@@ -69,6 +71,9 @@ struct DeflShared {
     uint32_t red[8];         // 0 matches, 1 extra bits, 2 adler A part, 3 adler B part, 4 dyn bits, 5 fixed bits, 6 cl bits
     uint32_t ncl, hlit, hclen;
     BuildScratchT<32> clb;   // scratch of the 19-symbol code-length code
+#ifdef S5_PROFILE
+    unsigned long long prof[16];
+#endif
 };
 
 struct ZOut {                // replicated uniformly in every lane's registers
@@ -342,15 +347,17 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     if (tid < 8) S.red[tid] = 0;
     if (tid < 20) S.clfreq[tid] = 0;
 
-    // ---- A: break mask, Adler partials ----
+    // ---- A: break mask, Adler partials; a run start is always a literal token: count it right here ----
     uint64_t brk = 0;
     uint32_t a_sum = 0, b_sum = 0;
     {
         int prev = -1;
         if (base > 0 && kk > 0) prev = buf[base - 1];
+        // the histogram must be zero before the first atomic: the zeroing above is ordered by this barrier
+        __syncthreads();
         for (int j = 0; j < kk; j++) {
             const int b = buf[base + j];
-            if (b != prev) brk |= 1ull << j;
+            if (b != prev) { brk |= 1ull << j; atomicAdd(&S.freq[b], 1u); }
             prev = b;
             a_sum += b;
             b_sum += (uint32_t)(len - (base + j)) * b;
@@ -362,12 +369,21 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     const int nextb = block_suffix_excl_min(local_first, len, S.ws);
     PROF_MARK(1);
 
+    // Positions inside a run (no break bit) are the only ones that need the run analysis; in signal data
+    // they are rare outside the key area.  tok = positions that emit a token, mat = those that are matches.
+    uint64_t tok = brk, mat = 0;
     uint32_t nmatch = 0, nextra = 0;
-    for (int j = 0; j < kk; j++) {
-        const Tok t = token_at(buf, base, j, brk, lastb, nextb);
-        if (t.sym >= 0) {
-            atomicAdd(&S.freq[t.sym], 1u);
-            if (t.sym > 256) { nmatch++; nextra += t.eb; }
+    {
+        uint64_t inrun = ~brk & (kk >= 64 ? ~0ull : ((1ull << kk) - 1));
+        while (inrun) {
+            const int j = __ffsll((long long)inrun) - 1;
+            inrun &= inrun - 1;
+            const Tok t = token_at(buf, base, j, brk, lastb, nextb);
+            if (t.sym >= 0) {
+                tok |= 1ull << j;
+                atomicAdd(&S.freq[t.sym], 1u);
+                if (t.sym > 256) { mat |= 1ull << j; nmatch++; nextra += t.eb; }
+            }
         }
     }
     nmatch = wave_sum(nmatch);
@@ -560,9 +576,16 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     PROF_MARK(10);
     // ---- tokens: per-lane bit totals -> prefix scan -> pack ----
     uint32_t mybits = 0;
-    for (int j = 0; j < kk; j++) {
-        const Tok t = token_at(buf, base, j, brk, lastb, nextb);
-        if (t.sym >= 0) mybits += (S.code[t.sym] >> 16) + t.eb + (t.sym > 256 ? dist_bits : 0);
+    {
+        uint64_t t = tok, mm = mat;
+        for (int j = 0; j < kk; j++, t >>= 1, mm >>= 1) {
+            if (!(t & 1)) continue;
+            if (!(mm & 1)) mybits += S.code[buf[base + j]] >> 16;
+            else {
+                const Tok tk = token_at(buf, base, j, brk, lastb, nextb);
+                mybits += (S.code[tk.sym] >> 16) + tk.eb + dist_bits;
+            }
+        }
     }
     uint32_t total_bits;
     const uint32_t start = pos0 + block_excl_add(mybits, S.ws, total_bits);
@@ -571,15 +594,20 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         uint32_t widx = (start >> 5) - z.flushed;
         uint32_t accbits = start & 31;
         uint64_t acc = 0;
-        for (int j = 0; j < kk; j++) {
-            const Tok t = token_at(buf, base, j, brk, lastb, nextb);
-            if (t.sym < 0) continue;
-            const uint32_t cc = S.code[t.sym];
-            uint32_t nb = cc >> 16;
-            uint32_t v = cc & 0xFFFF;
-            if (t.sym > 256) {
-                v |= t.ev << nb;
-                nb += t.eb;
+        uint64_t t = tok, mm = mat;
+        for (int j = 0; j < kk; j++, t >>= 1, mm >>= 1) {
+            if (!(t & 1)) continue;
+            uint32_t v, nb;
+            if (!(mm & 1)) {
+                const uint32_t cc = S.code[buf[base + j]];
+                nb = cc >> 16;
+                v = cc & 0xFFFF;
+            } else {
+                const Tok tk = token_at(buf, base, j, brk, lastb, nextb);
+                const uint32_t cc = S.code[tk.sym];
+                nb = cc >> 16;
+                v = (cc & 0xFFFF) | (tk.ev << nb);
+                nb += tk.eb;
                 v |= dist_code << nb;
                 nb += dist_bits;
             }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/slow5gpu.h"
@@ -34,6 +35,7 @@ struct EncParams {
     s5gpu_encode_args_t a;
     uint32_t obuf_words;   // LDS words of the bit buffer
     uint32_t pay_cap;      // LDS bytes of the payload buffer (fused) / staging buffer (staged)
+    uint32_t dbg;          // tools/ only (env S5GPU_DEBUG_STAGE): 1 = stop after the payload is built
 };
 
 __device__ __forceinline__ uint32_t payload_bound_dev(const s5gpu_read_desc_t &d, int sig_method) {
@@ -92,12 +94,16 @@ __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, 
 // K1+K5+K3+K6 fused: svb-zd -> pack -> one DEFLATE block -> zlib frame.  One read per workgroup, every
 // intermediate in LDS.  A read whose payload does not fit the LDS budget (p.pay_cap: long read, or an
 // unusually incompressible signal) is appended to the overflow list and redone by the staged kernels.
-__global__ __launch_bounds__(NT) void k_encode_fused(EncParams p) {
+__global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
     const uint32_t r = blockIdx.x;
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
     const s5gpu_read_desc_t d = p.a.desc[r];
+#ifdef S5_PROFILE
+    if (threadIdx.x < 16) S.prof[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     PROF_DECL
     const uint32_t plen = build_payload(p.a, d, pay, p.pay_cap, S.ws);
     if (plen == OVF) {
@@ -109,12 +115,19 @@ __global__ __launch_bounds__(NT) void k_encode_fused(EncParams p) {
     }
     __syncthreads();
     PROF_MARK(0);
+    if (p.dbg == 1) {   // stage-timing aid: svb-zd + pack only
+        if (threadIdx.x == 0) p.a.out_len[r] = plen + pay[plen - 1];
+        return;
+    }
     uint8_t *out = p.a.slots + d.out_off;
     const uint32_t total = zlib_compress_fused(S, obuf, p.obuf_words, pay, plen, out);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
     PROF_MARK(13);
 #ifdef S5_PROFILE
-    if (threadIdx.x == 0) atomicAdd(&g_prof[31], 1ull);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 14; k++) atomicAdd(&g_prof[k], S.prof[k]);
+        atomicAdd(&g_prof[31], 1ull);
+    }
 #endif
 }
 
@@ -537,6 +550,7 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EncParams p;
     p.a = *a;
+    p.dbg = getenv("S5GPU_DEBUG_STAGE") ? (uint32_t)atoi(getenv("S5GPU_DEBUG_STAGE")) : 0;
     if (a->rec_method == S5GPU_REC_NONE) {
         p.obuf_words = 0; p.pay_cap = 0;
         hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 1);
@@ -588,6 +602,7 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
     if ((rc = set_lds_attrs())) return rc;
     EncParams p;
     p.a = *a;
+    p.dbg = 0;
     p.obuf_words = (DEFL_BLK + 64) / 4;
     p.pay_cap = DEFL_BLK;
     const size_t lds = S_BYTES + B_BYTES + 4ull * p.obuf_words + DEFL_BLK;
@@ -621,6 +636,7 @@ extern "C" int s5gpu_svbzd_encode_dev(const s5gpu_encode_args_t *a, void *stream
     if (a->n_reads == 0) return S5GPU_OK;
     EncParams p;
     p.a = *a;
+    p.dbg = 0;
     p.obuf_words = 0; p.pay_cap = 0;
     hipLaunchKernelGGL(k_svbzd_encode, dim3(a->n_reads), dim3(NT), 0, (hipStream_t)stream_, p);
     HIP_TRY(hipGetLastError());

@@ -14,7 +14,7 @@ PROF_LIB = os.path.join(ROOT, "slow5tools_amd", "libslow5gpu_prof.so")
 NAMES = {0: "svb-zd encode + pack (HBM->LDS payload)", 1: "break mask + 2 scans + adler partials", 2: "tokenise + histogram",
          3: "lit/len rank sort", 4: "lit/len huffman merge (1 lane)", 5: "depths + limit + lengths", 6: "canonical codes (lit/len)",
          7: "hlit + code-length RLE (1 lane)", 8: "code-length code build", 9: "cost compare", 10: "header emit",
-         11: "token bit totals + scan", 12: "token pack", 13: "trailer + flush LDS->HBM"}
+         11: "token bit totals + scan", 12: "token pack", 13: "whole zlib_compress_fused (phases 1-12 + flush)"}
 
 
 def main():
@@ -28,7 +28,8 @@ def main():
 
     L = _lib.lib()
     _lib.check(L.s5gpu_init(0))
-    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200000
+    nums = [a for a in sys.argv[1:] if a.isdigit()]
+    n_reads = int(nums[0]) if nums else 200000
     n = 4000
     b = press.DeviceBatch(np.full(n_reads, n, dtype=np.uint64), with_stream_out=False)
     b.synth()
@@ -44,12 +45,12 @@ def main():
     torch.cuda.synchronize()
     L.s5gpu_prof_read(buf, 0)
     wgs = buf[31]
-    tot = sum(buf[k] for k in range(14))
+    tot = sum(buf[k] for k in range(13))
     print("k_encode_fused (profiled build): %d reads x %d samples, %.2f ms" % (n_reads, n, t0.elapsed_time(t1)))
     print("%-45s %12s %7s" % ("phase", "cycles/WG", "share"))
     for k in range(14):
         print("%-45s %12.0f %6.1f%%" % (NAMES[k], buf[k] / max(wgs, 1), 100.0 * buf[k] / max(tot, 1)))
-    print("%-45s %12.0f" % ("total (lane-0 timeline, 100 MHz s_memtime ticks?)", tot / max(wgs, 1)))
+    print("%-45s %12.0f" % ("sum of phases 0-12 (lane-0 timeline, shader cycles)", tot / max(wgs, 1)))
 
 
 if __name__ == "__main__":
