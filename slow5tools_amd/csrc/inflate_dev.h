@@ -3,8 +3,15 @@
 // Replaces the record-depress stage of slow5lib reached through slow5_rec_depress_parse / slow5_get
 // (/root/reference/src/view.c:38, src/get.c:45).  Accepts any conforming stream (stored / fixed /
 // dynamic blocks, distances up to 32 KiB): the reference's fixtures were written by stock zlib.
-// DEFLATE decoding is bit-serial per stream, so parallelism is across records: 64 lanes build the
-// lookup tables cooperatively, lane 0 walks the bit stream, all lanes replicate matches.
+//
+// DEFLATE decoding is bit-serial per stream, so the parallelism is across records (thousands of waves in
+// flight) and inside a wave only where the format allows it:
+//   - the compressed stream is staged through a 2 KiB LDS window (all lanes refill it with aligned
+//     dword loads + byte shift); lane 0 walks the bit stream out of LDS, never out of HBM
+//   - 64 lanes build the canonical tables and the 10-bit / 8-bit lookup tables with ballots
+//   - literals go to a 4 KiB LDS output ring, flushed to HBM by all lanes (coalesced) every 2 KiB;
+//     the Adler-32 is accumulated on the flushed bytes
+//   - matches are replicated by all lanes: out[o+k] = out[o-d + k mod d] (sources precede o)
 #pragma once
 #include "dev_common.h"
 
@@ -16,53 +23,93 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int INF_LBITS = 10;   // primary lit/len lookup bits
-constexpr int INF_DBITS = 8;    // primary distance lookup bits
+constexpr int INF_LBITS = 10;      // primary lit/len lookup bits
+constexpr int INF_DBITS = 8;       // primary distance lookup bits
+constexpr int INF_IW = 2048;       // input window, bytes
+constexpr int INF_OW = 4096;       // output ring, bytes
+constexpr int INF_FLUSH = 2048;    // flush the ring when this many bytes are pending
 
-struct InflShared {              // per wave
+struct InflShared {                  // per wave
+    uint32_t win[INF_IW / 4];        // compressed bytes [wbase, wbase + INF_IW) of the deflate data
+    uint8_t ring[INF_OW];            // output bytes, position o lives at ring[o % INF_OW]
     uint16_t llut[1 << INF_LBITS];   // sym | len << 9   (len == 0: long code -> canonical walk)
     uint16_t dlut[1 << INF_DBITS];   // sym | len << 5
     uint16_t lsym[288];              // canonical order symbols
     uint16_t dsym[32];
     uint16_t lcount[16], dcount[16];
-    uint8_t lens[352];           // [0,19) code-length code | [32, 32+316) dynamic lit/len+dist; fixed: [0,288)+[288,320)
-    uint32_t misc[4];
+    uint8_t lens[352];               // [0,19) code-length code | [32, 32+316) dynamic lit/len+dist; fixed: [0,288)+[288,320)
 };
 
 enum { INF_OK = 0, INF_ERR_HEADER = 1, INF_ERR_DATA = 2, INF_ERR_TRUNC = 3, INF_ERR_ADLER = 4, INF_ERR_OVERFLOW = 5 };
 
+// Bit reader over the LDS window (lane 0).  Refills in aligned dwords.
 struct BitIn {
-    const uint8_t *p, *end;
     uint64_t buf;
-    int cnt;
-    int over;   // bytes consumed past the end (error if any bit of them is used)
+    int cnt;           // valid bits in buf
+    uint32_t wpos;     // next dword of the window
+    uint32_t wbase;    // deflate-data byte offset of window dword 0
 };
-__device__ __forceinline__ void bi_refill(BitIn &b) {
-    while (b.cnt <= 56) {
-        uint64_t v = 0;
-        if (b.p < b.end) v = *b.p; else b.over++;
-        b.p++;
-        b.buf |= v << b.cnt;
-        b.cnt += 8;
+__device__ __forceinline__ void bi_need32(BitIn &b, const uint32_t *win) {   // afterwards cnt >= 33
+    if (b.cnt <= 32) {
+        b.buf |= (uint64_t)win[b.wpos++] << b.cnt;
+        b.cnt += 32;
     }
 }
-__device__ __forceinline__ uint32_t bi_get(BitIn &b, int n) {   // n <= 32, after refill
+// wave-uniform variant: every lane runs it on the same state; the LDS word is forced scalar so the
+// compiler keeps the bit reader in SGPRs and branches on SCC instead of juggling the exec mask
+__device__ __forceinline__ void bi_need32_u(BitIn &b, const uint32_t *win) {
+    if (b.cnt <= 32) {
+        const uint32_t w = __builtin_amdgcn_readfirstlane(win[b.wpos]);
+        b.wpos++;
+        b.buf |= (uint64_t)w << b.cnt;
+        b.cnt += 32;
+    }
+}
+__device__ __forceinline__ uint32_t bi_get(BitIn &b, int n) {   // n <= 32 <= cnt
     const uint32_t v = (uint32_t)(b.buf & ((1ull << n) - 1));
     b.buf >>= n;
     b.cnt -= n;
     return v;
 }
+__device__ __forceinline__ uint64_t bi_consumed_bits(const BitIn &b) { return 8ull * b.wbase + 32ull * b.wpos - (uint64_t)b.cnt; }
+
+// All 64 lanes: load the window so that window byte 0 = deflate byte `from` (any alignment).  Bytes at or
+// past `total` read as zero.  src = first deflate byte (stream + 2).
+__device__ __forceinline__ void infl_load_window(uint32_t *win, const uint8_t *src, uint32_t from, uint32_t total) {
+    const int lane = lane_id();
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(src) + from;
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(addr & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(addr & 3) * 8;
+    const uint32_t avail = from < total ? total - from : 0;   // bytes that exist from `from` on
+#pragma unroll 2
+    for (int q = 0; q < INF_IW / 4 / 64; q++) {
+        const uint32_t i = q * 64 + lane;
+        uint32_t w = 0;
+        if (4 * i < avail) {
+            const uint32_t lo = g[i];
+            w = lo;
+            if (sh) {
+                // the high dword may lie past the record; the C ABI asks for 8 readable bytes after `in`
+                const uint32_t hi = g[i + 1];
+                w = (lo >> sh) | (hi << (32 - sh));
+            }
+            const uint32_t left = avail - 4 * i;
+            if (left < 4) w &= (1u << (8 * left)) - 1;
+        }
+        win[i] = w;
+    }
+    wave_sync();
+}
 
 // Build canonical tables + LUT for one alphabet from lens[0..n).  All 64 lanes of the wave.
-// Returns 0 ok, nonzero if over-subscribed (incomplete codes are tolerated like zlib does for
-// single-code distance trees; an invalid code simply never matches and reports INF_ERR_DATA).
+// Returns nonzero if over-subscribed (incomplete codes are tolerated like zlib does for single-code
+// distance trees; a code that does not exist simply never matches and reports INF_ERR_DATA).
 __device__ __forceinline__ int infl_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *syms, uint16_t *lut,
                                           int lutbits, int lenshift) {
     const int lane = lane_id();
     if (lane < 16) count[lane] = 0;
     for (int i = lane; i < (1 << lutbits); i += 64) lut[i] = 0;
     wave_sync();
-    // counts per length and canonical first codes (serial over 15 lengths, cheap)
     uint32_t next[16], offs[16];
     {
         uint32_t cnt[16];
@@ -116,7 +163,7 @@ __device__ __forceinline__ int infl_build(const uint8_t *lens, int n, uint16_t *
     return 0;
 }
 
-// canonical bit-by-bit walk for codes longer than the LUT (puff-style); returns symbol or -1
+// canonical bit-by-bit walk for codes longer than the LUT (needs cnt >= 15); returns symbol or -1
 __device__ __forceinline__ int infl_slow(BitIn &b, const uint16_t *count, const uint16_t *syms) {
     int code = 0, first = 0, index = 0;
     for (int len = 1; len <= 15; len++) {
@@ -131,8 +178,31 @@ __device__ __forceinline__ int infl_slow(BitIn &b, const uint16_t *count, const 
     return -1;
 }
 
-// Inflate one zlib stream.  out may be HBM.  cap = bytes available at out.  Returns status; *out_len =
-// decoded length (also when INF_ERR_OVERFLOW: the size needed, nothing beyond cap is written).
+// All lanes: write ring bytes [from, to) to HBM (nothing at or beyond cap) and fold them into the Adler-32.
+__device__ __forceinline__ void infl_flush(const uint8_t *ring, uint8_t *out, uint32_t from, uint32_t to, uint32_t cap,
+                                           uint32_t &adA, uint32_t &adB) {
+    const int lane = lane_id();
+    const uint32_t n = to - from;
+    uint32_t sa = 0;
+    uint64_t sb = 0;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t x = ring[(from + i) & (INF_OW - 1)];
+        if (from + i < cap) out[from + i] = (uint8_t)x;
+        sa += x;
+        sb += (uint64_t)(n - i) * x;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sa += __shfl_xor(sa, d);
+        sb += __shfl_xor(sb, d);
+    }
+    adB = (uint32_t)(((uint64_t)adB + (uint64_t)n * adA + sb) % 65521u);
+    adA = (adA + sa) % 65521u;
+}
+
+// Inflate one zlib stream.  out: HBM, cap bytes.  Returns status; *out_len = decoded length (also when
+// INF_ERR_OVERFLOW: the size needed; nothing at or beyond cap is written).  Adler-32 verified.
+// `in` must have 8 readable bytes after in + in_len.
 __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *in, uint32_t in_len, uint8_t *out,
                                                  uint32_t cap, uint32_t *out_len) {
     const int lane = lane_id();
@@ -146,49 +216,64 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
         const uint32_t cmf = in[0], flg = in[1];
         if ((cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) return INF_ERR_HEADER;
     }
+    const uint8_t *src = in + 2;
+    const uint32_t total = in_len - 6;            // deflate data bytes (the Adler-32 trailer is not part of them)
+    const uint64_t total_bits = 8ull * total;
     BitIn b;
-    b.p = in + 2;
-    b.end = in + in_len - 4;   // the Adler-32 trailer is not part of the deflate data
-    b.buf = 0;
-    b.cnt = 0;
-    b.over = 0;
-    uint32_t o = 0;          // bytes produced (uniform: broadcast from lane 0 after each block step)
+    b.buf = 0; b.cnt = 0; b.wpos = 0; b.wbase = 0;
+    infl_load_window(T.win, src, 0, total);
+    uint32_t o = 0;              // bytes produced (uniform)
+    uint32_t flushed = 0;        // bytes already written to HBM (uniform)
+    uint32_t ring_lo = 0;        // lowest position whose byte is certainly still in the ring
+    uint32_t adA = 1, adB = 0;
     int status = INF_OK;
     int last = 0;
+    // The bit reader state `b` is WAVE-UNIFORM: every lane executes the same reads on the same LDS words, so
+    // no broadcast is ever needed and the compiler can keep the reader on the scalar unit.
     while (!last && status == INF_OK) {
-        // ---- block header (lane 0 reads, broadcast) ----
-        uint32_t hdr = 0;
-        if (lane == 0) { bi_refill(b); hdr = bi_get(b, 3); if (b.over > 8) hdr = 8; }
-        hdr = __shfl(hdr, 0);
-        if (hdr == 8) { status = INF_ERR_TRUNC; break; }   // ran off the end of the input
+        // ---- block header ----
+        if (b.wpos > INF_IW / 4 - 3) {   // window nearly used up: reload first
+            const uint32_t from = b.wbase + 4 * b.wpos;
+            infl_load_window(T.win, src, from, total);
+            b.wbase = from; b.wpos = 0;
+            continue;
+        }
+        bi_need32_u(b, T.win);
+        const uint32_t hdr = bi_get(b, 3);
+        if (bi_consumed_bits(b) > total_bits) { status = INF_ERR_TRUNC; break; }
         last = hdr & 1;
         const int type = hdr >> 1;
         if (type == 3) { status = INF_ERR_DATA; break; }
         if (type == 0) {
-            // stored: align to byte, LEN/NLEN, raw copy by all lanes
-            uint32_t len = 0, src_off = 0, bad = 0;
-            if (lane == 0) {
-                bi_get(b, b.cnt & 7);
-                bi_refill(b);
-                len = bi_get(b, 16);
-                const uint32_t nlen = bi_get(b, 16);
-                bad = (len ^ 0xFFFFu) != nlen;
-                // un-read the whole bytes still buffered so p points at the data
-                b.p -= b.cnt >> 3;
-                if (b.over) { const int back = min(b.over, b.cnt >> 3); b.over -= back; }
-                b.buf = 0;
-                b.cnt = 0;
-                src_off = (uint32_t)(b.p - in);
-                if (b.p + len > b.end) bad |= 2;
-                b.p += len;
+            // stored: align to a byte, LEN/NLEN, then raw bytes straight HBM -> HBM
+            bi_get(b, b.cnt & 7);
+            bi_need32_u(b, T.win);
+            const uint32_t len = bi_get(b, 16);
+            const uint32_t nlen = bi_get(b, 16);
+            const uint32_t pos = (uint32_t)(bi_consumed_bits(b) >> 3);   // byte offset of the raw data
+            if ((len ^ 0xFFFFu) != nlen) { status = INF_ERR_DATA; break; }
+            if (8ull * pos > total_bits || (uint64_t)pos + len > total) { status = INF_ERR_TRUNC; break; }
+            wave_sync();
+            infl_flush(T.ring, out, flushed, o, cap, adA, adB);
+            {
+                uint32_t sa = 0;
+                uint64_t sb = 0;
+                for (uint32_t i = lane; i < len; i += 64) {
+                    const uint32_t x = src[pos + i];
+                    if (o + i < cap) out[o + i] = (uint8_t)x;
+                    sa += x;
+                    sb += (uint64_t)(len - i) * x;
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+                adB = (uint32_t)(((uint64_t)adB + (uint64_t)len * adA + sb) % 65521u);
+                adA = (adA + sa) % 65521u;
             }
-            len = __shfl(len, 0);
-            src_off = __shfl(src_off, 0);
-            bad = __shfl(bad, 0);
-            if (bad) { status = (bad & 2) ? INF_ERR_TRUNC : INF_ERR_DATA; break; }
-            for (uint32_t i = lane; i < len; i += 64)
-                if (o + i < cap) out[o + i] = in[src_off + i];
             o += len;
+            flushed = o;
+            ring_lo = o;   // the ring holds none of these bytes: later matches read them back from HBM
+            infl_load_window(T.win, src, pos + len, total);
+            b.wbase = pos + len; b.wpos = 0; b.buf = 0; b.cnt = 0;
             continue;
         }
         // ---- code lengths ----
@@ -200,46 +285,60 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
             nd = 30;
             wave_sync();
         } else {
-            uint32_t hd = 0;
-            if (lane == 0) { bi_refill(b); hd = bi_get(b, 14); }
-            hd = __shfl(hd, 0);
+            // the whole dynamic header is at most 14 + 57 + 316 * 14 bits = 562 bytes: make sure it is in the window
+            if (b.wpos > INF_IW / 4 - 160) {
+                const uint32_t from = b.wbase + 4 * b.wpos;
+                infl_load_window(T.win, src, from, total);
+                b.wbase = from; b.wpos = 0;
+            }
+            bi_need32_u(b, T.win);
+            const uint32_t hd = bi_get(b, 14);
             nl = (int)(hd & 31) + 257;
             nd = (int)((hd >> 5) & 31) + 1;
             const int ncl = (int)(hd >> 10) + 4;
             if (nl > 286 || nd > 30) { status = INF_ERR_DATA; break; }
             if (lane < 19) T.lens[lane] = 0;
             wave_sync();
-            if (lane == 0) {
+            {
                 const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                for (int i = 0; i < ncl; i++) { bi_refill(b); T.lens[order[i]] = (uint8_t)bi_get(b, 3); }
+                for (int i = 0; i < ncl; i++) {
+                    bi_need32_u(b, T.win);
+                    const uint8_t v = (uint8_t)bi_get(b, 3);
+                    if (lane == 0) T.lens[order[i]] = v;
+                }
             }
             wave_sync();
             // the code-length code reuses the distance tables' storage (built before the real ones)
             if (infl_build(T.lens, 19, T.dcount, T.dsym, T.dlut, 7, 5)) { status = INF_ERR_DATA; break; }
             int bad = 0;
-            if (lane == 0) {
-                uint8_t tmp_prev = 0;
+            {
+                uint8_t prev = 0;
                 int idx = 0;
                 const int tot = nl + nd;
-                while (idx < tot && !bad) {
-                    bi_refill(b);
-                    const uint32_t e = T.dlut[b.buf & 127];
-                    int sym;
-                    if (e >> 5) { sym = e & 31; bi_get(b, e >> 5); } else { sym = -1; bad = 1; break; }
-                    if (sym < 16) { tmp_prev = (uint8_t)sym; T.lens[32 + idx++] = tmp_prev; }
+                while (idx < tot) {
+                    bi_need32_u(b, T.win);
+                    const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.dlut[(uint32_t)b.buf & 127]);
+                    if (!(e >> 5)) { bad = 1; break; }
+                    const int sym = e & 31;
+                    bi_get(b, e >> 5);
+                    if (sym < 16) { prev = (uint8_t)sym; if (lane == 0) T.lens[32 + idx] = prev; idx++; }
                     else {
-                        int rep; uint8_t v = 0;
-                        if (sym == 16) { if (idx == 0) { bad = 1; break; } v = tmp_prev; rep = 3 + (int)bi_get(b, 2); }
+                        int rep;
+                        uint8_t v = 0;
+                        if (sym == 16) { if (idx == 0) { bad = 1; break; } v = prev; rep = 3 + (int)bi_get(b, 2); }
                         else if (sym == 17) rep = 3 + (int)bi_get(b, 3);
                         else rep = 11 + (int)bi_get(b, 7);
                         if (idx + rep > tot) { bad = 1; break; }
-                        while (rep--) T.lens[32 + idx++] = v;
-                        if (sym != 16) tmp_prev = 0;
+                        if (lane < rep) T.lens[32 + idx + lane] = v;   // rep <= 138: two rounds at most
+                        if (lane + 64 < rep) T.lens[32 + idx + lane + 64] = v;
+                        if (lane + 128 < rep) T.lens[32 + idx + lane + 128] = v;
+                        idx += rep;
+                        if (sym != 16) prev = 0;
                     }
                 }
+                if (!bad && bi_consumed_bits(b) > total_bits) bad = 2;
             }
-            bad = __shfl(bad, 0);
-            if (bad) { status = INF_ERR_DATA; break; }
+            if (bad) { status = bad == 2 ? INF_ERR_TRUNC : INF_ERR_DATA; break; }
             wave_sync();
         }
         // tables: dynamic lengths sit at T.lens[32 ..] (lit/len then dist); fixed at [0..288) + [288..)
@@ -248,51 +347,69 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
         if (type == 2 && ll[256] == 0) { status = INF_ERR_DATA; break; }
         if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, INF_LBITS, 9)) { status = INF_ERR_DATA; break; }
         if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, INF_DBITS, 5)) { status = INF_ERR_DATA; break; }
-        // ---- symbols: lane 0 decodes, the wave replicates matches ----
+        // ---- symbols: lane 0 decodes out of LDS; the wave refills / flushes / replicates matches ----
         for (;;) {
-            // lane 0 decodes up to the next match or end of block, writing literals itself
-            uint32_t mlen = 0, mdist = 0, st = 0;   // st: 0 match, 1 end of block, 2 error, 3 truncated
-            if (lane == 0) {
+            // st: 0 match, 1 end of block, 2 data error, 3 truncated, 4 input window low, 5 ring needs a flush
+            uint32_t mlen = 0, mdist = 0, st = 0;
+            {   // wave-uniform: all lanes walk the same bits (scalar unit); only lane 0 stores the literal
                 for (;;) {
-                    bi_refill(b);
-                    if (b.over > 8) { st = 3; break; }   // zero-fill past the end must not decode forever
+                    if (b.wpos > INF_IW / 4 - 3) { st = 4; break; }
+                    if (o - flushed >= INF_FLUSH) { st = 5; break; }
+                    bi_need32_u(b, T.win);
                     int sym;
-                    const uint32_t e = T.llut[b.buf & ((1 << INF_LBITS) - 1)];
-                    if (e >> 9) { sym = e & 511; bi_get(b, e >> 9); } else sym = infl_slow(b, T.lcount, T.lsym);
+                    const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.llut[(uint32_t)b.buf & ((1 << INF_LBITS) - 1)]);
+                    if (e >> 9) { sym = e & 511; bi_get(b, e >> 9); }
+                    else sym = __builtin_amdgcn_readfirstlane(infl_slow(b, T.lcount, T.lsym));
                     if (sym < 0) { st = 2; break; }
-                    if (sym < 256) { if (o < cap) out[o] = (uint8_t)sym; o++; continue; }
+                    if (sym < 256) { if (lane == 0) T.ring[o & (INF_OW - 1)] = (uint8_t)sym; o++; continue; }
                     if (sym == 256) { st = 1; break; }
                     sym -= 257;
                     if (sym >= 29) { st = 2; break; }
                     mlen = lbase[sym] + bi_get(b, lext[sym]);
-                    bi_refill(b);
+                    bi_need32_u(b, T.win);
                     int ds;
-                    const uint32_t de = T.dlut[b.buf & ((1 << INF_DBITS) - 1)];
-                    if (de >> 5) { ds = de & 31; bi_get(b, de >> 5); } else ds = infl_slow(b, T.dcount, T.dsym);
+                    const uint32_t de = __builtin_amdgcn_readfirstlane((uint32_t)T.dlut[(uint32_t)b.buf & ((1 << INF_DBITS) - 1)]);
+                    if (de >> 5) { ds = de & 31; bi_get(b, de >> 5); }
+                    else ds = __builtin_amdgcn_readfirstlane(infl_slow(b, T.dcount, T.dsym));
                     if (ds < 0 || ds >= 30) { st = 2; break; }
                     mdist = dbase[ds] + bi_get(b, dext[ds]);
                     if (mdist > o) { st = 2; break; }
                     break;
                 }
+                if (st != 2 && bi_consumed_bits(b) > total_bits) st = 3;   // decoded out of the zero padding past the end
             }
-            st = __shfl(st, 0);
-            o = __shfl(o, 0);
-            if (st >= 2) { status = st == 2 ? INF_ERR_DATA : INF_ERR_TRUNC; break; }
+            if (st == 2 || st == 3) { status = st == 2 ? INF_ERR_DATA : INF_ERR_TRUNC; break; }
             if (st == 1) break;
-            mlen = __shfl(mlen, 0);
-            mdist = __shfl(mdist, 0);
-            // out[o+k] = out[o-dist + k mod dist]: every source byte precedes o, so lanes are independent
-            for (uint32_t k = lane; k < mlen; k += 64)
-                if (o + k < cap) out[o + k] = out[o - mdist + (k % mdist)];
+            if (st == 4) {
+                const uint32_t from = b.wbase + 4 * b.wpos;
+                infl_load_window(T.win, src, from, total);
+                b.wbase = from; b.wpos = 0;
+                continue;
+            }
+            if (st == 5) {
+                wave_sync();
+                infl_flush(T.ring, out, flushed, o, cap, adA, adB);
+                flushed = o;
+                continue;
+            }
+            wave_sync();
+            // sources older than what the ring still holds (or bytes of a stored block) come back from HBM
+            const uint32_t in_ring = max(ring_lo, o + mlen > (uint32_t)INF_OW ? o + mlen - INF_OW : 0u);
+            for (uint32_t k = lane; k < mlen; k += 64) {
+                const uint32_t sp = o - mdist + (k % mdist);
+                const uint8_t x = sp >= in_ring ? T.ring[sp & (INF_OW - 1)] : (sp < cap ? out[sp] : (uint8_t)0);
+                T.ring[(o + k) & (INF_OW - 1)] = x;
+            }
+            wave_sync();
             o += mlen;
         }
     }
-    // trailer
-    int over = __shfl(b.over, 0);
-    int cntbits = __shfl(b.cnt, 0);
+    wave_sync();
     if (status == INF_OK) {
-        // bits of bytes past the end must be unused: consumed bytes = (p - in) - cnt/8 <= in_len - 4
-        if (over * 8 > cntbits) status = INF_ERR_TRUNC;
+        infl_flush(T.ring, out, flushed, o, cap, adA, adB);
+        const uint8_t *t = in + in_len - 4;
+        const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+        if (o <= cap && ((adB << 16) | adA) != want) status = INF_ERR_ADLER;
     }
     *out_len = o;
     if (status == INF_OK && o > cap) status = INF_ERR_OVERFLOW;

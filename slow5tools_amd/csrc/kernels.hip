@@ -255,24 +255,7 @@ __global__ __launch_bounds__(64) void k_inflate(s5gpu_decode_args_t a) {
         if (status == INF_OK)
             for (uint32_t i = lane; i < d.in_len; i += 64) out[i] = in[i];
     } else {
-        status = zlib_inflate_wave(T, in, d.in_len, out, d.pay_cap, &olen);
-        if (status == INF_OK) {   // Adler-32 of what was written vs the big-endian trailer
-            uint64_t sa = 0, sb = 0;
-            for (uint32_t i = lane; i < olen; i += 64) {
-                const uint32_t x = out[i];
-                sa += x;
-                sb += (uint64_t)(olen - i) * x;
-            }
-            for (int dd = 32; dd >= 1; dd >>= 1) {
-                sa += __shfl_xor(sa, dd);
-                sb += __shfl_xor(sb, dd);
-            }
-            const uint32_t A = (uint32_t)((1 + sa) % 65521u);
-            const uint32_t B = (uint32_t)((sb + olen) % 65521u);
-            const uint8_t *t = in + d.in_len - 4;
-            const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
-            if (((B << 16) | A) != want) status = INF_ERR_ADLER;
-        }
+        status = zlib_inflate_wave(T, in, d.in_len, out, d.pay_cap, &olen);   // Adler-32 verified inside
     }
     if (lane == 0) {
         a.fields[r].status = status;
