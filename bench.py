@@ -29,7 +29,12 @@ def main():
     ap.add_argument("--samples", type=int, default=4000, help="int16 samples per read")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--svb-only", action="store_true", help="config 2: svb-zd stage alone")
+    ap.add_argument("--decode", action="store_true", help="config 5: random get-style decode (inflate + svb-zd unpack)")
+    ap.add_argument("--get-reads", type=int, default=100_000, help="--decode: random read ids to fetch (seed 1)")
+    ap.add_argument("--get-batch", type=int, default=4096, help="--decode: ids per batch (-K)")
     args = ap.parse_args()
+    if args.decode:
+        return bench_decode(args)
 
     import numpy as np
     import torch
@@ -170,7 +175,7 @@ def main():
         "bytes_per_sample": round(z_bytes / (n_reads * n), 4),
         "parity_spot_check": bool(parity),
         "kernel_ms": {"encode": round(float(np.mean(enc_ms)), 3), "compact": round(float(np.mean(cmp_ms)), 3)},
-        "roofline": {"bound": "hbm", "kernel": "k_svbzd_encode" if args.svb_only else "k_encode_fused",
+        "roofline": {"bound": "hbm", "kernel": "k_svbzd_encode" if args.svb_only else ("k_encode_fused" if b.tot["max_payload"] * 100 // 325 <= 4 * 16384 else "k_pack+k_deflate_staged"),
                      "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes},
@@ -179,6 +184,76 @@ def main():
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_decode(args):
+    """BASELINE config 5: decode for random `get` over an index of --reads records, batches of --get-batch ids.
+    Per batch (what src/get.c:321-386 does per -K batch, minus the preads): build the batch's record
+    descriptors from the index, upload them, inflate + unpack on the GPU, synchronise.  Every decoded signal
+    is compared with the generator.  Prints one JSON line (not the headline metric)."""
+    import numpy as np
+    import torch
+
+    from slow5tools_amd import _lib, press
+
+    L = _lib.lib()
+    _lib.check(L.s5gpu_init(0), "s5gpu_init")
+    dev = "cuda:0"
+    n_reads, n = args.reads, args.samples
+    b = press.DeviceBatch(np.full(n_reads, n, dtype=np.uint64), device=dev)
+    b.synth(seed=0x5105, first=0)
+    b.encode()
+    b.compact()
+    torch.cuda.synchronize()
+    rec_off = b.rec_off.cpu().numpy().astype(np.int64)          # the "index": offset/size per read (Appendix A.5)
+    rng = np.random.default_rng(1)
+    ids = rng.integers(0, n_reads, args.get_reads)
+    K = args.get_batch
+    pay_cap = 16 * ((int(b.tot["max_payload"]) + 31) // 16)
+    sig_cap = (n + 7) // 8 * 8
+    payload = torch.empty(K * pay_cap + 64, dtype=torch.uint8, device=dev)
+    sig = torch.empty(K * sig_cap + 64, dtype=torch.int16, device=dev)
+    fields = torch.zeros(K * 64, dtype=torch.uint8, device=dev)
+    desc_dev = torch.empty(K * _lib.REC_DESC.itemsize, dtype=torch.uint8, device=dev)
+    desc_pin = torch.empty(K * _lib.REC_DESC.itemsize, dtype=torch.uint8).pin_memory()
+    a = _lib.DecodeArgs()
+    a.rec_method, a.sig_method = 1, 1
+    a.desc, a.in_, a.payload, a.sig_out, a.fields = desc_dev.data_ptr(), b.stream_out.data_ptr(), payload.data_ptr(), sig.data_ptr(), fields.data_ptr()
+    lat, ok, done = [], True, 0
+    t_all = time.perf_counter()
+    for lo in range(0, len(ids), K):
+        sel = ids[lo:lo + K]
+        k = len(sel)
+        t0 = time.perf_counter()
+        d = np.zeros(k, dtype=_lib.REC_DESC)
+        d["in_off"] = rec_off[sel] + 8
+        d["in_len"] = rec_off[sel + 1] - rec_off[sel] - 8
+        d["pay_off"] = np.arange(k, dtype=np.uint64) * pay_cap
+        d["pay_cap"] = pay_cap
+        d["sig_off"] = np.arange(k, dtype=np.uint64) * sig_cap
+        d["sig_cap"] = sig_cap
+        desc_pin[: d.nbytes].copy_(torch.from_numpy(d.view(np.uint8)))
+        desc_dev[: d.nbytes].copy_(desc_pin[: d.nbytes], non_blocking=True)
+        a.n_recs = k
+        _lib.check(L.s5gpu_decode_dev(C.byref(a), b._stream()), "s5gpu_decode_dev")
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+        if lo >= 2 * K:   # the first two batches are warm-up (allocator, index_select)
+            done += k
+        st = fields[: k * 64].view(torch.int32).view(k, 16)[:, 0]
+        got = sig[: k * sig_cap].view(k, sig_cap)[:, :n]
+        want = b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[torch.from_numpy(sel).to(dev)][:, :n]
+        ok &= bool((st == 0).all().item()) and bool((got == want).all().item())
+    wall = time.perf_counter() - t_all
+    lat_ms = np.array(lat[2:]) * 1e3
+    busy = float(np.sum(lat[2:]))
+    line = {"metric": "blow5_get_decode_throughput", "value": round(done * 2 * n / busy / 1e9, 3), "unit": "GB/s",
+            "n_gpus": 1, "higher_is_better": True, "dtype": "u8->int16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: random get decode (inflate + svb-zd unpack), %d ids (seed 1) over a %d-read index, batches of %d, %d samples/read" % (len(ids), n_reads, K, n)},
+            "reads_per_s": round(done / busy, 1), "batch_latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p99": round(float(np.percentile(lat_ms, 99)), 3)},
+            "per_read_latency_us_p50": round(float(np.percentile(lat_ms, 50)) * 1e3 / K, 3),
+            "roundtrip_identical": bool(ok), "wall_s_including_verification": round(wall, 2)}
+    print(json.dumps(line))
 
 
 if __name__ == "__main__":
