@@ -325,7 +325,7 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
 template <bool FUSED>
 __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words,
                                               const uint8_t *buf, int len, bool final, ZOut &z, uint32_t &adA,
-                                              uint32_t &adB) {
+                                              uint32_t &adB, uint32_t dbg = 0) {
     const int tid = threadIdx.x;
     if (len == 0) {
         if (FUSED) {
@@ -369,20 +369,44 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     const int nextb = block_suffix_excl_min(local_first, len, S.ws);
     PROF_MARK(1);
 
-    // Positions inside a run (no break bit) are the only ones that need the run analysis; in signal data
-    // they are rare outside the key area.  tok = positions that emit a token, mat = those that are matches.
+    // Positions inside a run (no break bit) are the only ones that need the run analysis, and inside a run
+    // only a few positions can emit a token: the first position of each 258-byte chunk of the run body, and
+    // the last two bytes of the run (a chunk shorter than 3 is sent as literals).  So per maximal in-run
+    // segment of the lane's chunk at most three positions are evaluated — a lane that lies entirely inside
+    // a long run (the svb key area is mostly zeros) does O(1) work instead of O(K).
+    // tok = positions that emit a token, mat = those that are matches.
     uint64_t tok = brk, mat = 0;
     uint32_t nmatch = 0, nextra = 0;
     {
         uint64_t inrun = ~brk & (kk >= 64 ? ~0ull : ((1ull << kk) - 1));
         while (inrun) {
-            const int j = __ffsll((long long)inrun) - 1;
-            inrun &= inrun - 1;
-            const Tok t = token_at(buf, base, j, brk, lastb, nextb);
-            if (t.sym >= 0) {
-                tok |= 1ull << j;
-                atomicAdd(&S.freq[t.sym], 1u);
-                if (t.sym > 256) { mat |= 1ull << j; nmatch++; nextra += t.eb; }
+            const int j0 = __ffsll((long long)inrun) - 1;
+            const uint64_t rest = ~(inrun >> j0);                       // first zero = end of this segment
+            const int seg = rest ? __ffsll((long long)rest) - 1 : 64 - j0;
+            const int j1 = j0 + seg;                                    // segment = chunk positions [j0, j1)
+            inrun &= seg >= 64 ? 0ull : ~(((1ull << seg) - 1) << j0);
+            // run bounds of this segment (same for all its positions)
+            const uint64_t lo = brk & ((1ull << j0) - 1);
+            const int s = lo ? base + 63 - __clzll((long long)lo) : lastb;
+            const uint64_t hi = j1 < 64 ? (brk >> j1) : 0ull;
+            const int e = hi ? base + j1 + __ffsll((long long)hi) - 1 : nextb;
+            // candidates: chunk starts s+1+258c inside the segment, and the run's last two positions
+            const int p0 = base + j0, p1 = base + j1;
+            const int c0 = (p0 - s - 1 + 257) / 258;
+            int cand[3] = {s + 1 + 258 * c0, e - 2, e - 1};
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int p = cand[q];
+                if (p < p0 || p >= p1) continue;
+                if (q > 0 && p == cand[0]) continue;
+                if (q == 2 && p == cand[1]) continue;
+                const int j = p - base;
+                const Tok t = token_at(buf, base, j, brk, lastb, nextb);
+                if (t.sym >= 0) {
+                    tok |= 1ull << j;
+                    atomicAdd(&S.freq[t.sym], 1u);
+                    if (t.sym > 256) { mat |= 1ull << j; nmatch++; nextra += t.eb; }
+                }
             }
         }
     }
@@ -399,9 +423,11 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     if (tid == 0) atomicAdd(&S.freq[256], 1u);
     __syncthreads();
     PROF_MARK(2);
+    if (dbg == 2) { z.bitpos += S.freq[tid] + S.red[0]; return; }   // tools/stage_time.py cut-off
 
     // ---- B: codes ----
     build_lengths(S, B, S.freq, NLIT, 15, S.lens);
+    if (dbg == 3) { z.bitpos += S.lens[tid]; return; }
     PROF_RESET
     if (FUSED) {   // B is dead from here on: its storage becomes the bit buffer
         for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
@@ -502,6 +528,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     }
     __syncthreads();
     PROF_MARK(9);
+    if (dbg == 4) { z.bitpos += S.red[4] + S.red[6] + S.code[tid]; return; }
     const uint32_t matches = S.red[0], extra = S.red[1];
     const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
     const uint32_t dyn_total = hdr_dyn + S.red[4] + extra + matches * 1;
@@ -590,6 +617,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     uint32_t total_bits;
     const uint32_t start = pos0 + block_excl_add(mybits, S.ws, total_bits);
     PROF_MARK(11);
+    if (dbg == 5) { z.bitpos += start; return; }
     {
         uint32_t widx = (start >> 5) - z.flushed;
         uint32_t accbits = start & 31;
@@ -632,13 +660,14 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
 // block into HBM slot `out` (16-B aligned).  Slot layout: [u64 size][78 9c][block][adler32 BE].
 // obuf: LDS, obuf_words >= max(plen + 64, sizeof(BuildScratch)) / 4; returns total bytes incl. the prefix.
 __device__ __forceinline__ uint32_t zlib_compress_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words,
-                                                        const uint8_t *pay, uint32_t plen, uint8_t *out) {
+                                                        const uint8_t *pay, uint32_t plen, uint8_t *out, uint32_t dbg = 0) {
     const int tid = threadIdx.x;
     ZOut z;
     z.bitpos = 80;   // 64 bits of size prefix + 16 bits of zlib header, both written later
     z.flushed = 0;
     uint32_t adA = 1, adB = 0;
-    deflate_block<true>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB);
+    deflate_block<true>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg);
+    if (dbg) { if (tid == 0) *reinterpret_cast<uint32_t *>(out) = z.bitpos; return 16; }
     z.bitpos = (z.bitpos + 7) & ~7u;
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
     z.bitpos += 32;

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
         return;
     }
     uint8_t *out = p.a.slots + d.out_off;
-    const uint32_t total = zlib_compress_fused(S, obuf, p.obuf_words, pay, plen, out);
+    const uint32_t total = zlib_compress_fused(S, obuf, p.obuf_words, pay, plen, out, p.dbg);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
     PROF_MARK(13);
 #ifdef S5_PROFILE
@@ -213,18 +213,43 @@ __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list
     }
 }
 
-// K1 alone (BASELINE config 2): svb-zd blob of each read at slots + out_off.
+// K1 alone (BASELINE config 2): svb-zd blob of each read at slots + out_off.  The blob is assembled in LDS
+// (p.pay_cap bytes) and leaves as coalesced 16-B stores; a read whose blob does not fit is written
+// straight to HBM byte-wise (correct for any length, slower).
 __global__ __launch_bounds__(NT) void k_svbzd_encode(EncParams p) {
     __shared__ uint32_t ws[16];
     const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
     const s5gpu_read_desc_t d = p.a.desc[r];
     const int16_t *sig = p.a.sig + d.sig_off;
     uint8_t *blob = p.a.slots + d.out_off;
     const uint32_t n = d.n_samples, nk = (n + 3) >> 2;
-    uint8_t *keys = blob + 4, *data = keys + nk;
     uint32_t total = 0;
+    bool in_lds = (uint64_t)4 + nk + n <= p.pay_cap;
+    if (in_lds) {
+        uint8_t *keys = smem + 4, *data = keys + nk;
+        const uint32_t room = p.pay_cap - 4 - nk;
+        for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) {
+            const uint32_t t = svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws, room - total);
+            if (t > room - total) { in_lds = false; break; }   // uniform
+            total += t;
+        }
+    }
+    if (in_lds) {
+        if (tid < 4) smem[tid] = (uint8_t)(n >> (8 * tid));
+        __syncthreads();
+        const uint32_t len = 4 + nk + total;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(smem);
+        uint4 *d4 = reinterpret_cast<uint4 *>(blob);   // slot is 16-B aligned and has >= 16 spare bytes
+        for (uint32_t i = tid; i < (len + 15) / 16; i += NT) d4[i] = s4[i];
+        if (tid == 0) p.a.out_len[r] = len;
+        return;
+    }
+    __syncthreads();
+    uint8_t *keys = blob + 4, *data = keys + nk;
+    total = 0;
     for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) total += svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws, OVF);
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         *reinterpret_cast<uint32_t *>(blob) = n;
         p.a.out_len[r] = 4 + nk + total;
     }
@@ -521,6 +546,7 @@ static int set_lds_attrs() {
     if (g_attr_done) return S5GPU_OK;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svbzd_encode), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     g_attr_done = true;
     return S5GPU_OK;
 }
@@ -620,8 +646,13 @@ extern "C" int s5gpu_svbzd_encode_dev(const s5gpu_encode_args_t *a, void *stream
     EncParams p;
     p.a = *a;
     p.dbg = 0;
-    p.obuf_words = 0; p.pay_cap = 0;
-    hipLaunchKernelGGL(k_svbzd_encode, dim3(a->n_reads), dim3(NT), 0, (hipStream_t)stream_, p);
+    p.obuf_words = 0;
+    // LDS for one blob at ~1.55 bytes/sample (max_payload is the 3.25 bytes/sample bound), at most 64 KiB
+    uint64_t cap = a->lds_payload_cap ? a->lds_payload_cap : (uint64_t)a->max_payload * 155 / 325 + 128;
+    if (cap > 64 * 1024) cap = 64 * 1024;
+    p.pay_cap = (uint32_t)((cap + 15) & ~15ull);
+    if ((rc = set_lds_attrs())) return rc;
+    hipLaunchKernelGGL(k_svbzd_encode, dim3(a->n_reads), dim3(NT), p.pay_cap, (hipStream_t)stream_, p);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }
