@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-/* names from /root/reference/src/misc.c:253-263; values = on-disk codes */
+/* names from /root/reference/src/misc.c:253-263 (API enum; the on-disk codes of Appendix A.1 are mapped in blow5_file.c) */
 enum slow5_press_method {
     SLOW5_COMPRESS_NONE = 0,
     SLOW5_COMPRESS_ZLIB = 1,
@@ -70,18 +70,29 @@ struct slow5_rec {                            /* field uses: src/read_fast5.c:66
 };
 typedef struct slow5_rec slow5_rec_t;
 
+struct slow5_version { uint8_t major, minor, patch; };   /* src/stats.c:98 prints header->version.{major,minor,patch} */
+struct slow5_hdr {                            /* framing view of the header: the attribute API is out of scope */
+    struct slow5_version version;
+    uint32_t num_read_groups;                 /* src/stats.c:109 */
+    char *data;                               /* the header text exactly as stored after the u32 length (Appendix A.1) */
+    uint32_t data_len;
+};
+typedef struct slow5_hdr slow5_hdr_t;
+struct slow5_idx;                             /* read_id -> (offset, size), Appendix A.5 */
+
 struct slow5_file {                           /* fields read at src/stats.c:98-114, src/quickcheck.c:88-89 */
     FILE *fp;
     enum slow5_fmt format;
     struct slow5_press *compress;
-    void *header;
-    void *index;
-    struct { const char *pathname; } meta;
+    struct slow5_hdr *header;
+    struct slow5_idx *index;
+    struct { const char *pathname; uint64_t start_rec_offset; } meta;
 };
 typedef struct slow5_file slow5_file_t;
 
 extern __thread int slow5_errno;              /* thread-local like slow5lib's (workers run concurrently) */
-enum { SLOW5_ERR_OK = 0, SLOW5_ERR_ARG = -2, SLOW5_ERR_MEM = -10, SLOW5_ERR_PRESS = -13, SLOW5_ERR_RECPARSE = -15,
+enum { SLOW5_ERR_OK = 0, SLOW5_ERR_EOF = -1, SLOW5_ERR_ARG = -2, SLOW5_ERR_TRUNC = -3, SLOW5_ERR_IO = -5, SLOW5_ERR_NOIDX = -6,
+       SLOW5_ERR_NOTFOUND = -7, SLOW5_ERR_MEM = -10, SLOW5_ERR_PRESS = -13, SLOW5_ERR_MAGIC = -14, SLOW5_ERR_RECPARSE = -15,
        SLOW5_ERR_OTH = -20 };
 
 struct slow5_press *slow5_press_init(slow5_press_method_t method);
@@ -101,6 +112,25 @@ int slow5_rec_depress_parse(char **mem, size_t *bytes, const char *read_id, stru
                             struct slow5_file *s5p);
 struct slow5_rec *slow5_rec_init(void);
 void slow5_rec_free(struct slow5_rec *read);
+
+/* ---- BLOW5 file framing (layouts: Appendix A.1/A.2/A.4/A.5, test/misc/make_blow5.c:11-101) ----
+ * Only what view / merge / get need around the press path: open + header, sequential record framing, header and
+ * EOF writers, and the read_id index.  BLOW5 only. */
+slow5_file_t *slow5_open(const char *pathname, const char *mode);                 /* src/view.c:192, "r" only */
+int slow5_close(slow5_file_t *s5p);
+/* next record's bytes without the u64 size prefix, malloc'd; NULL + slow5_errno = SLOW5_ERR_EOF at the end
+ * marker (src/view.c:265-278) */
+void *slow5_get_next_mem(size_t *n, const slow5_file_t *s5p);
+/* 64-byte binary header + u32 length + header text; the version is raised to 0.2.0 when a signal press is set
+ * (fixture exp_1_lossless_zlib_svb_v0.2.0.blow5 vs exp_1_lossless_zlib.blow5).  Returns bytes written or -1. */
+int slow5_hdr_fwrite(FILE *fp, struct slow5_hdr *header, enum slow5_fmt format, slow5_press_method_t comp);
+long slow5_eof_fwrite(FILE *fp);                                                  /* "5WOLB", src/view.c:313 */
+int slow5_idx_create(slow5_file_t *s5p);   /* writes <pathname>.idx (slow5tools index, src/index.c) */
+int slow5_idx_load(slow5_file_t *s5p);     /* loads <pathname>.idx, building it first if absent (src/get.c:286) */
+void slow5_idx_unload(slow5_file_t *s5p);
+/* raw record bytes of read_id (pread by index), malloc'd; the decode half of slow5_get goes through the batch hooks */
+void *slow5_get_mem(const char *read_id, size_t *n, const slow5_file_t *s5p);
+int slow5_get(const char *read_id, struct slow5_rec **read, slow5_file_t *s5p);   /* src/get.c:45 */
 
 /* ---- batch hooks: one call per db_t batch instead of work_db(core, db, callback) ----
  * view / merge worker (src/view.c:35-57, src/merge.c:43-70): decode n input records, optionally rewrite

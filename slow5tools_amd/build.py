@@ -8,9 +8,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libslow5gpu.so")
+S5VIEW = os.path.join(HERE, "s5view")
 
 HIP_SOURCES = ["kernels.hip", "host_api.hip"]
-C_SOURCES = ["slow5_compat.c"]
+C_SOURCES = ["slow5_compat.c", "blow5_file.c"]
 DEPS = ["dev_common.h", "deflate_dev.h", "inflate_dev.h", "svb_dev.h",
         os.path.join(ROOT, "include", "slow5gpu.h"), os.path.join(ROOT, "include", "slow5_compat.h")]
 
@@ -54,6 +55,14 @@ def build(force=False, verbose=False):
         objs.append(o)
     if force or _newer(LIB, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    # the view-loop example / end-to-end harness (plain C against the two public headers)
+    ex = os.path.join(ROOT, "examples", "s5view.c")
+    if os.path.exists(ex) and (force or _newer(S5VIEW, [ex, LIB] + deps)):
+        cmd = ["gcc", "-O2", "-g", "-Wall", "-std=c11", "-I", os.path.join(ROOT, "include"), ex, "-o", S5VIEW,
+               "-L", HERE, "-lslow5gpu", "-Wl,-rpath," + HERE]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

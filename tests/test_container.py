@@ -1,0 +1,208 @@
+"""BLOW5 container framing + index through include/slow5_compat.h, and the end-to-end view loop
+(examples/s5view.c).  Mirrors the reference's golden-file diffs: test/test_view.sh:142-149 (zlib+svb -> uncompressed),
+test/test_index.sh cases 3 and 4 (.idx byte-identical), test/test_get.sh."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+from blow5_fixture import Blow5, golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+S5VIEW = os.path.join(ROOT, "slow5tools_amd", "s5view")
+
+
+class Version(C.Structure):
+    _fields_ = [("major", C.c_uint8), ("minor", C.c_uint8), ("patch", C.c_uint8)]
+
+
+class Hdr(C.Structure):
+    _fields_ = [("version", Version), ("num_read_groups", C.c_uint32), ("data", C.c_void_p), ("data_len", C.c_uint32)]
+
+
+class InnerPress(C.Structure):
+    _fields_ = [("method", C.c_int), ("stream", C.c_void_p)]
+
+
+class Press(C.Structure):
+    _fields_ = [("record_press", C.POINTER(InnerPress)), ("signal_press", C.POINTER(InnerPress))]
+
+
+class File(C.Structure):
+    _fields_ = [("fp", C.c_void_p), ("format", C.c_int), ("compress", C.POINTER(Press)), ("header", C.POINTER(Hdr)),
+                ("index", C.c_void_p), ("pathname", C.c_char_p), ("start_rec_offset", C.c_uint64)]
+
+
+class PressMethod(C.Structure):
+    _fields_ = [("record_method", C.c_int), ("signal_method", C.c_int)]
+
+
+@pytest.fixture(scope="module")
+def L():
+    from slow5tools_amd import _lib
+
+    lib = _lib.lib()
+    lib.slow5_open.restype = C.POINTER(File)
+    lib.slow5_open.argtypes = [C.c_char_p, C.c_char_p]
+    lib.slow5_close.argtypes = [C.POINTER(File)]
+    lib.slow5_get_next_mem.restype = C.c_void_p
+    lib.slow5_get_next_mem.argtypes = [C.POINTER(C.c_size_t), C.POINTER(File)]
+    lib.slow5_hdr_fwrite.argtypes = [C.c_void_p, C.POINTER(Hdr), C.c_int, PressMethod]
+    lib.slow5_eof_fwrite.restype = C.c_long
+    lib.slow5_eof_fwrite.argtypes = [C.c_void_p]
+    lib.slow5_idx_load.argtypes = [C.POINTER(File)]
+    lib.slow5_get_mem.restype = C.c_void_p
+    lib.slow5_get_mem.argtypes = [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(File)]
+    return lib
+
+
+libc = C.CDLL(None)
+libc.fopen.restype = C.c_void_p
+libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+libc.fclose.argtypes = [C.c_void_p]
+libc.free.argtypes = [C.c_void_p]
+
+
+def _errno(L):
+    return C.c_int.in_dll(L, "slow5_errno").value if False else None   # thread-local: not readable via in_dll
+
+
+@pytest.mark.parametrize("name", ["exp_1_lossless_zlib_svb_v0.2.0.blow5", "example_multi_rg_v0.2.0.blow5", "exp_1_lossless.blow5",
+                                  "merged_expected_zlib_svb.blow5"])
+def test_open_and_sequential_framing(L, name):
+    ref = Blow5(golden(name))
+    f = L.slow5_open(golden(name).encode(), b"r")
+    assert f
+    h = f.contents.header.contents
+    assert (h.version.major, h.version.minor, h.version.patch) == ref.version
+    assert h.num_read_groups == ref.num_read_groups
+    assert C.string_at(h.data, h.data_len) == ref.header_text
+    # API enum: record none/zlib = 0/1, signal none/svb-zd = 0/2
+    assert f.contents.compress.contents.record_press.contents.method == ref.rec_method
+    assert f.contents.compress.contents.signal_press.contents.method == (2 if ref.sig_method == 1 else 0)
+    got = []
+    n = C.c_size_t()
+    while True:
+        p = L.slow5_get_next_mem(C.byref(n), f)
+        if not p:
+            break
+        got.append(C.string_at(p, n.value))
+        libc.free(p)
+    assert got == ref.records
+    L.slow5_close(f)
+
+
+def test_open_rejects_bad_files(L, tmp_path):
+    bad = tmp_path / "bad.blow5"
+    bad.write_bytes(b"SLOW5\x01" + bytes(100))
+    assert not L.slow5_open(str(bad).encode(), b"r")
+    trunc = tmp_path / "trunc.blow5"
+    trunc.write_bytes(open(golden("sp1_dna.blow5"), "rb").read()[:40])
+    assert not L.slow5_open(str(trunc).encode(), b"r")
+    assert not L.slow5_open(str(tmp_path / "missing.blow5").encode(), b"r")
+    # a record cut short is reported by the sequential reader, not silently dropped (quickcheck-style)
+    cut = tmp_path / "cut.blow5"
+    raw = open(golden("sp1_dna.blow5"), "rb").read()
+    cut.write_bytes(raw[:-2000])
+    f = L.slow5_open(str(cut).encode(), b"r")
+    assert f
+    n = C.c_size_t()
+    k = 0
+    while True:
+        p = L.slow5_get_next_mem(C.byref(n), f)
+        if not p:
+            break
+        libc.free(p)
+        k += 1
+    assert k < 5
+    L.slow5_close(f)
+
+
+def test_header_writer_reproduces_golden_headers(L, tmp_path):
+    """header of the v0.1.0 uncompressed file written for zlib+svb-zd == header bytes of the reference's
+    zlib+svb golden (version raised to 0.2.0, press codes 1/1); same-method rewrite == original"""
+    src = L.slow5_open(golden("exp_1_lossless.blow5").encode(), b"r")
+    out = tmp_path / "h.bin"
+    fp = libc.fopen(str(out).encode(), b"wb")
+    nb = L.slow5_hdr_fwrite(fp, src.contents.header, 2, PressMethod(1, 2))
+    assert L.slow5_eof_fwrite(fp) == 5
+    libc.fclose(fp)
+    want = Blow5(golden("exp_1_lossless_zlib_svb_v0.2.0.blow5"))
+    wrote = out.read_bytes()
+    assert nb == len(wrote) - 5 and wrote[-5:] == b"5WOLB"
+    assert wrote[:-5] == want.raw[: 68 + len(want.header_text)]
+    fp = libc.fopen(str(out).encode(), b"wb")
+    L.slow5_hdr_fwrite(fp, src.contents.header, 2, PressMethod(0, 0))
+    libc.fclose(fp)
+    orig = Blow5(golden("exp_1_lossless.blow5"))
+    assert out.read_bytes() == orig.raw[: 68 + len(orig.header_text)]
+    L.slow5_close(src)
+
+
+def test_index_load_and_get_mem(L, tmp_path):
+    shutil.copy(golden("example_multi_rg_v0.2.0.blow5"), tmp_path / "f.blow5")
+    shutil.copy(golden("example_multi_rg_v0.2.0.blow5.idx.exp"), tmp_path / "f.blow5.idx")
+    ref = Blow5(golden("example_multi_rg_v0.2.0.blow5"))
+    f = L.slow5_open(str(tmp_path / "f.blow5").encode(), b"r")
+    assert L.slow5_idx_load(f) == 0
+    n = C.c_size_t()
+    import zlib
+
+    for rec in ref.records:
+        rid = zlib.decompress(rec)[2:38]
+        p = L.slow5_get_mem(rid, C.byref(n), f)
+        assert p and C.string_at(p, n.value) == rec
+        libc.free(p)
+    assert not L.slow5_get_mem(b"no-such-read", C.byref(n), f)
+    L.slow5_close(f)
+
+
+# ---------------------------------------------------------------- end to end on the GPU
+def _run(*args):
+    r = subprocess.run([S5VIEW] + [str(a) for a in args], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+@pytest.mark.gpu
+def test_view_zlib_svb_to_uncompressed_is_byte_identical_to_golden(tmp_path):
+    out = tmp_path / "o.blow5"
+    _run(golden("exp_1_lossless_zlib_svb_v0.2.0.blow5"), out, "none", "none")
+    assert out.read_bytes() == open(golden("exp_1_lossless_v0.2.0.blow5"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_index_cases_3_and_4_of_the_reference(tmp_path):
+    src = tmp_path / "example_multi_rg_v0.2.0.blow5"
+    shutil.copy(golden("example_multi_rg_v0.2.0.blow5"), src)
+    _run("--index", src)                                                     # test/test_index.sh case 3
+    assert open(str(src) + ".idx", "rb").read() == open(golden("example_multi_rg_v0.2.0.blow5.idx.exp"), "rb").read()
+    nn = tmp_path / "example_multi_rg_v0.2.0_none_none.blow5"
+    _run(src, nn, "none", "none")                                            # case 4: view -c none -s none, then index
+    _run("--index", nn)
+    assert open(str(nn) + ".idx", "rb").read() == open(golden("example_multi_rg_v0.2.0_none_none.blow5.idx.exp"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_view_roundtrip_and_get(tmp_path):
+    a, b, c = tmp_path / "a.blow5", tmp_path / "b.blow5", tmp_path / "c.blow5"
+    _run(golden("merged_expected_zlib_svb.blow5"), a, "none", "none", 4)     # batches of 4: crosses a batch boundary
+    _run(a, b, "zlib", "svb-zd", 3)
+    _run(b, c, "none", "none")
+    assert a.read_bytes() == c.read_bytes()
+    fb = Blow5(str(b))
+    ref = Blow5(golden("merged_expected_zlib_svb.blow5"))
+    assert fb.version == (0, 2, 0) and fb.rec_method == 1 and fb.sig_method == 1 and fb.header_text == ref.header_text
+    import zlib
+
+    assert [zlib.decompress(r) for r in fb.records] == [zlib.decompress(r) for r in ref.records]
+    assert sum(map(len, fb.records)) <= 1.02 * sum(map(len, ref.records))
+    rid = zlib.decompress(ref.records[2])[2:38].decode()
+    r = _run("--get", b, rid)
+    d = ob.rec_parse(zlib.decompress(ref.records[2]), 1)
+    f = r.stdout.strip().split("\t")
+    assert f[0] == rid and int(f[2]) == len(d["signal"]) and f[3] == ",".join(str(int(x)) for x in d["signal"][:8])
