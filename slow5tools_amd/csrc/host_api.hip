@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/slow5gpu.h"
@@ -142,6 +143,18 @@ extern "C" int s5gpu_event_destroy(void *ev) {
 
 static inline uint64_t up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
+// host-side packing / unpacking of a batch is plain memcpy work: spread it over a few threads
+template <class F>
+static void parallel_for(uint32_t n, uint64_t bytes, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = hw ? (hw < 16 ? hw : 16) : 4;
+    if (bytes < (8u << 20) || n < 64 || nt < 2) { fn(0u, n); return; }
+    std::vector<std::thread> th;
+    const uint32_t step = (n + nt - 1) / nt;
+    for (uint32_t lo = 0; lo < n; lo += step) th.emplace_back(fn, lo, lo + step < n ? lo + step : n);
+    for (auto &t : th) t.join();
+}
+
 // The whole batch in one call: H2D of signals/headers, one launch, D2H of the slots, one malloc per
 // record (the ownership contract of slow5_rec_to_mem: caller frees each buffer, src/view.c:298).
 extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
@@ -176,18 +189,20 @@ extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const u
     const size_t sig_bytes = (size_t)so * 2 + 64, in_bytes = up(sig_bytes, 64) + up(ho + 64, 64) + up(ao + 64, 64) + sizeof(s5gpu_read_desc_t) * n;
     if ((rc = c->h_in.reserve(in_bytes)) || (rc = c->d_sig.reserve(sig_bytes)) || (rc = c->d_hdr.reserve(ho + 64)) ||
         (rc = c->d_aux.reserve(ao + 64)) || (rc = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * n)) ||
-        (rc = c->d_slots.reserve(oo + 64)) || (rc = c->d_len.reserve(4ull * n)) || (rc = c->h_out.reserve(oo + 64 + 4ull * n)))
+        (rc = c->d_slots.reserve(oo + 64)) || (rc = c->d_len.reserve(4ull * n)) || (rc = c->h_out.reserve(up(4ull * n, 64) + 64)))
         return rc;
     if ((rc = c->d_ovf.reserve(4ull * n + 64))) return rc;
     // pack into pinned staging
     uint8_t *hs = (uint8_t *)c->h_in.p;
     uint8_t *hh = hs + up(sig_bytes, 64), *ha = hh + up(ho + 64, 64), *hd = ha + up(ao + 64, 64);
-    for (uint32_t i = 0; i < n; i++) {
-        const s5gpu_read_desc_t &d = desc[i];
-        if (d.n_samples) memcpy(hs + 2 * d.sig_off, sig[i], 2ull * d.n_samples);
-        memcpy(hh + d.hdr_off, hdr[i], d.hdr_len);
-        if (d.aux_len) memcpy(ha + d.aux_off, aux[i], d.aux_len);
-    }
+    parallel_for(n, (uint64_t)so * 2, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; i++) {
+            const s5gpu_read_desc_t &d = desc[i];
+            if (d.n_samples) memcpy(hs + 2 * d.sig_off, sig[i], 2ull * d.n_samples);
+            memcpy(hh + d.hdr_off, hdr[i], d.hdr_len);
+            if (d.aux_len) memcpy(ha + d.aux_off, aux[i], d.aux_len);
+        }
+    });
     memcpy(hd, desc.data(), sizeof(s5gpu_read_desc_t) * n);
     HIP_TRY(hipMemcpyAsync(c->d_sig.p, hs, (size_t)so * 2, hipMemcpyHostToDevice, c->st));
     HIP_TRY(hipMemcpyAsync(c->d_hdr.p, hh, ho, hipMemcpyHostToDevice, c->st));
@@ -203,31 +218,42 @@ extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const u
     a.lds_payload_cap = 0;
     a.ovf = (uint32_t *)c->d_ovf.p;
     if ((rc = s5gpu_encode_dev(&a, c->st))) return rc;
+    // slots are worst-case sized: gather them on the device into the contiguous record stream (the bytes the
+    // ordered fwrite loop emits), bring back only what was produced, then hand out one malloc per record
     uint8_t *ho_len = (uint8_t *)c->h_out.p;
-    uint8_t *ho_slots = ho_len + up(4ull * n, 64);
     HIP_TRY(hipMemcpyAsync(ho_len, c->d_len.p, 4ull * n, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     const uint32_t *lens = (const uint32_t *)ho_len;
-    // D2H only the bytes that were produced: one copy per run of slots would need a compaction on device;
-    // slots are worst-case sized, so copy each record's prefix individually when that is much smaller.
-    uint64_t produced = 0;
-    for (uint32_t i = 0; i < n; i++) produced += lens[i];
-    if (c->h_out.cap < up(4ull * n, 64) + oo + 64) return S5GPU_ERR_NOMEM;
-    if (produced * 3 < oo && n <= 65536) {
-        for (uint32_t i = 0; i < n; i++)
-            HIP_TRY(hipMemcpyAsync(ho_slots + desc[i].out_off, (uint8_t *)c->d_slots.p + desc[i].out_off, lens[i], hipMemcpyDeviceToHost, c->st));
-    } else {
-        HIP_TRY(hipMemcpyAsync(ho_slots, c->d_slots.p, oo, hipMemcpyDeviceToHost, c->st));
-    }
-    HIP_TRY(hipStreamSynchronize(c->st));
+    std::vector<uint64_t> off(n + 1);
+    off[0] = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (lens[i] < 8 || lens[i] > desc[i].slot_cap) { s5gpu_set_error("read %u: device produced an impossible length %u", i, lens[i]); return S5GPU_ERR_HIP; }
-        void *b = malloc(lens[i]);
-        if (!b) { for (uint32_t j = 0; j < i; j++) { free(out[j]); out[j] = NULL; } return S5GPU_ERR_NOMEM; }
-        memcpy(b, ho_slots + desc[i].out_off, lens[i]);
-        out[i] = b;
-        out_len[i] = lens[i];
+        off[i + 1] = off[i] + lens[i];
     }
+    const uint64_t produced = off[n];
+    if ((rc = c->d_pay.reserve(produced + 64)) || (rc = c->d_fields.reserve(8ull * (n + 1) + 8ull * (n / 1024 + 8))) ||
+        (rc = c->h_out.reserve(up(4ull * n, 64) + produced + 64)))
+        return rc;
+    lens = (const uint32_t *)c->h_out.p;   // h_out may have moved; lens were consumed into off[] already
+    uint64_t *d_off = (uint64_t *)c->d_fields.p, *d_tmp = d_off + (n + 1);
+    if ((rc = s5gpu_compact_dev(n, (const s5gpu_read_desc_t *)c->d_desc.p, (const uint8_t *)c->d_slots.p, (const uint32_t *)c->d_len.p,
+                                d_off, (uint8_t *)c->d_pay.p, d_tmp, c->st)))
+        return rc;
+    uint8_t *ho_stream = (uint8_t *)c->h_out.p + up(4ull * n, 64);
+    HIP_TRY(hipMemcpyAsync(ho_stream, c->d_pay.p, produced, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    int oom = 0;
+    parallel_for(n, produced, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; i++) {
+            const size_t len = (size_t)(off[i + 1] - off[i]);
+            void *b = malloc(len);
+            if (!b) { oom = 1; out[i] = NULL; continue; }
+            memcpy(b, ho_stream + off[i], len);
+            out[i] = b;
+            out_len[i] = len;
+        }
+    });
+    if (oom) { for (uint32_t j = 0; j < n; j++) { free(out[j]); out[j] = NULL; } return S5GPU_ERR_NOMEM; }
     return S5GPU_OK;
 }
 
