@@ -55,7 +55,13 @@ struct BuildScratchT {
     uint16_t npar[CAP];             // internal node -> parent
     uint16_t rsym[CAP];             // rank -> symbol
 };
-typedef BuildScratchT<288> BuildScratch;
+// Scratch of the counting sort of the 286 lit/len frequencies (lives right behind the build scratch).
+struct SortScratch {
+    uint32_t bm[64 * 9];     // per frequency bucket: 288-bit membership bitmap of its symbols
+    uint32_t cnt[64];        // symbols per bucket (bucket = min(freq, 63))
+    uint32_t ovl[288];       // keys of the symbols in the overflow bucket (freq >= 63), in symbol order
+};
+struct BuildScratch : BuildScratchT<288> { SortScratch sort; };
 
 struct DeflShared {
     alignas(16) uint32_t freq[320];   // histogram: [0,288) lit/len, [288,320) dist
@@ -89,47 +95,77 @@ __device__ __forceinline__ void put_bits(uint32_t *obuf, const ZOut &z, uint32_t
 
 // ---- length-limited Huffman code lengths for freq[0..n4), n <= 2*NT ----
 // freq must be 16-B aligned, readable (and zero) up to the next multiple of 4 entries.
-template <int CAP>
-__device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> &B, const uint32_t *freq, int n, int maxbits,
-                                              uint8_t *lens) {
-    const int tid = threadIdx.x;
+// WAVE = true: the whole construction runs inside the calling wave64 (n <= 64), with wave-scope syncs only.
+template <int CAP, bool WAVE = false>
+__device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> &B, SortScratch *Q, const uint32_t *freq, int n,
+                                              int maxbits, uint8_t *lens) {
+    const int tid = WAVE ? lane_id() : (int)threadIdx.x;
+    constexpr int NTH = WAVE ? 64 : NT;
+    auto sync = [&]() { if (WAVE) wave_sync(); else __syncthreads(); };
     PROF_DECL
-    for (int s = tid; s < n; s += NT) lens[s] = 0;
+    for (int s = tid; s < n; s += NTH) lens[s] = 0;
     if (tid < 16) { S.blcount[tid] = 0; S.icount[tid] = 0; }
-    // Rank sort on unique keys (freq << 9 | symbol; unused symbols = ~0): rank = number of smaller keys.
-    // Keys go to LDS once (S.nf is free until the merge), then one compare + add per element, read as
-    // 16-B LDS broadcasts.  Symbols >= 256 (at most 30 of them) are ranked by wave 0 only.
+    // Sort the symbols by (frequency, symbol).
     const uint32_t f0 = tid < n ? freq[tid] : 0;
-    const uint32_t f1 = tid + NT < n ? freq[tid + NT] : 0;
+    const uint32_t f1 = !WAVE && tid + NT < n ? freq[tid + NT] : 0;
     const uint32_t key0 = f0 ? (f0 << 9) | (uint32_t)tid : 0xFFFFFFFFu;
     const uint32_t key1 = f1 ? (f1 << 9) | (uint32_t)(tid + NT) : 0xFFFFFFFFu;
-    const int n4 = (n + 3) >> 2;
-    if (tid < 4 * n4) B.nf[tid] = key0;
-    if (tid + NT < 4 * n4) B.nf[tid + NT] = key1;
-    __syncthreads();
     int r0 = 0, r1 = 0, m = 0;
-    {
+    if constexpr (CAP > 64) {
+        // Counting sort, deterministic.  Frequencies are small: bucket = min(freq, 63).  Each bucket keeps a
+        // 288-bit bitmap of its symbols, so a symbol's rank inside its bucket is a popcount of the bits below
+        // it (symbol order), and the bucket's first rank is a 64-entry prefix sum.  Only the overflow bucket
+        // (freq >= 63: a handful of symbols) needs real comparisons, among its own members.
+        for (int i = tid; i < 64 * 9 + 64; i += NT) Q->bm[i] = 0;   // bm and cnt are contiguous
+        sync();
+        const uint32_t b0 = min(f0, 63u), b1 = min(f1, 63u);
+        if (f0) { atomicAdd(&Q->cnt[b0], 1u); atomicOr(&Q->bm[b0 * 9 + (tid >> 5)], 1u << (tid & 31)); }
+        if (f1) { atomicAdd(&Q->cnt[b1], 1u); atomicOr(&Q->bm[b1 * 9 + 8], 1u << (tid & 31)); }   // symbols 256.. sit in word 8
+        sync();
+        if (wave_id() == 0) {   // first rank of every bucket (B.nf is free until the merge)
+            const uint32_t c = Q->cnt[lane_id()];
+            const uint32_t incl = wave_incl_add(c);
+            B.nf[lane_id()] = incl - c;
+            if (lane_id() == 63) B.nf[64] = incl;
+        }
+        uint32_t w0 = 0, w1 = 0;
+        if (f0) {
+            const int w = tid >> 5;
+            w0 = __popc(Q->bm[b0 * 9 + w] & ((1u << (tid & 31)) - 1));
+            for (int q = 0; q < w; q++) w0 += __popc(Q->bm[b0 * 9 + q]);
+            if (b0 == 63) Q->ovl[w0] = key0;
+        }
+        if (f1) {
+            w1 = __popc(Q->bm[b1 * 9 + 8] & ((1u << (tid & 31)) - 1));
+            for (int q = 0; q < 8; q++) w1 += __popc(Q->bm[b1 * 9 + q]);
+            if (b1 == 63) Q->ovl[w1] = key1;
+        }
+        sync();
+        const uint32_t novf = Q->cnt[63];
+        if (f0 && b0 == 63) { w0 = 0; for (uint32_t q = 0; q < novf; q++) w0 += Q->ovl[q] < key0; }
+        if (f1 && b1 == 63) { w1 = 0; for (uint32_t q = 0; q < novf; q++) w1 += Q->ovl[q] < key1; }
+        r0 = (int)(B.nf[b0] + w0);
+        r1 = (int)(B.nf[b1] + w1);
+        m = (int)B.nf[64];
+    } else {
+        // small alphabets (the 19-symbol code-length code): rank = number of smaller keys
+        const int n4 = (n + 3) >> 2;
+        if (tid < 4 * n4) B.nf[tid] = key0;
+        if (tid + NT < 4 * n4) B.nf[tid + NT] = key1;
+        sync();
         const uint4 *k4 = reinterpret_cast<const uint4 *>(B.nf);
-#pragma unroll 8
         for (int q = 0; q < n4; q++) {
             const uint4 v = k4[q];
             r0 += (v.x < key0) + (v.y < key0) + (v.z < key0) + (v.w < key0);
+            r1 += (v.x < key1) + (v.y < key1) + (v.z < key1) + (v.w < key1);
+            m += (v.x != 0xFFFFFFFFu) + (v.y != 0xFFFFFFFFu) + (v.z != 0xFFFFFFFFu) + (v.w != 0xFFFFFFFFu);
         }
-        if (wave_id() == 0 && n > NT) {
-#pragma unroll 8
-            for (int q = 0; q < n4; q++) {
-                const uint4 v = k4[q];
-                r1 += (v.x < key1) + (v.y < key1) + (v.z < key1) + (v.w < key1);
-            }
-        }
-        for (int b = 0; b < 4 * n4; b += 64)
-            m += __popcll(__ballot(b + lane_id() < 4 * n4 && B.nf[b + lane_id()] != 0xFFFFFFFFu));
     }
-    __syncthreads();
+    sync();
     if (f0) { B.lf[r0] = f0; B.rsym[r0] = (uint16_t)tid; }
     if (f1) { B.lf[r1] = f1; B.rsym[r1] = (uint16_t)(tid + NT); }
-    __syncthreads();
-    PROF_MARK(n > 19 ? 3 : 8);
+    sync();
+    if (!WAVE) PROF_MARK(3);
     if (m <= 1) {   // degenerate: keep the code complete with two 1-bit codes
         if (tid == 0) {
             int sym = m ? B.rsym[0] : 0;
@@ -137,10 +173,10 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             lens[sym == 0 ? 1 : 0] = 1;
             S.blcount[1] = 2;
         }
-        __syncthreads();
+        sync();
         return;
     }
-    if (wave_id() == 0) {
+    if (WAVE || wave_id() == 0) {
         // Huffman tree by ROUNDS instead of one merge per step (the serial two-queue loop costs ~400
         // cycles per merge on a GPU).  Leaves ascending in S.lf, internal nodes are produced ascending
         // into S.nf.  Per round, one wave64: take the next 64 leaves and the next 64 nodes, bitonic-merge
@@ -192,16 +228,16 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             k += c >> 1;
         }
     }
-    __syncthreads();
-    PROF_MARK(n > 19 ? 4 : 8);
+    sync();
+    if (!WAVE) PROF_MARK(4);
     // Depth of every internal node by a parallel parent walk (root = node m-2, depth 0).  Leaves at
     // depth L = 2 * I[L-1] - I[L]; sorted order makes depth monotone in rank, so counts are enough.
-    for (int q = tid; q < m - 1; q += NT) {
+    for (int q = tid; q < m - 1; q += NTH) {
         int d = 0, p = q;
         while (p != m - 2) { p = B.npar[p]; d++; }
         atomicAdd(&S.icount[min(d, maxbits)], 1u);
     }
-    __syncthreads();
+    sync();
     if (tid == 0) {
         uint32_t used = 0;
         for (int L = 1; L < maxbits; L++) {
@@ -221,20 +257,20 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             }
         }
     }
-    __syncthreads();
-    for (int r = tid; r < m; r += NT) {   // rarest symbols get the longest codes
+    sync();
+    for (int r = tid; r < m; r += NTH) {   // rarest symbols get the longest codes
         uint32_t cum = 0;
         int L = maxbits;
         for (; L > 1; L--) { cum += S.blcount[L]; if ((uint32_t)r < cum) break; }
         lens[B.rsym[r]] = (uint8_t)L;
     }
-    __syncthreads();
-    PROF_MARK(n > 19 ? 5 : 8);
+    sync();
+    if (!WAVE) PROF_MARK(5);
 }
 
 // ---- canonical codes from lengths (wave 0; S.blcount must match lens) ----
-__device__ __forceinline__ void assign_codes(DeflShared &S, const uint8_t *lens, int n, uint32_t *code_out) {
-    if (wave_id() == 0) {
+__device__ __forceinline__ void assign_codes_wave(DeflShared &S, const uint8_t *lens, int n, uint32_t *code_out) {
+    {
         uint32_t next[16];
         uint32_t c = 0;
         next[0] = 0;
@@ -254,7 +290,7 @@ __device__ __forceinline__ void assign_codes(DeflShared &S, const uint8_t *lens,
             if (s < n) code_out[s] = l ? ((__brev(mine) >> (32 - l)) | ((uint32_t)l << 16)) : 0u;
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 __device__ __forceinline__ int fixed_len(int s) { return s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8; }
@@ -426,7 +462,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     if (dbg == 2) { z.bitpos += S.freq[tid] + S.red[0]; return; }   // tools/stage_time.py cut-off
 
     // ---- B: codes ----
-    build_lengths(S, B, S.freq, NLIT, 15, S.lens);
+    build_lengths(S, B, &B.sort, S.freq, NLIT, 15, S.lens);
     if (dbg == 3) { z.bitpos += S.lens[tid]; return; }
     PROF_RESET
     if (FUSED) {   // B is dead from here on: its storage becomes the bit buffer
@@ -434,97 +470,114 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         __syncthreads();
         if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);   // CMF/FLG 78 9c (deflate, 32K window, default level)
     }
-    assign_codes(S, S.lens, NLIT, S.code);
-    PROF_MARK(6);
-    // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
-    if (tid == 0) {
-        S.lens[DOFF] = 1; S.lens[DOFF + 1] = 1;
-        S.code[DOFF] = 0u | (1u << 16); S.code[DOFF + 1] = 1u | (1u << 16);
-        S.hlit = 257;
-    }
-    __syncthreads();
-    if (tid < 29 && S.lens[257 + tid]) atomicMax(&S.hlit, 258u + tid);
-    __syncthreads();
-    {
-        // Run-length code the hlit + 2 code lengths (RFC 1951 3.2.7, symbols 16/17/18), in parallel:
-        // lane t owns positions 2t, 2t+1; run bounds from one prefix-max and one suffix-min scan; every
-        // position decides alone whether it emits an entry; a prefix sum compacts the entries.
-        const int hlit = (int)S.hlit, n = hlit + 2;
-        const int p0 = 2 * tid;
-        int v[2], prevv = -1;
-        if (p0 - 1 >= 0 && p0 - 1 < n) prevv = p0 - 1 < hlit ? S.lens[p0 - 1] : S.lens[DOFF + p0 - 1 - hlit];
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int p = p0 + q;
-            v[q] = p < n ? (p < hlit ? S.lens[p] : S.lens[DOFF + p - hlit]) : -2 - q;   // past the end: never equal
+    // ---- codes, code-length header and block costs.  Wave 0 does everything that is small and sequential in
+    // nature with wave-scope syncs only (no workgroup barrier inside): canonical lit/len codes, the run-length
+    // coding of the code lengths, the 19-symbol code-length Huffman code and its header cost.  Waves 1..3 sum
+    // the dynamic / fixed body costs meanwhile.  One barrier at the end.
+    if (wave_id() == 0) {
+        const int lane = lane_id();
+        assign_codes_wave(S, S.lens, NLIT, S.code);
+        PROF_MARK(6);
+        // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
+        if (lane == 0) {
+            S.lens[DOFF] = 1; S.lens[DOFF + 1] = 1;
+            S.code[DOFF] = 0u | (1u << 16); S.code[DOFF + 1] = 1u | (1u << 16);
         }
-        const bool brk0 = p0 < n && v[0] != prevv, brk1 = p0 + 1 < n && v[1] != v[0];
-        const int local_last = brk1 ? p0 + 1 : brk0 ? p0 : -1;
-        const int local_first = brk0 ? p0 : brk1 ? p0 + 1 : n;
-        const int lastb = block_excl_max(local_last, -1, S.ws);
-        const int nextb = block_suffix_excl_min(local_first, n, S.ws);
-        uint32_t ent[2], nent = 0;
+        int hl = lane < 29 && S.lens[257 + lane] ? 258 + lane : 257;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int p = p0 + q;
-            ent[q] = 0xFFFFFFFFu;
-            if (p >= n) continue;
-            const int s = q == 0 ? (brk0 ? p0 : lastb) : (brk1 ? p0 + 1 : brk0 ? p0 : lastb);
-            const int e = q == 0 ? (brk1 ? p0 + 1 : nextb) : nextb;
-            const int R = e - s, rel = p - s;
-            if (v[q] == 0) {
-                const int c = rel / 138, off = rel - c * 138, Lc = min(138, R - c * 138);
-                if (Lc >= 11) { if (off == 0) ent[q] = 18u | ((uint32_t)(Lc - 11) << 5); }
-                else if (Lc >= 3) { if (off == 0) ent[q] = 17u | ((uint32_t)(Lc - 3) << 5); }
-                else ent[q] = 0;
-            } else if (rel == 0) {
-                ent[q] = (uint32_t)v[q];
-            } else {
-                const int mm = rel - 1, c = mm / 6, off = mm - c * 6, Lc = min(6, R - 1 - c * 6);
-                if (Lc >= 3) { if (off == 0) ent[q] = 16u | ((uint32_t)(Lc - 3) << 5); }
-                else ent[q] = (uint32_t)v[q];
+        for (int d = 32; d >= 1; d >>= 1) hl = max(hl, __shfl_xor(hl, d));
+        const int hlit = hl, n = hlit + 2;
+        if (lane == 0) S.hlit = (uint32_t)hlit;
+        wave_sync();
+        {
+            // Run-length code the hlit + 2 code lengths (RFC 1951 3.2.7, symbols 16/17/18): lane t owns
+            // positions 5t..5t+4; run bounds from a wave prefix-max and suffix-min; every position decides
+            // alone whether it emits an entry; a wave prefix sum compacts the entries.
+            constexpr int PP = 5;
+            const int p0 = PP * lane;
+            int v[PP];
+            int prevv = -1;
+            if (p0 - 1 >= 0 && p0 - 1 < n) prevv = p0 - 1 < hlit ? S.lens[p0 - 1] : S.lens[DOFF + p0 - 1 - hlit];
+            uint32_t bk = 0;
+#pragma unroll
+            for (int q = 0; q < PP; q++) {
+                const int p = p0 + q;
+                v[q] = p < n ? (p < hlit ? S.lens[p] : S.lens[DOFF + p - hlit]) : -2 - q;   // past the end: never equal
+                if (p < n && v[q] != (q == 0 ? prevv : v[q - 1])) bk |= 1u << q;
             }
-            nent += ent[q] != 0xFFFFFFFFu;
+            const int local_last = bk ? p0 + 31 - __clz(bk) : -1;
+            const int local_first = bk ? p0 + __ffs(bk) - 1 : n;
+            int lastb = wave_incl_max(local_last);
+            lastb = __shfl_up(lastb, 1);
+            if (lane == 0) lastb = -1;
+            int nextb = wave_suffix_incl_min(local_first);
+            nextb = __shfl_down(nextb, 1);
+            if (lane == 63) nextb = n;
+            uint32_t ent[PP], nent = 0;
+#pragma unroll
+            for (int q = 0; q < PP; q++) {
+                const int p = p0 + q;
+                ent[q] = 0xFFFFFFFFu;
+                if (p >= n) continue;
+                const uint32_t lo = bk & ((2u << q) - 1), hi = bk >> (q + 1);
+                const int s = lo ? p0 + 31 - __clz(lo) : lastb;
+                const int e = hi ? p + __ffs(hi) : nextb;
+                const int R = e - s, rel = p - s;
+                if (v[q] == 0) {
+                    const int c = rel / 138, off = rel - c * 138, Lc = min(138, R - c * 138);
+                    if (Lc >= 11) { if (off == 0) ent[q] = 18u | ((uint32_t)(Lc - 11) << 5); }
+                    else if (Lc >= 3) { if (off == 0) ent[q] = 17u | ((uint32_t)(Lc - 3) << 5); }
+                    else ent[q] = 0;
+                } else if (rel == 0) {
+                    ent[q] = (uint32_t)v[q];
+                } else {
+                    const int mm = rel - 1, c = mm / 6, off = mm - c * 6, Lc = min(6, R - 1 - c * 6);
+                    if (Lc >= 3) { if (off == 0) ent[q] = 16u | ((uint32_t)(Lc - 3) << 5); }
+                    else ent[q] = (uint32_t)v[q];
+                }
+                nent += ent[q] != 0xFFFFFFFFu;
+            }
+            const uint32_t incl = wave_incl_add(nent);
+            uint32_t at = incl - nent;
+#pragma unroll
+            for (int q = 0; q < PP; q++)
+                if (ent[q] != 0xFFFFFFFFu) {
+                    S.clseq[at++] = (uint16_t)ent[q];
+                    atomicAdd(&S.clfreq[ent[q] & 31], 1u);
+                }
+            if (lane == 63) S.ncl = incl;
         }
-        uint32_t tot;
-        uint32_t at = block_excl_add(nent, S.ws, tot);
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-            if (ent[q] != 0xFFFFFFFFu) {
-                S.clseq[at++] = (uint16_t)ent[q];
-                atomicAdd(&S.clfreq[ent[q] & 31], 1u);
+        wave_sync();
+        PROF_MARK(7);
+        build_lengths<32, true>(S, S.clb, (SortScratch *)nullptr, S.clfreq, 19, 7, S.cllens);
+        assign_codes_wave(S, S.cllens, 19, S.clcode);
+        {
+            const int ncl = (int)S.ncl;
+            uint32_t clb = 0;
+            for (int e = lane; e < ncl; e += 64) {
+                const int sym = S.clseq[e] & 31;
+                clb += S.cllens[sym] + (sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0);
             }
-        if (tid == 0) S.ncl = tot;
-    }
-    __syncthreads();
-    PROF_MARK(7);
-    build_lengths(S, S.clb, S.clfreq, 19, 7, S.cllens);
-    assign_codes(S, S.cllens, 19, S.clcode);
-    PROF_RESET
-
-    // ---- C: cost of the three block types ----
-    {
-        uint32_t dynb = 0, fixb = 0, clb = 0;
-        for (int s = tid; s < NLIT; s += NT) {
+            clb = wave_sum(clb);
+            if (lane == 0) {
+                S.red[6] = clb;
+                const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                int h = 19;
+                while (h > 4 && S.cllens[order[h - 1]] == 0) h--;
+                S.hclen = h;
+            }
+        }
+        PROF_MARK(8);
+    } else {
+        uint32_t dynb = 0, fixb = 0;
+        for (int s = tid - 64; s < NLIT; s += NT - 64) {
             const uint32_t f = S.freq[s];
             dynb += f * S.lens[s];
             fixb += f * fixed_len(s);
         }
-        const int ncl = S.ncl;
-        for (int e = tid; e < ncl; e += NT) {
-            const int sym = S.clseq[e] & 31;
-            clb += S.cllens[sym] + (sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0);
-        }
         dynb = wave_sum(dynb);
         fixb = wave_sum(fixb);
-        clb = wave_sum(clb);
-        if (lane_id() == 0) { atomicAdd(&S.red[4], dynb); atomicAdd(&S.red[5], fixb); atomicAdd(&S.red[6], clb); }
-        if (tid == 0) {
-            const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-            int h = 19;
-            while (h > 4 && S.cllens[order[h - 1]] == 0) h--;
-            S.hclen = h;
-        }
+        if (lane_id() == 0) { atomicAdd(&S.red[4], dynb); atomicAdd(&S.red[5], fixb); }
     }
     __syncthreads();
     PROF_MARK(9);

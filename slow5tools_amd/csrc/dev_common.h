@@ -12,6 +12,12 @@ constexpr int NW = NT / 64;      // wave64 per workgroup
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// same-wave LDS/HBM hand-off: memory ops of one wave execute in order; this only pins the compiler
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---- wave-level scans (64 lanes) ----
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
 #pragma unroll

@@ -17,12 +17,6 @@
 
 namespace s5 {
 
-// same-wave LDS/HBM hand-off: memory ops of one wave execute in order; this only pins the compiler
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 constexpr int INF_LBITS = 10;      // primary lit/len lookup bits
 constexpr int INF_DBITS = 8;       // primary distance lookup bits
 constexpr int INF_IW = 2048;       // input window, bytes
