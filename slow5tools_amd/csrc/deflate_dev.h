@@ -612,6 +612,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     const bool use_fixed = fix_total < dyn_total;
     uint32_t pos0;   // bit position of the first token
     uint32_t dist_bits, dist_code = 0;
+    uint32_t clv[2] = {0, 0}, clnb[2] = {0, 0};   // this lane's two code-length-sequence entries (dynamic only)
     if (use_fixed) {
         for (int s = tid; s < 288; s += NT) S.code[s] = fixed_code(s);
         if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
@@ -619,42 +620,34 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         dist_bits = 5;
         __syncthreads();
     } else {
-        if (tid == 0) {
+        // block header: BFINAL, BTYPE=10, HLIT, HDIST (2 codes), HCLEN in one 17-bit field; the HCLEN 3-bit
+        // code-length-code lengths one per lane
+        const uint32_t hclen = S.hclen;
+        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (2u << 1) | ((S.hlit - 257) << 3) | (1u << 8) | ((hclen - 4) << 13), 17);
+        if (tid < (int)hclen) {
             const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-            uint32_t p = z.bitpos;
-            put_bits(obuf, z, p, (final ? 1u : 0u) | (2u << 1), 3);
-            put_bits(obuf, z, p + 3, S.hlit - 257, 5);
-            put_bits(obuf, z, p + 8, 1, 5);            // HDIST = 2 codes
-            put_bits(obuf, z, p + 13, S.hclen - 4, 4);
-            p += 17;
-            for (uint32_t i = 0; i < S.hclen; i++, p += 3) put_bits(obuf, z, p, S.cllens[order[i]], 3);
+            put_bits(obuf, z, z.bitpos + 17 + 3 * tid, S.cllens[order[tid]], 3);
         }
         // code-length sequence: lane t owns entries 2t, 2t+1
         const int ncl = S.ncl;
-        uint32_t v[2], nb[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int e = 2 * tid + q;
-            v[q] = 0; nb[q] = 0;
             if (e < ncl) {
                 const uint32_t ent = S.clseq[e];
                 const uint32_t sym = ent & 31, cc = S.clcode[sym], cl = cc >> 16;
                 const uint32_t eb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
-                v[q] = (cc & 0xFFFF) | ((ent >> 5) << cl);
-                nb[q] = cl + eb;
+                clv[q] = (cc & 0xFFFF) | ((ent >> 5) << cl);
+                clnb[q] = cl + eb;
             }
         }
-        uint32_t tot;
-        uint32_t off = block_excl_add(nb[0] + nb[1], S.ws, tot);
-        const uint32_t p = z.bitpos + 17 + 3 * S.hclen + off;
-        if (nb[0]) put_bits(obuf, z, p, v[0], nb[0]);
-        if (nb[1]) put_bits(obuf, z, p + nb[0], v[1], nb[1]);
         pos0 = z.bitpos + hdr_dyn;
         dist_bits = 1;
     }
 
     PROF_MARK(10);
-    // ---- tokens: per-lane bit totals -> prefix scan -> pack ----
+    // ---- per-lane bit totals (code-length entries and tokens share ONE prefix scan: the two sums are packed
+    // into one word, 13 bits for the <= 320 * 14 header bits, 19 for the <= 16384 * 15 token bits) ----
     uint32_t mybits = 0;
     {
         uint64_t t = tok, mm = mat;
@@ -667,8 +660,15 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             }
         }
     }
-    uint32_t total_bits;
-    const uint32_t start = pos0 + block_excl_add(mybits, S.ws, total_bits);
+    uint32_t packed_total;
+    const uint32_t packed = block_excl_add((clnb[0] + clnb[1]) | (mybits << 13), S.ws, packed_total);
+    const uint32_t total_bits = packed_total >> 13;
+    const uint32_t start = pos0 + (packed >> 13);
+    if (!use_fixed) {
+        const uint32_t p = z.bitpos + 17 + 3 * S.hclen + (packed & 0x1FFF);
+        if (clnb[0]) put_bits(obuf, z, p, clv[0], clnb[0]);
+        if (clnb[1]) put_bits(obuf, z, p + clnb[0], clv[1], clnb[1]);
+    }
     PROF_MARK(11);
     if (dbg == 5) { z.bitpos += start; return; }
     {
