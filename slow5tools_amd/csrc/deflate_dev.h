@@ -306,7 +306,7 @@ __device__ __forceinline__ uint32_t fixed_code(int s) {
 struct Tok { int sym; uint32_t eb, ev; };   // sym < 0: position covered by a match
 
 // token at position base+j of the block for the lane that owns it
-__device__ __forceinline__ Tok token_at(const uint8_t *buf, int base, int j, uint64_t brk, int lastb, int nextb) {
+__device__ __forceinline__ Tok token_at(const uint8_t *__restrict__ buf, int base, int j, uint64_t brk, int lastb, int nextb) {
     const uint64_t lo = brk & ((2ull << j) - 1);
     const int s = lo ? base + 63 - __clzll((long long)lo) : lastb;
     const uint64_t hi = j < 63 ? (brk >> (j + 1)) : 0ull;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
 // written here once B is dead (caller passes z.bitpos = 80, z.flushed = 0, obuf_words = size to zero).
 template <bool FUSED>
 __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words,
-                                              const uint8_t *buf, int len, bool final, ZOut &z, uint32_t &adA,
+                                              const uint8_t *__restrict__ buf, int len, bool final, ZOut &z, uint32_t &adA,
                                               uint32_t &adB, uint32_t dbg = 0) {
     const int tid = threadIdx.x;
     if (len == 0) {
@@ -391,7 +391,20 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         if (base > 0 && kk > 0) prev = buf[base - 1];
         // the histogram must be zero before the first atomic: the zeroing above is ordered by this barrier
         __syncthreads();
-        for (int j = 0; j < kk; j++) {
+        // four byte loads in flight per step (the compiler will not hoist LDS loads over the LDS atomics itself)
+        int j = 0;
+        for (; j + 4 <= kk; j += 4) {
+            const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
+            if (b0 != prev) { brk |= 1ull << j; atomicAdd(&S.freq[b0], 1u); }
+            if (b1 != b0) { brk |= 2ull << j; atomicAdd(&S.freq[b1], 1u); }
+            if (b2 != b1) { brk |= 4ull << j; atomicAdd(&S.freq[b2], 1u); }
+            if (b3 != b2) { brk |= 8ull << j; atomicAdd(&S.freq[b3], 1u); }
+            prev = b3;
+            a_sum += b0 + b1 + b2 + b3;
+            const uint32_t w = (uint32_t)(len - (base + j));
+            b_sum += w * b0 + (w - 1) * b1 + (w - 2) * b2 + (w - 3) * b3;
+        }
+        for (; j < kk; j++) {
             const int b = buf[base + j];
             if (b != prev) { brk |= 1ull << j; atomicAdd(&S.freq[b], 1u); }
             prev = b;
@@ -651,7 +664,21 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     uint32_t mybits = 0;
     {
         uint64_t t = tok, mm = mat;
-        for (int j = 0; j < kk; j++, t >>= 1, mm >>= 1) {
+        int j = 0;
+        for (; j + 4 <= kk; j += 4, t >>= 4, mm >>= 4) {   // 4 byte loads, then 4 code loads, in flight together
+            const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
+            const uint32_t c0 = S.code[b0] >> 16, c1 = S.code[b1] >> 16, c2 = S.code[b2] >> 16, c3 = S.code[b3] >> 16;
+            const uint32_t lit = (uint32_t)t & ~(uint32_t)mm & 15u;
+            mybits += (lit & 1 ? c0 : 0) + (lit & 2 ? c1 : 0) + (lit & 4 ? c2 : 0) + (lit & 8 ? c3 : 0);
+            uint32_t mt = (uint32_t)t & (uint32_t)mm & 15u;
+            while (mt) {
+                const int q = __ffs(mt) - 1;
+                mt &= mt - 1;
+                const Tok tk = token_at(buf, base, j + q, brk, lastb, nextb);
+                mybits += (S.code[tk.sym] >> 16) + tk.eb + dist_bits;
+            }
+        }
+        for (; j < kk; j++, t >>= 1, mm >>= 1) {
             if (!(t & 1)) continue;
             if (!(mm & 1)) mybits += S.code[buf[base + j]] >> 16;
             else {
@@ -676,22 +703,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         uint32_t accbits = start & 31;
         uint64_t acc = 0;
         uint64_t t = tok, mm = mat;
-        for (int j = 0; j < kk; j++, t >>= 1, mm >>= 1) {
-            if (!(t & 1)) continue;
-            uint32_t v, nb;
-            if (!(mm & 1)) {
-                const uint32_t cc = S.code[buf[base + j]];
-                nb = cc >> 16;
-                v = cc & 0xFFFF;
-            } else {
-                const Tok tk = token_at(buf, base, j, brk, lastb, nextb);
-                const uint32_t cc = S.code[tk.sym];
-                nb = cc >> 16;
-                v = (cc & 0xFFFF) | (tk.ev << nb);
-                nb += tk.eb;
-                v |= dist_code << nb;
-                nb += dist_bits;
-            }
+        auto emit = [&](uint32_t v, uint32_t nb) {
             acc |= (uint64_t)v << accbits;
             accbits += nb;
             if (accbits >= 32) {
@@ -699,6 +711,32 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
                 acc >>= 32;
                 accbits -= 32;
             }
+        };
+        auto emit_match = [&](int j) {
+            const Tok tk = token_at(buf, base, j, brk, lastb, nextb);
+            const uint32_t cc = S.code[tk.sym];
+            uint32_t nb = cc >> 16;
+            uint32_t v = (cc & 0xFFFF) | (tk.ev << nb);
+            nb += tk.eb;
+            v |= dist_code << nb;
+            nb += dist_bits;
+            emit(v, nb);
+        };
+        int j = 0;
+        for (; j + 4 <= kk; j += 4, t >>= 4, mm >>= 4) {
+            const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
+            const uint32_t cc[4] = {S.code[b0], S.code[b1], S.code[b2], S.code[b3]};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (!((t >> q) & 1)) continue;
+                if (!((mm >> q) & 1)) emit(cc[q] & 0xFFFF, cc[q] >> 16);
+                else emit_match(j + q);
+            }
+        }
+        for (; j < kk; j++, t >>= 1, mm >>= 1) {
+            if (!(t & 1)) continue;
+            if (!(mm & 1)) { const uint32_t c1 = S.code[buf[base + j]]; emit(c1 & 0xFFFF, c1 >> 16); }
+            else emit_match(j);
         }
         if (accbits && acc) atomicOr(&obuf[widx], (uint32_t)acc);
     }
