@@ -73,6 +73,7 @@ struct DeflShared {
     uint8_t cllens[20];
     uint32_t blcount[16];
     uint32_t icount[16];     // internal nodes per depth
+    uint32_t clblcount[16], clicount[16];   // the same for the code-length code (built concurrently by wave 0)
     uint32_t ws[16];         // cross-wave scan scratch
     uint32_t red[8];         // 0 matches, 1 extra bits, 2 adler A part, 3 adler B part, 4 dyn bits, 5 fixed bits, 6 cl bits
     uint32_t ncl, hlit, hclen;
@@ -98,13 +99,13 @@ __device__ __forceinline__ void put_bits(uint32_t *obuf, const ZOut &z, uint32_t
 // WAVE = true: the whole construction runs inside the calling wave64 (n <= 64), with wave-scope syncs only.
 template <int CAP, bool WAVE = false>
 __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> &B, SortScratch *Q, const uint32_t *freq, int n,
-                                              int maxbits, uint8_t *lens) {
+                                              int maxbits, uint8_t *lens, uint32_t *blcount, uint32_t *icount) {
     const int tid = WAVE ? lane_id() : (int)threadIdx.x;
     constexpr int NTH = WAVE ? 64 : NT;
     auto sync = [&]() { if (WAVE) wave_sync(); else __syncthreads(); };
     PROF_DECL
     for (int s = tid; s < n; s += NTH) lens[s] = 0;
-    if (tid < 16) { S.blcount[tid] = 0; S.icount[tid] = 0; }
+    if (tid < 16) { blcount[tid] = 0; icount[tid] = 0; }
     // Sort the symbols by (frequency, symbol).
     const uint32_t f0 = tid < n ? freq[tid] : 0;
     const uint32_t f1 = !WAVE && tid + NT < n ? freq[tid + NT] : 0;
@@ -165,18 +166,51 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
     if (f0) { B.lf[r0] = f0; B.rsym[r0] = (uint16_t)tid; }
     if (f1) { B.lf[r1] = f1; B.rsym[r1] = (uint16_t)(tid + NT); }
     sync();
-    if (!WAVE) PROF_MARK(3);
+    PROF_MARK(WAVE ? 8 : 3);
     if (m <= 1) {   // degenerate: keep the code complete with two 1-bit codes
         if (tid == 0) {
             int sym = m ? B.rsym[0] : 0;
             lens[sym] = 1;
             lens[sym == 0 ? 1 : 0] = 1;
-            S.blcount[1] = 2;
+            blcount[1] = 2;
         }
         sync();
         return;
     }
     if (WAVE || wave_id() == 0) {
+      if (m <= 32) {
+        // small alphabet (always the case for the 19-symbol code-length code): same rounds as below with a
+        // 32 + 32 window in ONE register — leaves ascending in lanes 0..31, nodes descending in lanes 32..63
+        const int lane = lane_id();
+        const uint32_t INF = 0xFFFFFFFFu;
+        int i = 0, j = 0, k = 0;
+        while (k < m - 1) {
+            const int qn = 63 - lane;
+            const uint32_t ov = lane < 32 ? (i + lane < m ? B.lf[i + lane] : INF) : (j + qn < k ? B.nf[j + qn] : INF);
+            uint32_t x = ov == INF ? INF : (ov << 8) | (lane < 32 ? (uint32_t)lane : 64u | (uint32_t)qn);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t px = __shfl_xor(x, d);
+                x = (lane & d) ? max(x, px) : min(x, px);
+            }
+            const uint32_t x0 = __builtin_amdgcn_readlane(x, 0), x1 = __builtin_amdgcn_readlane(x, 1);
+            uint32_t T = (x0 >> 8) + (x1 >> 8);
+            if (j + 32 < k) T = min(T, __builtin_amdgcn_readlane(ov, 32));   // nodes beyond the window (leaves never are)
+            const uint32_t vx = x >> 8;
+            int c = __popcll(__ballot(x != INF && vx <= T));
+            c &= ~1;
+            c = max(c, 2);
+            c = min(c, 2 * (m - 1 - k));
+            const uint32_t sx = vx + __shfl_xor(vx, 1);
+            if (!(lane & 1) && lane < c) B.nf[k + (lane >> 1)] = sx;
+            const bool inx = lane < c;
+            if (inx && (x & 64u)) B.npar[j + (x & 63u)] = (uint16_t)(k + (lane >> 1));
+            const int nn = __popcll(__ballot(inx && (x & 64u)));
+            i += c - nn;
+            j += nn;
+            k += c >> 1;
+        }
+      } else {
         // Huffman tree by ROUNDS instead of one merge per step (the serial two-queue loop costs ~400
         // cycles per merge on a GPU).  Leaves ascending in S.lf, internal nodes are produced ascending
         // into S.nf.  Per round, one wave64: take the next 64 leaves and the next 64 nodes, bitonic-merge
@@ -227,32 +261,33 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             j += nn;
             k += c >> 1;
         }
+      }
     }
     sync();
-    if (!WAVE) PROF_MARK(4);
+    PROF_MARK(WAVE ? 14 : 4);
     // Depth of every internal node by a parallel parent walk (root = node m-2, depth 0).  Leaves at
     // depth L = 2 * I[L-1] - I[L]; sorted order makes depth monotone in rank, so counts are enough.
     for (int q = tid; q < m - 1; q += NTH) {
         int d = 0, p = q;
         while (p != m - 2) { p = B.npar[p]; d++; }
-        atomicAdd(&S.icount[min(d, maxbits)], 1u);
+        atomicAdd(&icount[min(d, maxbits)], 1u);
     }
     sync();
     if (tid == 0) {
         uint32_t used = 0;
         for (int L = 1; L < maxbits; L++) {
-            const uint32_t c = 2 * S.icount[L - 1] - S.icount[L];
-            S.blcount[L] = c;
+            const uint32_t c = 2 * icount[L - 1] - icount[L];
+            blcount[L] = c;
             used += c;
         }
-        S.blcount[maxbits] = (uint32_t)m - used;   // every leaf at depth >= maxbits, clamped
-        if (S.icount[maxbits]) {   // some leaf was deeper than maxbits: repair the Kraft sum on the counts
+        blcount[maxbits] = (uint32_t)m - used;   // every leaf at depth >= maxbits, clamped
+        if (icount[maxbits]) {   // some leaf was deeper than maxbits: repair the Kraft sum on the counts
             uint32_t total = 0;
-            for (int b = maxbits; b >= 1; b--) total += S.blcount[b] << (maxbits - b);
+            for (int b = maxbits; b >= 1; b--) total += blcount[b] << (maxbits - b);
             while (total != (1u << maxbits)) {
-                S.blcount[maxbits]--;
+                blcount[maxbits]--;
                 for (int b = maxbits - 1; b > 0; b--)
-                    if (S.blcount[b]) { S.blcount[b]--; S.blcount[b + 1] += 2; break; }
+                    if (blcount[b]) { blcount[b]--; blcount[b + 1] += 2; break; }
                 total--;
             }
         }
@@ -261,21 +296,21 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
     for (int r = tid; r < m; r += NTH) {   // rarest symbols get the longest codes
         uint32_t cum = 0;
         int L = maxbits;
-        for (; L > 1; L--) { cum += S.blcount[L]; if ((uint32_t)r < cum) break; }
+        for (; L > 1; L--) { cum += blcount[L]; if ((uint32_t)r < cum) break; }
         lens[B.rsym[r]] = (uint8_t)L;
     }
     sync();
-    if (!WAVE) PROF_MARK(5);
+    PROF_MARK(WAVE ? 15 : 5);
 }
 
 // ---- canonical codes from lengths (wave 0; S.blcount must match lens) ----
-__device__ __forceinline__ void assign_codes_wave(DeflShared &S, const uint8_t *lens, int n, uint32_t *code_out) {
+__device__ __forceinline__ void assign_codes_wave(const uint32_t *blcount, const uint8_t *lens, int n, uint32_t *code_out) {
     {
         uint32_t next[16];
         uint32_t c = 0;
         next[0] = 0;
 #pragma unroll
-        for (int b = 1; b < 16; b++) { c = (c + (b > 1 ? S.blcount[b - 1] : 0)) << 1; next[b] = c; }
+        for (int b = 1; b < 16; b++) { c = (c + (b > 1 ? blcount[b - 1] : 0)) << 1; next[b] = c; }
         const uint64_t lt = (1ull << lane_id()) - 1;
         for (int base = 0; base < n; base += 64) {
             const int s = base + lane_id();
@@ -475,7 +510,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     if (dbg == 2) { z.bitpos += S.freq[tid] + S.red[0]; return; }   // tools/stage_time.py cut-off
 
     // ---- B: codes ----
-    build_lengths(S, B, &B.sort, S.freq, NLIT, 15, S.lens);
+    build_lengths(S, B, &B.sort, S.freq, NLIT, 15, S.lens, S.blcount, S.icount);
     if (dbg == 3) { z.bitpos += S.lens[tid]; return; }
     PROF_RESET
     if (FUSED) {   // B is dead from here on: its storage becomes the bit buffer
@@ -483,14 +518,12 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         __syncthreads();
         if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);   // CMF/FLG 78 9c (deflate, 32K window, default level)
     }
-    // ---- codes, code-length header and block costs.  Wave 0 does everything that is small and sequential in
-    // nature with wave-scope syncs only (no workgroup barrier inside): canonical lit/len codes, the run-length
-    // coding of the code lengths, the 19-symbol code-length Huffman code and its header cost.  Waves 1..3 sum
-    // the dynamic / fixed body costs meanwhile.  One barrier at the end.
+    // ---- codes, code-length header and block costs: three independent jobs on different waves, wave-scope
+    // syncs only, ONE workgroup barrier at the end.  Wave 0: run-length coding of the code lengths, the 19-symbol
+    // code-length Huffman code and the header cost.  Wave 1: canonical lit/len codes.  Waves 2-3: dynamic /
+    // fixed body costs.
     if (wave_id() == 0) {
         const int lane = lane_id();
-        assign_codes_wave(S, S.lens, NLIT, S.code);
-        PROF_MARK(6);
         // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
         if (lane == 0) {
             S.lens[DOFF] = 1; S.lens[DOFF + 1] = 1;
@@ -562,8 +595,9 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         }
         wave_sync();
         PROF_MARK(7);
-        build_lengths<32, true>(S, S.clb, (SortScratch *)nullptr, S.clfreq, 19, 7, S.cllens);
-        assign_codes_wave(S, S.cllens, 19, S.clcode);
+        build_lengths<32, true>(S, S.clb, (SortScratch *)nullptr, S.clfreq, 19, 7, S.cllens, S.clblcount, S.clicount);
+        PROF_RESET
+        assign_codes_wave(S.clblcount, S.cllens, 19, S.clcode);
         {
             const int ncl = (int)S.ncl;
             uint32_t clb = 0;
@@ -580,10 +614,12 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
                 S.hclen = h;
             }
         }
-        PROF_MARK(8);
+        PROF_MARK(6);
+    } else if (wave_id() == 1) {
+        assign_codes_wave(S.blcount, S.lens, NLIT, S.code);   // canonical lit/len codes, concurrently with wave 0
     } else {
         uint32_t dynb = 0, fixb = 0;
-        for (int s = tid - 64; s < NLIT; s += NT - 64) {
+        for (int s = tid - 128; s < NLIT; s += NT - 128) {
             const uint32_t f = S.freq[s];
             dynb += f * S.lens[s];
             fixb += f * fixed_len(s);

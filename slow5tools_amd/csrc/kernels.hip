@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
     PROF_MARK(13);
 #ifdef S5_PROFILE
     if (threadIdx.x == 0) {
-        for (int k = 0; k < 14; k++) atomicAdd(&g_prof[k], S.prof[k]);
+        for (int k = 0; k < 16; k++) atomicAdd(&g_prof[k], S.prof[k]);
         atomicAdd(&g_prof[31], 1ull);
     }
 #endif

@@ -11,9 +11,10 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "slow5tools_amd", "csrc")
 PROF_LIB = os.path.join(ROOT, "slow5tools_amd", "libslow5gpu_prof.so")
 
-NAMES = {0: "svb-zd encode + pack (HBM->LDS payload)", 1: "break mask + 2 scans + adler partials", 2: "tokenise + histogram",
-         3: "lit/len rank sort", 4: "lit/len huffman merge (1 lane)", 5: "depths + limit + lengths", 6: "canonical codes (lit/len)",
-         7: "hlit + code-length RLE (1 lane)", 8: "code-length code build", 9: "cost compare", 10: "header emit",
+NAMES = {14: "code-length code: merge rounds (wave 0)", 15: "code-length code: depths + lengths (wave 0)",
+         0: "svb-zd encode + pack (HBM->LDS payload)", 1: "break mask + 2 scans + adler partials", 2: "tokenise + histogram",
+         3: "lit/len rank sort", 4: "lit/len huffman merge (1 lane)", 5: "depths + limit + lengths", 6: "code-length canonical codes + header cost (wave 0)",
+         7: "hlit + code-length RLE (wave 0)", 8: "code-length code: sort (wave 0)", 9: "cost compare", 10: "header emit",
          11: "token bit totals + scan", 12: "token pack", 13: "whole zlib_compress_fused (phases 1-12 + flush)"}
 
 
@@ -45,10 +46,10 @@ def main():
     torch.cuda.synchronize()
     L.s5gpu_prof_read(buf, 0)
     wgs = buf[31]
-    tot = sum(buf[k] for k in range(13))
+    tot = sum(buf[k] for k in list(range(13)) + [14, 15])
     print("k_encode_fused (profiled build): %d reads x %d samples, %.2f ms" % (n_reads, n, t0.elapsed_time(t1)))
     print("%-45s %12s %7s" % ("phase", "cycles/WG", "share"))
-    for k in range(14):
+    for k in list(range(13)) + [14, 15, 13]:
         print("%-45s %12.0f %6.1f%%" % (NAMES[k], buf[k] / max(wgs, 1), 100.0 * buf[k] / max(tot, 1)))
     print("%-45s %12.0f" % ("sum of phases 0-12 (lane-0 timeline, shader cycles)", tot / max(wgs, 1)))
 
