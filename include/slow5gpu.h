@@ -105,7 +105,8 @@ typedef struct s5gpu_decode_args {
     uint32_t n_recs;
     int32_t rec_method, sig_method;
     const s5gpu_rec_desc_t *desc;    /* device                                                       */
-    const uint8_t *in;               /* device, compressed records                                   */
+    const uint8_t *in;               /* device, compressed records; 16 readable bytes must follow the */
+                                     /*   last record (the inflate kernels fetch aligned dwords ahead) */
     uint8_t *payload;                /* device, out: uncompressed record per slot                    */
     int16_t *sig_out;                /* device, out: raw_signal per record                           */
     s5gpu_rec_fields_t *fields;      /* device, out                                                  */
@@ -116,6 +117,9 @@ int s5gpu_init(int device);              /* select device; S5GPU_ERR_NODEV if it
 void s5gpu_shutdown(void);
 const char *s5gpu_last_error(void);
 int s5gpu_device_count(void);
+/* tuning knobs.  "inflate_simt_min": batches with at least this many zlib records use the lane-per-record
+ * inflate kernel (throughput), smaller ones the wave-per-record kernel (latency); default 16384. */
+int s5gpu_set_option(const char *key, long value);
 
 /* ---- device-resident entry points (asynchronous on `hip_stream`, a hipStream_t; NULL = default) ---- */
 int s5gpu_encode_dev(const s5gpu_encode_args_t *args, void *hip_stream);

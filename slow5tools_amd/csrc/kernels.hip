@@ -10,6 +10,7 @@
 #include "../../include/slow5gpu.h"
 #include "deflate_dev.h"
 #include "inflate_dev.h"
+#include "inflate_simt_dev.h"
 #include "svb_dev.h"
 
 using namespace s5;
@@ -286,6 +287,18 @@ __global__ __launch_bounds__(64) void k_inflate(s5gpu_decode_args_t a) {
         a.fields[r].status = status;
         a.fields[r].payload_len = olen;
     }
+}
+
+// K4, throughput form: one record per LANE (inflate_simt_dev.h); 64 records per workgroup, tables in dynamic LDS
+__global__ __launch_bounds__(64) void k_inflate_simt(s5gpu_decode_args_t a) {
+    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= a.n_recs) return;
+    LaneTables &T = reinterpret_cast<LaneTables *>(smem)[threadIdx.x];
+    const s5gpu_rec_desc_t d = a.desc[r];
+    uint32_t olen = 0;
+    const int status = zlib_inflate_lane(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+    a.fields[r].status = status;
+    a.fields[r].payload_len = olen;
 }
 
 // K2 + field parse: payload -> primary fields + int16 raw_signal (slow5_rec_depress_parse, a7/a8)
@@ -620,6 +633,29 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
     return S5GPU_OK;
 }
 
+// Small batches (a single slow5_get) take the wave-per-record decoder (lowest latency); from
+// g_inflate_simt_min records on, the lane-per-record decoder (highest throughput).
+static uint32_t g_inflate_simt_min = 16384;
+extern "C" int s5gpu_set_option(const char *key, long value) {
+    if (key && strcmp(key, "inflate_simt_min") == 0 && value >= 0) { g_inflate_simt_min = (uint32_t)value; return S5GPU_OK; }
+    s5gpu_set_error("s5gpu_set_option: unknown option");
+    return S5GPU_ERR_ARG;
+}
+static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st) {
+    if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
+        static bool attr = false;
+        if (!attr) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate_simt), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            attr = true;
+        }
+        hipLaunchKernelGGL(k_inflate_simt, dim3((a->n_recs + 63) / 64), dim3(64), 64 * sizeof(LaneTables), st, *a);
+    } else {
+        hipLaunchKernelGGL(k_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
+    }
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
 static int dec_check(const s5gpu_decode_args_t *a, bool need_payload, bool need_sig) {
     if (!a || (a->n_recs && (!a->desc || !a->in || !a->fields || (need_payload && !a->payload) || (need_sig && !a->sig_out)))) return S5GPU_ERR_ARG;
     return S5GPU_OK;
@@ -627,9 +663,7 @@ static int dec_check(const s5gpu_decode_args_t *a, bool need_payload, bool need_
 extern "C" int s5gpu_inflate_dev(const s5gpu_decode_args_t *a, void *stream_) {
     if (dec_check(a, true, false)) { s5gpu_set_error("s5gpu_inflate_dev: bad arguments"); return S5GPU_ERR_ARG; }
     if (a->n_recs == 0) return S5GPU_OK;
-    hipLaunchKernelGGL(k_inflate, dim3(a->n_recs), dim3(64), 0, (hipStream_t)stream_, *a);
-    HIP_TRY(hipGetLastError());
-    return S5GPU_OK;
+    return launch_inflate(a, (hipStream_t)stream_);
 }
 extern "C" int s5gpu_svbzd_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
     if (dec_check(a, false, true)) { s5gpu_set_error("s5gpu_svbzd_decode_dev: bad arguments"); return S5GPU_ERR_ARG; }
@@ -669,7 +703,8 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
     }
     if (a->n_recs == 0) return S5GPU_OK;
     hipStream_t st = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
+    int rc = launch_inflate(a, st);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_unpack, dim3(a->n_recs), dim3(NT), 0, st, *a);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;

@@ -201,8 +201,19 @@ def test_reencode_fixture_records(press, name):
 
 
 # ---------------------------------------------------------------- decode
+@pytest.fixture(params=["wave-per-record", "lane-per-record"])
+def inflate_kernel(request, press):
+    """both inflate kernels must pass every decode test: force one or the other through the tuning knob"""
+    from slow5tools_amd import _lib
+
+    L = _lib.lib()
+    _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 1 if request.param == "lane-per-record" else 1 << 30))
+    yield request.param
+    _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 16384))
+
+
 @pytest.mark.parametrize("name", ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES + NONE_NONE_FIXTURES)
-def test_decode_fixture_records(press, name):
+def test_decode_fixture_records(press, inflate_kernel, name):
     """records written by the reference (stock zlib, arbitrary LZ77 distances) decode to the oracle's answer"""
     f = Blow5(golden(name))
     got = press.decode_records(f.records, f.rec_method, f.sig_method)
@@ -216,7 +227,7 @@ def test_decode_fixture_records(press, name):
             assert g[k] == d[k], k
 
 
-def test_roundtrip_own_streams(press):
+def test_roundtrip_own_streams(press, inflate_kernel):
     n_reads, n = 300, 4000
     sig = ob.synth_reads(0x5105, 77, n_reads, n)
     hdrs = [_hdr(press, 77 + i) for i in range(n_reads)]
@@ -226,7 +237,7 @@ def test_roundtrip_own_streams(press):
         assert g["status"] == 0 and np.array_equal(g["signal"], sig[i]) and g["read_id"] == ob.synth_read_id(77 + i)
 
 
-def test_decode_rejects_corrupt_records(press):
+def test_decode_rejects_corrupt_records(press, inflate_kernel):
     sig = ob.synth_reads(0x5105, 0, 4, 4000)
     hdrs = [_hdr(press, i) for i in range(4)]
     recs = [r[8:] for r in press.encode_records(list(sig), hdrs)]
@@ -240,7 +251,7 @@ def test_decode_rejects_corrupt_records(press):
         press.decode_records([trunc])
 
 
-def test_decode_stored_and_fixed_blocks(press):
+def test_decode_stored_and_fixed_blocks(press, inflate_kernel):
     """streams from other encoders: zlib level 0 (stored), Z_FIXED, and a 32 KiB-distance match"""
     rng = np.random.default_rng(3)
     sig = (500 + 30 * rng.standard_normal(70000)).astype(np.int16)
