@@ -340,20 +340,36 @@ __device__ __forceinline__ uint32_t fixed_code(int s) {
 
 struct Tok { int sym; uint32_t eb, ev; };   // sym < 0: position covered by a match
 
+// Per-lane position masks: a lane owns K = ceil(len / 256) contiguous bytes; K <= 32 (blocks up to 8 KiB, the
+// case of a 4000-sample read) fits a 32-bit mask, which halves the cost of every mask operation on gfx950.
+template <typename M> struct MaskOps;
+template <> struct MaskOps<uint32_t> {
+    static constexpr int BITS = 32;
+    static __device__ __forceinline__ int msb(uint32_t m) { return 31 - __clz((int)m); }
+    static __device__ __forceinline__ int lsb(uint32_t m) { return __ffs((int)m) - 1; }
+};
+template <> struct MaskOps<uint64_t> {
+    static constexpr int BITS = 64;
+    static __device__ __forceinline__ int msb(uint64_t m) { return 63 - __clzll((long long)m); }
+    static __device__ __forceinline__ int lsb(uint64_t m) { return __ffsll((long long)m) - 1; }
+};
+
 // token at position base+j of the block for the lane that owns it
-__device__ __forceinline__ Tok token_at(const uint8_t *__restrict__ buf, int base, int j, uint64_t brk, int lastb, int nextb) {
-    const uint64_t lo = brk & ((2ull << j) - 1);
-    const int s = lo ? base + 63 - __clzll((long long)lo) : lastb;
-    const uint64_t hi = j < 63 ? (brk >> (j + 1)) : 0ull;
-    const int e = hi ? base + j + __ffsll((long long)hi) : nextb;
-    const int rel = base + j - s, M = e - s - 1;
+template <typename M>
+__device__ __forceinline__ Tok token_at(const uint8_t *__restrict__ buf, int base, int j, M brk, int lastb, int nextb) {
+    using MO = MaskOps<M>;
+    const M lo = brk & (M)(((M)2 << j) - 1);
+    const int s = lo ? base + MO::msb(lo) : lastb;
+    const M hi = j < MO::BITS - 1 ? (M)(brk >> (j + 1)) : (M)0;
+    const int e = hi ? base + j + 1 + MO::lsb(hi) : nextb;
+    const int rel = base + j - s, body = e - s - 1;   // body = bytes of the run after its first one
     Tok t;
     t.sym = buf[base + j];
     t.eb = 0;
     t.ev = 0;
-    if (rel > 0 && M >= 3) {
+    if (rel > 0 && body >= 3) {
         const int m = rel - 1, c = m / 258, off = m - c * 258;
-        const int Lc = min(258, M - c * 258);
+        const int Lc = min(258, body - c * 258);
         if (Lc >= 3) {
             if (off != 0) { t.sym = -1; return t; }
             const int l = Lc - 3;
@@ -393,10 +409,11 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
 // All NT lanes call with uniform arguments.  adA/adB: running Adler-32 halves (uniform).
 // FUSED: single-block stream whose build scratch B overlays obuf; obuf is zeroed and the zlib header
 // written here once B is dead (caller passes z.bitpos = 80, z.flushed = 0, obuf_words = size to zero).
-template <bool FUSED>
+template <bool FUSED, typename M = uint64_t>
 __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words,
                                               const uint8_t *__restrict__ buf, int len, bool final, ZOut &z, uint32_t &adA,
                                               uint32_t &adB, uint32_t dbg = 0) {
+    using MO = MaskOps<M>;
     const int tid = threadIdx.x;
     if (len == 0) {
         if (FUSED) {
@@ -419,7 +436,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     if (tid < 20) S.clfreq[tid] = 0;
 
     // ---- A: break mask, Adler partials; a run start is always a literal token: count it right here ----
-    uint64_t brk = 0;
+    M brk = 0;
     uint32_t a_sum = 0, b_sum = 0;
     {
         int prev = -1;
@@ -430,25 +447,28 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         int j = 0;
         for (; j + 4 <= kk; j += 4) {
             const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
-            if (b0 != prev) { brk |= 1ull << j; atomicAdd(&S.freq[b0], 1u); }
-            if (b1 != b0) { brk |= 2ull << j; atomicAdd(&S.freq[b1], 1u); }
-            if (b2 != b1) { brk |= 4ull << j; atomicAdd(&S.freq[b2], 1u); }
-            if (b3 != b2) { brk |= 8ull << j; atomicAdd(&S.freq[b3], 1u); }
+            if (b0 != prev) { brk |= (M)1 << j; atomicAdd(&S.freq[b0], 1u); }
+            if (b1 != b0) { brk |= (M)2 << j; atomicAdd(&S.freq[b1], 1u); }
+            if (b2 != b1) { brk |= (M)4 << j; atomicAdd(&S.freq[b2], 1u); }
+            if (b3 != b2) { brk |= (M)8 << j; atomicAdd(&S.freq[b3], 1u); }
             prev = b3;
-            a_sum += b0 + b1 + b2 + b3;
-            const uint32_t w = (uint32_t)(len - (base + j));
-            b_sum += w * b0 + (w - 1) * b1 + (w - 2) * b2 + (w - 3) * b3;
+            a_sum += b0; b_sum += a_sum;   // B as a running sum of A: two adds per byte, no multiply
+            a_sum += b1; b_sum += a_sum;
+            a_sum += b2; b_sum += a_sum;
+            a_sum += b3; b_sum += a_sum;
         }
         for (; j < kk; j++) {
             const int b = buf[base + j];
-            if (b != prev) { brk |= 1ull << j; atomicAdd(&S.freq[b], 1u); }
+            if (b != prev) { brk |= (M)1 << j; atomicAdd(&S.freq[b], 1u); }
             prev = b;
             a_sum += b;
-            b_sum += (uint32_t)(len - (base + j)) * b;
+            b_sum += a_sum;
         }
+        // b_sum = sum (kk - j) x_j so far; the bytes of later lanes each add this lane's byte sum once more
+        b_sum += a_sum * (uint32_t)max(0, len - (base + kk));
     }
-    const int local_last = brk ? base + 63 - __clzll((long long)brk) : -1;
-    const int local_first = brk ? base + __ffsll((long long)brk) - 1 : len;
+    const int local_last = brk ? base + MO::msb(brk) : -1;
+    const int local_first = brk ? base + MO::lsb(brk) : len;
     const int lastb = block_excl_max(local_last, -1, S.ws);
     const int nextb = block_suffix_excl_min(local_first, len, S.ws);
     PROF_MARK(1);
@@ -459,21 +479,21 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     // segment of the lane's chunk at most three positions are evaluated — a lane that lies entirely inside
     // a long run (the svb key area is mostly zeros) does O(1) work instead of O(K).
     // tok = positions that emit a token, mat = those that are matches.
-    uint64_t tok = brk, mat = 0;
+    M tok = brk, mat = 0;
     uint32_t nmatch = 0, nextra = 0;
     {
-        uint64_t inrun = ~brk & (kk >= 64 ? ~0ull : ((1ull << kk) - 1));
+        M inrun = (M)~brk & (kk >= MO::BITS ? (M)~(M)0 : (M)(((M)1 << kk) - 1));
         while (inrun) {
-            const int j0 = __ffsll((long long)inrun) - 1;
-            const uint64_t rest = ~(inrun >> j0);                       // first zero = end of this segment
-            const int seg = rest ? __ffsll((long long)rest) - 1 : 64 - j0;
+            const int j0 = MO::lsb(inrun);
+            const M rest = (M)~(M)(inrun >> j0);                        // first zero = end of this segment
+            const int seg = rest ? MO::lsb(rest) : MO::BITS - j0;
             const int j1 = j0 + seg;                                    // segment = chunk positions [j0, j1)
-            inrun &= seg >= 64 ? 0ull : ~(((1ull << seg) - 1) << j0);
+            inrun &= seg >= MO::BITS ? (M)0 : (M)~(M)((((M)1 << seg) - 1) << j0);
             // run bounds of this segment (same for all its positions)
-            const uint64_t lo = brk & ((1ull << j0) - 1);
-            const int s = lo ? base + 63 - __clzll((long long)lo) : lastb;
-            const uint64_t hi = j1 < 64 ? (brk >> j1) : 0ull;
-            const int e = hi ? base + j1 + __ffsll((long long)hi) - 1 : nextb;
+            const M lo = brk & (M)(((M)1 << j0) - 1);
+            const int s = lo ? base + MO::msb(lo) : lastb;
+            const M hi = j1 < MO::BITS ? (M)(brk >> j1) : (M)0;
+            const int e = hi ? base + j1 + MO::lsb(hi) : nextb;
             // candidates: chunk starts s+1+258c inside the segment, and the run's last two positions
             const int p0 = base + j0, p1 = base + j1;
             const int c0 = (p0 - s - 1 + 257) / 258;
@@ -487,9 +507,9 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
                 const int j = p - base;
                 const Tok t = token_at(buf, base, j, brk, lastb, nextb);
                 if (t.sym >= 0) {
-                    tok |= 1ull << j;
+                    tok |= (M)1 << j;
                     atomicAdd(&S.freq[t.sym], 1u);
-                    if (t.sym > 256) { mat |= 1ull << j; nmatch++; nextra += t.eb; }
+                    if (t.sym > 256) { mat |= (M)1 << j; nmatch++; nextra += t.eb; }
                 }
             }
         }
@@ -699,7 +719,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     // into one word, 13 bits for the <= 320 * 14 header bits, 19 for the <= 16384 * 15 token bits) ----
     uint32_t mybits = 0;
     {
-        uint64_t t = tok, mm = mat;
+        M t = tok, mm = mat;
         int j = 0;
         for (; j + 4 <= kk; j += 4, t >>= 4, mm >>= 4) {   // 4 byte loads, then 4 code loads, in flight together
             const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
@@ -738,7 +758,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         uint32_t widx = (start >> 5) - z.flushed;
         uint32_t accbits = start & 31;
         uint64_t acc = 0;
-        uint64_t t = tok, mm = mat;
+        M t = tok, mm = mat;
         auto emit = [&](uint32_t v, uint32_t nb) {
             acc |= (uint64_t)v << accbits;
             accbits += nb;
@@ -786,6 +806,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
 // Fused path: zlib-frame a payload of at most DEFL_BLK bytes that sits in LDS (`pay`) as ONE DEFLATE
 // block into HBM slot `out` (16-B aligned).  Slot layout: [u64 size][78 9c][block][adler32 BE].
 // obuf: LDS, obuf_words >= max(plen + 64, sizeof(BuildScratch)) / 4; returns total bytes incl. the prefix.
+template <typename M>
 __device__ __forceinline__ uint32_t zlib_compress_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words,
                                                         const uint8_t *pay, uint32_t plen, uint8_t *out, uint32_t dbg = 0) {
     const int tid = threadIdx.x;
@@ -793,7 +814,7 @@ __device__ __forceinline__ uint32_t zlib_compress_fused(DeflShared &S, uint32_t 
     z.bitpos = 80;   // 64 bits of size prefix + 16 bits of zlib header, both written later
     z.flushed = 0;
     uint32_t adA = 1, adB = 0;
-    deflate_block<true>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg);
+    deflate_block<true, M>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg);
     if (dbg) { if (tid == 0) *reinterpret_cast<uint32_t *>(out) = z.bitpos; return 16; }
     z.bitpos = (z.bitpos + 7) & ~7u;
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);

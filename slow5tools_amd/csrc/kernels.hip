@@ -95,6 +95,7 @@ __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, 
 // K1+K5+K3+K6 fused: svb-zd -> pack -> one DEFLATE block -> zlib frame.  One read per workgroup, every
 // intermediate in LDS.  A read whose payload does not fit the LDS budget (p.pay_cap: long read, or an
 // unusually incompressible signal) is appended to the overflow list and redone by the staged kernels.
+template <typename M>
 __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
     const uint32_t r = blockIdx.x;
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
         return;
     }
     uint8_t *out = p.a.slots + d.out_off;
-    const uint32_t total = zlib_compress_fused(S, obuf, p.obuf_words, pay, plen, out, p.dbg);
+    const uint32_t total = zlib_compress_fused<M>(S, obuf, p.obuf_words, pay, plen, out, p.dbg);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
     PROF_MARK(13);
 #ifdef S5_PROFILE
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list
                 for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
             }
             __syncthreads();
-            deflate_block<false>(S, B, obuf, 0, stage, (int)blen, final, z, adA, adB);
+            deflate_block<false, uint64_t>(S, B, obuf, 0, stage, (int)blen, final, z, adA, adB);
             done += blen;
             if (!final) flush_words(obuf, out32, z, false);
         } while (done < plen);
@@ -557,7 +558,8 @@ static int enc_check(const s5gpu_encode_args_t *a) {
 static bool g_attr_done = false;
 static int set_lds_attrs() {
     if (g_attr_done) return S5GPU_OK;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svbzd_encode), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     g_attr_done = true;
@@ -602,7 +604,9 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         p.pay_cap = cap;
         p.obuf_words = (cap + 64 > B_BYTES ? cap + 64 : B_BYTES) / 4;
         const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
-        hipLaunchKernelGGL(k_encode_fused, dim3(a->n_reads), dim3(NT), lds, st, p);
+        // a lane owns ceil(len / 256) bytes: payloads up to 8 KiB need 32-bit position masks only
+        if (cap <= 8192) hipLaunchKernelGGL(k_encode_fused<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p);
+        else hipLaunchKernelGGL(k_encode_fused<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p);
         // overflow reads (usually none: the two launches below then exit at once)
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
         const uint32_t g = a->n_reads < 1024 ? a->n_reads : 1024;
