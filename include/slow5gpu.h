@@ -139,6 +139,8 @@ int s5gpu_svbzd_decode_dev(const s5gpu_decode_args_t *args, void *hip_stream);
  * rec_off[i] = byte offset of record i in `stream`, rec_off[n] = total bytes.  tmp: >= 8*(n/1024+2) bytes. */
 int s5gpu_compact_dev(uint32_t n_reads, const s5gpu_read_desc_t *desc, const uint8_t *slots, const uint32_t *out_len,
                       uint64_t *rec_off, uint8_t *stream, uint64_t *tmp, void *hip_stream);
+/* write val[i] (little-endian u32) at base + off[i]: the read_group rewrite of merge (src/merge.c:51) on device */
+int s5gpu_patch_u32_dev(uint8_t *base, const uint64_t *off, const uint32_t *val, uint32_t n, void *hip_stream);
 /* synthetic reads on device (bench/test workload; bit-identical to oracle/synth.c) */
 int s5gpu_synth_dev(int16_t *sig, uint64_t n_reads, uint64_t n_samples, uint64_t stride_samples, uint64_t seed,
                     uint64_t first_read_idx, void *hip_stream);
@@ -160,6 +162,14 @@ int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_
 /* Decode n records (bytes without the u64 prefix).  payload[i] and sig[i] receive malloc'd buffers. */
 int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int rec_method, int sig_method,
                        void **payload, int16_t **sig, s5gpu_rec_fields_t *fields);
+
+/* The whole view / merge worker for a batch of BLOW5 records (src/view.c:35-57, src/merge.c:43-70): decode with
+ * (from_rec, from_sig), optionally rewrite read_group and drop the aux fields, re-encode with (to_rec, to_sig).
+ * Only compressed bytes cross PCIe: decoded signals and payloads stay in HBM between the two halves.
+ * out[i] malloc'd [u64 size][record]; a corrupt input record fails the call (status[i], may be NULL, says which). */
+int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                           int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                           int32_t *status);
 
 /* ---- one-stage host-buffer calls behind slow5_ptr_compress_solo / slow5_ptr_depress_solo ----
  * stage: 0 zlib compress, 1 zlib inflate, 2 svb-zd encode (in = int16 samples, in_len in bytes),

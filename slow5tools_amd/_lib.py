@@ -95,5 +95,5 @@ EXPORTS = [
     "s5gpu_encode_dev", "s5gpu_decode_dev", "s5gpu_svbzd_encode_dev", "s5gpu_compact_dev", "s5gpu_synth_dev",
     "s5gpu_synth_hdr_dev", "s5gpu_event_create", "s5gpu_event_record", "s5gpu_event_elapsed_ms", "s5gpu_event_destroy",
     "s5gpu_encode_batch", "s5gpu_decode_batch", "s5gpu_solo_batch", "s5gpu_deflate_parked_dev", "s5gpu_inflate_dev",
-    "s5gpu_svbzd_decode_dev", "s5gpu_set_option",
+    "s5gpu_svbzd_decode_dev", "s5gpu_set_option", "s5gpu_recompress_batch", "s5gpu_patch_u32_dev",
 ]

@@ -82,7 +82,7 @@ struct Buf {
     void release() { if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
 };
 struct Ctx {
-    Buf d_sig, d_hdr, d_aux, d_desc, d_slots, d_len, d_ovf, d_in, d_pay, d_fields;
+    Buf d_sig, d_hdr, d_aux, d_desc, d_slots, d_len, d_ovf, d_in, d_pay, d_fields, d_stream, d_scan, d_sig2, d_desc2, d_patch;
     Buf h_in, h_out;   // pinned staging
     hipStream_t st = nullptr;
     Ctx() { h_in.pinned = true; h_out.pinned = true; }
@@ -111,7 +111,8 @@ extern "C" void s5gpu_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_ctx) {
         Buf *bs[] = {&g_ctx->d_sig, &g_ctx->d_hdr, &g_ctx->d_aux, &g_ctx->d_desc, &g_ctx->d_slots, &g_ctx->d_len,
-                     &g_ctx->d_ovf, &g_ctx->d_in, &g_ctx->d_pay, &g_ctx->d_fields, &g_ctx->h_in, &g_ctx->h_out};
+                     &g_ctx->d_ovf, &g_ctx->d_in, &g_ctx->d_pay, &g_ctx->d_fields, &g_ctx->d_stream, &g_ctx->d_scan, &g_ctx->d_sig2,
+                     &g_ctx->d_desc2, &g_ctx->d_patch, &g_ctx->h_in, &g_ctx->h_out};
         for (Buf *b : bs) b->release();
         if (g_ctx->st) (void)hipStreamDestroy(g_ctx->st);
         delete g_ctx;
@@ -155,6 +156,54 @@ static void parallel_for(uint32_t n, uint64_t bytes, F fn) {
     for (auto &t : th) t.join();
 }
 
+// Launch the encode for descriptors already on the device (a.desc/sig/hdr/aux set by the caller), gather the
+// worst-case slots into the contiguous record stream on the device (the bytes the ordered fwrite loop emits),
+// bring back only what was produced and hand out one malloc per record.
+static int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
+                              void **out, size_t *out_len) {
+    int rc;
+    if ((rc = c->d_slots.reserve(slots_bytes + 64)) || (rc = c->d_len.reserve(4ull * n)) || (rc = c->d_ovf.reserve(4ull * n + 64)) ||
+        (rc = c->h_out.reserve(up(4ull * n, 64) + 64)))
+        return rc;
+    a.slots = (uint8_t *)c->d_slots.p; a.out_len = (uint32_t *)c->d_len.p;
+    a.lds_payload_cap = 0;
+    a.ovf = (uint32_t *)c->d_ovf.p;
+    if ((rc = s5gpu_encode_dev(&a, c->st))) return rc;
+    uint8_t *ho_len = (uint8_t *)c->h_out.p;
+    HIP_TRY(hipMemcpyAsync(ho_len, c->d_len.p, 4ull * n, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    const uint32_t *lens = (const uint32_t *)ho_len;
+    std::vector<uint64_t> off(n + 1);
+    off[0] = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (lens[i] < 8 || lens[i] > desc[i].slot_cap) { s5gpu_set_error("read %u: device produced an impossible length %u", i, lens[i]); return S5GPU_ERR_HIP; }
+        off[i + 1] = off[i] + lens[i];
+    }
+    const uint64_t produced = off[n];
+    if ((rc = c->d_stream.reserve(produced + 64)) || (rc = c->d_scan.reserve(8ull * (n + 1) + 8ull * (n / 1024 + 8))) ||
+        (rc = c->h_out.reserve(up(4ull * n, 64) + produced + 64)))   // may move h_out: lens were consumed into off[] already
+        return rc;
+    uint64_t *d_off = (uint64_t *)c->d_scan.p, *d_tmp = d_off + (n + 1);
+    if ((rc = s5gpu_compact_dev(n, a.desc, (const uint8_t *)c->d_slots.p, (const uint32_t *)c->d_len.p, d_off, (uint8_t *)c->d_stream.p, d_tmp, c->st)))
+        return rc;
+    uint8_t *ho_stream = (uint8_t *)c->h_out.p + up(4ull * n, 64);
+    HIP_TRY(hipMemcpyAsync(ho_stream, c->d_stream.p, produced, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    int oom = 0;
+    parallel_for(n, produced, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; i++) {
+            const size_t len = (size_t)(off[i + 1] - off[i]);
+            void *b = malloc(len);
+            if (!b) { oom = 1; out[i] = NULL; continue; }
+            memcpy(b, ho_stream + off[i], len);
+            out[i] = b;
+            out_len[i] = len;
+        }
+    });
+    if (oom) { for (uint32_t j = 0; j < n; j++) { free(out[j]); out[j] = NULL; } return S5GPU_ERR_NOMEM; }
+    return S5GPU_OK;
+}
+
 // The whole batch in one call: H2D of signals/headers, one launch, D2H of the slots, one malloc per
 // record (the ownership contract of slow5_rec_to_mem: caller frees each buffer, src/view.c:298).
 extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
@@ -188,10 +237,8 @@ extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const u
     }
     const size_t sig_bytes = (size_t)so * 2 + 64, in_bytes = up(sig_bytes, 64) + up(ho + 64, 64) + up(ao + 64, 64) + sizeof(s5gpu_read_desc_t) * n;
     if ((rc = c->h_in.reserve(in_bytes)) || (rc = c->d_sig.reserve(sig_bytes)) || (rc = c->d_hdr.reserve(ho + 64)) ||
-        (rc = c->d_aux.reserve(ao + 64)) || (rc = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * n)) ||
-        (rc = c->d_slots.reserve(oo + 64)) || (rc = c->d_len.reserve(4ull * n)) || (rc = c->h_out.reserve(up(4ull * n, 64) + 64)))
+        (rc = c->d_aux.reserve(ao + 64)) || (rc = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * n)))
         return rc;
-    if ((rc = c->d_ovf.reserve(4ull * n + 64))) return rc;
     // pack into pinned staging
     uint8_t *hs = (uint8_t *)c->h_in.p;
     uint8_t *hh = hs + up(sig_bytes, 64), *ha = hh + up(ho + 64, 64), *hd = ha + up(ao + 64, 64);
@@ -213,48 +260,8 @@ extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const u
     a.n_reads = n; a.rec_method = rec_method; a.sig_method = sig_method;
     a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
     a.sig = (const int16_t *)c->d_sig.p; a.hdr = (const uint8_t *)c->d_hdr.p; a.aux = (const uint8_t *)c->d_aux.p;
-    a.slots = (uint8_t *)c->d_slots.p; a.out_len = (uint32_t *)c->d_len.p;
     a.max_payload = max_payload;
-    a.lds_payload_cap = 0;
-    a.ovf = (uint32_t *)c->d_ovf.p;
-    if ((rc = s5gpu_encode_dev(&a, c->st))) return rc;
-    // slots are worst-case sized: gather them on the device into the contiguous record stream (the bytes the
-    // ordered fwrite loop emits), bring back only what was produced, then hand out one malloc per record
-    uint8_t *ho_len = (uint8_t *)c->h_out.p;
-    HIP_TRY(hipMemcpyAsync(ho_len, c->d_len.p, 4ull * n, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(hipStreamSynchronize(c->st));
-    const uint32_t *lens = (const uint32_t *)ho_len;
-    std::vector<uint64_t> off(n + 1);
-    off[0] = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        if (lens[i] < 8 || lens[i] > desc[i].slot_cap) { s5gpu_set_error("read %u: device produced an impossible length %u", i, lens[i]); return S5GPU_ERR_HIP; }
-        off[i + 1] = off[i] + lens[i];
-    }
-    const uint64_t produced = off[n];
-    if ((rc = c->d_pay.reserve(produced + 64)) || (rc = c->d_fields.reserve(8ull * (n + 1) + 8ull * (n / 1024 + 8))) ||
-        (rc = c->h_out.reserve(up(4ull * n, 64) + produced + 64)))
-        return rc;
-    lens = (const uint32_t *)c->h_out.p;   // h_out may have moved; lens were consumed into off[] already
-    uint64_t *d_off = (uint64_t *)c->d_fields.p, *d_tmp = d_off + (n + 1);
-    if ((rc = s5gpu_compact_dev(n, (const s5gpu_read_desc_t *)c->d_desc.p, (const uint8_t *)c->d_slots.p, (const uint32_t *)c->d_len.p,
-                                d_off, (uint8_t *)c->d_pay.p, d_tmp, c->st)))
-        return rc;
-    uint8_t *ho_stream = (uint8_t *)c->h_out.p + up(4ull * n, 64);
-    HIP_TRY(hipMemcpyAsync(ho_stream, c->d_pay.p, produced, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(hipStreamSynchronize(c->st));
-    int oom = 0;
-    parallel_for(n, produced, [&](uint32_t lo, uint32_t hi) {
-        for (uint32_t i = lo; i < hi; i++) {
-            const size_t len = (size_t)(off[i + 1] - off[i]);
-            void *b = malloc(len);
-            if (!b) { oom = 1; out[i] = NULL; continue; }
-            memcpy(b, ho_stream + off[i], len);
-            out[i] = b;
-            out_len[i] = len;
-        }
-    });
-    if (oom) { for (uint32_t j = 0; j < n; j++) { free(out[j]); out[j] = NULL; } return S5GPU_ERR_NOMEM; }
-    return S5GPU_OK;
+    return encode_and_collect(c, n, desc, a, oo, out, out_len);
 }
 
 extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int rec_method, int sig_method,
@@ -480,4 +487,104 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
     }
     if (overall) s5gpu_set_error("s5gpu_solo_batch: at least one input is corrupt (see status[i])");
     return overall;
+}
+
+
+// ---- view / merge worker for a whole batch, device-resident between decode and encode ----
+extern "C" int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                      int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                                      int32_t *status) {
+    if (n == 0) return S5GPU_OK;
+    if (!rec || !rec_len || !out || !out_len) { s5gpu_set_error("s5gpu_recompress_batch: NULL argument"); return S5GPU_ERR_ARG; }
+    Ctx *c;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
+    std::vector<uint32_t> pcap(n), scap(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (rec_len[i] > 0xFFFFFF00ull / 8) { s5gpu_set_error("record %u too large", i); return S5GPU_ERR_ARG; }
+        pcap[i] = (uint32_t)(from_rec == S5GPU_REC_ZLIB ? 4ull * rec_len[i] + 4096 : rec_len[i]);
+        scap[i] = pcap[i];   // a sample takes at least one payload byte in either signal format
+    }
+    std::vector<s5gpu_rec_desc_t> rd(n);
+    std::vector<s5gpu_rec_fields_t> ff(n);
+    for (int attempt = 0;; attempt++) {
+        uint64_t io = 0, po = 0, so = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            s5gpu_rec_desc_t &d = rd[i];
+            d.in_off = io; d.pay_off = po; d.sig_off = so;
+            d.in_len = (uint32_t)rec_len[i]; d.pay_cap = pcap[i]; d.sig_cap = scap[i]; d.reserved = 0;
+            io += up(rec_len[i] + 16, 16); po += up((uint64_t)pcap[i] + 16, 16); so += up((uint64_t)scap[i] + 8, 8);
+        }
+        if ((rc = c->h_in.reserve(up(io + 64, 64) + sizeof(s5gpu_rec_desc_t) * n)) || (rc = c->d_in.reserve(io + 64)) ||
+            (rc = c->d_desc2.reserve(sizeof(s5gpu_rec_desc_t) * n)) || (rc = c->d_pay.reserve(po + 64)) ||
+            (rc = c->d_sig2.reserve(so * 2 + 64)) || (rc = c->d_fields.reserve(sizeof(s5gpu_rec_fields_t) * n)))
+            return rc;
+        uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + up(io + 64, 64);
+        parallel_for(n, io, [&](uint32_t lo, uint32_t hi_) {
+            for (uint32_t i = lo; i < hi_; i++) memcpy(hi + rd[i].in_off, rec[i], rec_len[i]);
+        });
+        memcpy(hd, rd.data(), sizeof(s5gpu_rec_desc_t) * n);
+        HIP_TRY(hipMemcpyAsync(c->d_in.p, hi, io, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->d_desc2.p, hd, sizeof(s5gpu_rec_desc_t) * n, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemsetAsync(c->d_fields.p, 0, sizeof(s5gpu_rec_fields_t) * n, c->st));
+        s5gpu_decode_args_t da;
+        memset(&da, 0, sizeof da);
+        da.n_recs = n; da.rec_method = from_rec; da.sig_method = from_sig;
+        da.desc = (const s5gpu_rec_desc_t *)c->d_desc2.p; da.in = (const uint8_t *)c->d_in.p;
+        da.payload = (uint8_t *)c->d_pay.p; da.sig_out = (int16_t *)c->d_sig2.p; da.fields = (s5gpu_rec_fields_t *)c->d_fields.p;
+        if ((rc = s5gpu_decode_dev(&da, c->st))) return rc;
+        HIP_TRY(hipMemcpyAsync(ff.data(), c->d_fields.p, sizeof(s5gpu_rec_fields_t) * n, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        bool retry = false, bad = false;
+        for (uint32_t i = 0; i < n; i++) {
+            if (ff[i].status == 5 && attempt < 2) { pcap[i] = ff[i].payload_len; if (scap[i] < pcap[i]) scap[i] = pcap[i]; retry = true; }
+            else if (ff[i].status == 6 && attempt < 2) { scap[i] = ff[i].n_samples; retry = true; }
+            else if (ff[i].status != 0) { bad = true; if (status) status[i] = ff[i].status; }
+        }
+        if (bad) { s5gpu_set_error("s5gpu_recompress_batch: at least one input record is corrupt (see status[i])"); return S5GPU_ERR_DATA; }
+        if (!retry) break;   // rare: a record inflated to more than 4x its size; the whole batch is decoded again with exact slots
+    }
+    // encode descriptors straight from the decoded fields: heads and aux tails are read out of the decoded payloads
+    std::vector<s5gpu_read_desc_t> ed(n);
+    uint64_t oo = 0;
+    uint32_t max_payload = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        s5gpu_read_desc_t &d = ed[i];
+        const s5gpu_rec_fields_t &f = ff[i];
+        d.sig_off = rd[i].sig_off;
+        d.hdr_off = rd[i].pay_off;
+        d.aux_off = rd[i].pay_off + f.aux_off;
+        d.out_off = oo;
+        d.n_samples = f.n_samples;
+        d.hdr_len = 2 + f.read_id_len + 4 + 32;
+        d.aux_len = drop_aux ? 0 : f.aux_len;
+        const uint64_t pb = s5gpu_payload_bound(d.n_samples, d.hdr_len, d.aux_len, to_sig);
+        const uint64_t sb = s5gpu_slot_bound(d.n_samples, d.hdr_len, d.aux_len, to_rec, to_sig);
+        if (pb > 0xFFFFFF00ull) { s5gpu_set_error("read %u: record larger than 4 GiB", i); return S5GPU_ERR_ARG; }
+        d.slot_cap = (uint32_t)sb;
+        if (pb > max_payload) max_payload = (uint32_t)pb;
+        oo += sb;
+    }
+    if ((rc = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * n))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_desc.p, ed.data(), sizeof(s5gpu_read_desc_t) * n, hipMemcpyHostToDevice, c->st));
+    if (new_read_group) {   // src/merge.c:51
+        if ((rc = c->d_patch.reserve(12ull * n + 64))) return rc;
+        std::vector<uint64_t> po(n);
+        for (uint32_t i = 0; i < n; i++) po[i] = rd[i].pay_off + 2 + ff[i].read_id_len;
+        uint64_t *d_po = (uint64_t *)c->d_patch.p;
+        uint32_t *d_val = (uint32_t *)(d_po + n);
+        HIP_TRY(hipMemcpyAsync(d_po, po.data(), 8ull * n, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(d_val, new_read_group, 4ull * n, hipMemcpyHostToDevice, c->st));
+        if ((rc = s5gpu_patch_u32_dev((uint8_t *)c->d_pay.p, d_po, d_val, n, c->st))) return rc;
+        HIP_TRY(hipStreamSynchronize(c->st));   // po / new_read_group are pageable host memory
+    }
+    s5gpu_encode_args_t a;
+    memset(&a, 0, sizeof a);
+    a.n_reads = n; a.rec_method = to_rec; a.sig_method = to_sig;
+    a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
+    a.sig = (const int16_t *)c->d_sig2.p; a.hdr = (const uint8_t *)c->d_pay.p; a.aux = (const uint8_t *)c->d_pay.p;
+    a.max_payload = max_payload;
+    return encode_and_collect(c, n, ed, a, oo, out, out_len);
 }

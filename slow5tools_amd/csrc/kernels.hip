@@ -397,6 +397,15 @@ __global__ __launch_bounds__(NT) void k_svbzd_decode(s5gpu_decode_args_t a) {
     }
 }
 
+// read_group rewrite of the merge worker (src/merge.c:51) on decoded payloads: 4 bytes at base + off[i]
+__global__ __launch_bounds__(NT) void k_patch_u32(uint8_t *base, const uint64_t *off, const uint32_t *val, uint32_t n) {
+    const uint32_t i = blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    uint8_t *p = base + off[i];
+    const uint32_t v = val[i];
+    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+}
+
 // ------------------------------------------------------------------------------------------------
 // compaction: slots -> contiguous record stream (the ordered fwrite of src/view.c:296-299)
 // ------------------------------------------------------------------------------------------------
@@ -724,6 +733,14 @@ extern "C" int s5gpu_compact_dev(uint32_t n, const s5gpu_read_desc_t *desc, cons
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(NT), 0, st, tmp, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(NT), 0, st, out_len, n, tmp, rec_off);
     hipLaunchKernelGGL(k_compact, dim3(n), dim3(NT), 0, st, desc, slots, out_len, rec_off, stream);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
+extern "C" int s5gpu_patch_u32_dev(uint8_t *base, const uint64_t *off, const uint32_t *val, uint32_t n, void *stream_) {
+    if (n == 0) return S5GPU_OK;
+    if (!base || !off || !val) return S5GPU_ERR_ARG;
+    hipLaunchKernelGGL(k_patch_u32, dim3((n + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream_, base, off, val, n);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }

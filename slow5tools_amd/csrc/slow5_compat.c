@@ -207,19 +207,15 @@ int slow5_rec_depress_parse(char **mem, size_t *bytes, const char *read_id, stru
 
 int slow5_gpu_recompress_batch(int64_t n, char **mem, size_t *bytes, slow5_press_method_t from, slow5_press_method_t to,
                                const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len) {
-    if (n <= 0) return n == 0 ? 0 : -1;
-    struct slow5_rec **reads = (struct slow5_rec **)calloc(n, sizeof(void *));
-    if (!reads) { slow5_errno = SLOW5_ERR_MEM; return -1; }
-    int ret = slow5_gpu_depress_parse_batch(n, mem, bytes, from, reads);
-    if (ret == 0) {
-        for (int64_t i = 0; i < n; i++) {
-            free(mem[i]);   /* the reference's worker frees the input record after parsing (src/view.c:41) */
-            mem[i] = NULL;
-            if (new_read_group) reads[i]->read_group = new_read_group[i];   /* src/merge.c:51 */
-        }
-        ret = slow5_gpu_rec_to_mem_batch(n, reads, drop_aux, to, out, out_len);
+    const int fr = rec_code(from.record_method), fs = sig_code(from.signal_method);
+    const int tr = rec_code(to.record_method), ts = sig_code(to.signal_method);
+    if (n < 0 || fr < 0 || fs < 0 || tr < 0 || ts < 0) { slow5_errno = SLOW5_ERR_PRESS; return -1; }
+    if (n == 0) return 0;
+    /* one device-resident pass: only compressed bytes cross PCIe (decoded signals stay in HBM) */
+    if (s5gpu_recompress_batch((uint32_t)n, (const void *const *)mem, bytes, fr, fs, tr, ts, new_read_group, drop_aux, out, out_len, NULL) != S5GPU_OK) {
+        slow5_errno = SLOW5_ERR_RECPARSE;
+        return -1;
     }
-    for (int64_t i = 0; i < n; i++) slow5_rec_free(reads[i]);
-    free(reads);
-    return ret;
+    for (int64_t i = 0; i < n; i++) { free(mem[i]); mem[i] = NULL; }   /* the reference's worker frees the input record (src/view.c:41) */
+    return 0;
 }
