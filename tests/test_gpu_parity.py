@@ -237,6 +237,30 @@ def test_roundtrip_own_streams(press, inflate_kernel):
         assert g["status"] == 0 and np.array_equal(g["signal"], sig[i]) and g["read_id"] == ob.synth_read_id(77 + i)
 
 
+def test_decode_highly_compressible_records_retry_with_exact_slots(press, inflate_kernel):
+    """a constant signal deflates > 100x: the first payload-slot guess (4x + 4 KiB) overflows, the decoder reports
+    the size it needs and the batch call retries (status 5 -> exact slot), transparently"""
+    sigs = [np.full(50000, 321, np.int16), np.zeros(200000, np.int16), ob.synth_read(0x5105, 3, 4000)]
+    hdrs = [_hdr(press, i) for i in range(3)]
+    recs = [r[8:] for r in press.encode_records(sigs, hdrs)]
+    assert len(recs[0]) < 1000 and len(recs[1]) < 2000
+    for g, s in zip(press.decode_records(recs), sigs):
+        assert g["status"] == 0 and np.array_equal(g["signal"], s)
+
+
+def test_very_long_read_roundtrip(press):
+    """2 M samples (the reference's longest fixture read, p2solo_ulk114_dna, is 2 050 027): ~160 DEFLATE blocks
+    through the staged kernels, in place in the slot"""
+    sig = ob.synth_read(0x5105, 9, 2_050_027)
+    hdr = _hdr(press, 9)
+    rec = press.encode_records([sig], [hdr])[0]
+    payload, ref = _oracle_payload(hdr, sig, b"", 1)
+    assert zlib.decompress(rec[8:]) == payload
+    assert len(rec) <= 1.01 * len(ref)
+    g = press.decode_records([rec[8:]])[0]
+    assert g["status"] == 0 and np.array_equal(g["signal"], sig)
+
+
 def test_decode_rejects_corrupt_records(press, inflate_kernel):
     sig = ob.synth_reads(0x5105, 0, 4, 4000)
     hdrs = [_hdr(press, i) for i in range(4)]
