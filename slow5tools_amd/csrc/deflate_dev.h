@@ -76,7 +76,7 @@ struct DeflShared {
     uint32_t clblcount[16], clicount[16];   // the same for the code-length code (built concurrently by wave 0)
     uint32_t ws[16];         // cross-wave scan scratch
     uint32_t red[8];         // 0 matches, 1 extra bits, 2 adler A part, 3 adler B part, 4 dyn bits, 5 fixed bits, 6 cl bits
-    uint32_t ncl, hlit, hclen;
+    uint32_t ncl, hlit, hclen, dbg;
     BuildScratchT<32> clb;   // scratch of the 19-symbol code-length code
 #ifdef S5_PROFILE
     unsigned long long prof[16];
@@ -167,6 +167,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
     if (f1) { B.lf[r1] = f1; B.rsym[r1] = (uint16_t)(tid + NT); }
     sync();
     PROF_MARK(WAVE ? 8 : 3);
+    if (!WAVE && S.dbg == 31) return;   // tools/stage_time.py cut-off: after the sort
     if (m <= 1) {   // degenerate: keep the code complete with two 1-bit codes
         if (tid == 0) {
             int sym = m ? B.rsym[0] : 0;
@@ -265,6 +266,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
     }
     sync();
     PROF_MARK(WAVE ? 14 : 4);
+    if (!WAVE && S.dbg == 32) return;   // cut-off: after the merge
     // Depth of every internal node by a parallel parent walk (root = node m-2, depth 0).  Leaves at
     // depth L = 2 * I[L-1] - I[L]; sorted order makes depth monotone in rank, so counts are enough.
     for (int q = tid; q < m - 1; q += NTH) {
@@ -273,15 +275,16 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
         atomicAdd(&icount[min(d, maxbits)], 1u);
     }
     sync();
-    if (tid == 0) {
-        uint32_t used = 0;
-        for (int L = 1; L < maxbits; L++) {
-            const uint32_t c = 2 * icount[L - 1] - icount[L];
-            blcount[L] = c;
-            used += c;
-        }
-        blcount[maxbits] = (uint32_t)m - used;   // every leaf at depth >= maxbits, clamped
-        if (icount[maxbits]) {   // some leaf was deeper than maxbits: repair the Kraft sum on the counts
+    if (WAVE || wave_id() == 0) {
+        // leaves per depth from the internal-node counts, one depth per lane; the clamp bucket takes the rest
+        const int L = lane_id();
+        uint32_t c = 0;
+        if (L >= 1 && L < maxbits) c = 2 * icount[L - 1] - icount[L];
+        const uint32_t used = wave_sum(c);
+        if (L >= 1 && L < maxbits) blcount[L] = c;
+        if (L == 0) blcount[maxbits] = (uint32_t)m - used;   // every leaf at depth >= maxbits, clamped
+        wave_sync();
+        if (L == 0 && icount[maxbits]) {   // some leaf was deeper than maxbits: repair the Kraft sum on the counts
             uint32_t total = 0;
             for (int b = maxbits; b >= 1; b--) total += blcount[b] << (maxbits - b);
             while (total != (1u << maxbits)) {
@@ -530,8 +533,9 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     if (dbg == 2) { z.bitpos += S.freq[tid] + S.red[0]; return; }   // tools/stage_time.py cut-off
 
     // ---- B: codes ----
+    if (tid == 0) S.dbg = dbg;   // ordered before its first use by the barriers inside build_lengths
     build_lengths(S, B, &B.sort, S.freq, NLIT, 15, S.lens, S.blcount, S.icount);
-    if (dbg == 3) { z.bitpos += S.lens[tid]; return; }
+    if (dbg == 3 || dbg == 31 || dbg == 32) { z.bitpos += S.lens[tid] + B.lf[tid] + B.nf[tid]; return; }
     PROF_RESET
     if (FUSED) {   // B is dead from here on: its storage becomes the bit buffer
         for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
