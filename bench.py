@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — BLOW5 encode throughput (svb-zd + DEFLATE, BASELINE.json config 3) on N MI355X.
 
-A step = one pass of the hot path over one resident batch of synthetic reads:
-    k_encode_fused  (svb-zd -> pack -> DEFLATE -> zlib frame, one read per workgroup)
-  + s5gpu_compact   (slots -> contiguous BLOW5 record stream, what the ordered fwrite emits)
+A step = one pass of the hot path over one resident batch of synthetic reads, ending in the contiguous BLOW5
+record stream the ordered fwrite loop emits:
+    k_encode_stream (svb-zd -> pack -> DEFLATE -> zlib frame, one read per workgroup, records placed by a
+                     decoupled look-back: one launch)                                   [default]
+    or k_encode_fused into worst-case slots + s5gpu_compact (--two-pass, long reads, --svb-only)
 Inputs (int16 signals, 74-byte record heads) are already in HBM when the timed region starts.
 Reads shard across ranks with no collective (weak scaling: every rank encodes its own batch).
 Prints ONE JSON line on rank 0.
@@ -29,6 +31,7 @@ def main():
     ap.add_argument("--samples", type=int, default=4000, help="int16 samples per read")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--svb-only", action="store_true", help="config 2: svb-zd stage alone")
+    ap.add_argument("--two-pass", action="store_true", help="encode into worst-case slots + compaction pass instead of the ordered single-pass stream")
     ap.add_argument("--decode", action="store_true", help="config 5: random get-style decode (inflate + svb-zd unpack)")
     ap.add_argument("--get-reads", type=int, default=100_000, help="--decode: random read ids to fetch (seed 1)")
     ap.add_argument("--get-batch", type=int, default=4096, help="--decode: ids per batch (-K)")
@@ -61,15 +64,33 @@ def main():
     b.synth(seed=0x5105, first=first)
     torch.cuda.synchronize()
 
-    step = b.svbzd_encode if args.svb_only else b.encode
+    # Full encode, default: ONE launch per step — k_encode_stream writes every record straight to its place in the
+    # contiguous BLOW5 record stream (ordered single pass, decoupled look-back).  It needs every read to fit the LDS
+    # budget (true for 4000-sample reads); long reads, --two-pass and --svb-only use slots + the compaction pass.
+    single_pass = not args.svb_only and not args.two_pass and b.tot["max_payload"] * 100 // 325 <= 16384
+
+    def run_step():
+        if single_pass:
+            b.encode_stream()
+        else:
+            (b.svbzd_encode if args.svb_only else b.encode)()
+
+    def second_half():
+        if not single_pass:
+            b.compact()
+
     st = b._stream()
 
     barrier = shard.barrier
 
     for _ in range(args.warmup):
-        step()
-        b.compact()
+        run_step()
+        second_half()
     torch.cuda.synchronize()
+    if single_pass and not b.stream_ok():   # a read overflowed the LDS budget: the stream is invalid, use the two-pass path
+        single_pass = False
+        run_step(); second_half()
+        torch.cuda.synchronize()
 
     K = args.steps
     evs = []
@@ -82,9 +103,9 @@ def main():
     t0 = time.perf_counter()
     for k in range(K):
         L.s5gpu_event_record(evs[3 * k], st)
-        step()
+        run_step()
         L.s5gpu_event_record(evs[3 * k + 1], st)
-        b.compact()
+        second_half()
         L.s5gpu_event_record(evs[3 * k + 2], st)
     torch.cuda.synchronize()
     barrier()
@@ -124,7 +145,7 @@ def main():
     traffic = None
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if not args.svb_only and t.get("samples_per_read") == n:
+        if not args.svb_only and t.get("samples_per_read") == n and t.get("kernel") == ("k_encode_stream" if single_pass else "k_encode_fused"):
             traffic = int(t["hbm_bytes_per_read"] * n_reads)
     except Exception:
         pass
@@ -135,8 +156,8 @@ def main():
     import oracle_bind as ob
 
     idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
-    recs = b.records(idx)
-    parity = True
+    recs = b.stream_records(idx) if single_pass else b.records(idx)
+    parity = b.stream_ok() if single_pass else True
     for i, rec in zip(idx, recs):
         sig = ob.synth_read(0x5105, first + i, n)
         if args.svb_only:
@@ -174,8 +195,9 @@ def main():
         "reads_per_s": round(reads_per_s, 1),
         "bytes_per_sample": round(z_bytes / (n_reads * n), 4),
         "parity_spot_check": bool(parity),
-        "kernel_ms": {"encode": round(float(np.mean(enc_ms)), 3), "compact": round(float(np.mean(cmp_ms)), 3)},
-        "roofline": {"bound": "hbm", "kernel": "k_svbzd_encode" if args.svb_only else ("k_encode_fused" if b.tot["max_payload"] * 100 // 325 <= 4 * 16384 else "k_pack+k_deflate_staged"),
+        "kernel_ms": {"encode": round(float(np.mean(enc_ms)), 3), "compact": round(float(np.mean(cmp_ms)), 3) if not single_pass else 0.0},
+        "output": "ordered single-pass record stream (k_encode_stream)" if single_pass else "worst-case slots + compaction pass",
+        "roofline": {"bound": "hbm", "kernel": "k_svbzd_encode" if args.svb_only else ("k_encode_stream" if single_pass else "k_encode_fused" if b.tot["max_payload"] * 100 // 325 <= 4 * 16384 else "k_pack+k_deflate_staged"),
                      "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes},

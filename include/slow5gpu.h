@@ -126,6 +126,13 @@ int s5gpu_encode_dev(const s5gpu_encode_args_t *args, void *hip_stream);
 int s5gpu_decode_dev(const s5gpu_decode_args_t *args, void *hip_stream);
 /* svb-zd only (BASELINE config 2): blob per read written at slots+out_off, out_len = blob bytes */
 int s5gpu_svbzd_encode_dev(const s5gpu_encode_args_t *args, void *hip_stream);
+/* Encode with ORDERED SINGLE-PASS OUTPUT (zlib record press): records go straight into the contiguous BLOW5 record
+ * stream, rec_off[i] / rec_off[n] as s5gpu_compact_dev would produce them; no slots, no second pass.  args->slots and
+ * args->ovf are not used.  state: n_reads u64 of scratch; ctl: 4 u32 of scratch, read them back after completion:
+ * ctl[0] != 0 (some read did not fit the LDS budget) or ctl[2] != 0 (look-back timed out) => the stream is invalid,
+ * fall back to s5gpu_encode_dev + s5gpu_compact_dev.  stream_out must hold the sum of the slot bounds. */
+int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *args, uint8_t *stream_out, uint64_t *rec_off, uint64_t *state,
+                            uint32_t *ctl, void *hip_stream);
 /* single stages, for the solo press calls (slow5_ptr_compress_solo / slow5_ptr_depress_solo):
  *  deflate_parked: zlib-compress byte ranges already parked in their slots — read i's bytes sit at
  *    slots + out_off + ((slot_cap - s5gpu_payload_bound(desc i)) & ~15), out_len[i] = their length on entry

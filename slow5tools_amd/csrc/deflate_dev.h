@@ -83,6 +83,19 @@ struct DeflShared {
 #endif
 };
 
+// Ordered single-pass output: as soon as a single-block record's final size is known (right after the bit-offset
+// scan, before the tokens are packed) it is published for the look-back of the following reads.
+struct EarlySize {
+    unsigned long long *state;   // nullptr: nothing to publish
+    uint32_t r;
+};
+__device__ __forceinline__ void publish_size(const EarlySize &es, uint32_t end_bitpos) {
+    if (es.state && threadIdx.x == 0) {
+        const unsigned long long total = ((end_bitpos + 7) >> 3) + 4;   // + Adler-32
+        __hip_atomic_store(&es.state[es.r], (1ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 struct ZOut {                // replicated uniformly in every lane's registers
     uint32_t bitpos;         // absolute bit position in the record slot (slot byte 0 = bit 0)
     uint32_t flushed;        // 32-bit words already copied to HBM; obuf[0] holds word `flushed`
@@ -415,7 +428,7 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
 template <bool FUSED, typename M = uint64_t>
 __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words,
                                               const uint8_t *__restrict__ buf, int len, bool final, ZOut &z, uint32_t &adA,
-                                              uint32_t &adB, uint32_t dbg = 0) {
+                                              uint32_t &adB, uint32_t dbg = 0, EarlySize es = EarlySize{nullptr, 0}) {
     using MO = MaskOps<M>;
     const int tid = threadIdx.x;
     if (len == 0) {
@@ -426,6 +439,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         }   // empty stream: fixed block holding only end-of-block
         if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 10);
         z.bitpos += 10;
+        publish_size(es, z.bitpos);
         __syncthreads();
         return;
     }
@@ -670,6 +684,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     if (sto_total <= dyn_total && sto_total <= fix_total) {
         // ---- stored block ----
         const uint32_t bytepos = (z.bitpos + 3 + 7) >> 3;
+        publish_size(es, (bytepos + 4 + (uint32_t)len) * 8);
         uint8_t *ob8 = reinterpret_cast<uint8_t *>(obuf) + (bytepos - z.flushed * 4);
         if (tid == 0) {
             put_bits(obuf, z, z.bitpos, final ? 1u : 0u, 3);
@@ -751,6 +766,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     const uint32_t packed = block_excl_add((clnb[0] + clnb[1]) | (mybits << 13), S.ws, packed_total);
     const uint32_t total_bits = packed_total >> 13;
     const uint32_t start = pos0 + (packed >> 13);
+    publish_size(es, pos0 + total_bits + (S.code[256] >> 16));
     if (!use_fixed) {
         const uint32_t p = z.bitpos + 17 + 3 * S.hclen + (packed & 0x1FFF);
         if (clnb[0]) put_bits(obuf, z, p, clv[0], clnb[0]);
@@ -807,27 +823,91 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     PROF_MARK(12);
 }
 
-// Fused path: zlib-frame a payload of at most DEFL_BLK bytes that sits in LDS (`pay`) as ONE DEFLATE
-// block into HBM slot `out` (16-B aligned).  Slot layout: [u64 size][78 9c][block][adler32 BE].
-// obuf: LDS, obuf_words >= max(plen + 64, sizeof(BuildScratch)) / 4; returns total bytes incl. the prefix.
+// Fused path: zlib-frame a payload of at most DEFL_BLK bytes that sits in LDS (`pay`) as ONE DEFLATE block.
+// Leaves the whole record in the LDS bit buffer, bytes [8, total): 78 9c | block | adler32 BE (bytes [0, 8) are
+// reserved for the u64 size prefix) and returns total.  obuf_words >= max(plen + 64, sizeof(BuildScratch)) / 4.
 template <typename M>
-__device__ __forceinline__ uint32_t zlib_compress_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words,
-                                                        const uint8_t *pay, uint32_t plen, uint8_t *out, uint32_t dbg = 0) {
+__device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words, const uint8_t *pay,
+                                                     uint32_t plen, ZOut &z, uint32_t dbg = 0, EarlySize es = EarlySize{nullptr, 0}) {
     const int tid = threadIdx.x;
-    ZOut z;
     z.bitpos = 80;   // 64 bits of size prefix + 16 bits of zlib header, both written later
     z.flushed = 0;
     uint32_t adA = 1, adB = 0;
-    deflate_block<true, M>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg);
-    if (dbg) { if (tid == 0) *reinterpret_cast<uint32_t *>(out) = z.bitpos; return 16; }
+    deflate_block<true, M>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es);
+    if (dbg) return 16;
     z.bitpos = (z.bitpos + 7) & ~7u;
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
     z.bitpos += 32;
     __syncthreads();
+    return z.bitpos >> 3;
+}
+
+// ... then into a 16-B aligned HBM slot: [u64 size][record]
+template <typename M>
+__device__ __forceinline__ uint32_t zlib_compress_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words,
+                                                        const uint8_t *pay, uint32_t plen, uint8_t *out, uint32_t dbg = 0) {
+    ZOut z;
+    const uint32_t total = zlib_frame_fused<M>(S, obuf, obuf_words, pay, plen, z, dbg);
+    if (dbg) { if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(out) = z.bitpos; return 16; }
     flush_words(obuf, reinterpret_cast<uint32_t *>(out), z, true);
-    const uint32_t total = z.bitpos >> 3;
-    if (tid == 0) *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
+    if (threadIdx.x == 0) *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
     return total;
+}
+
+// ---- ordered single-pass output (decoupled look-back over the record sizes) ----
+// state word per read: flag << 62 | value; flag 1 = this read's size, 2 = inclusive prefix up to and including it.
+// One 8-byte agent-scope store carries flag and value together, so no fence is needed (G16 R2).
+constexpr uint64_t LB_MASK = (1ull << 62) - 1;
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+// wave 0 of the workgroup that owns read r (reads are taken in ticket = start order, so every predecessor is
+// already resident and will publish).  Returns the exclusive prefix (byte offset of this record in the stream).
+__device__ __forceinline__ uint64_t lookback_offset(unsigned long long *st, uint32_t r, uint64_t mysize, uint32_t *err, bool published) {
+    const int lane = lane_id();
+    if (!published && lane == 0) __hip_atomic_store(&st[r], (1ull << 62) | mysize, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t excl = 0;
+    long long base = (long long)r - 1;
+    uint32_t spins = 0;
+    for (;;) {
+        const long long idx = base - lane;
+        const uint64_t v = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+        const uint32_t f = (uint32_t)(v >> 62);
+        const uint64_t m0 = __ballot(f == 0), m2 = __ballot(f == 2);
+        const int first0 = m0 ? __ffsll((long long)m0) - 1 : 64;
+        const int first2 = m2 ? __ffsll((long long)m2) - 1 : 64;
+        if (first2 < first0) {   // a prefix is reachable through published sizes: done
+            excl += wave_sum64(lane <= first2 ? (v & LB_MASK) : 0ull);
+            break;
+        }
+        // take the published sizes in front of the first unpublished predecessor, then wait for that one
+        excl += wave_sum64(lane < first0 ? (v & LB_MASK) : 0ull);
+        base -= first0;
+        if (first0 < 64) {
+            if (++spins > (1u << 22)) { if (lane == 0) *err = 1; break; }   // never hang the GPU: report instead
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    if (lane == 0) __hip_atomic_store(&st[r], (2ull << 62) | (excl + mysize), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+// copy `total` bytes of the LDS record image (word-aligned at obuf) to a byte-aligned HBM destination
+__device__ __forceinline__ void copy_record_out(const uint32_t *obuf, uint32_t total, uint8_t *dst) {
+    const int tid = threadIdx.x;
+    const uint8_t *ob8 = reinterpret_cast<const uint8_t *>(obuf);
+    const uint32_t head = min(total, (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3));
+    if ((uint32_t)tid < head) dst[tid] = ob8[tid];
+    const uint32_t nw = (total - head) >> 2;
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
+    const uint32_t sh = head * 8;
+    for (uint32_t i = tid; i < nw; i += NT) {
+        const uint32_t lo = obuf[i], hi = obuf[i + 1];
+        d32[i] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    }
+    const uint32_t tail0 = head + 4 * nw;
+    if ((uint32_t)tid < total - tail0) dst[tail0 + tid] = ob8[tail0 + tid];
 }
 
 }  // namespace s5

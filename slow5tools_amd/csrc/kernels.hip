@@ -133,6 +133,51 @@ __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
 #endif
 }
 
+// The same with ORDERED SINGLE-PASS OUTPUT: no slots, no compaction pass.  Reads are taken in ticket (start) order;
+// once a record's size is known its byte offset in the contiguous BLOW5 record stream comes from a decoupled
+// look-back over the sizes of the preceding reads, and the record goes straight from LDS to its final place.
+// ctl: [0] overflow count (a read that does not fit the LDS budget cannot be placed: the caller must fall back
+// to s5gpu_encode_dev + s5gpu_compact_dev), [1] ticket counter, [2] look-back timeout flag.
+struct StreamParams {
+    unsigned long long *state;   // n_reads words, zeroed
+    uint32_t *ctl;               // 4 words, zeroed
+    uint8_t *stream;
+    uint64_t *rec_off;           // n_reads + 1
+};
+template <typename M>
+__global__ __launch_bounds__(NT, 8) void k_encode_stream(EncParams p, StreamParams sp) {
+    __shared__ uint32_t s_r;
+    __shared__ uint64_t s_off;
+    DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
+    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
+    uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
+    if (threadIdx.x == 0) s_r = atomicAdd(&sp.ctl[1], 1u);
+    __syncthreads();
+    const uint32_t r = s_r;
+    const s5gpu_read_desc_t d = p.a.desc[r];
+    const uint32_t plen = build_payload(p.a, d, pay, p.pay_cap, S.ws);
+    uint32_t total = 0;
+    if (plen == OVF) {
+        if (threadIdx.x == 0) atomicAdd(&sp.ctl[0], 1u);   // size 0 keeps the chain alive; the stream is invalid
+    } else {
+        __syncthreads();
+        ZOut z;
+        total = zlib_frame_fused<M>(S, obuf, p.obuf_words, pay, plen, z, 0, EarlySize{sp.state, r});
+        if (threadIdx.x == 0) { obuf[0] = total - 8; obuf[1] = 0; }   // u64 size prefix
+    }
+    if (wave_id() == 0) {
+        const uint64_t off = lookback_offset(sp.state, r, total, &sp.ctl[2], plen != OVF);
+        if (lane_id() == 0) {
+            s_off = off;
+            sp.rec_off[r] = off;
+            if (r == p.a.n_reads - 1) sp.rec_off[p.a.n_reads] = off + total;
+            p.a.out_len[r] = total;
+        }
+    }
+    __syncthreads();
+    if (total) copy_record_out(obuf, total, sp.stream + s_off);
+}
+
 // Staged path works IN PLACE in the read's slot: the payload is parked at the slot's tail
 // (offset slot_cap - payload_bound, 16-B aligned) and the zlib stream grows from the slot's head.  The
 // slot bound leaves more room than the worst-case (all-stored) framing overhead, and each 16 KiB block
@@ -569,6 +614,8 @@ static int set_lds_attrs() {
     if (g_attr_done) return S5GPU_OK;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svbzd_encode), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     g_attr_done = true;
@@ -626,6 +673,48 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
         hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0);
     }
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
+static uint32_t fused_cap(const s5gpu_encode_args_t *a) {
+    uint32_t cap = a->lds_payload_cap;
+    if (cap == 0) {
+        const bool svb = a->sig_method == S5GPU_SIG_SVB_ZD;
+        cap = svb ? (uint32_t)((uint64_t)a->max_payload * 155 / 325) + 128 : a->max_payload;
+    }
+    if (cap > a->max_payload) cap = a->max_payload;
+    if (cap > (uint32_t)DEFL_BLK) cap = DEFL_BLK;
+    return (cap + 15u) & ~15u;
+}
+
+extern "C" int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *a, uint8_t *stream_out, uint64_t *rec_off, uint64_t *state,
+                                       uint32_t *ctl, void *stream_) {
+    if (!a || !a->desc || !a->sig || !a->hdr || !a->out_len || !stream_out || !rec_off || !state || !ctl ||
+        a->rec_method != S5GPU_REC_ZLIB || (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD)) {
+        s5gpu_set_error("s5gpu_encode_stream_dev: bad arguments (zlib record press only)");
+        return S5GPU_ERR_ARG;
+    }
+    if (a->n_reads == 0) return S5GPU_OK;
+    int rc;
+    if ((rc = set_lds_attrs())) return rc;
+    hipStream_t st = (hipStream_t)stream_;
+    EncParams p;
+    p.a = *a;
+    p.dbg = 0;
+    const uint32_t cap = fused_cap(a);
+    p.pay_cap = cap;
+    p.obuf_words = (cap + 64 > B_BYTES ? cap + 64 : B_BYTES) / 4;
+    const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
+    StreamParams sp;
+    sp.state = reinterpret_cast<unsigned long long *>(state);
+    sp.ctl = ctl;
+    sp.stream = stream_out;
+    sp.rec_off = rec_off;
+    HIP_TRY(hipMemsetAsync(state, 0, 8ull * a->n_reads, st));
+    HIP_TRY(hipMemsetAsync(ctl, 0, 16, st));
+    if (cap <= 8192) hipLaunchKernelGGL(k_encode_stream<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p, sp);
+    else hipLaunchKernelGGL(k_encode_stream<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p, sp);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }

@@ -208,6 +208,21 @@ class DeviceBatch:
     def encode(self):
         check(_lib.lib().s5gpu_encode_dev(C.byref(self.args), self._stream()), "s5gpu_encode_dev")
 
+    def encode_stream(self):
+        """ordered single-pass encode straight into stream_out / rec_off (no slots, no compaction pass)"""
+        if not hasattr(self, "lb_state"):
+            t = self.torch
+            self.lb_state = t.zeros(self.n + 1, dtype=t.int64, device=self.dev)
+            self.lb_ctl = t.zeros(4, dtype=t.int32, device=self.dev)
+        check(_lib.lib().s5gpu_encode_stream_dev(C.byref(self.args), self.stream_out.data_ptr(), self.rec_off.data_ptr(),
+                                                 self.lb_state.data_ptr(), self.lb_ctl.data_ptr(), self._stream()),
+              "s5gpu_encode_stream_dev")
+
+    def stream_ok(self):
+        """after a synchronise: True if the single-pass stream is valid (no LDS overflow, no look-back timeout)"""
+        c = self.lb_ctl.cpu().numpy()
+        return int(c[0]) == 0 and int(c[2]) == 0
+
     def svbzd_encode(self):
         check(_lib.lib().s5gpu_svbzd_encode_dev(C.byref(self.args), self._stream()), "s5gpu_svbzd_encode_dev")
 
@@ -226,6 +241,12 @@ class DeviceBatch:
             o = int(self.desc_np["out_off"][i])
             out.append(self.slots[o:o + int(lens[i])].cpu().numpy().tobytes())
         return out
+
+    def stream_records(self, idx):
+        """records idx out of the contiguous stream (after compact() or encode_stream())"""
+        self.torch.cuda.synchronize(self.dev)
+        off = self.rec_off.cpu().numpy()
+        return [self.stream_out[int(off[i]):int(off[i + 1])].cpu().numpy().tobytes() for i in idx]
 
     def stream_bytes(self):
         self.torch.cuda.synchronize(self.dev)

@@ -113,6 +113,41 @@ def test_full_encode_synthetic_4000(press):
     assert list(off[: n_reads + 1]) == list(np.concatenate([[0], np.cumsum([len(r) for r in recs])]))
 
 
+@pytest.mark.parametrize("n_reads", [1, 7, 300, 20000])
+def test_single_pass_stream_equals_slots_plus_compaction(press, n_reads):
+    """ordered single-pass output (decoupled look-back) == encode into slots + compaction, byte for byte"""
+    n = 4000
+    b = press.DeviceBatch([n] * n_reads)
+    b.synth(seed=0x5105, first=31)
+    b.encode()
+    b.compact()
+    want, off_want = b.stream_bytes()
+    want_len = b.out_len[:n_reads].cpu().numpy().copy()
+    b.stream_out.zero_()
+    b.rec_off.zero_()
+    for _ in range(3):   # repeated launches reuse the look-back state: it must be reset every call
+        b.encode_stream()
+    got, off_got = b.stream_bytes()
+    assert b.stream_ok()
+    assert list(off_got[: n_reads + 1]) == list(off_want[: n_reads + 1])
+    assert got == want
+    assert (b.out_len[:n_reads].cpu().numpy() == want_len).all()
+
+
+def test_single_pass_stream_reports_lds_overflow(press):
+    rng = np.random.default_rng(3)
+    sig = ob.synth_reads(0x5105, 0, 64, 4000)
+    sig[11] = rng.integers(-32768, 32768, 4000, dtype=np.int16)     # does not fit the LDS budget
+    b = press.DeviceBatch([4000] * 64)
+    b.upload(list(sig), [_hdr(press, i) for i in range(64)])
+    b.encode_stream()
+    b.torch.cuda.synchronize()
+    assert not b.stream_ok() and int(b.lb_ctl[0].item()) == 1        # the caller falls back to encode + compact
+    b.encode()
+    b.compact()
+    _check_records(press, sig, [_hdr(press, i) for i in range(64)], None, b.records(), 1, 1)
+
+
 @pytest.mark.parametrize("rec_method,sig_method", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_encode_all_method_combinations_ragged(press, rec_method, sig_method):
     rng = np.random.default_rng(11)
