@@ -162,7 +162,49 @@ static void parallel_for(uint32_t n, uint64_t bytes, F fn) {
 static int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
                               void **out, size_t *out_len) {
     int rc;
-    if ((rc = c->d_slots.reserve(slots_bytes + 64)) || (rc = c->d_len.reserve(4ull * n)) || (rc = c->d_ovf.reserve(4ull * n + 64)) ||
+    if ((rc = c->d_len.reserve(4ull * n))) return rc;
+    a.out_len = (uint32_t *)c->d_len.p;
+    // First choice: ordered single-pass output — records land in the contiguous stream directly.  It needs every read
+    // to fit the LDS budget of the fused kernel; if the device reports otherwise, the slot path below redoes the batch.
+    if (a.rec_method == S5GPU_REC_ZLIB && (uint64_t)a.max_payload * 100 / 325 <= 16384) {
+        const size_t scan_bytes = 8ull * (n + 1) + 8ull * n + 16;
+        if ((rc = c->d_stream.reserve(slots_bytes + 64)) || (rc = c->d_scan.reserve(scan_bytes)) ||
+            (rc = c->h_out.reserve(up(8ull * (n + 1) + 16, 64) + 64)))
+            return rc;
+        uint64_t *d_off = (uint64_t *)c->d_scan.p, *d_state = d_off + (n + 1);
+        uint32_t *d_ctl = (uint32_t *)(d_state + n);
+        if ((rc = s5gpu_encode_stream_dev(&a, (uint8_t *)c->d_stream.p, d_off, d_state, d_ctl, c->st))) return rc;
+        uint8_t *h = (uint8_t *)c->h_out.p;
+        HIP_TRY(hipMemcpyAsync(h, d_off, 8ull * (n + 1), hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipMemcpyAsync(h + 8ull * (n + 1), d_ctl, 16, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        const uint32_t *ctl = (const uint32_t *)(h + 8ull * (n + 1));
+        if (ctl[0] == 0 && ctl[2] == 0) {
+            std::vector<uint64_t> off(n + 1);
+            memcpy(off.data(), h, 8ull * (n + 1));
+            const uint64_t produced = off[n];
+            for (uint32_t i = 0; i < n; i++)
+                if (off[i + 1] < off[i] + 8 || off[i + 1] - off[i] > desc[i].slot_cap) { s5gpu_set_error("read %u: device produced an impossible record extent", i); return S5GPU_ERR_HIP; }
+            if ((rc = c->h_out.reserve(produced + 64))) return rc;
+            uint8_t *ho_stream = (uint8_t *)c->h_out.p;
+            HIP_TRY(hipMemcpyAsync(ho_stream, c->d_stream.p, produced, hipMemcpyDeviceToHost, c->st));
+            HIP_TRY(hipStreamSynchronize(c->st));
+            int oom = 0;
+            parallel_for(n, produced, [&](uint32_t lo, uint32_t hi) {
+                for (uint32_t i = lo; i < hi; i++) {
+                    const size_t len = (size_t)(off[i + 1] - off[i]);
+                    void *b = malloc(len);
+                    if (!b) { oom = 1; out[i] = NULL; continue; }
+                    memcpy(b, ho_stream + off[i], len);
+                    out[i] = b;
+                    out_len[i] = len;
+                }
+            });
+            if (oom) { for (uint32_t j = 0; j < n; j++) { free(out[j]); out[j] = NULL; } return S5GPU_ERR_NOMEM; }
+            return S5GPU_OK;
+        }
+    }
+    if ((rc = c->d_slots.reserve(slots_bytes + 64)) || (rc = c->d_ovf.reserve(4ull * n + 64)) ||
         (rc = c->h_out.reserve(up(4ull * n, 64) + 64)))
         return rc;
     a.slots = (uint8_t *)c->d_slots.p; a.out_len = (uint32_t *)c->d_len.p;
