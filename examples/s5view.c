@@ -1,12 +1,13 @@
 /*
- * s5view.c — the batch loop of `slow5tools view` (BLOW5 -> BLOW5 recompression) on the GPU press path.
+ * s5view.c — the batch loop of `slow5tools view` (SLOW5 / BLOW5 -> SLOW5 / BLOW5) on the GPU press path.
  *
  * Not a CLI re-implementation: this is slow5_convert_parallel (/root/reference/src/view.c:241-323) with the
- * work_db() call at src/view.c:292 replaced by ONE slow5_gpu_recompress_batch() per batch, written against
+ * work_db() call at src/view.c:292 replaced by ONE slow5_gpu_convert_batch() per batch, written against
  * include/slow5_compat.h only.  It doubles as the end-to-end harness of tests/test_container.py.
  *
- *   s5view in.blow5 out.blow5 [record: none|zlib] [signal: none|svb-zd] [batch K]     (defaults zlib svb-zd 4096,
- *                                                                                       src/misc.c:54-58, src/cmd.h:8)
+ *   s5view in.[b|s]low5 out.[b|s]low5 [record: none|zlib] [signal: none|svb-zd] [batch K]   (defaults zlib svb-zd 4096,
+ *        src/misc.c:54-58, src/cmd.h:8; the input format is sniffed, the output format follows the extension as in
+ *        src/view.c:170-190; press methods are ignored for a .slow5 output)
  *   s5view --index in.blow5          writes in.blow5.idx (slow5tools index)
  *   s5view --get in.blow5 read_id    prints len_raw_signal and the first samples of one read (slow5tools get)
  */
@@ -56,7 +57,9 @@ int main(int argc, char **argv) {
     if (!in) return die("cannot open input");
     FILE *out = fopen(argv[2], "wb");
     if (!out) return die("cannot open output");
-    if (slow5_hdr_fwrite(out, in->header, SLOW5_FORMAT_BINARY, to) < 0) return die("header write failed");
+    const size_t ol = strlen(argv[2]);
+    const enum slow5_fmt fmt_out = ol > 6 && strcmp(argv[2] + ol - 6, ".slow5") == 0 ? SLOW5_FORMAT_ASCII : SLOW5_FORMAT_BINARY;
+    if (slow5_hdr_fwrite(out, in->header, fmt_out, to) < 0) return die("header write failed");
     slow5_press_method_t from = {in->compress->record_press->method, in->compress->signal_press->method};
 
     char **mem = (char **)calloc(K, sizeof(char *));
@@ -74,14 +77,15 @@ int main(int argc, char **argv) {
         }
         if (n == 0) break;
         /* compute phase: the work_db() of src/view.c:292, one call for the whole batch */
-        if (slow5_gpu_recompress_batch(n, mem, bytes, from, to, NULL, 0, bufs, lens) != 0) return die("GPU press path failed");
+        if (slow5_gpu_convert_batch(n, mem, bytes, in->format, from, in->header->aux_meta, fmt_out, to, NULL, 0, bufs, lens) != 0)
+            return die("GPU press path failed");
         for (int64_t i = 0; i < n; i++) {                           /* ordered write phase, src/view.c:296-299 */
             if (fwrite(bufs[i], 1, lens[i], out) != lens[i]) return die("write failed");
             free(bufs[i]);
         }
         total += (uint64_t)n;
     }
-    if (slow5_eof_fwrite(out) < 0) return die("eof write failed");
+    if (fmt_out == SLOW5_FORMAT_BINARY && slow5_eof_fwrite(out) < 0) return die("eof write failed");   /* src/view.c:311-313 */
     fclose(out);
     slow5_close(in);
     free(mem); free(bytes); free(bufs); free(lens);

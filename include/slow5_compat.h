@@ -16,7 +16,8 @@
  * slow5lib's private headers.  Two deliberate differences, both outside the press path:
  *   - aux fields travel as their already-serialised BLOW5 bytes (aux_blob / aux_len) instead of
  *     slow5lib's khash map: the aux/header attribute API is out of scope;
- *   - only the binary format (BLOW5) is handled; SLOW5 ASCII parsing/formatting is SURVEY §8(f) row 2.
+ *   - SLOW5 ASCII is handled at the same level: slow5_open / slow5_get_next_mem / slow5_hdr_fwrite
+ *     understand .slow5 files and slow5_gpu_convert_batch parses / prints whole batches of record lines.
  * A maintainer integrating into the real slow5lib keeps slow5lib's structs and calls the s5gpu_*
  * functions from slow5lib's own slow5_rec_to_mem / slow5_rec_depress_parse — see INTEGRATION.md.
  */
@@ -53,7 +54,11 @@ typedef struct slow5_press slow5_press_t;
 
 enum slow5_fmt { SLOW5_FORMAT_UNKNOWN = 0, SLOW5_FORMAT_ASCII = 1, SLOW5_FORMAT_BINARY = 2 };
 
-struct slow5_aux_meta;                        /* opaque: only tested against NULL (src/merge.c:58-62) */
+struct slow5_aux_meta {                       /* slow5tools only tests it against NULL (src/merge.c:58-62); here it carries */
+    uint32_t num;                             /* the aux column types of the header's types line, S5GPU_AUX_* codes        */
+    uint8_t *types;
+};
+typedef struct slow5_aux_meta slow5_aux_meta_t;
 
 struct slow5_rec {                            /* field uses: src/read_fast5.c:665-666,736-763,1136-1138; src/merge.c:51 */
     uint16_t read_id_len;
@@ -76,6 +81,7 @@ struct slow5_hdr {                            /* framing view of the header: the
     uint32_t num_read_groups;                 /* src/stats.c:109 */
     char *data;                               /* the header text exactly as stored after the u32 length (Appendix A.1) */
     uint32_t data_len;
+    struct slow5_aux_meta *aux_meta;          /* NULL when the file has no aux columns (src/merge.c:58) */
 };
 typedef struct slow5_hdr slow5_hdr_t;
 struct slow5_idx;                             /* read_id -> (offset, size), Appendix A.5 */
@@ -115,7 +121,9 @@ void slow5_rec_free(struct slow5_rec *read);
 
 /* ---- BLOW5 file framing (layouts: Appendix A.1/A.2/A.4/A.5, test/misc/make_blow5.c:11-101) ----
  * Only what view / merge / get need around the press path: open + header, sequential record framing, header and
- * EOF writers, and the read_id index.  BLOW5 only. */
+ * EOF writers, and the read_id index.  slow5_open tells BLOW5 from SLOW5 ASCII by the file's first bytes; for ASCII,
+ * slow5_get_next_mem returns one record line (with its newline) and slow5_hdr_fwrite prints the two '#' version lines
+ * followed by the same header text.  The index calls are BLOW5 only. */
 slow5_file_t *slow5_open(const char *pathname, const char *mode);                 /* src/view.c:192, "r" only */
 int slow5_close(slow5_file_t *s5p);
 /* next record's bytes without the u64 size prefix, malloc'd; NULL + slow5_errno = SLOW5_ERR_EOF at the end
@@ -139,6 +147,12 @@ int slow5_get(const char *read_id, struct slow5_rec **read, slow5_file_t *s5p); 
 int slow5_gpu_recompress_batch(int64_t n, char **mem, size_t *bytes, slow5_press_method_t from,
                                slow5_press_method_t to, const uint32_t *new_read_group, int drop_aux, void **out,
                                size_t *out_len);
+/* The same worker when either side may be SLOW5 ASCII (src/view.c:35-57 with s5p->format / core->format_out ASCII):
+ * mem[i] are record lines or BLOW5 records according to from_fmt; out[i] likewise for to_fmt (lines end in '\n').
+ * aux_meta = the input header's (NULL: no aux columns).  Press methods are ignored on an ASCII side. */
+int slow5_gpu_convert_batch(int64_t n, char **mem, size_t *bytes, enum slow5_fmt from_fmt, slow5_press_method_t from,
+                            const struct slow5_aux_meta *aux_meta, enum slow5_fmt to_fmt, slow5_press_method_t to,
+                            const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len);
 /* get worker (src/get.c:37-66) after the pread: decode n records into slow5_rec_t's */
 int slow5_gpu_depress_parse_batch(int64_t n, char **mem, size_t *bytes, slow5_press_method_t from,
                                   struct slow5_rec **reads);

@@ -184,6 +184,43 @@ int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec
 int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t *in_len, void **out, size_t *out_len,
                      int32_t *status);
 
+/* ---- SLOW5 ASCII <-> BLOW5 (the parse/format half of slow5_rec_depress_parse / slow5_rec_to_mem
+ * when one side of `view` is a .slow5 file, /root/reference/src/view.c:35-57) ----
+ * The raw_signal column (comma-separated decimal int16) is ~95 % of an ASCII record: it is parsed / formatted on the
+ * device, one read per workgroup.  The handful of scalar columns and the aux columns are converted on the host. */
+typedef struct {             /* 32 B: one read's raw_signal text on the device */
+    uint64_t txt_off;        /* byte offset of the text in `text` (16-byte aligned for the parser) */
+    uint64_t sig_off;        /* int16 index of the first sample in `sig` */
+    uint32_t txt_len;        /* parse: length of the text; format: capacity of the text slot (7 bytes/sample is enough) */
+    uint32_t n_samples;      /* parse: the count the len_raw_signal column promised; format: samples to print */
+    uint32_t reserved[2];
+} s5gpu_txt_desc_t;
+/* status[i]: 0 ok, 1 bad character, 2 value out of int16 range / too many digits, 3 empty number, 4 count mismatch,
+ * 5 text slot too small.  `text` needs 32 readable bytes after the last read. */
+int s5gpu_ascii_parse_dev(uint32_t n, const s5gpu_txt_desc_t *desc, const uint8_t *text, int16_t *sig, int32_t *status, void *stream);
+int s5gpu_ascii_format_dev(uint32_t n, const s5gpu_txt_desc_t *desc, const int16_t *sig, uint8_t *text, uint32_t *txt_len,
+                           int32_t *status, void *stream);
+/* copy n byte ranges src[src_off[i] .. +len[i]) -> dst[dst_off[i] ..) on the device */
+int s5gpu_gather_dev(uint32_t n, const uint64_t *src_off, const uint32_t *len, const uint64_t *dst_off, const uint8_t *src, uint8_t *dst,
+                     void *stream);
+
+/* aux column types of a SLOW5 header, in column order: low 4 bits = element kind, bit 7 = array ("type*"; char* = string) */
+enum { S5GPU_AUX_INT8 = 0, S5GPU_AUX_INT16, S5GPU_AUX_INT32, S5GPU_AUX_INT64, S5GPU_AUX_UINT8, S5GPU_AUX_UINT16, S5GPU_AUX_UINT32,
+       S5GPU_AUX_UINT64, S5GPU_AUX_FLOAT, S5GPU_AUX_DOUBLE, S5GPU_AUX_CHAR, S5GPU_AUX_ENUM, S5GPU_AUX_ARRAY = 0x80 };
+/* Types line of a SLOW5 header ("#char*\tuint32_t\t...") -> aux type codes of the columns after raw_signal.
+ * Returns the number of aux columns (<= cap), or a negative S5GPU_ERR_*. */
+int s5gpu_aux_types_parse(const char *types_line, size_t len, uint8_t *aux_type, uint32_t cap);
+
+/* ASCII records (one line each, with or without the trailing newline) -> BLOW5 records [u64 size][press(payload)].
+ * new_read_group / drop_aux as in s5gpu_recompress_batch.  status[i] (may be NULL): 0 ok, 1-5 as above, 16 malformed line. */
+int s5gpu_ascii_to_blow5_batch(uint32_t n, const char *const *line, const size_t *line_len, uint32_t n_aux, const uint8_t *aux_type,
+                               int to_rec, int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                               int32_t *status);
+/* BLOW5 records (bytes without the u64 prefix) -> ASCII lines ending in a newline; out[i] malloc'd. */
+int s5gpu_blow5_to_ascii_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, uint32_t n_aux,
+                               const uint8_t *aux_type, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                               int32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,15 @@ uint64_t s5o_encode_batch_mt(const int16_t *sig, uint64_t n_reads, uint64_t n_sa
                              int rec_method, int sig_method, int n_threads, int batch_size, double *secs,
                              uint64_t *checksum);
 
+/* ---- §8f row 2: SLOW5 ASCII record lines <-> uncompressed payloads (ascii.c) ---- */
+/* aux type codes: low 4 bits 0..11 = int8,int16,int32,int64,uint8,uint16,uint32,uint64,float,double,char,enum; 0x80 = array */
+int s5o_aux_types(const char *types_line, size_t len, uint8_t *types, unsigned cap);
+size_t s5o_double_to_text(double v, char *out);
+size_t s5o_signal_to_text(const int16_t *sig, uint64_t n, char *out);                      /* out >= 7n bytes */
+int64_t s5o_text_to_signal(const char *txt, size_t len, int16_t *out, uint64_t cap);       /* -1 on malformed text */
+size_t s5o_ascii_line_to_payload(const char *line, size_t len, const uint8_t *types, unsigned n_aux, uint8_t *out);
+size_t s5o_payload_to_ascii_line(const uint8_t *pay, size_t len, const uint8_t *types, unsigned n_aux, char *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,12 @@ def lib():
     L.s5gpu_deflate_parked_dev.argtypes = [C.POINTER(EncodeArgs), vp]
     L.s5gpu_inflate_dev.argtypes = [C.POINTER(DecodeArgs), vp]
     L.s5gpu_svbzd_decode_dev.argtypes = [C.POINTER(DecodeArgs), vp]
+    L.s5gpu_ascii_parse_dev.argtypes = [u32, vp, vp, vp, vp, vp]
+    L.s5gpu_ascii_format_dev.argtypes = [u32, vp, vp, vp, vp, vp, vp]
+    L.s5gpu_gather_dev.argtypes = [u32, vp, vp, vp, vp, vp, vp]
+    L.s5gpu_aux_types_parse.argtypes = [C.c_char_p, C.c_size_t, vp, u32]
+    L.s5gpu_ascii_to_blow5_batch.argtypes = [u32, vp, vp, u32, vp, i32, i32, vp, i32, vp, vp, vp]
+    L.s5gpu_blow5_to_ascii_batch.argtypes = [u32, vp, vp, i32, i32, u32, vp, vp, i32, vp, vp, vp]
     _LIB = L
     return L
 

@@ -4,15 +4,17 @@
  * slow5lib's slow5_open / slow5_get_next_mem / slow5_hdr_fwrite / slow5_eof_fwrite / slow5_idx_* as called
  * from /root/reference/src/view.c:192,246,265-278,313, src/get.c:286,45 and src/index.c.  slow5lib is an
  * absent submodule, so the layouts follow SURVEY.md Appendix A (verified on the golden files) and the
- * reference's own literal statement in test/misc/make_blow5.c:11-101.  BLOW5 only; header attributes are kept
- * as the opaque text blob.  No codec work happens here: read ids for the index come from the GPU batch decode.
+ * reference's own literal statement in test/misc/make_blow5.c:11-101.  Header attributes are kept as the opaque
+ * text blob; SLOW5 ASCII files (same text after two '#' version lines, one record per line) are framed here too.  No codec work happens here: read ids for the index come from the GPU batch decode.
  */
 #define _GNU_SOURCE
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
 #include <unistd.h>
 
 #include "../../include/slow5_compat.h"
+#include "../../include/slow5gpu.h"
 
 static const char BLOW5_MAGIC[6] = {'B', 'L', 'O', 'W', '5', '\1'};
 static const char BLOW5_EOF[5] = {'5', 'W', 'O', 'L', 'B'};
@@ -33,13 +35,103 @@ static enum slow5_press_method sig_from_code(uint8_t c) { return c == 0 ? SLOW5_
 static int rec_to_code(enum slow5_press_method m) { return m == SLOW5_COMPRESS_NONE ? 0 : m == SLOW5_COMPRESS_ZLIB ? 1 : m == SLOW5_COMPRESS_ZSTD ? 2 : -1; }
 static int sig_to_code(enum slow5_press_method m) { return m == SLOW5_COMPRESS_NONE ? 0 : m == SLOW5_COMPRESS_SVB_ZD ? 1 : m == SLOW5_COMPRESS_EX_ZD ? 2 : -1; }
 
+/* aux column types from the header text's types line (the line before "#read_id...") */
+static int aux_meta_build(struct slow5_hdr *hd) {
+    hd->aux_meta = NULL;
+    if (hd->data_len < 2) return 0;
+    /* last line = names, the one before = types */
+    const char *d = hd->data;
+    size_t end = hd->data_len;
+    if (d[end - 1] == '\n') end--;
+    size_t names = end;
+    while (names > 0 && d[names - 1] != '\n') names--;
+    if (names == 0) return 0;
+    size_t tend = names - 1, types = tend;
+    while (types > 0 && d[types - 1] != '\n') types--;
+    uint8_t codes[1024];
+    int n = s5gpu_aux_types_parse(d + types, tend - types, codes, 1024);
+    if (n < 0) return -1;
+    if (n == 0) return 0;
+    struct slow5_aux_meta *am = (struct slow5_aux_meta *)calloc(1, sizeof *am);
+    if (!am) return -1;
+    am->types = (uint8_t *)malloc((size_t)n);
+    if (!am->types) { free(am); return -1; }
+    memcpy(am->types, codes, (size_t)n);
+    am->num = (uint32_t)n;
+    hd->aux_meta = am;
+    return 0;
+}
+
+static slow5_file_t *open_ascii(FILE *fp, const char *pathname) {
+    /* "#slow5_version\tM.m.p\n#num_read_groups\tN\n" then the header text up to and including the "#read_id" line */
+    char *line = NULL;
+    size_t cap = 0;
+    ssize_t got;
+    unsigned maj, min, pat, nrg;
+    slow5_file_t *s = (slow5_file_t *)calloc(1, sizeof *s);
+    struct slow5_hdr *hd = (struct slow5_hdr *)calloc(1, sizeof *hd);
+    char *text = NULL;
+    size_t tlen = 0, tcap = 0;
+    int ok = 0;
+    if (!s || !hd) goto done;
+    if ((got = getline(&line, &cap, fp)) <= 0 || sscanf(line, "#slow5_version\t%u.%u.%u", &maj, &min, &pat) != 3) { slow5_errno = SLOW5_ERR_MAGIC; goto done; }
+    if ((got = getline(&line, &cap, fp)) <= 0 || sscanf(line, "#num_read_groups\t%u", &nrg) != 1) { slow5_errno = SLOW5_ERR_TRUNC; goto done; }
+    slow5_errno = SLOW5_ERR_TRUNC;
+    for (;;) {
+        if ((got = getline(&line, &cap, fp)) <= 0) goto done;
+        if (line[0] != '#' && line[0] != '@') goto done;
+        if (tlen + (size_t)got + 1 > tcap) {
+            tcap = (tlen + (size_t)got + 1) * 2;
+            char *nt = (char *)realloc(text, tcap);
+            if (!nt) { slow5_errno = SLOW5_ERR_MEM; goto done; }
+            text = nt;
+        }
+        memcpy(text + tlen, line, (size_t)got);
+        tlen += (size_t)got;
+        if (strncmp(line, "#read_id", 8) == 0) break;
+    }
+    if (tlen > 0xFFFFFFFFull) goto done;
+    hd->version.major = (uint8_t)maj; hd->version.minor = (uint8_t)min; hd->version.patch = (uint8_t)pat;
+    hd->num_read_groups = nrg;
+    hd->data = text;
+    hd->data_len = (uint32_t)tlen;
+    text = NULL;
+    if (aux_meta_build(hd) != 0) { slow5_errno = SLOW5_ERR_OTH; goto done; }
+    s->fp = fp;
+    s->format = SLOW5_FORMAT_ASCII;
+    s->header = hd;
+    s->meta.pathname = strdup(pathname);
+    s->meta.start_rec_offset = (uint64_t)ftello(fp);
+    {
+        slow5_press_method_t m = {SLOW5_COMPRESS_NONE, SLOW5_COMPRESS_NONE};
+        s->compress = slow5_press_init(m);
+    }
+    ok = s->compress != NULL;
+done:
+    free(line);
+    free(text);
+    if (!ok) {
+        if (hd) { free(hd->data); if (hd->aux_meta) { free(hd->aux_meta->types); free(hd->aux_meta); } free(hd); }
+        free(s);
+        fclose(fp);
+        return NULL;
+    }
+    slow5_errno = SLOW5_ERR_OK;
+    return s;
+}
+
 slow5_file_t *slow5_open(const char *pathname, const char *mode) {
     if (!pathname || !mode || mode[0] != 'r') { slow5_errno = SLOW5_ERR_ARG; return NULL; }
     FILE *fp = fopen(pathname, "rb");
     if (!fp) { slow5_errno = SLOW5_ERR_IO; return NULL; }
     uint8_t h[64];
     uint32_t hl = 0;
-    if (fread(h, 1, 64, fp) != 64 || fread(&hl, 4, 1, fp) != 1) { fclose(fp); slow5_errno = SLOW5_ERR_TRUNC; return NULL; }
+    size_t got = fread(h, 1, 64, fp);
+    if (got >= 14 && memcmp(h, "#slow5_version", 14) == 0) {
+        rewind(fp);
+        return open_ascii(fp, pathname);
+    }
+    if (got != 64 || fread(&hl, 4, 1, fp) != 1) { fclose(fp); slow5_errno = SLOW5_ERR_TRUNC; return NULL; }
     if (memcmp(h, BLOW5_MAGIC, 6) != 0) { fclose(fp); slow5_errno = SLOW5_ERR_MAGIC; return NULL; }
     slow5_file_t *s = (slow5_file_t *)calloc(1, sizeof *s);
     struct slow5_hdr *hd = (struct slow5_hdr *)calloc(1, sizeof *hd);
@@ -58,6 +150,7 @@ slow5_file_t *slow5_open(const char *pathname, const char *mode) {
     s->meta.start_rec_offset = 68ull + hl;
     s->compress = slow5_press_init(m);   /* NULL (SLOW5_ERR_PRESS) for zstd / ex-zd files: not built yet */
     if (!s->compress) { slow5_close(s); slow5_errno = SLOW5_ERR_PRESS; return NULL; }
+    if (aux_meta_build(hd) != 0) { slow5_close(s); slow5_errno = SLOW5_ERR_OTH; return NULL; }
     return s;
 }
 
@@ -65,7 +158,11 @@ int slow5_close(slow5_file_t *s) {
     if (!s) return 0;
     slow5_idx_unload(s);
     if (s->fp) fclose(s->fp);
-    if (s->header) { free(s->header->data); free(s->header); }
+    if (s->header) {
+        if (s->header->aux_meta) { free(s->header->aux_meta->types); free(s->header->aux_meta); }
+        free(s->header->data);
+        free(s->header);
+    }
     slow5_press_free(s->compress);
     free((void *)s->meta.pathname);
     free(s);
@@ -74,6 +171,15 @@ int slow5_close(slow5_file_t *s) {
 
 void *slow5_get_next_mem(size_t *n, const slow5_file_t *s) {
     if (!s || !s->fp) { slow5_errno = SLOW5_ERR_ARG; return NULL; }
+    if (s->format == SLOW5_FORMAT_ASCII) {
+        char *line = NULL;
+        size_t cap = 0;
+        ssize_t got = getline(&line, &cap, s->fp);
+        if (got <= 0) { free(line); slow5_errno = feof(s->fp) ? SLOW5_ERR_EOF : SLOW5_ERR_IO; return NULL; }
+        if (n) *n = (size_t)got;
+        slow5_errno = SLOW5_ERR_OK;
+        return line;
+    }
     uint8_t pre[8];
     size_t got = fread(pre, 1, 8, s->fp);
     if (got >= 5 && memcmp(pre, BLOW5_EOF, 5) == 0) {
@@ -94,6 +200,12 @@ void *slow5_get_next_mem(size_t *n, const slow5_file_t *s) {
 }
 
 int slow5_hdr_fwrite(FILE *fp, struct slow5_hdr *header, enum slow5_fmt format, slow5_press_method_t comp) {
+    if (fp && header && format == SLOW5_FORMAT_ASCII) {
+        int w = fprintf(fp, "#slow5_version\t%u.%u.%u\n#num_read_groups\t%u\n", header->version.major, header->version.minor,
+                        header->version.patch, header->num_read_groups);
+        if (w < 0 || (header->data_len && fwrite(header->data, 1, header->data_len, fp) != header->data_len)) { slow5_errno = SLOW5_ERR_IO; return -1; }
+        return w + (int)header->data_len;
+    }
     if (!fp || !header || format != SLOW5_FORMAT_BINARY || rec_to_code(comp.record_method) < 0 || sig_to_code(comp.signal_method) < 0) {
         slow5_errno = SLOW5_ERR_ARG;
         return -1;
@@ -268,7 +380,7 @@ static struct slow5_idx *idx_read(const char *path) {
 }
 
 int slow5_idx_create(slow5_file_t *s) {
-    if (!s || !s->fp) { slow5_errno = SLOW5_ERR_ARG; return -1; }
+    if (!s || !s->fp || s->format != SLOW5_FORMAT_BINARY) { slow5_errno = SLOW5_ERR_ARG; return -1; }   /* BLOW5 only here */
     struct slow5_idx *ix = idx_scan(s);
     if (!ix) return -1;
     char *p = idx_path(s);
@@ -280,7 +392,7 @@ int slow5_idx_create(slow5_file_t *s) {
 }
 
 int slow5_idx_load(slow5_file_t *s) {
-    if (!s || !s->fp) { slow5_errno = SLOW5_ERR_ARG; return -1; }
+    if (!s || !s->fp || s->format != SLOW5_FORMAT_BINARY) { slow5_errno = SLOW5_ERR_ARG; return -1; }
     if (s->index) return 0;
     char *p = idx_path(s);
     if (!p) { slow5_errno = SLOW5_ERR_MEM; return -1; }

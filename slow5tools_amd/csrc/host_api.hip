@@ -15,10 +15,12 @@
 #include <vector>
 
 #include "../../include/slow5gpu.h"
+#include "host_ctx.h"
 
 static thread_local char g_err[512] = "";
 static int g_device = -1;
-static std::mutex g_mu;
+namespace s5host { std::mutex g_mu; }
+using s5host::g_mu;
 
 extern "C" void s5gpu_set_error(const char *fmt, ...) {
     va_list ap;
@@ -27,15 +29,6 @@ extern "C" void s5gpu_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" const char *s5gpu_last_error(void) { return g_err; }
-
-#define HIP_TRY(x)                                                                                   \
-    do {                                                                                             \
-        hipError_t e_ = (x);                                                                         \
-        if (e_ != hipSuccess) {                                                                      \
-            s5gpu_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return S5GPU_ERR_HIP;                                                                    \
-        }                                                                                            \
-    } while (0)
 
 extern "C" int s5gpu_device_count(void) {
     int n = 0;
@@ -65,31 +58,9 @@ extern "C" int s5gpu_init(int device) {
     return S5GPU_OK;
 }
 
-// ---- grow-only device / pinned workspaces for the host-buffer batch calls ----
-struct Buf {
-    void *p = nullptr;
-    size_t cap = 0;
-    bool pinned = false;
-    int reserve(size_t n) {
-        if (n <= cap) return S5GPU_OK;
-        if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = n + n / 4 + 4096;
-        hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
-        if (e != hipSuccess) { s5gpu_set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); p = nullptr; return S5GPU_ERR_NOMEM; }
-        cap = want;
-        return S5GPU_OK;
-    }
-    void release() { if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
-};
-struct Ctx {
-    Buf d_sig, d_hdr, d_aux, d_desc, d_slots, d_len, d_ovf, d_in, d_pay, d_fields, d_stream, d_scan, d_sig2, d_desc2, d_patch;
-    Buf h_in, h_out;   // pinned staging
-    hipStream_t st = nullptr;
-    Ctx() { h_in.pinned = true; h_out.pinned = true; }
-};
 static Ctx *g_ctx = nullptr;
 
-static int ctx_get(Ctx **out) {
+int s5host::ctx_get(Ctx **out) {
     if (g_device < 0) {
         int rc = s5gpu_init(0);
         if (rc) return rc;
@@ -107,12 +78,15 @@ static int ctx_get(Ctx **out) {
     return S5GPU_OK;
 }
 
+using s5host::ctx_get;
+using s5host::encode_and_collect;
+
 extern "C" void s5gpu_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_ctx) {
         Buf *bs[] = {&g_ctx->d_sig, &g_ctx->d_hdr, &g_ctx->d_aux, &g_ctx->d_desc, &g_ctx->d_slots, &g_ctx->d_len,
                      &g_ctx->d_ovf, &g_ctx->d_in, &g_ctx->d_pay, &g_ctx->d_fields, &g_ctx->d_stream, &g_ctx->d_scan, &g_ctx->d_sig2,
-                     &g_ctx->d_desc2, &g_ctx->d_patch, &g_ctx->h_in, &g_ctx->h_out};
+                     &g_ctx->d_desc2, &g_ctx->d_patch, &g_ctx->d_txt, &g_ctx->d_tdesc, &g_ctx->d_gather, &g_ctx->h_in, &g_ctx->h_out};
         for (Buf *b : bs) b->release();
         if (g_ctx->st) (void)hipStreamDestroy(g_ctx->st);
         delete g_ctx;
@@ -142,24 +116,10 @@ extern "C" int s5gpu_event_destroy(void *ev) {
     return S5GPU_OK;
 }
 
-static inline uint64_t up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
-
-// host-side packing / unpacking of a batch is plain memcpy work: spread it over a few threads
-template <class F>
-static void parallel_for(uint32_t n, uint64_t bytes, F fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned nt = hw ? (hw < 16 ? hw : 16) : 4;
-    if (bytes < (8u << 20) || n < 64 || nt < 2) { fn(0u, n); return; }
-    std::vector<std::thread> th;
-    const uint32_t step = (n + nt - 1) / nt;
-    for (uint32_t lo = 0; lo < n; lo += step) th.emplace_back(fn, lo, lo + step < n ? lo + step : n);
-    for (auto &t : th) t.join();
-}
-
 // Launch the encode for descriptors already on the device (a.desc/sig/hdr/aux set by the caller), gather the
 // worst-case slots into the contiguous record stream on the device (the bytes the ordered fwrite loop emits),
 // bring back only what was produced and hand out one malloc per record.
-static int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
+int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
                               void **out, size_t *out_len) {
     int rc;
     if ((rc = c->d_len.reserve(4ull * n))) return rc;
@@ -532,25 +492,19 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
 }
 
 
-// ---- view / merge worker for a whole batch, device-resident between decode and encode ----
-extern "C" int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
-                                      int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
-                                      int32_t *status) {
-    if (n == 0) return S5GPU_OK;
-    if (!rec || !rec_len || !out || !out_len) { s5gpu_set_error("s5gpu_recompress_batch: NULL argument"); return S5GPU_ERR_ARG; }
-    Ctx *c;
-    int rc = ctx_get(&c);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
-    for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
+// Decode n host records on the device and leave payloads (c->d_pay) and signals (c->d_sig2) resident; rd[i] says where,
+// ff[i] what was found.  Records that overflow their guessed slots are redone once with exact sizes.
+int s5host::decode_resident(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
+                            std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status) {
+    int rc;
     std::vector<uint32_t> pcap(n), scap(n);
     for (uint32_t i = 0; i < n; i++) {
         if (rec_len[i] > 0xFFFFFF00ull / 8) { s5gpu_set_error("record %u too large", i); return S5GPU_ERR_ARG; }
         pcap[i] = (uint32_t)(from_rec == S5GPU_REC_ZLIB ? 4ull * rec_len[i] + 4096 : rec_len[i]);
         scap[i] = pcap[i];   // a sample takes at least one payload byte in either signal format
     }
-    std::vector<s5gpu_rec_desc_t> rd(n);
-    std::vector<s5gpu_rec_fields_t> ff(n);
+    rd.resize(n);
+    ff.resize(n);
     for (int attempt = 0;; attempt++) {
         uint64_t io = 0, po = 0, so = 0;
         for (uint32_t i = 0; i < n; i++) {
@@ -585,9 +539,26 @@ extern "C" int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const 
             else if (ff[i].status == 6 && attempt < 2) { scap[i] = ff[i].n_samples; retry = true; }
             else if (ff[i].status != 0) { bad = true; if (status) status[i] = ff[i].status; }
         }
-        if (bad) { s5gpu_set_error("s5gpu_recompress_batch: at least one input record is corrupt (see status[i])"); return S5GPU_ERR_DATA; }
+        if (bad) { s5gpu_set_error("at least one input record is corrupt (see status[i])"); return S5GPU_ERR_DATA; }
         if (!retry) break;   // rare: a record inflated to more than 4x its size; the whole batch is decoded again with exact slots
     }
+    return S5GPU_OK;
+}
+
+// ---- view / merge worker for a whole batch, device-resident between decode and encode ----
+extern "C" int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                      int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                                      int32_t *status) {
+    if (n == 0) return S5GPU_OK;
+    if (!rec || !rec_len || !out || !out_len) { s5gpu_set_error("s5gpu_recompress_batch: NULL argument"); return S5GPU_ERR_ARG; }
+    Ctx *c;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
+    std::vector<s5gpu_rec_desc_t> rd;
+    std::vector<s5gpu_rec_fields_t> ff;
+    if ((rc = s5host::decode_resident(c, n, rec, rec_len, from_rec, from_sig, rd, ff, status))) return rc;
     // encode descriptors straight from the decoded fields: heads and aux tails are read out of the decoded payloads
     std::vector<s5gpu_read_desc_t> ed(n);
     uint64_t oo = 0;

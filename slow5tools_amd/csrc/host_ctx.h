@@ -1,0 +1,74 @@
+// host_ctx.h — shared by the host-side translation units of libslow5gpu.so (host_api.hip, ascii_api.hip):
+// error macro, grow-only workspaces, the per-process context and the threaded host loop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/slow5gpu.h"
+
+extern "C" void s5gpu_set_error(const char *fmt, ...);
+
+#define HIP_TRY(x)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) {                                                                      \
+            s5gpu_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return S5GPU_ERR_HIP;                                                                    \
+        }                                                                                            \
+    } while (0)
+
+// ---- grow-only device / pinned workspaces for the host-buffer batch calls ----
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    int reserve(size_t n) {
+        if (n <= cap) return S5GPU_OK;
+        if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 4 + 4096;
+        hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (e != hipSuccess) { s5gpu_set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); p = nullptr; return S5GPU_ERR_NOMEM; }
+        cap = want;
+        return S5GPU_OK;
+    }
+    void release() { if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
+};
+struct Ctx {
+    Buf d_sig, d_hdr, d_aux, d_desc, d_slots, d_len, d_ovf, d_in, d_pay, d_fields, d_stream, d_scan, d_sig2, d_desc2, d_patch;
+    Buf d_txt, d_tdesc, d_gather;   // SLOW5 ASCII path (ascii_api.hip)
+    Buf h_in, h_out;   // pinned staging
+    hipStream_t st = nullptr;
+    Ctx() { h_in.pinned = true; h_out.pinned = true; }
+};
+
+namespace s5host {
+extern std::mutex g_mu;
+int ctx_get(Ctx **out);
+// encode descriptors already on the device -> one malloc per record on the host (host_api.hip)
+int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
+                       void **out, size_t *out_len);
+// decode host records, results resident in c->d_pay / c->d_sig2 (host_api.hip)
+int decode_resident(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
+                    std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status);
+}  // namespace s5host
+
+static inline uint64_t up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// host-side packing / unpacking of a batch is plain memcpy work: spread it over a few threads
+template <class F>
+static void parallel_for(uint32_t n, uint64_t bytes, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = hw ? (hw < 16 ? hw : 16) : 4;
+    if (bytes < (8u << 20) || n < 64 || nt < 2) { fn(0u, n); return; }
+    std::vector<std::thread> th;
+    const uint32_t step = (n + nt - 1) / nt;
+    for (uint32_t lo = 0; lo < n; lo += step) th.emplace_back(fn, lo, lo + step < n ? lo + step : n);
+    for (auto &t : th) t.join();
+}
+

@@ -205,6 +205,47 @@ int slow5_rec_depress_parse(char **mem, size_t *bytes, const char *read_id, stru
     return slow5_gpu_depress_parse_batch(1, mem, bytes, m, read);
 }
 
+int slow5_gpu_convert_batch(int64_t n, char **mem, size_t *bytes, enum slow5_fmt from_fmt, slow5_press_method_t from,
+                            const struct slow5_aux_meta *aux_meta, enum slow5_fmt to_fmt, slow5_press_method_t to,
+                            const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len) {
+    if (from_fmt == SLOW5_FORMAT_BINARY && to_fmt == SLOW5_FORMAT_BINARY)
+        return slow5_gpu_recompress_batch(n, mem, bytes, from, to, new_read_group, drop_aux, out, out_len);
+    const uint32_t n_aux = aux_meta ? aux_meta->num : 0;
+    const uint8_t *types = aux_meta ? aux_meta->types : NULL;
+    if (n < 0 || (from_fmt != SLOW5_FORMAT_ASCII && from_fmt != SLOW5_FORMAT_BINARY) || (to_fmt != SLOW5_FORMAT_ASCII && to_fmt != SLOW5_FORMAT_BINARY)) {
+        slow5_errno = SLOW5_ERR_ARG;
+        return -1;
+    }
+    if (n == 0) return 0;
+    int rc;
+    if (from_fmt == SLOW5_FORMAT_ASCII && to_fmt == SLOW5_FORMAT_BINARY) {
+        const int tr = rec_code(to.record_method), ts = sig_code(to.signal_method);
+        if (tr < 0 || ts < 0) { slow5_errno = SLOW5_ERR_PRESS; return -1; }
+        rc = s5gpu_ascii_to_blow5_batch((uint32_t)n, (const char *const *)mem, bytes, n_aux, types, tr, ts, new_read_group, drop_aux, out, out_len, NULL);
+    } else if (from_fmt == SLOW5_FORMAT_BINARY) {
+        const int fr = rec_code(from.record_method), fs = sig_code(from.signal_method);
+        if (fr < 0 || fs < 0) { slow5_errno = SLOW5_ERR_PRESS; return -1; }
+        rc = s5gpu_blow5_to_ascii_batch((uint32_t)n, (const void *const *)mem, bytes, fr, fs, n_aux, types, new_read_group, drop_aux, out, out_len, NULL);
+    } else {
+        /* ASCII -> ASCII: the reference parses and prints again; through BLOW5 (none, none) gives the same canonical text */
+        void **mid = (void **)calloc((size_t)n, sizeof *mid);
+        size_t *mid_len = (size_t *)calloc((size_t)n, sizeof *mid_len);
+        if (!mid || !mid_len) { free(mid); free(mid_len); slow5_errno = SLOW5_ERR_MEM; return -1; }
+        rc = s5gpu_ascii_to_blow5_batch((uint32_t)n, (const char *const *)mem, bytes, n_aux, types, S5GPU_REC_NONE, S5GPU_SIG_NONE, new_read_group,
+                                        drop_aux, mid, mid_len, NULL);
+        if (rc == S5GPU_OK) {
+            for (int64_t i = 0; i < n; i++) { memmove(mid[i], (char *)mid[i] + 8, mid_len[i] - 8); mid_len[i] -= 8; }   /* drop the u64 prefix */
+            rc = s5gpu_blow5_to_ascii_batch((uint32_t)n, (const void *const *)mid, mid_len, S5GPU_REC_NONE, S5GPU_SIG_NONE, drop_aux ? 0 : n_aux, types, NULL,
+                                            0, out, out_len, NULL);
+        }
+        for (int64_t i = 0; i < n; i++) free(mid[i]);
+        free(mid); free(mid_len);
+    }
+    if (rc != S5GPU_OK) { slow5_errno = SLOW5_ERR_RECPARSE; return -1; }
+    for (int64_t i = 0; i < n; i++) { free(mem[i]); mem[i] = NULL; }
+    return 0;
+}
+
 int slow5_gpu_recompress_batch(int64_t n, char **mem, size_t *bytes, slow5_press_method_t from, slow5_press_method_t to,
                                const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len) {
     const int fr = rec_code(from.record_method), fs = sig_code(from.signal_method);

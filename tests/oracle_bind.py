@@ -34,8 +34,11 @@ def lib():
     if _LIB is not None:
         return _LIB
     so = os.path.join(ORACLE_DIR, "libs5oracle.so")
-    if not os.path.exists(so):
+    try:   # cheap when up to date; keeps the .so in step with the sources
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(so):
+            raise
     L = C.CDLL(so)
     L.s5o_svbzd_bound.restype = C.c_size_t
     L.s5o_svbzd_bound.argtypes = [C.c_uint64]
@@ -68,6 +71,16 @@ def lib():
     L.s5o_encode_batch_mt.restype = C.c_uint64
     L.s5o_encode_batch_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.s5o_aux_types.restype = C.c_int
+    L.s5o_aux_types.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint]
+    L.s5o_signal_to_text.restype = C.c_size_t
+    L.s5o_signal_to_text.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.s5o_text_to_signal.restype = C.c_int64
+    L.s5o_text_to_signal.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint64]
+    L.s5o_ascii_line_to_payload.restype = C.c_size_t
+    L.s5o_ascii_line_to_payload.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint, C.c_void_p]
+    L.s5o_payload_to_ascii_line.restype = C.c_size_t
+    L.s5o_payload_to_ascii_line.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint, C.c_void_p]
     _LIB = L
     return L
 
@@ -203,3 +216,37 @@ def encode_batch_mt(sig2d, first_idx, n_threads, batch_size=4096, rec_method=REC
     total = lib().s5o_encode_batch_mt(_ptr(sig2d), sig2d.shape[0], sig2d.shape[1], first_idx, rec_method, sig_method,
                                       n_threads, batch_size, C.byref(secs), C.byref(ck))
     return total, secs.value, ck.value
+
+
+# ---- §8f row 2: SLOW5 ASCII ----
+def aux_types(types_line):
+    buf = (C.c_uint8 * 1024)()
+    n = lib().s5o_aux_types(types_line, len(types_line), buf, 1024)
+    assert n >= 0, "bad types line"
+    return bytes(buf[:n])
+
+
+def signal_to_text(sig):
+    sig = np.ascontiguousarray(sig, dtype=np.int16)
+    out = C.create_string_buffer(7 * sig.size + 16)
+    n = lib().s5o_signal_to_text(_ptr(sig), sig.size, out)
+    return out.raw[:n]
+
+
+def text_to_signal(txt, cap=None):
+    cap = cap if cap is not None else len(txt) // 2 + 2
+    out = np.empty(cap, dtype=np.int16)
+    n = lib().s5o_text_to_signal(txt, len(txt), _ptr(out), cap)
+    return None if n < 0 else out[:n].copy()
+
+
+def line_to_payload(line, types=b""):
+    out = C.create_string_buffer(2 * len(line) + 64)
+    n = lib().s5o_ascii_line_to_payload(line, len(line), types, len(types), out)
+    return out.raw[:n] if n else None
+
+
+def payload_to_line(payload, types=b""):
+    out = C.create_string_buffer(8 * len(payload) + 512)
+    n = lib().s5o_payload_to_ascii_line(payload, len(payload), types, len(types), out)
+    return out.raw[:n] if n else None

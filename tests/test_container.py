@@ -21,7 +21,8 @@ class Version(C.Structure):
 
 
 class Hdr(C.Structure):
-    _fields_ = [("version", Version), ("num_read_groups", C.c_uint32), ("data", C.c_void_p), ("data_len", C.c_uint32)]
+    _fields_ = [("version", Version), ("num_read_groups", C.c_uint32), ("data", C.c_void_p), ("data_len", C.c_uint32),
+                ("aux_meta", C.c_void_p)]
 
 
 class InnerPress(C.Structure):
