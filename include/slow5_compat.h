@@ -122,7 +122,7 @@ void slow5_rec_free(struct slow5_rec *read);
 /* ---- BLOW5 file framing (layouts: Appendix A.1/A.2/A.4/A.5, test/misc/make_blow5.c:11-101) ----
  * Only what view / merge / get need around the press path: open + header, sequential record framing, header and
  * EOF writers, and the read_id index.  slow5_open tells BLOW5 from SLOW5 ASCII by the file's first bytes; for ASCII,
- * slow5_get_next_mem returns one record line (with its newline) and slow5_hdr_fwrite prints the two '#' version lines
+ * slow5_get_next_mem returns one record line (without its newline) and slow5_hdr_fwrite prints the two '#' version lines
  * followed by the same header text.  The index calls are BLOW5 only. */
 slow5_file_t *slow5_open(const char *pathname, const char *mode);                 /* src/view.c:192, "r" only */
 int slow5_close(slow5_file_t *s5p);

@@ -176,6 +176,7 @@ void *slow5_get_next_mem(size_t *n, const slow5_file_t *s) {
         size_t cap = 0;
         ssize_t got = getline(&line, &cap, s->fp);
         if (got <= 0) { free(line); slow5_errno = feof(s->fp) ? SLOW5_ERR_EOF : SLOW5_ERR_IO; return NULL; }
+        if (line[got - 1] == '\n') line[--got] = 0;   /* the line without its newline */
         if (n) *n = (size_t)got;
         slow5_errno = SLOW5_ERR_OK;
         return line;

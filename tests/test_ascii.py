@@ -86,7 +86,7 @@ def test_open_ascii_and_line_framing(L, slow5):
             break
         got.append(C.string_at(p, n.value))
         libc.free(p)
-    assert got == recs
+    assert got == [r[:-1] for r in recs]                        # lines come back without the newline
     L.slow5_close(f)
 
 
