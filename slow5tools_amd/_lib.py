@@ -54,6 +54,13 @@ def lib():
     path = os.environ.get("S5GPU_LIB") or _build.LIB   # S5GPU_LIB: e.g. the -DS5_PROFILE build (tools/phase_profile.py)
     if not os.path.exists(path):
         _build.build()
+    # One HIP runtime per process: the torch wheel carries its own libamdhip64 / libhsa-runtime64.  If libslow5gpu.so pulled in
+    # /opt/rocm's copies first, a later `import torch` would find "No HIP GPUs".  Python callers use torch for HBM buffers and
+    # streams anyway, so let it load its runtime first; the library then binds to the copies already in the process.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     L.s5gpu_last_error.restype = C.c_char_p
