@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
     # the view-loop example / end-to-end harness (plain C against the two public headers)
     ex = os.path.join(ROOT, "examples", "s5view.c")
     if os.path.exists(ex) and (force or _newer(S5VIEW, [ex, LIB] + deps)):
-        cmd = ["gcc", "-O2", "-g", "-Wall", "-std=c11", "-I", os.path.join(ROOT, "include"), ex, "-o", S5VIEW,
+        cmd = ["gcc", "-O2", "-g", "-Wall", "-std=c11", "-I", os.path.join(ROOT, "include"), ex, "-o", S5VIEW, "-pthread",
                "-L", HERE, "-lslow5gpu", "-Wl,-rpath," + HERE]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -19,8 +19,6 @@
 
 #include "host_ctx.h"
 
-using s5host::ctx_get;
-using s5host::g_mu;
 
 namespace {
 
@@ -282,10 +280,10 @@ extern "C" int s5gpu_ascii_to_blow5_batch(uint32_t n, const char *const *line, c
                                           int32_t *status) {
     if (n == 0) return S5GPU_OK;
     if (!line || !line_len || !out || !out_len || (n_aux && !aux_type)) { s5gpu_set_error("s5gpu_ascii_to_blow5_batch: NULL argument"); return S5GPU_ERR_ARG; }
-    Ctx *c;
-    int rc = ctx_get(&c);
+    s5host::CtxHold hold;
+    int rc = hold.acquire();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx *c = hold.c;
     for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
     std::vector<Line> L(n);
     uint64_t text_bytes = 0;
@@ -363,10 +361,10 @@ extern "C" int s5gpu_blow5_to_ascii_batch(uint32_t n, const void *const *rec, co
                                           int32_t *status) {
     if (n == 0) return S5GPU_OK;
     if (!rec || !rec_len || !out || !out_len || (n_aux && !aux_type)) { s5gpu_set_error("s5gpu_blow5_to_ascii_batch: NULL argument"); return S5GPU_ERR_ARG; }
-    Ctx *c;
-    int rc = ctx_get(&c);
+    s5host::CtxHold hold;
+    int rc = hold.acquire();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx *c = hold.c;
     for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
     std::vector<s5gpu_rec_desc_t> rd;
     std::vector<s5gpu_rec_fields_t> ff;

@@ -58,40 +58,61 @@ extern "C" int s5gpu_init(int device) {
     return S5GPU_OK;
 }
 
-static Ctx *g_ctx = nullptr;
+static const int MAX_CTX = 4;
+static Ctx *g_ctxs[MAX_CTX] = {nullptr, nullptr, nullptr, nullptr};
+static int g_nctx = 0;
 
-int s5host::ctx_get(Ctx **out) {
+int s5host::CtxHold::acquire() {
     if (g_device < 0) {
         int rc = s5gpu_init(0);
         if (rc) return rc;
     }
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_ctx) {
-        g_ctx = new Ctx();
-        if (hipStreamCreateWithFlags(&g_ctx->st, hipStreamNonBlocking) != hipSuccess) {
-            delete g_ctx; g_ctx = nullptr;
-            s5gpu_set_error("hipStreamCreate failed");
-            return S5GPU_ERR_HIP;
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        if (g_nctx == 0) {
+            const char *e = getenv("S5GPU_CONTEXTS");
+            int want = e ? atoi(e) : 2;
+            want = want < 1 ? 1 : want > MAX_CTX ? MAX_CTX : want;
+            for (int i = 0; i < want; i++) {
+                Ctx *c = new Ctx();
+                if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) {
+                    delete c;
+                    s5gpu_set_error("hipStreamCreate failed");
+                    if (g_nctx == 0) return S5GPU_ERR_HIP;
+                    break;
+                }
+                g_ctxs[g_nctx++] = c;
+            }
         }
     }
-    *out = g_ctx;
+    if (hipSetDevice(g_device) != hipSuccess) { s5gpu_set_error("hipSetDevice(%d) failed", g_device); return S5GPU_ERR_HIP; }   // per host thread
+    for (int i = 0; i < g_nctx; i++) {
+        std::unique_lock<std::mutex> t(g_ctxs[i]->mu, std::try_to_lock);
+        if (t.owns_lock()) { lk = std::move(t); c = g_ctxs[i]; return S5GPU_OK; }
+    }
+    const size_t pick = std::hash<std::thread::id>()(std::this_thread::get_id()) % (size_t)g_nctx;
+    lk = std::unique_lock<std::mutex>(g_ctxs[pick]->mu);
+    c = g_ctxs[pick];
     return S5GPU_OK;
 }
 
-using s5host::ctx_get;
 using s5host::encode_and_collect;
 
 extern "C" void s5gpu_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_ctx) {
-        Buf *bs[] = {&g_ctx->d_sig, &g_ctx->d_hdr, &g_ctx->d_aux, &g_ctx->d_desc, &g_ctx->d_slots, &g_ctx->d_len,
-                     &g_ctx->d_ovf, &g_ctx->d_in, &g_ctx->d_pay, &g_ctx->d_fields, &g_ctx->d_stream, &g_ctx->d_scan, &g_ctx->d_sig2,
-                     &g_ctx->d_desc2, &g_ctx->d_patch, &g_ctx->d_txt, &g_ctx->d_tdesc, &g_ctx->d_gather, &g_ctx->h_in, &g_ctx->h_out};
-        for (Buf *b : bs) b->release();
-        if (g_ctx->st) (void)hipStreamDestroy(g_ctx->st);
-        delete g_ctx;
-        g_ctx = nullptr;
+    for (int i = 0; i < g_nctx; i++) {
+        Ctx *c = g_ctxs[i];
+        {
+            std::lock_guard<std::mutex> own(c->mu);   // wait for a batch still running on it
+            Buf *bs[] = {&c->d_sig, &c->d_hdr, &c->d_aux, &c->d_desc, &c->d_slots, &c->d_len, &c->d_ovf, &c->d_in, &c->d_pay, &c->d_fields,
+                         &c->d_stream, &c->d_scan, &c->d_sig2, &c->d_desc2, &c->d_patch, &c->d_txt, &c->d_tdesc, &c->d_gather, &c->h_in, &c->h_out};
+            for (Buf *b : bs) b->release();
+            if (c->st) (void)hipStreamDestroy(c->st);
+        }
+        delete c;
+        g_ctxs[i] = nullptr;
     }
+    g_nctx = 0;
     g_device = -1;
 }
 
@@ -213,10 +234,10 @@ extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const u
                                   int sig_method, void **out, size_t *out_len) {
     if (n == 0) return S5GPU_OK;
     if (!sig || !n_samples || !hdr || !hdr_len || !out || !out_len) { s5gpu_set_error("s5gpu_encode_batch: NULL argument"); return S5GPU_ERR_ARG; }
-    Ctx *c;
-    int rc = ctx_get(&c);
+    s5host::CtxHold hold;
+    int rc = hold.acquire();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx *c = hold.c;
     std::vector<s5gpu_read_desc_t> desc(n);
     uint64_t so = 0, ho = 0, ao = 0, oo = 0;
     uint32_t max_payload = 0;
@@ -270,10 +291,10 @@ extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size
                                   void **payload, int16_t **sig, s5gpu_rec_fields_t *fields) {
     if (n == 0) return S5GPU_OK;
     if (!rec || !rec_len || !payload || !sig || !fields) { s5gpu_set_error("s5gpu_decode_batch: NULL argument"); return S5GPU_ERR_ARG; }
-    Ctx *c;
-    int rc = ctx_get(&c);
+    s5host::CtxHold hold;
+    int rc = hold.acquire();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx *c = hold.c;
     std::vector<s5gpu_rec_desc_t> desc(n);
     std::vector<uint8_t> done(n, 0);
     for (uint32_t i = 0; i < n; i++) { payload[i] = NULL; sig[i] = NULL; }
@@ -347,10 +368,10 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
                                 int32_t *status) {
     if (n == 0) return S5GPU_OK;
     if (!in || !in_len || !out || !out_len || stage < 0 || stage > 3) { s5gpu_set_error("s5gpu_solo_batch: bad argument"); return S5GPU_ERR_ARG; }
-    Ctx *c;
-    int rc = ctx_get(&c);
+    s5host::CtxHold hold;
+    int rc = hold.acquire();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx *c = hold.c;
     for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
     for (uint32_t i = 0; i < n; i++)
         if (in_len[i] > 0xFFFFFF00ull / 4) { s5gpu_set_error("item %u too large", i); return S5GPU_ERR_ARG; }
@@ -551,10 +572,10 @@ extern "C" int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const 
                                       int32_t *status) {
     if (n == 0) return S5GPU_OK;
     if (!rec || !rec_len || !out || !out_len) { s5gpu_set_error("s5gpu_recompress_batch: NULL argument"); return S5GPU_ERR_ARG; }
-    Ctx *c;
-    int rc = ctx_get(&c);
+    s5host::CtxHold hold;
+    int rc = hold.acquire();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx *c = hold.c;
     for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
     std::vector<s5gpu_rec_desc_t> rd;
     std::vector<s5gpu_rec_fields_t> ff;

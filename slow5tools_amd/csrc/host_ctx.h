@@ -44,12 +44,19 @@ struct Ctx {
     Buf d_txt, d_tdesc, d_gather;   // SLOW5 ASCII path (ascii_api.hip)
     Buf h_in, h_out;   // pinned staging
     hipStream_t st = nullptr;
+    std::mutex mu;      // held by the batch call that owns this context
     Ctx() { h_in.pinned = true; h_out.pinned = true; }
 };
 
 namespace s5host {
 extern std::mutex g_mu;
-int ctx_get(Ctx **out);
+// A batch call owns one of a few contexts (workspaces + stream) for its duration, so host threads can run batches
+// concurrently: one batch's PCIe copies overlap another's kernels.  S5GPU_CONTEXTS (default 2, max 4).
+struct CtxHold {
+    Ctx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    int acquire();
+};
 // encode descriptors already on the device -> one malloc per record on the host (host_api.hip)
 int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
                        void **out, size_t *out_len);

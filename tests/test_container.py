@@ -207,3 +207,44 @@ def test_view_roundtrip_and_get(tmp_path):
     d = ob.rec_parse(zlib.decompress(ref.records[2]), 1)
     f = r.stdout.strip().split("\t")
     assert f[0] == rid and int(f[2]) == len(d["signal"]) and f[3] == ",".join(str(int(x)) for x in d["signal"][:8])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,workers", [(1, 3), (2, 1), (3, 2), (4096, 3)])
+def test_pipelined_view_writes_the_same_bytes_as_the_serial_phases(tmp_path, K, workers):
+    """read || GPU || write must not change a byte or the record order (src/view.c:296-299)"""
+    src = golden("merged_expected_zlib_svb.blow5")
+    serial, piped = tmp_path / "s.blow5", tmp_path / "p.blow5"
+    _run(src, serial, "zlib", "svb-zd", K, 0)
+    _run(src, piped, "zlib", "svb-zd", K, workers)
+    assert serial.read_bytes() == piped.read_bytes()
+    back = tmp_path / "b.slow5"
+    _run(piped, back, "none", "none", K, workers)                # and through the ASCII printer
+    serial_txt = tmp_path / "st.slow5"
+    _run(serial, serial_txt, "none", "none", 4096, 0)
+    assert back.read_bytes() == serial_txt.read_bytes()
+
+
+@pytest.mark.gpu
+def test_concurrent_host_batches_from_threads():
+    """two host threads inside the batch API at once (each owns one context): results equal the single-threaded ones"""
+    import threading
+    from slow5tools_amd import press
+    rng = np.random.default_rng(9)
+    jobs = []
+    for t in range(4):
+        sigs = [(500 + rng.integers(-30, 30, int(rng.integers(1, 9000)))).astype(np.int16) for _ in range(300)]
+        hdrs = [press.pack_hdr(b"t%d_%d" % (t, i), t, 8192.0, 1.0, 1400.0, 4000.0) for i in range(300)]
+        jobs.append((sigs, hdrs))
+    want = [press.encode_records(s, h) for s, h in jobs]
+    got = [None] * 4
+    def run(k):
+        for _ in range(3):
+            got[k] = press.encode_records(*jobs[k])
+    th = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert got == want
+    for k in range(4):
+        dec = press.decode_records([r[8:] for r in got[k]])
+        assert all(d["status"] == 0 and np.array_equal(d["signal"], s) for d, s in zip(dec, jobs[k][0]))

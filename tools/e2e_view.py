@@ -30,11 +30,23 @@ del b
 torch.cuda.empty_cache()
 exe = os.path.join(ROOT, "slow5tools_amd", "s5view")
 raw_gb = n_reads * n * 2 / 1e9
-for (rm, sm, dst, K) in (("none", "none", "/tmp/e2e_raw.blow5", 4096), ("zlib", "svb-zd", "/tmp/e2e_z.blow5", 4096), ("zlib", "svb-zd", "/tmp/e2e_z2.blow5", 65536)):
+runs = [("none", "none", "/tmp/e2e_raw.blow5", 4096, 2)]
+for K in (4096, 65536):
+    for W in (0, 1, 2, 3):
+        runs.append(("zlib", "svb-zd", "/tmp/e2e_z_%d_%d.blow5" % (K, W), K, W))
+ref_out = None
+for (rm, sm, dst, K, W) in runs:
     inp = src if rm == "none" else "/tmp/e2e_raw.blow5"
     t0 = time.perf_counter()
-    r = subprocess.run([exe, inp, dst, rm, sm, str(K)], capture_output=True, text=True)
+    r = subprocess.run([exe, inp, dst, rm, sm, str(K), str(W)], capture_output=True, text=True)
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr
-    print("s5view %s -> (%s,%s) K=%d: %d reads in %.2f s = %.2f GB/s raw signal, %.0f k reads/s  [in %.0f MB, out %.0f MB]"
-          % (os.path.basename(inp), rm, sm, K, n_reads, dt, raw_gb / dt, n_reads / dt / 1e3, os.path.getsize(inp) / 1e6, os.path.getsize(dst) / 1e6))
+    print("s5view %s -> (%s,%s) K=%d workers=%d%s: %d reads in %.2f s = %.2f GB/s raw signal, %.0f k reads/s  [in %.0f MB, out %.0f MB]"
+          % (os.path.basename(inp), rm, sm, K, W, " (serial phases)" if W == 0 else "", n_reads, dt, raw_gb / dt, n_reads / dt / 1e3,
+             os.path.getsize(inp) / 1e6, os.path.getsize(dst) / 1e6))
+    if rm == "zlib":   # the pipeline must not change a byte
+        data = open(dst, "rb").read()
+        if ref_out is None:
+            ref_out = data
+        assert data == ref_out, "output differs between pipeline settings"
+        os.remove(dst)
