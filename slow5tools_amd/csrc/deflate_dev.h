@@ -484,33 +484,76 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         // b_sum = sum (kk - j) x_j so far; the bytes of later lanes each add this lane's byte sum once more
         b_sum += a_sum * (uint32_t)max(0, len - (base + kk));
     }
+    if (dbg == 21) { z.bitpos += (uint32_t)brk + a_sum + b_sum; return; }   // tools/stage_time.py cut-offs inside the tokeniser
     const int local_last = brk ? base + MO::msb(brk) : -1;
     const int local_first = brk ? base + MO::lsb(brk) : len;
-    const int lastb = block_excl_max(local_last, -1, S.ws);
-    const int nextb = block_suffix_excl_min(local_first, len, S.ws);
+    // lastb = last break before my chunk, nextb = first break after it.  Which lanes own a break at all is a 256-bit map
+    // (one ballot per wave); inside the wave the neighbour lane comes from the ballot in registers, across waves the
+    // answer is wave-uniform.  One barrier; S.code (not yet in use) carries every lane's first | last << 16.
+    int lastb, nextb;
+    {
+        const bool has = brk != 0;
+        const uint64_t bal = __ballot(has);
+        if (lane_id() == 0) { S.ws[2 * wave_id()] = (uint32_t)bal; S.ws[2 * wave_id() + 1] = (uint32_t)(bal >> 32); }
+        if (has) S.code[tid] = (uint32_t)local_first | ((uint32_t)local_last << 16);
+        __syncthreads();
+        int up_lane = -1, dn_lane = -1;            // wave-uniform: nearest break-owning lane in a later / earlier wave
+#pragma unroll
+        for (int w = NW - 1; w >= 0; w--) {
+            const uint64_t mw = (uint64_t)S.ws[2 * w] | ((uint64_t)S.ws[2 * w + 1] << 32);
+            if (w > wave_id() && mw) up_lane = w * 64 + __ffsll((long long)mw) - 1;
+        }
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint64_t mw = (uint64_t)S.ws[2 * w] | ((uint64_t)S.ws[2 * w + 1] << 32);
+            if (w < wave_id() && mw) dn_lane = w * 64 + 63 - __clzll((long long)mw);
+        }
+        const int lane = lane_id();
+        const uint64_t above = lane < 63 ? bal & ~((2ull << lane) - 1) : 0ull;
+        const uint64_t below = bal & ((1ull << lane) - 1);
+        const int up = above ? wave_id() * 64 + __ffsll((long long)above) - 1 : up_lane;
+        const int dn = below ? wave_id() * 64 + 63 - __clzll((long long)below) : dn_lane;
+        nextb = up >= 0 ? (int)(S.code[up] & 0xFFFFu) : len;
+        lastb = dn >= 0 ? (int)(S.code[dn] >> 16) : -1;
+    }   // S.ws / S.code are next written behind later barriers
     PROF_MARK(1);
+    if (dbg == 22) { z.bitpos += (uint32_t)brk + a_sum + b_sum + lastb + nextb; return; }
 
-    // Positions inside a run (no break bit) are the only ones that need the run analysis, and inside a run
-    // only a few positions can emit a token: the first position of each 258-byte chunk of the run body, and
-    // the last two bytes of the run (a chunk shorter than 3 is sent as literals).  So per maximal in-run
-    // segment of the lane's chunk at most three positions are evaluated — a lane that lies entirely inside
-    // a long run (the svb key area is mostly zeros) does O(1) work instead of O(K).
-    // tok = positions that emit a token, mat = those that are matches.
+    // Positions inside a run (no break bit) are the only ones that need the run analysis.  Most of them belong to runs of
+    // two or three equal bytes, which can never hold a match (a match needs a run of >= 4: one literal + 3 covered
+    // bytes): those positions are plain literals and are classified with mask arithmetic alone.  Only segments of
+    // >= 3 in-run positions, and segments that touch the lane's chunk boundary (their run continues in a neighbour
+    // lane), go through the per-segment analysis; there at most three positions can emit a token: the first position
+    // of each 258-byte chunk of the run body and the run's last two bytes (a chunk shorter than 3 is sent as
+    // literals) — a lane that lies entirely inside a long run (the svb key area is mostly zeros) does O(1) work.
+    // tok = positions that emit a token, mat = those that are matches; mc = the lane's first two matches, cached for
+    // the bit-count and pack passes (j | sym-257 << 6 | eb << 11 | ev << 14).
     M tok = brk, mat = 0;
     uint32_t nmatch = 0, nextra = 0;
+    uint32_t mc0 = 0xFFFFFFFFu, mc1 = 0xFFFFFFFFu;
     {
-        M inrun = (M)~brk & (kk >= MO::BITS ? (M)~(M)0 : (M)(((M)1 << kk) - 1));
-        while (inrun) {
-            const int j0 = MO::lsb(inrun);
-            const M rest = (M)~(M)(inrun >> j0);                        // first zero = end of this segment
+        const M valid = kk >= MO::BITS ? (M)~(M)0 : (M)(((M)1 << kk) - 1);
+        const M I = (M)~brk & valid;
+        const M L3 = I & (I >> 1) & (I >> 2);
+        const M longseg = L3 | (M)(L3 << 1) | (M)(L3 << 2);            // every position of a segment of >= 3
+        const M lowrun = I & (M)~(M)(I + 1);                            // segment that starts at my first byte
+        const M zer = (M)~I & valid;
+        const M highrun = zer ? (M)(I & (M)~(M)((((M)2 << MO::msb(zer)) - 1))) : I;   // segment that ends at my last byte
+        M slow = I & (longseg | lowrun | highrun);
+        M lits = I & (M)~slow;                                          // short interior segments: literals
+        while (slow) {
+            const int j0 = MO::lsb(slow);
+            const M rest = (M)~(M)(slow >> j0);                         // first zero = end of this segment
             const int seg = rest ? MO::lsb(rest) : MO::BITS - j0;
             const int j1 = j0 + seg;                                    // segment = chunk positions [j0, j1)
-            inrun &= seg >= MO::BITS ? (M)0 : (M)~(M)((((M)1 << seg) - 1) << j0);
+            const M segmask = seg >= MO::BITS ? (M)~(M)0 : (M)((((M)1 << seg) - 1) << j0);
+            slow &= (M)~segmask;
             // run bounds of this segment (same for all its positions)
             const M lo = brk & (M)(((M)1 << j0) - 1);
             const int s = lo ? base + MO::msb(lo) : lastb;
             const M hi = j1 < MO::BITS ? (M)(brk >> j1) : (M)0;
             const int e = hi ? base + j1 + MO::lsb(hi) : nextb;
+            if (e - s - 1 < 3) { lits |= segmask; continue; }           // run of < 4 bytes: all literals
             // candidates: chunk starts s+1+258c inside the segment, and the run's last two positions
             const int p0 = base + j0, p1 = base + j1;
             const int c0 = (p0 - s - 1 + 257) / 258;
@@ -526,11 +569,22 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
                 if (t.sym >= 0) {
                     tok |= (M)1 << j;
                     atomicAdd(&S.freq[t.sym], 1u);
-                    if (t.sym > 256) { mat |= (M)1 << j; nmatch++; nextra += t.eb; }
+                    if (t.sym > 256) {
+                        mat |= (M)1 << j; nmatch++; nextra += t.eb;
+                        const uint32_t pk = (uint32_t)j | ((uint32_t)(t.sym - 257) << 6) | (t.eb << 11) | (t.ev << 14);
+                        if (mc0 == 0xFFFFFFFFu) mc0 = pk; else if (mc1 == 0xFFFFFFFFu) mc1 = pk;
+                    }
                 }
             }
         }
+        tok |= lits;
+        while (lits) {                                                  // literal tokens inside short runs
+            const int j = MO::lsb(lits);
+            lits &= lits - 1;
+            atomicAdd(&S.freq[buf[base + j]], 1u);
+        }
     }
+    if (dbg == 23) { z.bitpos += (uint32_t)tok + (uint32_t)mat + a_sum + b_sum + nmatch + nextra + mc0 + mc1; return; }
     nmatch = wave_sum(nmatch);
     nextra = wave_sum(nextra);
     a_sum = wave_sum(a_sum);
@@ -736,6 +790,14 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     PROF_MARK(10);
     // ---- per-lane bit totals (code-length entries and tokens share ONE prefix scan: the two sums are packed
     // into one word, 13 bits for the <= 320 * 14 header bits, 19 for the <= 16384 * 15 token bits) ----
+    // (sym, extra bits, extra value) of the match token at chunk position j: from the lane's cache, else recomputed
+    auto match_tok = [&](int j, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+        uint32_t pk = 0xFFFFFFFFu;
+        if (mc0 != 0xFFFFFFFFu && (mc0 & 63u) == (uint32_t)j) pk = mc0;
+        else if (mc1 != 0xFFFFFFFFu && (mc1 & 63u) == (uint32_t)j) pk = mc1;
+        if (pk != 0xFFFFFFFFu) { sym = 257 + ((pk >> 6) & 31u); eb = (pk >> 11) & 7u; ev = pk >> 14; }
+        else { const Tok tk = token_at(buf, base, j, brk, lastb, nextb); sym = (uint32_t)tk.sym; eb = tk.eb; ev = tk.ev; }
+    };
     uint32_t mybits = 0;
     {
         M t = tok, mm = mat;
@@ -749,16 +811,18 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             while (mt) {
                 const int q = __ffs(mt) - 1;
                 mt &= mt - 1;
-                const Tok tk = token_at(buf, base, j + q, brk, lastb, nextb);
-                mybits += (S.code[tk.sym] >> 16) + tk.eb + dist_bits;
+                uint32_t sym, eb, ev;
+                match_tok(j + q, sym, eb, ev);
+                mybits += (S.code[sym] >> 16) + eb + dist_bits;
             }
         }
         for (; j < kk; j++, t >>= 1, mm >>= 1) {
             if (!(t & 1)) continue;
             if (!(mm & 1)) mybits += S.code[buf[base + j]] >> 16;
             else {
-                const Tok tk = token_at(buf, base, j, brk, lastb, nextb);
-                mybits += (S.code[tk.sym] >> 16) + tk.eb + dist_bits;
+                uint32_t sym, eb, ev;
+                match_tok(j, sym, eb, ev);
+                mybits += (S.code[sym] >> 16) + eb + dist_bits;
             }
         }
     }
@@ -789,11 +853,12 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             }
         };
         auto emit_match = [&](int j) {
-            const Tok tk = token_at(buf, base, j, brk, lastb, nextb);
-            const uint32_t cc = S.code[tk.sym];
+            uint32_t sym, eb, ev;
+            match_tok(j, sym, eb, ev);
+            const uint32_t cc = S.code[sym];
             uint32_t nb = cc >> 16;
-            uint32_t v = (cc & 0xFFFF) | (tk.ev << nb);
-            nb += tk.eb;
+            uint32_t v = (cc & 0xFFFF) | (ev << nb);
+            nb += eb;
             v |= dist_code << nb;
             nb += dist_bits;
             emit(v, nb);

@@ -19,22 +19,38 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // ---- wave-level scans (64 lanes) ----
+// Prefix scans and reductions run on the DPP data path (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast:15 and
+// row_bcast:31 carry the row totals up): six VALU instructions, no LDS crossbar traffic and no address arithmetic, against
+// six ds_bpermute round trips for the shuffle form.  All 64 lanes must be active at the call.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138, DPP_WAVE_SHL1 = 0x130;
+
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane_id() >= d) v += t;
-    }
+    v += dpp_u32<DPP_ROW_SHR1>(0, v);
+    v += dpp_u32<DPP_ROW_SHR2>(0, v);
+    v += dpp_u32<DPP_ROW_SHR4>(0, v);
+    v += dpp_u32<DPP_ROW_SHR8>(0, v);
+    v += dpp_u32<DPP_ROW_BCAST15, 0xA>(0, v);
+    v += dpp_u32<DPP_ROW_BCAST31, 0xC>(0, v);
     return v;
 }
 __device__ __forceinline__ int wave_incl_max(int v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d);
-        if (lane_id() >= d) v = max(v, t);
-    }
+    constexpr uint32_t ID = 0x80000000u;   // INT_MIN
+    v = max(v, (int)dpp_u32<DPP_ROW_SHR1>(ID, (uint32_t)v));
+    v = max(v, (int)dpp_u32<DPP_ROW_SHR2>(ID, (uint32_t)v));
+    v = max(v, (int)dpp_u32<DPP_ROW_SHR4>(ID, (uint32_t)v));
+    v = max(v, (int)dpp_u32<DPP_ROW_SHR8>(ID, (uint32_t)v));
+    v = max(v, (int)dpp_u32<DPP_ROW_BCAST15, 0xA>(ID, (uint32_t)v));
+    v = max(v, (int)dpp_u32<DPP_ROW_BCAST31, 0xC>(ID, (uint32_t)v));
     return v;
 }
+// value of the previous / next lane (lane 0 / lane 63 get `fill`)
+__device__ __forceinline__ uint32_t wave_prev(uint32_t v, uint32_t fill) { return dpp_u32<DPP_WAVE_SHR1>(fill, v); }
+__device__ __forceinline__ uint32_t wave_next(uint32_t v, uint32_t fill) { return dpp_u32<DPP_WAVE_SHL1>(fill, v); }
 __device__ __forceinline__ int wave_suffix_incl_min(int v) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -43,10 +59,8 @@ __device__ __forceinline__ int wave_suffix_incl_min(int v) {
     }
     return v;
 }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {   // uniform result (an SGPR)
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_add(v), 63);
 }
 
 // ---- workgroup scans; ws = LDS scratch of >= NW words. Two barriers each. ----
@@ -77,8 +91,7 @@ __device__ __forceinline__ int block_excl_max(int v, int ident, uint32_t *ws) {
         if (w < wave_id()) base = max(base, x);
     }
     __syncthreads();
-    int prev = __shfl_up(incl, 1);
-    if (lane_id() == 0) prev = ident;
+    const int prev = (int)wave_prev((uint32_t)incl, (uint32_t)ident);
     return max(base, prev);
 }
 // exclusive suffix min: min over threads t' > t (identity `ident`)
