@@ -326,8 +326,10 @@ __device__ __forceinline__ void assign_codes_wave(const uint32_t *blcount, const
         uint32_t c = 0;
         next[0] = 0;
 #pragma unroll
-        for (int b = 1; b < 16; b++) { c = (c + (b > 1 ? blcount[b - 1] : 0)) << 1; next[b] = c; }
-        const uint64_t lt = (1ull << lane_id()) - 1;
+        for (int b = 1; b < 16; b++) {   // first code of every length, wave-uniform: keep the table in SGPRs
+            c = (c + (b > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)blcount[b - 1]) : 0u)) << 1;
+            next[b] = c;
+        }
         for (int base = 0; base < n; base += 64) {
             const int s = base + lane_id();
             const int l = s < n ? lens[s] : 0;
@@ -335,7 +337,10 @@ __device__ __forceinline__ void assign_codes_wave(const uint32_t *blcount, const
 #pragma unroll
             for (int b = 1; b < 16; b++) {
                 const uint64_t mask = __ballot(l == b);
-                if (l == b) mine = next[b] + __popcll(mask & lt);
+                if (mask == 0) continue;                                  // uniform: no symbol of this length in the slice
+                // rank among the lanes with the same length = set bits of the ballot below my lane (v_mbcnt)
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (l == b) mine = next[b] + below;
                 next[b] += __popcll(mask);
             }
             if (s < n) code_out[s] = l ? ((__brev(mine) >> (32 - l)) | ((uint32_t)l << 16)) : 0u;
@@ -354,7 +359,7 @@ __device__ __forceinline__ uint32_t fixed_code(int s) {
     return (__brev(c) >> (32 - l)) | (l << 16);
 }
 
-struct Tok { int sym; uint32_t eb, ev; };   // sym < 0: position covered by a match
+struct Tok { int sym; uint32_t eb, ev, mlen; };   // sym < 0: position covered by a match; mlen: bytes a match covers
 
 // Per-lane position masks: a lane owns K = ceil(len / 256) contiguous bytes; K <= 32 (blocks up to 8 KiB, the
 // case of a 4000-sample read) fits a 32-bit mask, which halves the cost of every mask operation on gfx950.
@@ -383,12 +388,14 @@ __device__ __forceinline__ Tok token_at(const uint8_t *__restrict__ buf, int bas
     t.sym = buf[base + j];
     t.eb = 0;
     t.ev = 0;
+    t.mlen = 0;
     if (rel > 0 && body >= 3) {
         const int m = rel - 1, c = m / 258, off = m - c * 258;
         const int Lc = min(258, body - c * 258);
         if (Lc >= 3) {
             if (off != 0) { t.sym = -1; return t; }
             const int l = Lc - 3;
+            t.mlen = (uint32_t)Lc;
             if (Lc == 258) t.sym = 285;
             else if (l < 8) t.sym = 257 + l;
             else {
@@ -452,7 +459,9 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     if (tid < 8) S.red[tid] = 0;
     if (tid < 20) S.clfreq[tid] = 0;
 
-    // ---- A: break mask, Adler partials; a run start is always a literal token: count it right here ----
+    // ---- A: break mask, Adler partials; a run start is always a literal token: count it right here.  (Counting every byte
+    // and taking matched bytes out again would make the loop branch-free, but the zero runs of the svb key area then put
+    // 64 same-address LDS atomics into one instruction: measured 3.5x slower.) ----
     M brk = 0;
     uint32_t a_sum = 0, b_sum = 0;
     {
@@ -497,16 +506,21 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         if (lane_id() == 0) { S.ws[2 * wave_id()] = (uint32_t)bal; S.ws[2 * wave_id() + 1] = (uint32_t)(bal >> 32); }
         if (has) S.code[tid] = (uint32_t)local_first | ((uint32_t)local_last << 16);
         __syncthreads();
-        int up_lane = -1, dn_lane = -1;            // wave-uniform: nearest break-owning lane in a later / earlier wave
+        int up_lane = -1, dn_lane = -1;            // wave-uniform (kept in SGPRs): nearest break-owning lane in a later / earlier wave
+        const int wv = __builtin_amdgcn_readfirstlane(wave_id());
 #pragma unroll
         for (int w = NW - 1; w >= 0; w--) {
-            const uint64_t mw = (uint64_t)S.ws[2 * w] | ((uint64_t)S.ws[2 * w + 1] << 32);
-            if (w > wave_id() && mw) up_lane = w * 64 + __ffsll((long long)mw) - 1;
+            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w]);
+            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w + 1]);
+            const uint64_t mw = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
+            if (w > wv && mw) up_lane = w * 64 + __ffsll((long long)mw) - 1;
         }
 #pragma unroll
         for (int w = 0; w < NW; w++) {
-            const uint64_t mw = (uint64_t)S.ws[2 * w] | ((uint64_t)S.ws[2 * w + 1] << 32);
-            if (w < wave_id() && mw) dn_lane = w * 64 + 63 - __clzll((long long)mw);
+            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w]);
+            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w + 1]);
+            const uint64_t mw = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
+            if (w < wv && mw) dn_lane = w * 64 + 63 - __clzll((long long)mw);
         }
         const int lane = lane_id();
         const uint64_t above = lane < 63 ? bal & ~((2ull << lane) - 1) : 0ull;
@@ -541,6 +555,17 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         const M highrun = zer ? (M)(I & (M)~(M)((((M)2 << MO::msb(zer)) - 1))) : I;   // segment that ends at my last byte
         M slow = I & (longseg | lowrun | highrun);
         M lits = I & (M)~slow;                                          // short interior segments: literals
+        // the two boundary segments continue in a neighbour lane; their run length follows from lastb / nextb without a
+        // loop, and nearly all of them are runs of < 4 bytes, i.e. literals too
+        if (lowrun) {
+            const M nz = (M)~I;                                         // first position after the segment
+            const int e = (nz & valid) ? base + MO::lsb(nz) : nextb;    // the run ends inside my chunk, or runs on
+            if (e - lastb - 1 < 3) { lits |= lowrun; slow &= (M)~lowrun; }
+        }
+        if (highrun && highrun != lowrun) {
+            const int s0 = base + MO::msb(zer);                         // zer != 0 here: the break in front of the segment
+            if (nextb - s0 - 1 < 3) { lits |= highrun; slow &= (M)~highrun; }
+        }
         while (slow) {
             const int j0 = MO::lsb(slow);
             const M rest = (M)~(M)(slow >> j0);                         // first zero = end of this segment
@@ -800,30 +825,26 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     };
     uint32_t mybits = 0;
     {
-        M t = tok, mm = mat;
+        // literal tokens: branch-free over groups of four positions (4 byte loads, then 4 code loads, in flight together)
+        M lt = tok & (M)~mat;
         int j = 0;
-        for (; j + 4 <= kk; j += 4, t >>= 4, mm >>= 4) {   // 4 byte loads, then 4 code loads, in flight together
+        for (; j + 4 <= kk; j += 4, lt >>= 4) {
             const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
             const uint32_t c0 = S.code[b0] >> 16, c1 = S.code[b1] >> 16, c2 = S.code[b2] >> 16, c3 = S.code[b3] >> 16;
-            const uint32_t lit = (uint32_t)t & ~(uint32_t)mm & 15u;
+            const uint32_t lit = (uint32_t)lt & 15u;
             mybits += (lit & 1 ? c0 : 0) + (lit & 2 ? c1 : 0) + (lit & 4 ? c2 : 0) + (lit & 8 ? c3 : 0);
-            uint32_t mt = (uint32_t)t & (uint32_t)mm & 15u;
-            while (mt) {
-                const int q = __ffs(mt) - 1;
-                mt &= mt - 1;
-                uint32_t sym, eb, ev;
-                match_tok(j + q, sym, eb, ev);
-                mybits += (S.code[sym] >> 16) + eb + dist_bits;
-            }
         }
-        for (; j < kk; j++, t >>= 1, mm >>= 1) {
-            if (!(t & 1)) continue;
-            if (!(mm & 1)) mybits += S.code[buf[base + j]] >> 16;
-            else {
-                uint32_t sym, eb, ev;
-                match_tok(j, sym, eb, ev);
-                mybits += (S.code[sym] >> 16) + eb + dist_bits;
-            }
+        for (; j < kk; j++, lt >>= 1)
+            if (lt & 1) mybits += S.code[buf[base + j]] >> 16;
+        // match tokens: the cached ones directly, any further ones (a lane with more than two matches) by recomputation
+        M rest = mat;
+        if (mc0 != 0xFFFFFFFFu) { mybits += (S.code[257 + ((mc0 >> 6) & 31u)] >> 16) + ((mc0 >> 11) & 7u) + dist_bits; rest &= (M)~((M)1 << (mc0 & 63u)); }
+        if (mc1 != 0xFFFFFFFFu) { mybits += (S.code[257 + ((mc1 >> 6) & 31u)] >> 16) + ((mc1 >> 11) & 7u) + dist_bits; rest &= (M)~((M)1 << (mc1 & 63u)); }
+        while (rest) {
+            const int jm = MO::lsb(rest);
+            rest &= rest - 1;
+            const Tok tk = token_at(buf, base, jm, brk, lastb, nextb);
+            mybits += (S.code[tk.sym] >> 16) + tk.eb + dist_bits;
         }
     }
     uint32_t packed_total;
@@ -839,47 +860,81 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     PROF_MARK(11);
     if (dbg == 5) { z.bitpos += start; return; }
     {
-        uint32_t widx = (start >> 5) - z.flushed;
-        uint32_t accbits = start & 31;
-        uint64_t acc = 0;
-        M t = tok, mm = mat;
-        auto emit = [&](uint32_t v, uint32_t nb) {
-            acc |= (uint64_t)v << accbits;
-            accbits += nb;
-            if (accbits >= 32) {
-                atomicOr(&obuf[widx++], (uint32_t)acc);
-                acc >>= 32;
-                accbits -= 32;
-            }
+        // The lane's tokens go straight into the LDS bit buffer, four byte positions at a time: positions without a token
+        // contribute zero bits, the (<= 15-bit) literal codes of a group are merged into one <= 60-bit value and ORed in
+        // at its bit position — three word ORs, no accumulator, no flush test, no per-token branch.  Match tokens (rare
+        // outside the key area) take the same route one at a time.
+        uint32_t pos = start;
+        auto or_bits = [&](uint64_t v, uint32_t nb) {          // nb <= 60
+            const uint32_t w = (pos >> 5) - z.flushed, sh = pos & 31;
+            const uint64_t lo = v << sh;
+            atomicOr(&obuf[w], (uint32_t)lo);
+            atomicOr(&obuf[w + 1], (uint32_t)(lo >> 32));
+            if (sh + nb > 64) atomicOr(&obuf[w + 2], (uint32_t)(v >> (64 - sh)));   // rare: four long codes in one group
+            pos += nb;
         };
-        auto emit_match = [&](int j) {
+        auto match_bits = [&](int j, uint32_t &nb) -> uint32_t {   // code | extra | distance code, <= 15 + 5 + 5 bits
             uint32_t sym, eb, ev;
             match_tok(j, sym, eb, ev);
             const uint32_t cc = S.code[sym];
-            uint32_t nb = cc >> 16;
+            nb = cc >> 16;
             uint32_t v = (cc & 0xFFFF) | (ev << nb);
             nb += eb;
             v |= dist_code << nb;
             nb += dist_bits;
-            emit(v, nb);
+            return v;
         };
-        int j = 0;
-        for (; j + 4 <= kk; j += 4, t >>= 4, mm >>= 4) {
-            const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
-            const uint32_t cc[4] = {S.code[b0], S.code[b1], S.code[b2], S.code[b3]};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (!((t >> q) & 1)) continue;
-                if (!((mm >> q) & 1)) emit(cc[q] & 0xFFFF, cc[q] >> 16);
-                else emit_match(j + q);
+        // Lanes with only a few tokens (the key area: long zero runs, one match per 258 bytes) walk their token bits one
+        // by one; lanes with many tokens (the data area: almost every byte is a literal) take the grouped path.  A wave
+        // that holds only one kind runs only that loop.
+        if (__popcll((unsigned long long)tok) <= 6) {
+            M t = tok;
+            while (t) {
+                const int j = MO::lsb(t);
+                t &= t - 1;
+                if (!((mat >> j) & 1)) { const uint32_t c1 = S.code[buf[base + j]]; or_bits((uint64_t)(c1 & 0xFFFF), c1 >> 16); }
+                else { uint32_t nb; const uint32_t mv = match_bits(j, nb); or_bits((uint64_t)mv, nb); }
+            }
+        } else {
+            M t = tok, mm = mat;
+            int j = 0;
+            for (; j + 4 <= kk; j += 4, t >>= 4, mm >>= 4) {
+                const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
+                const uint32_t cc[4] = {S.code[b0], S.code[b1], S.code[b2], S.code[b3]};
+                const uint32_t tt = (uint32_t)t & ~(uint32_t)mm;   // literal tokens of the group
+                uint32_t n[4], v[4];
+    #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    n[q] = (tt >> q) & 1u ? cc[q] >> 16 : 0u;
+                    v[q] = (tt >> q) & 1u ? cc[q] & 0xFFFFu : 0u;
+                }
+                if ((uint32_t)mm & 15u) {                          // a match in the group: patch its slot(s) in
+    #pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (((uint32_t)mm >> q) & 1u) {
+                            // tokens leave in position order: first the literals still pending in front of the match ...
+                            if (q == 1) { or_bits((uint64_t)v[0], n[0]); }
+                            else if (q == 2) { or_bits((uint64_t)(v[0] | (v[1] << n[0])), n[0] + n[1]); }
+                            else if (q == 3) { or_bits((uint64_t)(v[0] | (v[1] << n[0])) | ((uint64_t)v[2] << (n[0] + n[1])), n[0] + n[1] + n[2]); }
+    #pragma unroll
+                            for (int e = 0; e < q; e++) { v[e] = 0; n[e] = 0; }
+                            // ... then the match itself (up to 25 bits)
+                            uint32_t nb;
+                            const uint32_t mv = match_bits(j + q, nb);
+                            or_bits((uint64_t)mv, nb);
+                        }
+                }
+                const uint32_t lo = v[0] | (v[1] << n[0]), nlo = n[0] + n[1];
+                const uint32_t hi = v[2] | (v[3] << n[2]), nhi = n[2] + n[3];
+                or_bits((uint64_t)lo | ((uint64_t)hi << nlo), nlo + nhi);
+            }
+            for (; j < kk; j++, t >>= 1, mm >>= 1) {
+                if (!(t & 1)) continue;
+                if (!(mm & 1)) { const uint32_t c1 = S.code[buf[base + j]]; or_bits((uint64_t)(c1 & 0xFFFF), c1 >> 16); }
+                else { uint32_t nb; const uint32_t mv = match_bits(j, nb); or_bits((uint64_t)mv, nb); }
             }
         }
-        for (; j < kk; j++, t >>= 1, mm >>= 1) {
-            if (!(t & 1)) continue;
-            if (!(mm & 1)) { const uint32_t c1 = S.code[buf[base + j]]; emit(c1 & 0xFFFF, c1 >> 16); }
-            else emit_match(j);
-        }
-        if (accbits && acc) atomicOr(&obuf[widx], (uint32_t)acc);
+        if (dbg == 6) { z.bitpos += pos; return; }
     }
     const uint32_t eob = S.code[256];
     if (tid == 0) put_bits(obuf, z, pos0 + total_bits, eob & 0xFFFF, eob >> 16);
