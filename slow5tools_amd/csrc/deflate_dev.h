@@ -202,10 +202,10 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             const int qn = 63 - lane;
             const uint32_t ov = lane < 32 ? (i + lane < m ? B.lf[i + lane] : INF) : (j + qn < k ? B.nf[j + qn] : INF);
             uint32_t x = ov == INF ? INF : (ov << 8) | (lane < 32 ? (uint32_t)lane : 64u | (uint32_t)qn);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const uint32_t px = __shfl_xor(x, d);
-                x = (lane & d) ? max(x, px) : min(x, px);
+            {
+                auto step = [&](uint32_t px, int d) { x = (lane & d) ? max(x, px) : min(x, px); };
+                step(wave_xor<32>(x), 32); step(wave_xor<16>(x), 16); step(wave_xor<8>(x), 8);
+                step(wave_xor<4>(x), 4); step(wave_xor<2>(x), 2); step(wave_xor<1>(x), 1);
             }
             const uint32_t x0 = __builtin_amdgcn_readlane(x, 0), x1 = __builtin_amdgcn_readlane(x, 1);
             uint32_t T = (x0 >> 8) + (x1 >> 8);
@@ -215,7 +215,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             c &= ~1;
             c = max(c, 2);
             c = min(c, 2 * (m - 1 - k));
-            const uint32_t sx = vx + __shfl_xor(vx, 1);
+            const uint32_t sx = vx + wave_xor<1>(vx);
             if (!(lane & 1) && lane < c) B.nf[k + (lane >> 1)] = sx;
             const bool inx = lane < c;
             if (inx && (x & 64u)) B.npar[j + (x & 63u)] = (uint16_t)(k + (lane >> 1));
@@ -245,13 +245,14 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             {   // bitonic merge of 128 keys: stride 64 across the two registers, then 32..1 inside each
                 const uint32_t lo = min(a, b), hi = max(a, b);
                 a = lo; b = hi;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const uint32_t pa = __shfl_xor(a, d), pb = __shfl_xor(b, d);
+                auto step = [&](uint32_t pa, uint32_t pb, int d) {
                     const bool up = (lane & d) != 0;
                     a = up ? max(a, pa) : min(a, pa);
                     b = up ? max(b, pb) : min(b, pb);
-                }
+                };
+                step(wave_xor<32>(a), wave_xor<32>(b), 32); step(wave_xor<16>(a), wave_xor<16>(b), 16);
+                step(wave_xor<8>(a), wave_xor<8>(b), 8); step(wave_xor<4>(a), wave_xor<4>(b), 4);
+                step(wave_xor<2>(a), wave_xor<2>(b), 2); step(wave_xor<1>(a), wave_xor<1>(b), 1);
             }
             // a[lane] = X[lane], b[lane] = X[64 + lane] in ascending order
             const uint32_t x0 = __builtin_amdgcn_readlane(a, 0), x1 = __builtin_amdgcn_readlane(a, 1);
@@ -264,7 +265,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             c = max(c, 2);
             c = min(c, 2 * (m - 1 - k));
             // pairs (X[2p], X[2p+1]) -> node k + p
-            const uint32_t sa = va + __shfl_xor(va, 1), sb = vb + __shfl_xor(vb, 1);
+            const uint32_t sa = va + wave_xor<1>(va), sb = vb + wave_xor<1>(vb);
             if (!(lane & 1) && lane < c) B.nf[k + (lane >> 1)] = sa;
             if (!(lane & 1) && 64 + lane < c) B.nf[k + 32 + (lane >> 1)] = sb;
             const bool ina = lane < c, inb = 64 + lane < c;
@@ -647,9 +648,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             S.code[DOFF] = 0u | (1u << 16); S.code[DOFF + 1] = 1u | (1u << 16);
         }
         int hl = lane < 29 && S.lens[257 + lane] ? 258 + lane : 257;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) hl = max(hl, __shfl_xor(hl, d));
-        const int hlit = hl, n = hlit + 2;
+        const int hlit = __builtin_amdgcn_readlane(wave_incl_max(hl), 63), n = hlit + 2;
         if (lane == 0) S.hlit = (uint32_t)hlit;
         wave_sync();
         {

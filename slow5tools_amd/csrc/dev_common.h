@@ -51,6 +51,21 @@ __device__ __forceinline__ int wave_incl_max(int v) {
 // value of the previous / next lane (lane 0 / lane 63 get `fill`)
 __device__ __forceinline__ uint32_t wave_prev(uint32_t v, uint32_t fill) { return dpp_u32<DPP_WAVE_SHR1>(fill, v); }
 __device__ __forceinline__ uint32_t wave_next(uint32_t v, uint32_t fill) { return dpp_u32<DPP_WAVE_SHL1>(fill, v); }
+// value of lane (lane ^ D): quad permutes and row rotations on the DPP path, the gfx950 row / half-wave swaps above that —
+// no LDS crossbar round trip (ds_bpermute) for the butterfly steps of the bitonic merges
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_bank_u32(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, BANK_MASK, false);
+}
+template <int D>
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+    if constexpr (D == 1) return dpp_u32<0xB1>(v, v);                 // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return dpp_u32<0x4E>(v, v);            // quad_perm [2,3,0,1]
+    else if constexpr (D == 4) return dpp_bank_u32<0x114, 0xA>(dpp_bank_u32<0x104, 0x5>(v, v), v);   // row_shl:4 into banks 0,2; row_shr:4 into 1,3
+    else if constexpr (D == 8) return dpp_u32<0x128>(v, v);           // row_ror:8
+    else if constexpr (D == 16) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane_id() & 16) ? r[0] : r[1]; }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane_id() & 32) ? r[0] : r[1]; }
+}
 __device__ __forceinline__ int wave_suffix_incl_min(int v) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
