@@ -73,11 +73,9 @@ struct DeflShared {
     uint8_t cllens[20];
     uint32_t blcount[16];
     uint32_t icount[16];     // internal nodes per depth
-    uint32_t clblcount[16], clicount[16];   // the same for the code-length code (built concurrently by wave 0)
     uint32_t ws[16];         // cross-wave scan scratch
     uint32_t red[8];         // 0 matches, 1 extra bits, 2 adler A part, 3 adler B part, 4 dyn bits, 5 fixed bits, 6 cl bits
     uint32_t ncl, hlit, hclen, dbg;
-    BuildScratchT<32> clb;   // scratch of the 19-symbol code-length code
 #ifdef S5_PROFILE
     unsigned long long prof[16];
 #endif
@@ -711,24 +709,24 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         }
         wave_sync();
         PROF_MARK(7);
-        build_lengths<32, true>(S, S.clb, (SortScratch *)nullptr, S.clfreq, 19, 7, S.cllens, S.clblcount, S.clicount);
-        PROF_RESET
-        assign_codes_wave(S.clblcount, S.cllens, 19, S.clcode);
         {
-            const int ncl = (int)S.ncl;
-            uint32_t clb = 0;
-            for (int e = lane; e < ncl; e += 64) {
-                const int sym = S.clseq[e] & 31;
-                clb += S.cllens[sym] + (sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0);
-            }
-            clb = wave_sum(clb);
-            if (lane == 0) {
-                S.red[6] = clb;
-                const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                int h = 19;
-                while (h > 4 && S.cllens[order[h - 1]] == 0) h--;
-                S.hclen = h;
-            }
+            // The 19-symbol code-length code is not built per read: it is picked from two static prefix codes by cost.
+            // Its lengths travel in the block header (HCLEN x 3 bits), so any complete code is valid DEFLATE.  Code A is the
+            // 7-bit-limited optimum (package-merge) for the aggregate code-length statistics of svb-zd signal payloads
+            // (tools/clfreq_dump.py: 0.08 % larger records than a per-read optimum); code B covers every symbol for payloads
+            // that use code lengths 14 / 15.  Saves the serial Huffman construction on the critical wave.
+            static constexpr uint32_t CLA[19] = {0x30001, 0x7002f, 0x7006f, 0x7001f, 0x7005f, 0x50003, 0x50013, 0x5000b, 0x5001b, 0x50007,
+                                                 0x30005, 0x20000, 0x20002, 0x7003f, 0x00000, 0x00000, 0x50017, 0x6000f, 0x7007f};
+            static constexpr uint32_t CLB[19] = {0x30002, 0x60017, 0x7002f, 0x7006f, 0x60037, 0x5000b, 0x40005, 0x5001b, 0x50007, 0x4000d,
+                                                 0x30006, 0x30001, 0x20000, 0x7001f, 0x7005f, 0x7003f, 0x40003, 0x6000f, 0x7007f};
+            const uint32_t ca = lane < 19 ? CLA[lane] : 0u, cb = lane < 19 ? CLB[lane] : 0u;
+            const uint32_t f = lane < 19 ? S.clfreq[lane] : 0u;
+            const uint32_t eb = lane == 16 ? 2u : lane == 17 ? 3u : lane == 18 ? 7u : 0u;
+            const uint32_t costA = wave_sum(f * ((ca >> 16) + eb) + ((f && !(ca >> 16)) ? (1u << 24) : 0u));   // A lacks symbols 14, 15
+            const uint32_t costB = wave_sum(f * ((cb >> 16) + eb));
+            const bool useA = costA <= costB;
+            if (lane < 19) { const uint32_t c = useA ? ca : cb; S.clcode[lane] = c; S.cllens[lane] = (uint8_t)(c >> 16); }
+            if (lane == 0) { S.red[6] = useA ? costA : costB; S.hclen = useA ? 18u : 19u; }   // A: trailing zero length of symbol 15 is not sent
         }
         PROF_MARK(6);
     } else if (wave_id() == 1) {
@@ -746,7 +744,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     }
     __syncthreads();
     PROF_MARK(9);
-    if (dbg == 4) { z.bitpos += S.red[4] + S.red[6] + S.code[tid]; return; }
+    if (dbg == 4 || dbg == 41) { z.bitpos += S.red[4] + S.red[6] + S.code[tid]; return; }
     const uint32_t matches = S.red[0], extra = S.red[1];
     const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
     const uint32_t dyn_total = hdr_dyn + S.red[4] + extra + matches * 1;
@@ -967,7 +965,11 @@ __device__ __forceinline__ uint32_t zlib_compress_fused(DeflShared &S, uint32_t 
                                                         const uint8_t *pay, uint32_t plen, uint8_t *out, uint32_t dbg = 0) {
     ZOut z;
     const uint32_t total = zlib_frame_fused<M>(S, obuf, obuf_words, pay, plen, z, dbg);
-    if (dbg) { if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(out) = z.bitpos; return 16; }
+    if (dbg) {
+        if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(out) = z.bitpos;
+        if (dbg == 41 && threadIdx.x < 20) reinterpret_cast<uint32_t *>(out)[4 + threadIdx.x] = threadIdx.x < 19 ? S.clfreq[threadIdx.x] : S.red[6];   // tools/clfreq_dump.py
+        return 16;
+    }
     flush_words(obuf, reinterpret_cast<uint32_t *>(out), z, true);
     if (threadIdx.x == 0) *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
     return total;
