@@ -190,6 +190,9 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
         return;
     }
     if (WAVE || wave_id() == 0) {
+      // direction of every butterfly step as a per-lane constant: the upper lane of a pair keeps the max (med3 with ~0), the lower the min
+      const uint32_t dir32 = (lane_id() & 32) ? ~0u : 0u, dir16 = (lane_id() & 16) ? ~0u : 0u, dir8 = (lane_id() & 8) ? ~0u : 0u;
+      const uint32_t dir4 = (lane_id() & 4) ? ~0u : 0u, dir2 = (lane_id() & 2) ? ~0u : 0u, dir1 = (lane_id() & 1) ? ~0u : 0u;
       if (m <= 32) {
         // small alphabet (always the case for the 19-symbol code-length code): same rounds as below with a
         // 32 + 32 window in ONE register — leaves ascending in lanes 0..31, nodes descending in lanes 32..63
@@ -200,11 +203,8 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             const int qn = 63 - lane;
             const uint32_t ov = lane < 32 ? (i + lane < m ? B.lf[i + lane] : INF) : (j + qn < k ? B.nf[j + qn] : INF);
             uint32_t x = ov == INF ? INF : (ov << 8) | (lane < 32 ? (uint32_t)lane : 64u | (uint32_t)qn);
-            {
-                auto step = [&](uint32_t px, int d) { x = (lane & d) ? max(x, px) : min(x, px); };
-                step(wave_xor<32>(x), 32); step(wave_xor<16>(x), 16); step(wave_xor<8>(x), 8);
-                step(wave_xor<4>(x), 4); step(wave_xor<2>(x), 2); step(wave_xor<1>(x), 1);
-            }
+            x = umed3(x, wave_xor<32>(x), dir32); x = umed3(x, wave_xor<16>(x), dir16); x = umed3(x, wave_xor<8>(x), dir8);
+            x = umed3(x, wave_xor<4>(x), dir4); x = umed3(x, wave_xor<2>(x), dir2); x = umed3(x, wave_xor<1>(x), dir1);
             const uint32_t x0 = __builtin_amdgcn_readlane(x, 0), x1 = __builtin_amdgcn_readlane(x, 1);
             uint32_t T = (x0 >> 8) + (x1 >> 8);
             if (j + 32 < k) T = min(T, __builtin_amdgcn_readlane(ov, 32));   // nodes beyond the window (leaves never are)
@@ -243,14 +243,12 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             {   // bitonic merge of 128 keys: stride 64 across the two registers, then 32..1 inside each
                 const uint32_t lo = min(a, b), hi = max(a, b);
                 a = lo; b = hi;
-                auto step = [&](uint32_t pa, uint32_t pb, int d) {
-                    const bool up = (lane & d) != 0;
-                    a = up ? max(a, pa) : min(a, pa);
-                    b = up ? max(b, pb) : min(b, pb);
-                };
-                step(wave_xor<32>(a), wave_xor<32>(b), 32); step(wave_xor<16>(a), wave_xor<16>(b), 16);
-                step(wave_xor<8>(a), wave_xor<8>(b), 8); step(wave_xor<4>(a), wave_xor<4>(b), 4);
-                step(wave_xor<2>(a), wave_xor<2>(b), 2); step(wave_xor<1>(a), wave_xor<1>(b), 1);
+                a = umed3(a, wave_xor<32>(a), dir32); b = umed3(b, wave_xor<32>(b), dir32);
+                a = umed3(a, wave_xor<16>(a), dir16); b = umed3(b, wave_xor<16>(b), dir16);
+                a = umed3(a, wave_xor<8>(a), dir8); b = umed3(b, wave_xor<8>(b), dir8);
+                a = umed3(a, wave_xor<4>(a), dir4); b = umed3(b, wave_xor<4>(b), dir4);
+                a = umed3(a, wave_xor<2>(a), dir2); b = umed3(b, wave_xor<2>(b), dir2);
+                a = umed3(a, wave_xor<1>(a), dir1); b = umed3(b, wave_xor<1>(b), dir1);
             }
             // a[lane] = X[lane], b[lane] = X[64 + lane] in ascending order
             const uint32_t x0 = __builtin_amdgcn_readlane(a, 0), x1 = __builtin_amdgcn_readlane(a, 1);

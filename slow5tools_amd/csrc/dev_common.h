@@ -66,6 +66,9 @@ __device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
     else if constexpr (D == 16) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane_id() & 16) ? r[0] : r[1]; }
     else { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane_id() & 32) ? r[0] : r[1]; }
 }
+// median of three unsigned values (v_med3_u32).  med3(x, p, 0) = min(x, p), med3(x, p, ~0) = max(x, p): one instruction for a
+// compare-exchange whose direction is a per-lane constant
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { return min(max(a, b), max(min(a, b), c)); }
 __device__ __forceinline__ int wave_suffix_incl_min(int v) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
