@@ -823,14 +823,14 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         // literal tokens: branch-free over groups of four positions (4 byte loads, then 4 code loads, in flight together)
         M lt = tok & (M)~mat;
         int j = 0;
-        for (; j + 4 <= kk; j += 4, lt >>= 4) {
+        // the last group may reach up to three bytes past the lane's chunk: those positions carry no token bit and the
+        // bytes read there are in-bounds LDS (neighbour chunk / slack), so no separate tail loop is needed
+        for (; j < kk; j += 4, lt >>= 4) {
             const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
             const uint32_t c0 = S.code[b0] >> 16, c1 = S.code[b1] >> 16, c2 = S.code[b2] >> 16, c3 = S.code[b3] >> 16;
             const uint32_t lit = (uint32_t)lt & 15u;
             mybits += (lit & 1 ? c0 : 0) + (lit & 2 ? c1 : 0) + (lit & 4 ? c2 : 0) + (lit & 8 ? c3 : 0);
         }
-        for (; j < kk; j++, lt >>= 1)
-            if (lt & 1) mybits += S.code[buf[base + j]] >> 16;
         // match tokens: the cached ones directly, any further ones (a lane with more than two matches) by recomputation
         M rest = mat;
         if (mc0 != 0xFFFFFFFFu) { mybits += (S.code[257 + ((mc0 >> 6) & 31u)] >> 16) + ((mc0 >> 11) & 7u) + dist_bits; rest &= (M)~((M)1 << (mc0 & 63u)); }
@@ -893,25 +893,25 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         } else {
             M t = tok, mm = mat;
             int j = 0;
-            for (; j + 4 <= kk; j += 4, t >>= 4, mm >>= 4) {
+            for (; j < kk; j += 4, t >>= 4, mm >>= 4) {   // the last group may overhang the chunk: no token bits there
                 const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
                 const uint32_t cc[4] = {S.code[b0], S.code[b1], S.code[b2], S.code[b3]};
                 const uint32_t tt = (uint32_t)t & ~(uint32_t)mm;   // literal tokens of the group
                 uint32_t n[4], v[4];
-    #pragma unroll
+#pragma unroll
                 for (int q = 0; q < 4; q++) {
                     n[q] = (tt >> q) & 1u ? cc[q] >> 16 : 0u;
                     v[q] = (tt >> q) & 1u ? cc[q] & 0xFFFFu : 0u;
                 }
                 if ((uint32_t)mm & 15u) {                          // a match in the group: patch its slot(s) in
-    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < 4; q++)
                         if (((uint32_t)mm >> q) & 1u) {
                             // tokens leave in position order: first the literals still pending in front of the match ...
                             if (q == 1) { or_bits((uint64_t)v[0], n[0]); }
                             else if (q == 2) { or_bits((uint64_t)(v[0] | (v[1] << n[0])), n[0] + n[1]); }
                             else if (q == 3) { or_bits((uint64_t)(v[0] | (v[1] << n[0])) | ((uint64_t)v[2] << (n[0] + n[1])), n[0] + n[1] + n[2]); }
-    #pragma unroll
+#pragma unroll
                             for (int e = 0; e < q; e++) { v[e] = 0; n[e] = 0; }
                             // ... then the match itself (up to 25 bits)
                             uint32_t nb;
@@ -922,11 +922,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
                 const uint32_t lo = v[0] | (v[1] << n[0]), nlo = n[0] + n[1];
                 const uint32_t hi = v[2] | (v[3] << n[2]), nhi = n[2] + n[3];
                 or_bits((uint64_t)lo | ((uint64_t)hi << nlo), nlo + nhi);
-            }
-            for (; j < kk; j++, t >>= 1, mm >>= 1) {
-                if (!(t & 1)) continue;
-                if (!(mm & 1)) { const uint32_t c1 = S.code[buf[base + j]]; or_bits((uint64_t)(c1 & 0xFFFF), c1 >> 16); }
-                else { uint32_t nb; const uint32_t mv = match_bits(j, nb); or_bits((uint64_t)mv, nb); }
             }
         }
         if (dbg == 6) { z.bitpos += pos; return; }
