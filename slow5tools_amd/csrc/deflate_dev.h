@@ -879,16 +879,30 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             nb += dist_bits;
             return v;
         };
-        // Lanes with only a few tokens (the key area: long zero runs, one match per 258 bytes) walk their token bits one
-        // by one; lanes with many tokens (the data area: almost every byte is a literal) take the grouped path.  A wave
-        // that holds only one kind runs only that loop.
-        if (__popcll((unsigned long long)tok) <= 6) {
+        // Lanes with only a few tokens, or with a match among not too many (the key area: long zero runs broken by the
+        // occasional non-zero key byte), walk their token bits one by one — literal and match take the same
+        // branch-free route (one code lookup, extra bits and distance code are zero-width for a literal).  Lanes full of
+        // literals (the data area) take the grouped path.  A wave that holds only one kind runs only that loop.
+        const int ntok = __popcll((unsigned long long)tok);
+        if (ntok <= 6 || (mat != 0 && ntok <= 16)) {
             M t = tok;
             while (t) {
                 const int j = MO::lsb(t);
                 t &= t - 1;
-                if (!((mat >> j) & 1)) { const uint32_t c1 = S.code[buf[base + j]]; or_bits((uint64_t)(c1 & 0xFFFF), c1 >> 16); }
-                else { uint32_t nb; const uint32_t mv = match_bits(j, nb); or_bits((uint64_t)mv, nb); }
+                const bool ism = (mat >> j) & 1;
+                uint32_t sym = buf[base + j], eb = 0, ev = 0;
+                if (ism) {
+                    if (mc0 != 0xFFFFFFFFu && (mc0 & 63u) == (uint32_t)j) { sym = 257 + ((mc0 >> 6) & 31u); eb = (mc0 >> 11) & 7u; ev = mc0 >> 14; }
+                    else if (mc1 != 0xFFFFFFFFu && (mc1 & 63u) == (uint32_t)j) { sym = 257 + ((mc1 >> 6) & 31u); eb = (mc1 >> 11) & 7u; ev = mc1 >> 14; }
+                    else { const Tok tk = token_at(buf, base, j, brk, lastb, nextb); sym = (uint32_t)tk.sym; eb = tk.eb; ev = tk.ev; }
+                }
+                const uint32_t cc = S.code[sym];
+                uint32_t nb = cc >> 16;
+                uint32_t v = (cc & 0xFFFF) | (ev << nb);
+                nb += eb;
+                v |= (ism ? dist_code : 0u) << nb;
+                nb += ism ? dist_bits : 0u;
+                or_bits((uint64_t)v, nb);
             }
         } else {
             M t = tok, mm = mat;
