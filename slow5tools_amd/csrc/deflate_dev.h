@@ -576,27 +576,40 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             const M hi = j1 < MO::BITS ? (M)(brk >> j1) : (M)0;
             const int e = hi ? base + j1 + MO::lsb(hi) : nextb;
             if (e - s - 1 < 3) { lits |= segmask; continue; }           // run of < 4 bytes: all literals
-            // candidates: chunk starts s+1+258c inside the segment, and the run's last two positions
+            // A run of body = e-s-1 >= 3 bytes after its first one is sent as matches of up to 258 bytes (chunks starting at
+            // s+1+258c); a last chunk of 1 or 2 bytes is sent as literals.  My segment (< 258 positions) can hold at most one
+            // chunk start, and at most the run's last two positions as literals.
+            const int body = e - s - 1;
             const int p0 = base + j0, p1 = base + j1;
-            const int c0 = (p0 - s - 1 + 257) / 258;
-            int cand[3] = {s + 1 + 258 * c0, e - 2, e - 1};
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int p = cand[q];
-                if (p < p0 || p >= p1) continue;
-                if (q > 0 && p == cand[0]) continue;
-                if (q == 2 && p == cand[1]) continue;
-                const int j = p - base;
-                const Tok t = token_at(buf, base, j, brk, lastb, nextb);
-                if (t.sym >= 0) {
-                    tok |= (M)1 << j;
-                    atomicAdd(&S.freq[t.sym], 1u);
-                    if (t.sym > 256) {
-                        mat |= (M)1 << j; nmatch++; nextra += t.eb;
-                        const uint32_t pk = (uint32_t)j | ((uint32_t)(t.sym - 257) << 6) | (t.eb << 11) | (t.ev << 14);
-                        if (mc0 == 0xFFFFFFFFu) mc0 = pk; else if (mc1 == 0xFFFFFFFFu) mc1 = pk;
+            const int c0 = ((p0 - s - 1 + 257) * 16257) >> 22;          // ceil((p0-s-1) / 258); x / 258 == x * 16257 >> 22 for x < 70000
+            const int pstart = s + 1 + 258 * c0;
+            if (pstart < p1) {
+                const int Lc = min(258, body - 258 * c0);
+                if (Lc >= 3) {
+                    const int j = pstart - base, l = Lc - 3;
+                    uint32_t sym, eb = 0, ev = 0;
+                    if (Lc == 258) sym = 285;
+                    else if (l < 8) sym = 257 + l;
+                    else {
+                        const int nb = 29 - __clz(l);
+                        sym = 261 + 4 * nb + ((l >> nb) & 3);
+                        eb = nb;
+                        ev = l & ((1 << nb) - 1);
                     }
+                    tok |= (M)1 << j;
+                    mat |= (M)1 << j;
+                    atomicAdd(&S.freq[sym], 1u);
+                    nmatch++;
+                    nextra += eb;
+                    const uint32_t pk = (uint32_t)j | ((sym - 257) << 6) | (eb << 11) | (ev << 14);
+                    if (mc0 == 0xFFFFFFFFu) mc0 = pk; else if (mc1 == 0xFFFFFFFFu) mc1 = pk;
                 }
+            }
+            const int rem = body - 258 * ((body * 16257) >> 22);
+            if (rem == 1 || rem == 2) {                                  // the run's last rem bytes are literals
+                const int pa = e - 1, pb = e - 2;
+                if (pa >= p0 && pa < p1) lits |= (M)1 << (pa - base);
+                if (rem == 2 && pb >= p0 && pb < p1) lits |= (M)1 << (pb - base);
             }
         }
         tok |= lits;
