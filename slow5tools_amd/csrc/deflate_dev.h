@@ -193,21 +193,27 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
       // direction of every butterfly step as a per-lane constant: the upper lane of a pair keeps the max (med3 with ~0), the lower the min
       const uint32_t dir32 = (lane_id() & 32) ? ~0u : 0u, dir16 = (lane_id() & 16) ? ~0u : 0u, dir8 = (lane_id() & 8) ? ~0u : 0u;
       const uint32_t dir4 = (lane_id() & 4) ? ~0u : 0u, dir2 = (lane_id() & 2) ? ~0u : 0u, dir1 = (lane_id() & 1) ? ~0u : 0u;
-      if (m <= 32) {
-        // small alphabet (always the case for the 19-symbol code-length code): same rounds as below with a
-        // 32 + 32 window in ONE register — leaves ascending in lanes 0..31, nodes descending in lanes 32..63
-        const int lane = lane_id();
-        const uint32_t INF = 0xFFFFFFFFu;
-        int i = 0, j = 0, k = 0;
-        while (k < m - 1) {
+      // Huffman tree by ROUNDS instead of one merge per step (the serial two-queue loop costs ~400 cycles per merge on a
+      // GPU).  Leaves ascending in B.lf, internal nodes are produced ascending into B.nf.  Per round, one wave64 takes the
+      // next leaves and the next nodes, bitonic-merges them ([leaves asc | nodes desc] is a bitonic sequence), and pairs up
+      // EVERY item not larger than T = X0 + X1 at once — no node created in this round can be smaller than T, so the pairs
+      // are exactly the ones the serial algorithm would form.  The smallest remaining weight at least doubles per round:
+      // ~12 rounds for a 210-symbol alphabet (m-1 rounds only for Fibonacci-like weights).  While more than 32 leaves or 32
+      // nodes are pending the window is 64 + 64 keys in two registers; after that (about half of the rounds, and always for
+      // small alphabets) 32 + 32 keys in one register.
+      const int lane = lane_id();
+      const uint32_t INF = 0xFFFFFFFFu;
+      int i = 0, j = 0, k = 0;
+      while (k < m - 1) {
+        if (m - i <= 32 && k - j <= 32) {
+            // leaves ascending in lanes 0..31, nodes descending in lanes 32..63; key = weight << 8 | is_node << 6 | window index
             const int qn = 63 - lane;
             const uint32_t ov = lane < 32 ? (i + lane < m ? B.lf[i + lane] : INF) : (j + qn < k ? B.nf[j + qn] : INF);
             uint32_t x = ov == INF ? INF : (ov << 8) | (lane < 32 ? (uint32_t)lane : 64u | (uint32_t)qn);
             x = umed3(x, wave_xor<32>(x), dir32); x = umed3(x, wave_xor<16>(x), dir16); x = umed3(x, wave_xor<8>(x), dir8);
             x = umed3(x, wave_xor<4>(x), dir4); x = umed3(x, wave_xor<2>(x), dir2); x = umed3(x, wave_xor<1>(x), dir1);
             const uint32_t x0 = __builtin_amdgcn_readlane(x, 0), x1 = __builtin_amdgcn_readlane(x, 1);
-            uint32_t T = (x0 >> 8) + (x1 >> 8);
-            if (j + 32 < k) T = min(T, __builtin_amdgcn_readlane(ov, 32));   // nodes beyond the window (leaves never are)
+            const uint32_t T = (x0 >> 8) + (x1 >> 8);          // everything pending is inside the window
             const uint32_t vx = x >> 8;
             int c = __popcll(__ballot(x != INF && vx <= T));
             c &= ~1;
@@ -221,22 +227,10 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
             i += c - nn;
             j += nn;
             k += c >> 1;
-        }
-      } else {
-        // Huffman tree by ROUNDS instead of one merge per step (the serial two-queue loop costs ~400
-        // cycles per merge on a GPU).  Leaves ascending in S.lf, internal nodes are produced ascending
-        // into S.nf.  Per round, one wave64: take the next 64 leaves and the next 64 nodes, bitonic-merge
-        // the 128 keys in two registers, and pair up EVERY item not larger than T = X0 + X1 at once —
-        // no node created in this round can be smaller than T, so the pairs are exactly the ones the
-        // serial algorithm would form.  The smallest remaining weight at least doubles per round:
-        // ~13 rounds for a 240-symbol alphabet (m-1 rounds only for Fibonacci-like weights).
-        const int lane = lane_id();
-        const uint32_t INF = 0xFFFFFFFFu;
-        int i = 0, j = 0, k = 0;
-        while (k < m - 1) {
+        } else {
             // key = weight << 8 | is_node << 6 | window index; weights < 2^24
             const uint32_t lv = i + lane < m ? B.lf[i + lane] : INF;
-            const int qn = 63 - lane;   // node window is loaded descending: [leaves asc | nodes desc] is bitonic
+            const int qn = 63 - lane;   // node window is loaded descending
             const uint32_t nv = j + qn < k ? B.nf[j + qn] : INF;
             uint32_t a = lv == INF ? INF : (lv << 8) | (uint32_t)lane;
             uint32_t b = nv == INF ? INF : (nv << 8) | 64u | (uint32_t)qn;
