@@ -272,7 +272,7 @@ def bench_decode(args):
     line = {"metric": "blow5_get_decode_throughput", "value": round(done * 2 * n / busy / 1e9, 3), "unit": "GB/s",
             "n_gpus": 1, "higher_is_better": True, "dtype": "u8->int16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: random get decode (inflate + svb-zd unpack), %d ids (seed 1) over a %d-read index, batches of %d, %d samples/read" % (len(ids), n_reads, K, n)},
-            "reads_per_s": round(done / busy, 1), "batch_latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p99": round(float(np.percentile(lat_ms, 99)), 3)},
+            "reads_per_s": round(done / busy, 1), "slowest_batches": [int(x) for x in np.argsort(lat_ms)[-3:][::-1]], "batch_latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p99": round(float(np.percentile(lat_ms, 99)), 3)},
             "per_read_latency_us_p50": round(float(np.percentile(lat_ms, 50)) * 1e3 / K, 3),
             "roundtrip_identical": bool(ok), "wall_s_including_verification": round(wall, 2)}
     print(json.dumps(line))

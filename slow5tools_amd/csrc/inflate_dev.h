@@ -350,6 +350,35 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
                     if (b.wpos > INF_IW / 4 - 3) { st = 4; break; }
                     if (o - flushed >= INF_FLUSH) { st = 5; break; }
                     bi_need32_u(b, T.win);
+                    // A run of literals out of the bits in hand, in one round: lane L looks up the code that WOULD start at
+                    // bit offset L (one LDS read for all 64 offsets); the scalar unit then hops from code to code through
+                    // those results (v_readlane with a scalar index: a few cycles per symbol instead of an LDS round trip),
+                    // and the lanes at the visited offsets store their literals side by side.  Stops at the first symbol
+                    // that is not a LUT-resolved literal (match, end of block, long code) or when the bits run out; that
+                    // symbol takes the one-at-a-time route below.
+                    {
+                        const uint32_t ev = T.llut[(uint32_t)(b.buf >> lane) & ((1 << INF_LBITS) - 1)];
+                        // per lane: is the code at my offset a LUT-resolved literal, and where would the next code start
+                        const uint64_t lit_at = __ballot((ev >> 9) != 0 && (ev & 511u) < 256u);
+                        const uint32_t nxt = (uint32_t)lane + (ev >> 9);
+                        uint32_t off = 0;
+                        uint64_t visited = 0;
+                        while ((lit_at >> off) & 1) {
+                            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)off);
+                            if (n2 > (uint32_t)b.cnt) break;            // the code runs past the bits in hand
+                            visited |= 1ull << off;
+                            off = n2;
+                            if (off >= 64) break;
+                        }
+                        if (visited) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(visited >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)visited, 0u));
+                            if ((visited >> lane) & 1) T.ring[(o + rank) & (INF_OW - 1)] = (uint8_t)ev;
+                            o += (uint32_t)__popcll(visited);
+                            b.buf = off < 64 ? b.buf >> off : 0ull;
+                            b.cnt -= (int)off;
+                            continue;
+                        }
+                    }
                     int sym;
                     const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.llut[(uint32_t)b.buf & ((1 << INF_LBITS) - 1)]);
                     if (e >> 9) { sym = e & 511; bi_get(b, e >> 9); }
