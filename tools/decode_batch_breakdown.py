@@ -1,4 +1,5 @@
 import sys, time, os, ctypes as C
+"""Per-batch host/GPU time breakdown of get-style decode batches (used to find the 90 ms stall of torch pinned non_blocking copies)."""
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, torch
 from slow5tools_amd import _lib, press

@@ -1,4 +1,5 @@
 import sys, time, ctypes as C
+"""Decode latency vs batch size (k_inflate + k_unpack), one line per batch."""
 import os; sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, torch
 from slow5tools_amd import _lib, press

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/dp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d /tmp/dp -o dp -- python $GRAFT_REPO_ROOT/gpurun_tmp/dbg_decode.py > /tmp/dp.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d /tmp/dp -o dp -- python $GRAFT_REPO_ROOT/tools/decode_latency.py > /tmp/dp.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("/tmp/dp/**/*counter_collection.csv", recursive=True)[0]
