@@ -442,8 +442,23 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         return;
     }
     PROF_DECL
-    const int K = (len + NT - 1) / NT;
+    // A lane owns K contiguous bytes.  Big blocks (64-bit masks: the HBM-staged path and fused payloads over 8 KiB) run at low
+    // occupancy and are LDS-latency bound: there K is a multiple of 4 and every group of four positions is ONE aligned LDS
+    // dword (buf is 4-byte aligned) — measured +28 % on 100 k-sample reads.  Small blocks (32-bit masks, 8 workgroups per CU)
+    // are VALU bound: byte loads arrive zero-extended and save the extraction instructions — measured 3 % faster than dwords.
+    constexpr bool DW = sizeof(M) == 8;
+    const int K = DW ? (((len + NT - 1) / NT + 3) & ~3) : (len + NT - 1) / NT;
     const int base = tid * K;
+    auto load4 = [&](int j, int &b0, int &b1, int &b2, int &b3) -> uint32_t {
+        if constexpr (DW) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(buf + base + j);
+            b0 = w & 255u; b1 = (w >> 8) & 255u; b2 = (w >> 16) & 255u; b3 = w >> 24;
+            return w;
+        } else {
+            b0 = buf[base + j]; b1 = buf[base + j + 1]; b2 = buf[base + j + 2]; b3 = buf[base + j + 3];
+            return 0u;
+        }
+    };
     const int kk = max(0, min(K, len - base));
 
     for (int i = tid; i < 320; i += NT) S.freq[i] = 0;
@@ -463,16 +478,23 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         // four byte loads in flight per step (the compiler will not hoist LDS loads over the LDS atomics itself)
         int j = 0;
         for (; j + 4 <= kk; j += 4) {
-            const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
+            int b0, b1, b2, b3;
+            const uint32_t w = load4(j, b0, b1, b2, b3);
             if (b0 != prev) { brk |= (M)1 << j; atomicAdd(&S.freq[b0], 1u); }
             if (b1 != b0) { brk |= (M)2 << j; atomicAdd(&S.freq[b1], 1u); }
             if (b2 != b1) { brk |= (M)4 << j; atomicAdd(&S.freq[b2], 1u); }
             if (b3 != b2) { brk |= (M)8 << j; atomicAdd(&S.freq[b3], 1u); }
             prev = b3;
-            a_sum += b0; b_sum += a_sum;   // B as a running sum of A: two adds per byte, no multiply
-            a_sum += b1; b_sum += a_sum;
-            a_sum += b2; b_sum += a_sum;
-            a_sum += b3; b_sum += a_sum;
+            if constexpr (DW) {
+                // Adler halves of four bytes with two dot products: A += b0+b1+b2+b3, B += 4 A_old + 4 b0 + 3 b1 + 2 b2 + b3
+                b_sum = __builtin_amdgcn_udot4(w, 0x01020304u, b_sum + 4u * a_sum, false);
+                a_sum = __builtin_amdgcn_udot4(w, 0x01010101u, a_sum, false);
+            } else {
+                a_sum += b0; b_sum += a_sum;   // B as a running sum of A: two adds per byte, no multiply
+                a_sum += b1; b_sum += a_sum;
+                a_sum += b2; b_sum += a_sum;
+                a_sum += b3; b_sum += a_sum;
+            }
         }
         for (; j < kk; j++) {
             const int b = buf[base + j];
@@ -833,7 +855,8 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         // the last group may reach up to three bytes past the lane's chunk: those positions carry no token bit and the
         // bytes read there are in-bounds LDS (neighbour chunk / slack), so no separate tail loop is needed
         for (; j < kk; j += 4, lt >>= 4) {
-            const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
+            int b0, b1, b2, b3;
+            load4(j, b0, b1, b2, b3);
             const uint32_t c0 = S.code[b0] >> 16, c1 = S.code[b1] >> 16, c2 = S.code[b2] >> 16, c3 = S.code[b3] >> 16;
             const uint32_t lit = (uint32_t)lt & 15u;
             mybits += (lit & 1 ? c0 : 0) + (lit & 2 ? c1 : 0) + (lit & 4 ? c2 : 0) + (lit & 8 ? c3 : 0);
@@ -915,7 +938,8 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             M t = tok, mm = mat;
             int j = 0;
             for (; j < kk; j += 4, t >>= 4, mm >>= 4) {   // the last group may overhang the chunk: no token bits there
-                const int b0 = buf[base + j], b1 = buf[base + j + 1], b2 = buf[base + j + 2], b3 = buf[base + j + 3];
+                int b0, b1, b2, b3;
+                load4(j, b0, b1, b2, b3);
                 const uint32_t cc[4] = {S.code[b0], S.code[b1], S.code[b2], S.code[b3]};
                 const uint32_t tt = (uint32_t)t & ~(uint32_t)mm;   // literal tokens of the group
                 uint32_t n[4], v[4];
