@@ -97,6 +97,7 @@ __device__ __forceinline__ void publish_size(const EarlySize &es, uint32_t end_b
 struct ZOut {                // replicated uniformly in every lane's registers
     uint32_t bitpos;         // absolute bit position in the record slot (slot byte 0 = bit 0)
     uint32_t flushed;        // 32-bit words already copied to HBM; obuf[0] holds word `flushed`
+    uint32_t carry = 0;      // MODE 2 only: the partial word obuf[0] must hold when a block starts writing (see deflate_block)
 };
 
 __device__ __forceinline__ void put_bits(uint32_t *obuf, const ZOut &z, uint32_t pos, uint32_t v, uint32_t nb) {
@@ -421,19 +422,22 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
 
 // Encode one DEFLATE block of `len` bytes at LDS `buf` into the LDS bit buffer `obuf`.
 // All NT lanes call with uniform arguments.  adA/adB: running Adler-32 halves (uniform).
-// FUSED: single-block stream whose build scratch B overlays obuf; obuf is zeroed and the zlib header
-// written here once B is dead (caller passes z.bitpos = 80, z.flushed = 0, obuf_words = size to zero).
-template <bool FUSED, typename M = uint64_t>
+// MODE 0: B is separate LDS.  MODE 1 (fused): single-block stream whose build scratch B overlays obuf; obuf is zeroed and the
+// zlib header written here once B is dead (caller passes z.bitpos = 80, z.flushed = 0, obuf_words = size to zero).
+// MODE 2 (staged, multi-block): B overlays obuf as well; between blocks the only live word of obuf is the partial word
+// obuf[0], which travels in z.carry and is put back after the zeroing.
+template <int MODE, typename M = uint64_t>
 __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words,
                                               const uint8_t *__restrict__ buf, int len, bool final, ZOut &z, uint32_t &adA,
                                               uint32_t &adB, uint32_t dbg = 0, EarlySize es = EarlySize{nullptr, 0}) {
     using MO = MaskOps<M>;
     const int tid = threadIdx.x;
+    constexpr bool FUSED = MODE == 1;
     if (len == 0) {
-        if (FUSED) {
+        if (MODE != 0) {
             for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
             __syncthreads();
-            if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);
+            if (tid == 0) { if (FUSED) put_bits(obuf, z, 64, 0x9c78u, 16); else obuf[0] = z.carry; }
         }   // empty stream: fixed block holding only end-of-block
         if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 10);
         z.bitpos += 10;
@@ -656,10 +660,13 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     build_lengths(S, B, &B.sort, S.freq, NLIT, 15, S.lens, S.blcount, S.icount);
     if (dbg == 3 || dbg == 31 || dbg == 32) { z.bitpos += S.lens[tid] + B.lf[tid] + B.nf[tid]; return; }
     PROF_RESET
-    if (FUSED) {   // B is dead from here on: its storage becomes the bit buffer
+    if (MODE != 0) {   // B is dead from here on: its storage becomes the bit buffer
         for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
         __syncthreads();
-        if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);   // CMF/FLG 78 9c (deflate, 32K window, default level)
+        if (tid == 0) {
+            if (FUSED) put_bits(obuf, z, 64, 0x9c78u, 16);   // CMF/FLG 78 9c (deflate, 32K window, default level)
+            else obuf[0] = z.carry;                          // the stream's pending partial word
+        }
     }
     // ---- codes, code-length header and block costs: three independent jobs on different waves, wave-scope
     // syncs only, ONE workgroup barrier at the end.  Wave 0: run-length coding of the code lengths, the 19-symbol
@@ -988,7 +995,7 @@ __device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *ob
     z.bitpos = 80;   // 64 bits of size prefix + 16 bits of zlib header, both written later
     z.flushed = 0;
     uint32_t adA = 1, adB = 0;
-    deflate_block<true, M>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es);
+    deflate_block<1, M>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es);
     if (dbg) return 16;
     z.bitpos = (z.bitpos + 7) & ~7u;
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);

@@ -92,6 +92,42 @@ __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, 
     return d.hdr_len + 8 + sig_bytes + d.aux_len;
 }
 
+// The same payload written to HBM (staged path, record compression "none").  The svb-zd bytes of a tile are assembled in
+// LDS and leave as aligned dwords: byte-granular stores straight to HBM cost 2.5x the time of the fused kernel's svb stage.
+__device__ __forceinline__ uint32_t build_payload_hbm(const s5gpu_encode_args_t &a, const s5gpu_read_desc_t &d, uint8_t *pay,
+                                                      uint32_t *ws, uint32_t *tile_keys, uint32_t *tile_data) {
+    const int tid = threadIdx.x;
+    const uint32_t n = d.n_samples;
+    if (a.sig_method != S5GPU_SIG_SVB_ZD) return build_payload(a, d, pay, OVF - 1, ws);
+    const uint32_t nk = (n + 3) >> 2;
+    const uint8_t *hdr = a.hdr + d.hdr_off;
+    for (uint32_t i = tid; i < d.hdr_len; i += NT) pay[i] = hdr[i];
+    uint8_t *lenp = pay + d.hdr_len;
+    uint8_t *sigp = lenp + 8;
+    const int16_t *sig = a.sig + d.sig_off;
+    uint8_t *keys = sigp + 4;
+    uint8_t *data = keys + nk;
+    uint32_t total = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) {
+        const uint32_t t = svb_encode_tile(sig, n, t0, reinterpret_cast<uint8_t *>(tile_keys), reinterpret_cast<uint8_t *>(tile_data), ws, OVF - 1);
+        __syncthreads();
+        const uint32_t tk = (min(n - t0, (uint32_t)SVB_TILE) + 3) >> 2;
+        copy_record_out(tile_keys, tk, keys + (t0 >> 2));
+        copy_record_out(tile_data, t, data + total);
+        total += t;
+        __syncthreads();
+    }
+    const uint64_t L = 4ull + nk + total;
+    if (tid < 4) sigp[tid] = (uint8_t)(n >> (8 * tid));
+    if (tid < 8) lenp[tid] = (uint8_t)(L >> (8 * tid));
+    if (d.aux_len) {
+        const uint8_t *aux = a.aux + d.aux_off;
+        uint8_t *ap = sigp + (uint32_t)L;
+        for (uint32_t i = tid; i < d.aux_len; i += NT) ap[i] = aux[i];
+    }
+    return d.hdr_len + 8 + (uint32_t)L + d.aux_len;
+}
+
 // K1+K5+K3+K6 fused: svb-zd -> pack -> one DEFLATE block -> zlib frame.  One read per workgroup, every
 // intermediate in LDS.  A read whose payload does not fit the LDS budget (p.pay_cap: long read, or an
 // unusually incompressible signal) is appended to the overflow list and redone by the staged kernels.
@@ -191,12 +227,14 @@ __device__ __forceinline__ uint32_t park_offset(const s5gpu_read_desc_t &d, int 
 // mode 2: like 0 but only the reads on the overflow list.
 __global__ __launch_bounds__(NT) void k_pack(EncParams p, int mode) {
     __shared__ uint32_t ws[16];
+    __shared__ uint32_t tile_keys[SVB_TILE / 16 + 4];       // one tile's key bytes (4096 / 4) ...
+    __shared__ uint32_t tile_data[3 * SVB_TILE / 4 + 4];    // ... and data bytes (at most 3 per int16 sample), + the copy's look-ahead word
     const uint32_t count = mode == 2 ? p.a.ovf[0] : p.a.n_reads;
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         const uint32_t r = mode == 2 ? p.a.ovf[1 + it] : it;
         const s5gpu_read_desc_t d = p.a.desc[r];
         uint8_t *dst = p.a.slots + d.out_off + (mode == 1 ? 8u : park_offset(d, p.a.sig_method));
-        const uint32_t plen = build_payload(p.a, d, dst, OVF - 1, ws);
+        const uint32_t plen = build_payload_hbm(p.a, d, dst, ws, tile_keys, tile_data);
         if (threadIdx.x == 0) {
             if (mode == 1) {
                 *reinterpret_cast<uint64_t *>(p.a.slots + d.out_off) = plen;
@@ -212,9 +250,9 @@ __global__ __launch_bounds__(NT) void k_pack(EncParams p, int mode) {
 // Staged path, step 2: DEFLATE a parked payload, 16 KiB block at a time through LDS.
 __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list) {
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
-    BuildScratch &B = *reinterpret_cast<BuildScratch *>(smem + S_BYTES);
-    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES + B_BYTES);
-    uint8_t *stage = smem + S_BYTES + B_BYTES + 4u * p.obuf_words;
+    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
+    BuildScratch &B = *reinterpret_cast<BuildScratch *>(obuf);   // dead whenever the bit buffer is live (deflate_block MODE 2)
+    uint8_t *stage = smem + S_BYTES + 4u * p.obuf_words;
     const int tid = threadIdx.x;
     const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
@@ -224,13 +262,10 @@ __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list
         const uint8_t *src = out + park_offset(d, p.a.sig_method);
         const uint32_t plen = p.a.out_len[r];
         __syncthreads();
-        for (uint32_t i = tid; i < p.obuf_words; i += NT) obuf[i] = 0;
-        __syncthreads();
         ZOut z;
-        z.bitpos = 64;
-        z.flushed = 0;
-        if (tid == 0) put_bits(obuf, z, 64, 0x9c78u, 16);
-        z.bitpos = 80;
+        z.bitpos = 80;        // u64 size prefix (words 0, 1: written last) + CMF/FLG 78 9c
+        z.flushed = 2;        // obuf[0] = stream word 2
+        z.carry = 0x9c78u;
         uint32_t adA = 1, adB = 0, done = 0;
         uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
         do {
@@ -242,9 +277,13 @@ __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list
                 for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
             }
             __syncthreads();
-            deflate_block<false, uint64_t>(S, B, obuf, 0, stage, (int)blen, final, z, adA, adB);
+            deflate_block<2, uint64_t>(S, B, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
             done += blen;
-            if (!final) flush_words(obuf, out32, z, false);
+            if (!final) {
+                flush_words(obuf, out32, z, false);
+                z.carry = obuf[0];      // uniform: every lane reads the same word (flush_words ends on a barrier)
+                __syncthreads();        // ... before the next block's scratch overwrites it
+            }
         } while (done < plen);
         z.bitpos = (z.bitpos + 7) & ~7u;
         if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
@@ -654,7 +693,7 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     const bool all_staged = a->sig_method == S5GPU_SIG_SVB_ZD ? (uint64_t)a->max_payload * 100 / 325 > 4ull * DEFL_BLK
                                                               : a->max_payload > 4u * DEFL_BLK;
     const uint32_t st_obuf = (DEFL_BLK + 64) / 4;
-    const size_t st_lds = S_BYTES + B_BYTES + 4ull * st_obuf + DEFL_BLK;
+    const size_t st_lds = S_BYTES + 4ull * st_obuf + DEFL_BLK;   // the build scratch overlays the bit buffer
     if (!all_staged) {
         HIP_TRY(hipMemsetAsync(a->ovf, 0, 4, st));
         p.pay_cap = cap;
@@ -729,7 +768,7 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
     p.dbg = 0;
     p.obuf_words = (DEFL_BLK + 64) / 4;
     p.pay_cap = DEFL_BLK;
-    const size_t lds = S_BYTES + B_BYTES + 4ull * p.obuf_words + DEFL_BLK;
+    const size_t lds = S_BYTES + 4ull * p.obuf_words + DEFL_BLK;
     hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
