@@ -704,7 +704,7 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         else hipLaunchKernelGGL(k_encode_fused<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p);
         // overflow reads (usually none: the two launches below then exit at once)
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
-        const uint32_t g = a->n_reads < 1024 ? a->n_reads : 1024;
+        const uint32_t g = a->n_reads < 8192 ? a->n_reads : 8192;   // persistent loops over the list; enough workgroups for the CUs to balance
         hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2);
         hipLaunchKernelGGL(k_deflate_staged, dim3(g), dim3(NT), st_lds, st, p, 1);
     } else {
