@@ -326,3 +326,49 @@ def test_decode_stored_and_fixed_blocks(press, inflate_kernel):
     payload2, _ = _oracle_payload(hdr, sig2, b"", 0)
     g = press.decode_records([zlib.compress(payload2, 9)], 1, 0)[0]
     assert g["status"] == 0 and np.array_equal(g["signal"], sig2)
+
+
+def test_decode_fuzzed_streams_terminate_and_never_pass_wrong_data(press, inflate_kernel):
+    """2000 damaged variants of valid records (bit flips, truncations, garbage tails, zero fill) through both inflate
+    kernels: the call returns (no hang — the whole test is bounded by the suite's timeout), every record gets a status, and
+    a record that still reports status 0 carries exactly the original signal (the Adler-32 + svb checks hold the line)."""
+    rng = np.random.default_rng(2024)
+    n0 = 40
+    sig = ob.synth_reads(0x5105, 100, n0, 4000)
+    hdrs = [_hdr(press, 100 + i) for i in range(n0)]
+    good = [r[8:] for r in press.encode_records(list(sig), hdrs)]
+    # also zlib-written streams (matches with real distances) of the same payloads
+    for i in range(8):
+        payload, _ = _oracle_payload(hdrs[i], sig[i], b"", 1)
+        good.append(zlib.compress(payload, 6))
+    src_of = []
+    bad = []
+    for v in range(2000):
+        k = int(rng.integers(0, len(good)))
+        b = bytearray(good[k])
+        mode = v % 5
+        if mode == 0:      # one bit flip somewhere
+            p = int(rng.integers(0, len(b)))
+            b[p] ^= 1 << int(rng.integers(0, 8))
+        elif mode == 1:    # burst of random bytes
+            p = int(rng.integers(0, len(b) - 8))
+            b[p:p + 8] = rng.integers(0, 256, 8, dtype=np.uint8).tobytes()
+        elif mode == 2:    # truncation
+            b = b[: int(rng.integers(1, len(b)))]
+        elif mode == 3:    # zero fill from a random point
+            p = int(rng.integers(2, len(b)))
+            b[p:] = bytes(len(b) - p)
+        else:              # garbage appended after a cut
+            p = int(rng.integers(2, len(b)))
+            b = b[:p] + rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8).tobytes()
+        bad.append(bytes(b))
+        src_of.append(k % n0 if k < n0 else k - n0)
+    got = press.decode_records(bad, raise_on_error=False)
+    assert len(got) == len(bad)
+    n_ok = 0
+    for g, k in zip(got, src_of):
+        assert 0 <= g["status"] <= 7
+        if g["status"] == 0:
+            n_ok += 1
+            assert np.array_equal(g["signal"], sig[k]), "a damaged record decoded to different data with status 0"
+    assert n_ok < len(bad) // 10          # almost every damage is caught (a flip in the unused tail of a byte may survive)
