@@ -17,7 +17,8 @@
 static size_t prim_len(const s5o_rec_t *r) { return 2 + (size_t)r->read_id_len + 4 + 4 * 8 + 8; }
 
 size_t s5o_payload_bound(const s5o_rec_t *r, int sig_method) {
-    size_t sig = sig_method == S5O_SIG_SVB_ZD ? s5o_svbzd_bound(r->len_raw_signal) : 2 * (size_t)r->len_raw_signal;
+    size_t sig = sig_method == S5O_SIG_SVB_ZD ? s5o_svbzd_bound(r->len_raw_signal)
+               : sig_method == S5O_SIG_EX_ZD ? s5o_exzd_bound(r->len_raw_signal) : 2 * (size_t)r->len_raw_signal;
     return prim_len(r) + sig + r->aux_len;
 }
 
@@ -33,12 +34,14 @@ size_t s5o_rec_pack(const s5o_rec_t *r, int sig_method, uint8_t *out) {
     uint64_t L;
     if (sig_method == S5O_SIG_SVB_ZD) {
         L = s5o_svbzd_encode(r->raw_signal, r->len_raw_signal, p + 8);
+    } else if (sig_method == S5O_SIG_EX_ZD) {
+        L = s5o_exzd_encode(r->raw_signal, r->len_raw_signal, p + 8);
     } else {
         L = r->len_raw_signal;
         memcpy(p + 8, r->raw_signal, 2 * (size_t)L);
     }
     memcpy(p, &L, 8); p += 8;
-    p += sig_method == S5O_SIG_SVB_ZD ? (size_t)L : 2 * (size_t)L;
+    p += sig_method == S5O_SIG_NONE ? 2 * (size_t)L : (size_t)L;
     if (r->aux_len) { memcpy(p, r->aux, r->aux_len); p += r->aux_len; }
     return (size_t)(p - out);
 }
@@ -79,6 +82,13 @@ int s5o_rec_parse(const uint8_t *payload, size_t len, int sig_method, s5o_rec_t 
         uint64_t n;
         int rc = s5o_svbzd_decode(p, (size_t)L, sig_out, &n);
         if (rc != 0) return rc - 10;
+        r->len_raw_signal = n;
+        p += L;
+    } else if (sig_method == S5O_SIG_EX_ZD) {
+        if ((uint64_t)(end - p) < L) return -2;
+        uint64_t n;
+        int rc = s5o_exzd_decode(p, (size_t)L, sig_out, &n);
+        if (rc != 0) return rc - 20;
         r->len_raw_signal = n;
         p += L;
     } else {

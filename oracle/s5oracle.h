@@ -30,7 +30,7 @@ extern "C" {
 
 /* on-disk method codes (names from src/misc.c:253-263) */
 enum { S5O_REC_NONE = 0, S5O_REC_ZLIB = 1 };
-enum { S5O_SIG_NONE = 0, S5O_SIG_SVB_ZD = 1 };
+enum { S5O_SIG_NONE = 0, S5O_SIG_SVB_ZD = 1, S5O_SIG_EX_ZD = 2 };
 
 /* ---- a5 / a8: svb-zd signal codec (StreamVByte 32-bit, 2-bit keys, zigzag delta) ---- */
 size_t s5o_svbzd_bound(uint64_t n);                       /* 4 + ceil(n/4) + 4n            */
@@ -89,6 +89,11 @@ size_t s5o_signal_to_text(const int16_t *sig, uint64_t n, char *out);           
 int64_t s5o_text_to_signal(const char *txt, size_t len, int16_t *out, uint64_t cap);       /* -1 on malformed text */
 size_t s5o_ascii_line_to_payload(const char *line, size_t len, const uint8_t *types, unsigned n_aux, uint8_t *out);
 size_t s5o_payload_to_ascii_line(const uint8_t *pay, size_t len, const uint8_t *types, unsigned n_aux, char *out);
+
+/* ---- §8f row 4: ex-zd signal codec (exzd.c; layout pinned on the reference's ex-zd fixtures) ---- */
+size_t s5o_exzd_bound(uint64_t n);
+size_t s5o_exzd_encode(const int16_t *x, uint64_t n, uint8_t *out);                        /* returns bytes, 0 on allocation failure */
+int s5o_exzd_decode(const uint8_t *in, size_t len, int16_t *out, uint64_t *n_out);          /* out = NULL: query n */
 
 #ifdef __cplusplus
 }

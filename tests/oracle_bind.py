@@ -71,6 +71,12 @@ def lib():
     L.s5o_encode_batch_mt.restype = C.c_uint64
     L.s5o_encode_batch_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.s5o_exzd_bound.restype = C.c_size_t
+    L.s5o_exzd_bound.argtypes = [C.c_uint64]
+    L.s5o_exzd_encode.restype = C.c_size_t
+    L.s5o_exzd_encode.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.s5o_exzd_decode.restype = C.c_int
+    L.s5o_exzd_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]
     L.s5o_aux_types.restype = C.c_int
     L.s5o_aux_types.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint]
     L.s5o_signal_to_text.restype = C.c_size_t
@@ -250,3 +256,25 @@ def payload_to_line(payload, types=b""):
     out = C.create_string_buffer(8 * len(payload) + 512)
     n = lib().s5o_payload_to_ascii_line(payload, len(payload), types, len(types), out)
     return out.raw[:n] if n else None
+
+
+# ---- §8f row 4: ex-zd ----
+SIG_EX_ZD = 2
+
+
+def exzd_encode(x):
+    x = np.ascontiguousarray(x, dtype=np.int16)
+    out = np.empty(lib().s5o_exzd_bound(x.size), dtype=np.uint8)
+    n = lib().s5o_exzd_encode(_ptr(x), x.size, _ptr(out))
+    return out[:n].tobytes()
+
+
+def exzd_decode(blob):
+    b = np.frombuffer(blob, dtype=np.uint8)
+    n = C.c_uint64(0)
+    if lib().s5o_exzd_decode(_ptr(b), len(b), None, C.byref(n)) != 0:
+        return None
+    out = np.empty(n.value, dtype=np.int16)
+    if lib().s5o_exzd_decode(_ptr(b), len(b), _ptr(out), C.byref(n)) != 0:
+        return None
+    return out

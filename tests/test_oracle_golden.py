@@ -262,3 +262,64 @@ def test_ascii_missing_values_and_types():
     assert ob.payload_to_line(pay, types) == full
     assert ob.line_to_payload(b"r1\t3\t8192\t-4\t1467.61\t4000\t3\t5,-6\n", b"") is None          # count mismatch
     assert ob.line_to_payload(b"r1\t3\t8192\t-4\t1467.61\t4000\t2\t5,-6\textra\n", b"") is None   # undeclared column
+
+
+# ---- §8f row 4: ex-zd signal codec, pinned on the reference's ex-zd fixtures ----
+EX_ZD_FIXTURES = ["exp_1_lossless_zlib_ex_zd.blow5",                  # 59676 samples, 656 exceptions, q = 0
+                  "PRPN119035_read1_b2.blow5",                         # `degrade -b 2`: q = 2
+                  "na12878_prom_merged_r9.4.1_chr22_read1_b2.blow5",
+                  "gridr10dna_b3.blow5"]                               # 8 reads, q = 3, no exceptions
+
+
+def _exzd_blobs(name):
+    b5 = Blow5(golden(name))
+    assert b5.sig_method == 2 and b5.rec_method == 1
+    out = []
+    for r in b5.records:
+        p = zlib.decompress(r)
+        idl = struct.unpack_from("<H", p, 0)[0]
+        at = 2 + idl + 4 + 32
+        (L,) = struct.unpack_from("<Q", p, at)
+        out.append((p, p[at + 8: at + 8 + L]))
+    return out
+
+
+@pytest.mark.parametrize("name", EX_ZD_FIXTURES)
+def test_exzd_decode_then_encode_reproduces_every_fixture_blob(name):
+    for payload, blob in _exzd_blobs(name):
+        sig = ob.exzd_decode(blob)
+        assert sig is not None and len(sig) == struct.unpack_from("<Q", blob, 1)[0]
+        assert ob.exzd_encode(sig) == blob                     # bit for bit, header fields and both exception sections included
+        rec = ob.rec_parse(payload, ob.SIG_EX_ZD)              # and through the record layer
+        assert np.array_equal(rec["signal"], sig)
+        r, keep = ob.make_rec(rec["read_id"], rec["read_group"], rec["digitisation"], rec["offset"], rec["range"], rec["sampling_rate"], sig, rec["aux"])
+        assert ob.rec_pack(r, ob.SIG_EX_ZD) == payload
+
+
+def test_exzd_lossless_fixture_equals_the_ascii_twin():
+    ascii_sig = read_slow5_ascii(golden("exp_1_lossless.slow5"))[0]["signal"]
+    (payload, blob), = _exzd_blobs("exp_1_lossless_zlib_ex_zd.blow5")
+    assert np.array_equal(ob.exzd_decode(blob), ascii_sig)
+    assert blob[9] == 0 and struct.unpack_from("<I", blob, 12)[0] == 656
+
+
+def test_exzd_degraded_fixture_is_the_source_with_low_bits_rounded():
+    """exp/degrade/*_b2: q = 2 in the blob, every decoded sample a multiple of 4"""
+    for name in ("PRPN119035_read1_b2.blow5", "na12878_prom_merged_r9.4.1_chr22_read1_b2.blow5"):
+        for payload, blob in _exzd_blobs(name):
+            assert blob[9] == 2
+            assert (ob.exzd_decode(blob) & 3 == 0).all()
+
+
+def test_exzd_round_trip_edge_cases():
+    rng = np.random.default_rng(8)
+    cases = [np.zeros(0, np.int16), np.array([5], np.int16), np.array([-32768], np.int16), np.zeros(100, np.int16),
+             np.array([32767, -32768] * 50, np.int16), (rng.integers(-32768, 32768, 5000)).astype(np.int16),
+             (500 + rng.integers(-40, 40, 5000)).astype(np.int16), (8 * rng.integers(-4000, 4000, 3000)).astype(np.int16),
+             np.full(1000, -32768, np.int16), np.arange(-300, 300, dtype=np.int16)]
+    for x in cases:
+        blob = ob.exzd_encode(x)
+        y = ob.exzd_decode(blob)
+        assert y is not None and np.array_equal(x, y), x[:8]
+    for bad in (b"", b"\x01" + bytes(9), ob.exzd_encode(cases[5])[:-1], ob.exzd_encode(cases[5]) + b"\x00"):
+        assert ob.exzd_decode(bad) is None
