@@ -13,7 +13,7 @@ from . import build as _build
 _LIB = None
 
 REC_NONE, REC_ZLIB = 0, 1
-SIG_NONE, SIG_SVB_ZD = 0, 1
+SIG_NONE, SIG_SVB_ZD, SIG_EX_ZD = 0, 1, 2
 
 # numpy mirrors of the C structs (same field order / padding as include/slow5gpu.h)
 READ_DESC = np.dtype([("sig_off", "<u8"), ("hdr_off", "<u8"), ("aux_off", "<u8"), ("out_off", "<u8"),

@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import check
 
 REC_NONE, REC_ZLIB = 0, 1
-SIG_NONE, SIG_SVB_ZD = 0, 1
+SIG_NONE, SIG_SVB_ZD, SIG_EX_ZD = 0, 1, 2
 
 
 def aux_types(types_line):

@@ -12,6 +12,7 @@
 #include "inflate_dev.h"
 #include "inflate_simt_dev.h"
 #include "svb_dev.h"
+#include "exzd_dev.h"
 
 using namespace s5;
 
@@ -41,7 +42,9 @@ struct EncParams {
 
 __device__ __forceinline__ uint32_t payload_bound_dev(const s5gpu_read_desc_t &d, int sig_method) {
     const uint32_t n = d.n_samples;
-    return d.hdr_len + 8 + (sig_method == S5GPU_SIG_SVB_ZD ? 4 + ((n + 3) >> 2) + 3 * n : 2 * n) + d.aux_len;
+    const uint32_t sig = sig_method == S5GPU_SIG_SVB_ZD ? 4 + ((n + 3) >> 2) + 3 * n
+                       : sig_method == S5GPU_SIG_EX_ZD ? 24 + 2 * (((n + 3) >> 2) + 4 * n) + n : 2 * n;   // ex-zd: oracle/exzd.c s5o_exzd_bound
+    return d.hdr_len + 8 + sig + d.aux_len;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -98,6 +101,19 @@ __device__ __forceinline__ uint32_t build_payload_hbm(const s5gpu_encode_args_t 
                                                       uint32_t *ws, uint32_t *tile_keys, uint32_t *tile_data) {
     const int tid = threadIdx.x;
     const uint32_t n = d.n_samples;
+    if (a.sig_method == S5GPU_SIG_EX_ZD) {
+        const uint8_t *hdr = a.hdr + d.hdr_off;
+        for (uint32_t i = tid; i < d.hdr_len; i += NT) pay[i] = hdr[i];
+        uint8_t *lenp = pay + d.hdr_len;
+        const uint32_t blen = exzd_encode_wg(a.sig + d.sig_off, n, lenp + 8, ws, tile_keys /* 8 words of reduction scratch */);
+        if (tid < 8) lenp[tid] = tid < 4 ? (uint8_t)(blen >> (8 * tid)) : 0;
+        if (d.aux_len) {
+            const uint8_t *aux = a.aux + d.aux_off;
+            uint8_t *ap = lenp + 8 + blen;
+            for (uint32_t i = tid; i < d.aux_len; i += NT) ap[i] = aux[i];
+        }
+        return d.hdr_len + 8 + blen + d.aux_len;
+    }
     if (a.sig_method != S5GPU_SIG_SVB_ZD) return build_payload(a, d, pay, OVF - 1, ws);
     const uint32_t nk = (n + 3) >> 2;
     const uint8_t *hdr = a.hdr + d.hdr_off;
@@ -428,6 +444,11 @@ __global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
         if (err) s_err = 1;
         __syncthreads();
         if (s_err || 4 + nk + total != L) { if (tid == 0) f.status = 7; return; }
+    } else if (a.sig_method == S5GPU_SIG_EX_ZD) {
+        if (L > avail) { if (tid == 0) f.status = 7; return; }
+        sig_bytes = (uint32_t)L;
+        const int st = exzd_decode_wg(sigp, L, out, d.sig_cap, &n, *reinterpret_cast<ExzdScratch *>(smem), ws);
+        if (st) { if (tid == 0) { f.status = st; if (st == 6) f.n_samples = n; } return; }
     } else {
         if (L > avail / 2) { if (tid == 0) f.status = 7; return; }
         n = (uint32_t)L;
@@ -631,7 +652,8 @@ extern "C" int s5gpu_prof_read(unsigned long long *out, int reset) {
 // launchers (C ABI)
 // ------------------------------------------------------------------------------------------------
 extern "C" uint64_t s5gpu_payload_bound(uint32_t n, uint32_t hdr_len, uint32_t aux_len, int sig_method) {
-    const uint64_t sig = sig_method == S5GPU_SIG_SVB_ZD ? 4ull + (n + 3ull) / 4 + 3ull * n : 2ull * n;
+    const uint64_t sig = sig_method == S5GPU_SIG_SVB_ZD ? 4ull + (n + 3ull) / 4 + 3ull * n
+                       : sig_method == S5GPU_SIG_EX_ZD ? 24ull + 2 * ((n + 3ull) / 4 + 4ull * n) + n : 2ull * n;
     return hdr_len + 8ull + sig + aux_len;
 }
 extern "C" uint64_t s5gpu_slot_bound(uint32_t n, uint32_t hdr_len, uint32_t aux_len, int rec_method, int sig_method) {
@@ -644,7 +666,7 @@ extern "C" uint64_t s5gpu_slot_bound(uint32_t n, uint32_t hdr_len, uint32_t aux_
 static int enc_check(const s5gpu_encode_args_t *a) {
     if (!a || (a->n_reads && (!a->desc || !a->sig || !a->hdr || !a->slots || !a->out_len))) return S5GPU_ERR_ARG;
     if (a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB) return S5GPU_ERR_ARG;
-    if (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD) return S5GPU_ERR_ARG;
+    if (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD && a->sig_method != S5GPU_SIG_EX_ZD) return S5GPU_ERR_ARG;
     return S5GPU_OK;
 }
 
@@ -690,7 +712,8 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     if (cap > (uint32_t)DEFL_BLK) cap = DEFL_BLK;
     cap = (cap + 15u) & ~15u;
     // every read certainly longer than the fused budget?  (min payload ~ 1.25 B/sample of a 3.25 B/sample bound)
-    const bool all_staged = a->sig_method == S5GPU_SIG_SVB_ZD ? (uint64_t)a->max_payload * 100 / 325 > 4ull * DEFL_BLK
+    const bool all_staged = a->sig_method == S5GPU_SIG_EX_ZD ? true   // ex-zd is built by the staged kernels only
+                          : a->sig_method == S5GPU_SIG_SVB_ZD ? (uint64_t)a->max_payload * 100 / 325 > 4ull * DEFL_BLK
                                                               : a->max_payload > 4u * DEFL_BLK;
     const uint32_t st_obuf = (DEFL_BLK + 64) / 4;
     const size_t st_lds = S_BYTES + 4ull * st_obuf + DEFL_BLK;   // the build scratch overlays the bit buffer
@@ -838,7 +861,7 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         return S5GPU_ERR_ARG;
     }
     if ((a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB) ||
-        (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD)) {
+        (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD && a->sig_method != S5GPU_SIG_EX_ZD)) {
         s5gpu_set_error("s5gpu_decode_dev: unsupported method");
         return S5GPU_ERR_ARG;
     }
@@ -846,7 +869,8 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     int rc = launch_inflate(a, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_unpack, dim3(a->n_recs), dim3(NT), 0, st, *a);
+    // the ex-zd decoder keeps one chunk of exceptions and a flag map in (dynamic) LDS; the other signal formats need none
+    hipLaunchKernelGGL(k_unpack, dim3(a->n_recs), dim3(NT), a->sig_method == S5GPU_SIG_EX_ZD ? sizeof(ExzdScratch) : 0, st, *a);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }

@@ -18,11 +18,13 @@
 __thread int slow5_errno = 0;
 
 static int rec_code(enum slow5_press_method m) { return m == SLOW5_COMPRESS_NONE ? S5GPU_REC_NONE : m == SLOW5_COMPRESS_ZLIB ? S5GPU_REC_ZLIB : -1; }
-static int sig_code(enum slow5_press_method m) { return m == SLOW5_COMPRESS_NONE ? S5GPU_SIG_NONE : m == SLOW5_COMPRESS_SVB_ZD ? S5GPU_SIG_SVB_ZD : -1; }
+static int sig_code(enum slow5_press_method m) {
+    return m == SLOW5_COMPRESS_NONE ? S5GPU_SIG_NONE : m == SLOW5_COMPRESS_SVB_ZD ? S5GPU_SIG_SVB_ZD : m == SLOW5_COMPRESS_EX_ZD ? S5GPU_SIG_EX_ZD : -1;
+}
 
 struct slow5_press *slow5_press_init(slow5_press_method_t method) {
     if (rec_code(method.record_method) < 0 || sig_code(method.signal_method) < 0) {
-        slow5_errno = SLOW5_ERR_PRESS;   /* zstd / ex-zd: SURVEY §8(f) row 4 */
+        slow5_errno = SLOW5_ERR_PRESS;   /* zstd: SURVEY §8(f) row 4 */
         return NULL;
     }
     struct slow5_press *p = (struct slow5_press *)calloc(1, sizeof *p);

@@ -13,7 +13,7 @@ import struct
 import numpy as np
 
 from . import _lib
-from ._lib import REC_NONE, REC_ZLIB, SIG_NONE, SIG_SVB_ZD, S5GpuError, check  # noqa: F401
+from ._lib import REC_NONE, REC_ZLIB, SIG_EX_ZD, SIG_NONE, SIG_SVB_ZD, S5GpuError, check  # noqa: F401
 
 
 def pack_hdr(read_id, read_group, digitisation, offset, rng, sampling_rate):
@@ -121,6 +121,8 @@ def make_read_desc(n_samples, hdr_len, aux_len, rec_method, sig_method):
     sig_pad = (n_samples + 7) // 8 * 8
     if sig_method == SIG_SVB_ZD:
         sigb = 4 + (n_samples + 3) // 4 + 3 * n_samples
+    elif sig_method == SIG_EX_ZD:
+        sigb = 24 + 2 * ((n_samples + 3) // 4 + 4 * n_samples) + n_samples
     else:
         sigb = 2 * n_samples
     pay = hdr_len + 8 + sigb + aux_len

@@ -77,8 +77,11 @@ def _malloc_copy(b):
 
 
 def test_press_init_rejects_unimplemented_codecs(L):
-    assert not L.slow5_press_init(PressMethod(3, 0))      # zstd
-    assert not L.slow5_press_init(PressMethod(1, 4))      # ex-zd
+    assert not L.slow5_press_init(PressMethod(3, 0))      # zstd record press: not built
+    assert not L.slow5_press_init(PressMethod(4, 0))      # ex-zd is a signal press, not a record press
+    q = L.slow5_press_init(PressMethod(ZLIB, 4))          # zlib + ex-zd: the `degrade` default
+    assert q and q.contents.signal_press.contents.method == 4
+    L.slow5_press_free(q)
     p = L.slow5_press_init(PressMethod(ZLIB, SVB))
     assert p and p.contents.record_press.contents.method == ZLIB and p.contents.signal_press.contents.method == SVB
     L.slow5_press_free(p)
