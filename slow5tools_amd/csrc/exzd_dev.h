@@ -89,14 +89,15 @@ __device__ __forceinline__ uint32_t exzd_encode_wg(const int16_t *__restrict__ x
         const int p0 = (int)(t0 + 16u * tid);
         const int local_last = exm ? p0 + 31 - __clz((int)exm) : -1;
         int lastp = max(block_excl_max(local_last, -1, ws), last_carry);
-        uint32_t m = exm;
-        while (m) {
-            const int k = __ffs((int)m) - 1;
-            m &= m - 1;
-            pos_bytes += svb32_len((uint32_t)(p0 + k - lastp - 1));
-            val_bytes += svb32_len(z[k] - 256u);
-            lastp = p0 + k;
-            nex++;
+        if (exm) {                                                 // static indices only: z[] must stay in registers
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if ((exm >> k) & 1u) {
+                    pos_bytes += svb32_len((uint32_t)(p0 + k - lastp - 1));
+                    val_bytes += svb32_len(z[k] - 256u);
+                    lastp = p0 + k;
+                    nex++;
+                }
         }
         // the tile's last exception position, for the next tile
         __syncthreads();
@@ -123,7 +124,9 @@ __device__ __forceinline__ uint32_t exzd_encode_wg(const int16_t *__restrict__ x
     uint8_t *pkeys = dst + o_pos, *pdata = pkeys + nk, *vkeys = dst + o_val, *vdata = vkeys + nk, *rest = dst + o_rest;
     if (nex) {
         for (uint32_t i = tid; i < nk; i += NT) { pkeys[i] = 0; vkeys[i] = 0; }
-        __threadfence();
+        // Workgroup scope is enough: the ORs below come from this workgroup and meet the zeroes in the same XCD's L2.  (An
+        // agent-scope fence writes the whole L2 back on this multi-XCD part: measured 12x slower for the kernel.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     __syncthreads();
     // pass 2b: write
@@ -138,16 +141,15 @@ __device__ __forceinline__ uint32_t exzd_encode_wg(const int16_t *__restrict__ x
         int lastp = max(block_excl_max(local_last, -1, ws), last_carry);
         // my section sizes first (same walk as pass 2a), then one scan per quantity
         uint32_t my_ex = (uint32_t)__popc(exm), my_pb = 0, my_vb = 0;
-        {
-            uint32_t m = exm;
+        if (exm) {
             int lp = lastp;
-            while (m) {
-                const int k = __ffs((int)m) - 1;
-                m &= m - 1;
-                my_pb += svb32_len((uint32_t)(p0 + k - lp - 1));
-                my_vb += svb32_len(z[k] - 256u);
-                lp = p0 + k;
-            }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if ((exm >> k) & 1u) {
+                    my_pb += svb32_len((uint32_t)(p0 + k - lp - 1));
+                    my_vb += svb32_len(z[k] - 256u);
+                    lp = p0 + k;
+                }
         }
         uint32_t tot_ex, tot_pb, tot_vb;
         uint32_t e = e_run + block_excl_add(my_ex, ws, tot_ex);
