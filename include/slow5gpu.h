@@ -30,7 +30,7 @@ extern "C" {
 /* on-disk method codes, identical to slow5lib's enum slow5_press_method values used by
  * /root/reference/src/misc.c:253-263 (SLOW5_COMPRESS_NONE/ZLIB, SLOW5_COMPRESS_NONE/SVB_ZD) */
 enum { S5GPU_REC_NONE = 0, S5GPU_REC_ZLIB = 1 };
-enum { S5GPU_SIG_NONE = 0, S5GPU_SIG_SVB_ZD = 1, S5GPU_SIG_EX_ZD = 2 };   /* ex-zd: always through the HBM-staged kernels */
+enum { S5GPU_SIG_NONE = 0, S5GPU_SIG_SVB_ZD = 1, S5GPU_SIG_EX_ZD = 2 };
 
 enum {
     S5GPU_OK = 0,

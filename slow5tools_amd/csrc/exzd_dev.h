@@ -42,7 +42,9 @@ __device__ __forceinline__ void put_le(uint8_t *p, uint32_t v, uint32_t nbytes) 
 
 // ---- encode: signal -> blob at dst (HBM, any alignment; dst - 3 .. dst + bound must be writable for the key ORs' aligned
 // words — the payload's 8-byte length field sits right in front).  Returns the blob length (uniform).
-__device__ __forceinline__ uint32_t exzd_encode_wg(const int16_t *__restrict__ x, uint32_t n, uint8_t *dst, uint32_t *ws, uint32_t *red) {
+// room: bytes dst can take; if the blob needs more, EXZD_ERR comes back (uniform) with at most the 10 header bytes written.
+__device__ __forceinline__ uint32_t exzd_encode_wg(const int16_t *__restrict__ x, uint32_t n, uint8_t *dst, uint32_t *ws, uint32_t *red,
+                                                   uint32_t room = 0xFFFFFFF0u) {
     const int tid = threadIdx.x;
     // pass 1: q
     uint32_t acc = 0;
@@ -55,6 +57,7 @@ __device__ __forceinline__ uint32_t exzd_encode_wg(const int16_t *__restrict__ x
     __syncthreads();
     acc = red[0];
     const uint32_t q = acc ? (uint32_t)__ffs((int)acc) - 1 : 0u;
+    if (room < 16) return EXZD_ERR;
     if (tid == 0) {
         dst[0] = 0;
         for (int b = 0; b < 8; b++) dst[1 + b] = b < 4 ? (uint8_t)(n >> (8 * b)) : 0;
@@ -115,6 +118,7 @@ __device__ __forceinline__ uint32_t exzd_encode_wg(const int16_t *__restrict__ x
     const uint32_t nk = (nex + 3) >> 2;
     const uint32_t pos_sec = nk + pos_bytes, val_sec = nk + val_bytes;
     const uint32_t o_pos = 20, o_val = o_pos + pos_sec + 4, o_rest = nex ? o_val + val_sec : 16;
+    if ((uint64_t)o_rest + (np - nex) + 4 > room) return EXZD_ERR;       // + 4: the key ORs touch whole aligned words
     if (tid == 0) {
         const int y0 = (int)x[0] >> q;
         put_le(dst + 10, zigzag32(y0) & 0xFFFFu, 2);

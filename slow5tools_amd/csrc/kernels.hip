@@ -53,9 +53,25 @@ __device__ __forceinline__ uint32_t payload_bound_dev(const s5gpu_read_desc_t &d
 // take; returns OVF (uniform, nothing useful written) if the payload would not fit.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, const s5gpu_read_desc_t &d,
-                                                  uint8_t *pay, uint32_t cap, uint32_t *ws) {
+                                                  uint8_t *pay, uint32_t cap, uint32_t *ws, uint32_t *red = nullptr) {
     const int tid = threadIdx.x;
     const uint32_t n = d.n_samples;
+    if (a.sig_method == S5GPU_SIG_EX_ZD) {   // red: 8 words of reduction scratch (required for this format)
+        const uint32_t fixed_x = d.hdr_len + 8 + d.aux_len;
+        if (fixed_x + 16 > cap) return OVF;
+        const uint8_t *hdr = a.hdr + d.hdr_off;
+        for (uint32_t i = tid; i < d.hdr_len; i += NT) pay[i] = hdr[i];
+        uint8_t *lenp = pay + d.hdr_len;
+        const uint32_t blen = exzd_encode_wg(a.sig + d.sig_off, n, lenp + 8, ws, red, cap - fixed_x);
+        if (blen == EXZD_ERR) return OVF;
+        if (tid < 8) lenp[tid] = tid < 4 ? (uint8_t)(blen >> (8 * tid)) : 0;
+        if (d.aux_len) {
+            const uint8_t *aux = a.aux + d.aux_off;
+            uint8_t *ap = lenp + 8 + blen;
+            for (uint32_t i = tid; i < d.aux_len; i += NT) ap[i] = aux[i];
+        }
+        return d.hdr_len + 8 + blen + d.aux_len;
+    }
     const bool svb = a.sig_method == S5GPU_SIG_SVB_ZD;
     const uint32_t nk = (n + 3) >> 2;
     const uint32_t fixed = d.hdr_len + 8 + (svb ? 4 + nk : 0) + d.aux_len;   // everything but the data bytes
@@ -101,19 +117,7 @@ __device__ __forceinline__ uint32_t build_payload_hbm(const s5gpu_encode_args_t 
                                                       uint32_t *ws, uint32_t *tile_keys, uint32_t *tile_data) {
     const int tid = threadIdx.x;
     const uint32_t n = d.n_samples;
-    if (a.sig_method == S5GPU_SIG_EX_ZD) {
-        const uint8_t *hdr = a.hdr + d.hdr_off;
-        for (uint32_t i = tid; i < d.hdr_len; i += NT) pay[i] = hdr[i];
-        uint8_t *lenp = pay + d.hdr_len;
-        const uint32_t blen = exzd_encode_wg(a.sig + d.sig_off, n, lenp + 8, ws, tile_keys /* 8 words of reduction scratch */);
-        if (tid < 8) lenp[tid] = tid < 4 ? (uint8_t)(blen >> (8 * tid)) : 0;
-        if (d.aux_len) {
-            const uint8_t *aux = a.aux + d.aux_off;
-            uint8_t *ap = lenp + 8 + blen;
-            for (uint32_t i = tid; i < d.aux_len; i += NT) ap[i] = aux[i];
-        }
-        return d.hdr_len + 8 + blen + d.aux_len;
-    }
+    if (a.sig_method == S5GPU_SIG_EX_ZD) return build_payload(a, d, pay, OVF - 1, ws, tile_keys /* 8 words of reduction scratch */);
     if (a.sig_method != S5GPU_SIG_SVB_ZD) return build_payload(a, d, pay, OVF - 1, ws);
     const uint32_t nk = (n + 3) >> 2;
     const uint8_t *hdr = a.hdr + d.hdr_off;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
     __syncthreads();
 #endif
     PROF_DECL
-    const uint32_t plen = build_payload(p.a, d, pay, p.pay_cap, S.ws);
+    const uint32_t plen = build_payload(p.a, d, pay, p.pay_cap, S.ws, S.red);
     if (plen == OVF) {
         if (threadIdx.x == 0) {
             const uint32_t at = atomicAdd(&p.a.ovf[0], 1u);
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(NT, 8) void k_encode_stream(EncParams p, StreamPara
     __syncthreads();
     const uint32_t r = s_r;
     const s5gpu_read_desc_t d = p.a.desc[r];
-    const uint32_t plen = build_payload(p.a, d, pay, p.pay_cap, S.ws);
+    const uint32_t plen = build_payload(p.a, d, pay, p.pay_cap, S.ws, S.red);
     uint32_t total = 0;
     if (plen == OVF) {
         if (threadIdx.x == 0) atomicAdd(&sp.ctl[0], 1u);   // size 0 keeps the chain alive; the stream is invalid
@@ -705,14 +709,15 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     // not fit is redone by the staged kernels (correct for any input, slower).
     uint32_t cap = a->lds_payload_cap;
     if (cap == 0) {
-        const bool svb = a->sig_method == S5GPU_SIG_SVB_ZD;
-        cap = svb ? (uint32_t)((uint64_t)a->max_payload * 155 / 325) + 128 : a->max_payload;
+        // the bounds assume the worst case (3 B/sample for svb-zd, 9.5 for ex-zd); real signals take ~1.27 / ~1.06
+        cap = a->sig_method == S5GPU_SIG_SVB_ZD ? (uint32_t)((uint64_t)a->max_payload * 155 / 325) + 128
+            : a->sig_method == S5GPU_SIG_EX_ZD ? (uint32_t)((uint64_t)a->max_payload * 130 / 950) + 256 : a->max_payload;
     }
     if (cap > a->max_payload) cap = a->max_payload;
     if (cap > (uint32_t)DEFL_BLK) cap = DEFL_BLK;
     cap = (cap + 15u) & ~15u;
     // every read certainly longer than the fused budget?  (min payload ~ 1.25 B/sample of a 3.25 B/sample bound)
-    const bool all_staged = a->sig_method == S5GPU_SIG_EX_ZD ? true   // ex-zd is built by the staged kernels only
+    const bool all_staged = a->sig_method == S5GPU_SIG_EX_ZD ? (uint64_t)a->max_payload * 100 / 950 > 4ull * DEFL_BLK
                           : a->sig_method == S5GPU_SIG_SVB_ZD ? (uint64_t)a->max_payload * 100 / 325 > 4ull * DEFL_BLK
                                                               : a->max_payload > 4u * DEFL_BLK;
     const uint32_t st_obuf = (DEFL_BLK + 64) / 4;
@@ -742,8 +747,9 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
 static uint32_t fused_cap(const s5gpu_encode_args_t *a) {
     uint32_t cap = a->lds_payload_cap;
     if (cap == 0) {
-        const bool svb = a->sig_method == S5GPU_SIG_SVB_ZD;
-        cap = svb ? (uint32_t)((uint64_t)a->max_payload * 155 / 325) + 128 : a->max_payload;
+        // the bounds assume the worst case (3 B/sample for svb-zd, 9.5 for ex-zd); real signals take ~1.27 / ~1.06
+        cap = a->sig_method == S5GPU_SIG_SVB_ZD ? (uint32_t)((uint64_t)a->max_payload * 155 / 325) + 128
+            : a->sig_method == S5GPU_SIG_EX_ZD ? (uint32_t)((uint64_t)a->max_payload * 130 / 950) + 256 : a->max_payload;
     }
     if (cap > a->max_payload) cap = a->max_payload;
     if (cap > (uint32_t)DEFL_BLK) cap = DEFL_BLK;
@@ -753,7 +759,7 @@ static uint32_t fused_cap(const s5gpu_encode_args_t *a) {
 extern "C" int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *a, uint8_t *stream_out, uint64_t *rec_off, uint64_t *state,
                                        uint32_t *ctl, void *stream_) {
     if (!a || !a->desc || !a->sig || !a->hdr || !a->out_len || !stream_out || !rec_off || !state || !ctl ||
-        a->rec_method != S5GPU_REC_ZLIB || (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD)) {
+        a->rec_method != S5GPU_REC_ZLIB || a->sig_method < S5GPU_SIG_NONE || a->sig_method > S5GPU_SIG_EX_ZD) {
         s5gpu_set_error("s5gpu_encode_stream_dev: bad arguments (zlib record press only)");
         return S5GPU_ERR_ARG;
     }
