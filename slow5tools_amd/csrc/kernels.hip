@@ -52,11 +52,14 @@ __device__ __forceinline__ uint32_t payload_bound_dev(const s5gpu_read_desc_t &d
 // dst may be LDS (fused kernel) or HBM (staged path / no record compression).  cap = bytes dst can
 // take; returns OVF (uniform, nothing useful written) if the payload would not fit.
 // ------------------------------------------------------------------------------------------------
+// EXZD is a compile-time switch: the ex-zd builder lives in its own kernel instantiations, so the svb-zd kernels the
+// headline runs on carry none of its code (1 % of their time when it was a run-time branch).
+template <bool EXZD = false>
 __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, const s5gpu_read_desc_t &d,
                                                   uint8_t *pay, uint32_t cap, uint32_t *ws, uint32_t *red = nullptr) {
     const int tid = threadIdx.x;
     const uint32_t n = d.n_samples;
-    if (a.sig_method == S5GPU_SIG_EX_ZD) {   // red: 8 words of reduction scratch (required for this format)
+    if constexpr (EXZD) {   // red: 8 words of reduction scratch
         const uint32_t fixed_x = d.hdr_len + 8 + d.aux_len;
         if (fixed_x + 16 > cap) return OVF;
         const uint8_t *hdr = a.hdr + d.hdr_off;
@@ -71,7 +74,7 @@ __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, 
             for (uint32_t i = tid; i < d.aux_len; i += NT) ap[i] = aux[i];
         }
         return d.hdr_len + 8 + blen + d.aux_len;
-    }
+    } else {
     const bool svb = a.sig_method == S5GPU_SIG_SVB_ZD;
     const uint32_t nk = (n + 3) >> 2;
     const uint32_t fixed = d.hdr_len + 8 + (svb ? 4 + nk : 0) + d.aux_len;   // everything but the data bytes
@@ -109,6 +112,7 @@ __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, 
         for (uint32_t i = tid; i < d.aux_len; i += NT) ap[i] = aux[i];
     }
     return d.hdr_len + 8 + sig_bytes + d.aux_len;
+    }
 }
 
 // The same payload written to HBM (staged path, record compression "none").  The svb-zd bytes of a tile are assembled in
@@ -117,7 +121,7 @@ __device__ __forceinline__ uint32_t build_payload_hbm(const s5gpu_encode_args_t 
                                                       uint32_t *ws, uint32_t *tile_keys, uint32_t *tile_data) {
     const int tid = threadIdx.x;
     const uint32_t n = d.n_samples;
-    if (a.sig_method == S5GPU_SIG_EX_ZD) return build_payload(a, d, pay, OVF - 1, ws, tile_keys /* 8 words of reduction scratch */);
+    if (a.sig_method == S5GPU_SIG_EX_ZD) return build_payload<true>(a, d, pay, OVF - 1, ws, tile_keys /* 8 words of reduction scratch */);
     if (a.sig_method != S5GPU_SIG_SVB_ZD) return build_payload(a, d, pay, OVF - 1, ws);
     const uint32_t nk = (n + 3) >> 2;
     const uint8_t *hdr = a.hdr + d.hdr_off;
@@ -151,7 +155,7 @@ __device__ __forceinline__ uint32_t build_payload_hbm(const s5gpu_encode_args_t 
 // K1+K5+K3+K6 fused: svb-zd -> pack -> one DEFLATE block -> zlib frame.  One read per workgroup, every
 // intermediate in LDS.  A read whose payload does not fit the LDS budget (p.pay_cap: long read, or an
 // unusually incompressible signal) is appended to the overflow list and redone by the staged kernels.
-template <typename M>
+template <typename M, bool EXZD = false>
 __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
     const uint32_t r = blockIdx.x;
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
     __syncthreads();
 #endif
     PROF_DECL
-    const uint32_t plen = build_payload(p.a, d, pay, p.pay_cap, S.ws, S.red);
+    const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
     if (plen == OVF) {
         if (threadIdx.x == 0) {
             const uint32_t at = atomicAdd(&p.a.ovf[0], 1u);
@@ -200,7 +204,7 @@ struct StreamParams {
     uint8_t *stream;
     uint64_t *rec_off;           // n_reads + 1
 };
-template <typename M>
+template <typename M, bool EXZD = false>
 __global__ __launch_bounds__(NT, 8) void k_encode_stream(EncParams p, StreamParams sp) {
     __shared__ uint32_t s_r;
     __shared__ uint64_t s_off;
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(NT, 8) void k_encode_stream(EncParams p, StreamPara
     __syncthreads();
     const uint32_t r = s_r;
     const s5gpu_read_desc_t d = p.a.desc[r];
-    const uint32_t plen = build_payload(p.a, d, pay, p.pay_cap, S.ws, S.red);
+    const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
     uint32_t total = 0;
     if (plen == OVF) {
         if (threadIdx.x == 0) atomicAdd(&sp.ctl[0], 1u);   // size 0 keeps the chain alive; the stream is invalid
@@ -681,6 +685,10 @@ static int set_lds_attrs() {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svbzd_encode), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     g_attr_done = true;
@@ -728,8 +736,9 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         p.obuf_words = (cap + 64 > B_BYTES ? cap + 64 : B_BYTES) / 4;
         const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
         // a lane owns ceil(len / 256) bytes: payloads up to 8 KiB need 32-bit position masks only
-        if (cap <= 8192) hipLaunchKernelGGL(k_encode_fused<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p);
-        else hipLaunchKernelGGL(k_encode_fused<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p);
+        const bool xz = a->sig_method == S5GPU_SIG_EX_ZD;
+        if (cap <= 8192) { if (xz) hipLaunchKernelGGL((k_encode_fused<uint32_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_encode_fused<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p); }
+        else { if (xz) hipLaunchKernelGGL((k_encode_fused<uint64_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_encode_fused<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p); }
         // overflow reads (usually none: the two launches below then exit at once)
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
         const uint32_t g = a->n_reads < 8192 ? a->n_reads : 8192;   // persistent loops over the list; enough workgroups for the CUs to balance
@@ -781,8 +790,9 @@ extern "C" int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *a, uint8_t *st
     sp.rec_off = rec_off;
     HIP_TRY(hipMemsetAsync(state, 0, 8ull * a->n_reads, st));
     HIP_TRY(hipMemsetAsync(ctl, 0, 16, st));
-    if (cap <= 8192) hipLaunchKernelGGL(k_encode_stream<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p, sp);
-    else hipLaunchKernelGGL(k_encode_stream<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p, sp);
+    const bool xz = a->sig_method == S5GPU_SIG_EX_ZD;
+    if (cap <= 8192) { if (xz) hipLaunchKernelGGL((k_encode_stream<uint32_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p, sp); else hipLaunchKernelGGL(k_encode_stream<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p, sp); }
+    else { if (xz) hipLaunchKernelGGL((k_encode_stream<uint64_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p, sp); else hipLaunchKernelGGL(k_encode_stream<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p, sp); }
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }
