@@ -51,7 +51,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.environ.get("S5GPU_LIB") or _build.LIB   # S5GPU_LIB: e.g. the -DS5_PROFILE build (tools/phase_profile.py)
+    path = os.environ.get("S5GPU_LIB") or _build.LIB   # S5GPU_LIB: an experimental build made by tools/variant.sh
     if not os.path.exists(path):
         _build.build()
     # One HIP runtime per process: the torch wheel carries its own libamdhip64 / libhsa-runtime64.  If libslow5gpu.so pulled in

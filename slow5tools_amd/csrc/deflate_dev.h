@@ -7,40 +7,20 @@
 //
 // Design (SURVEY.md §0 finding 6): on svb-zd payloads LZ77 buys < 1 %, run-length + dynamic Huffman
 // does the work.  Per block (<= 16 KiB of payload held in LDS), one workgroup of 256 lanes:
-//   A  tokenise: lane t owns K = ceil(len/256) contiguous bytes; run boundaries via a 64-bit break
-//      mask per lane + one prefix-max and one suffix-min workgroup scan; tokens = literal |
-//      (length 3..258, distance 1); LDS-atomic histogram of the 286 lit/len symbols; Adler-32 partials
-//   B  code construction: rank-sort of the symbol frequencies (all lanes), two-queue Huffman merge
-//      (one lane, LDS), leaf depths by parallel parent walks, length limiting, canonical codes via
-//      wave ballots; code-length alphabet the same way
-//   C  cost compare dynamic / fixed / stored; per-lane bit totals -> workgroup prefix scan of bit
-//      offsets -> each lane packs its tokens into a 64-bit accumulator and ORs 32-bit words into LDS
-// then coalesced word copy LDS -> HBM.  No MFMA: there is no contraction anywhere in this path.
+//   A  tokenise: lane t owns K = ceil(len/256) contiguous bytes and a break mask; the neighbouring breaks come from one
+//      ballot per wave; in-run positions are classified with mask arithmetic, only long runs reach per-segment code;
+//      tokens = literal | (length 3..258, distance 1); LDS-atomic histogram of the 286 lit/len symbols; Adler-32 partials
+//   B  code construction: counting sort of the symbol frequencies (all lanes), round-based Huffman merge in one wave
+//      (DPP / permlane butterflies), leaf depths by parallel parent walks, length limiting, canonical codes via wave
+//      ballots; the 19-symbol code-length code is picked from two static prefix codes by cost
+//   C  cost compare dynamic / fixed / stored; per-lane bit totals -> workgroup prefix scan of bit offsets -> each lane ORs
+//      its tokens into the LDS bit buffer, four byte positions (<= 60 bits) at a time
+// then coalesced word copy LDS -> HBM.  No MFMA: there is no contraction anywhere in this path.  DESIGN.md §4.1 has the
+// measurements behind each of these choices.
 #pragma once
 #include "dev_common.h"
 
 namespace s5 {
-
-// Optional per-phase cycle accounting (build with -DS5_PROFILE; never in the product library).
-#ifdef S5_PROFILE
-// lane 0 accumulates per-phase cycles in LDS (S.prof) and the kernel adds them to g_prof once at its end,
-// so the accounting itself stays out of the measured phases
-__device__ unsigned long long g_prof[32];
-#define PROF_DECL unsigned long long prof_t_ = clock64();
-#define PROF_MARK(k)                                                                  \
-    do {                                                                              \
-        if (threadIdx.x == 0) {                                                       \
-            const unsigned long long now_ = clock64();                                \
-            S.prof[k] += now_ - prof_t_;                                              \
-            prof_t_ = now_;                                                           \
-        }                                                                             \
-    } while (0)
-#define PROF_RESET prof_t_ = clock64();
-#else
-#define PROF_DECL
-#define PROF_MARK(k)
-#define PROF_RESET
-#endif
 
 constexpr int DEFL_BLK = NT * 64;    // max payload bytes per DEFLATE block (64 per lane: one break mask)
 constexpr int NLIT = 286;            // literal/length symbols in use
@@ -76,9 +56,6 @@ struct DeflShared {
     uint32_t ws[16];         // cross-wave scan scratch
     uint32_t red[8];         // 0 matches, 1 extra bits, 2 adler A part, 3 adler B part, 4 dyn bits, 5 fixed bits, 6 cl bits
     uint32_t ncl, hlit, hclen, dbg;
-#ifdef S5_PROFILE
-    unsigned long long prof[16];
-#endif
 };
 
 // Ordered single-pass output: as soon as a single-block record's final size is known (right after the bit-offset
@@ -106,25 +83,23 @@ __device__ __forceinline__ void put_bits(uint32_t *obuf, const ZOut &z, uint32_t
     if (sh + nb > 32) atomicOr(&obuf[w + 1], v >> (32 - sh));
 }
 
-// ---- length-limited Huffman code lengths for freq[0..n4), n <= 2*NT ----
-// freq must be 16-B aligned, readable (and zero) up to the next multiple of 4 entries.
-// WAVE = true: the whole construction runs inside the calling wave64 (n <= 64), with wave-scope syncs only.
-template <int CAP, bool WAVE = false>
+// ---- length-limited Huffman code lengths for freq[0..n), 256 < n <= 288 (the lit/len alphabet), all NT lanes ----
+template <int CAP>
 __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> &B, SortScratch *Q, const uint32_t *freq, int n,
                                               int maxbits, uint8_t *lens, uint32_t *blcount, uint32_t *icount) {
-    const int tid = WAVE ? lane_id() : (int)threadIdx.x;
-    constexpr int NTH = WAVE ? 64 : NT;
-    auto sync = [&]() { if (WAVE) wave_sync(); else __syncthreads(); };
-    PROF_DECL
+    static_assert(CAP > NT, "the counting sort below is laid out for the 286-symbol alphabet");
+    const int tid = (int)threadIdx.x;
+    constexpr int NTH = NT;
+    auto sync = [&]() { __syncthreads(); };
     for (int s = tid; s < n; s += NTH) lens[s] = 0;
     if (tid < 16) { blcount[tid] = 0; icount[tid] = 0; }
     // Sort the symbols by (frequency, symbol).
     const uint32_t f0 = tid < n ? freq[tid] : 0;
-    const uint32_t f1 = !WAVE && tid + NT < n ? freq[tid + NT] : 0;
+    const uint32_t f1 = tid + NT < n ? freq[tid + NT] : 0;
     const uint32_t key0 = f0 ? (f0 << 9) | (uint32_t)tid : 0xFFFFFFFFu;
     const uint32_t key1 = f1 ? (f1 << 9) | (uint32_t)(tid + NT) : 0xFFFFFFFFu;
     int r0 = 0, r1 = 0, m = 0;
-    if constexpr (CAP > 64) {
+    {
         // Counting sort, deterministic.  Frequencies are small: bucket = min(freq, 63).  Each bucket keeps a
         // 288-bit bitmap of its symbols, so a symbol's rank inside its bucket is a popcount of the bits below
         // it (symbol order), and the bucket's first rank is a 64-entry prefix sum.  Only the overflow bucket
@@ -160,26 +135,12 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
         r0 = (int)(B.nf[b0] + w0);
         r1 = (int)(B.nf[b1] + w1);
         m = (int)B.nf[64];
-    } else {
-        // small alphabets (the 19-symbol code-length code): rank = number of smaller keys
-        const int n4 = (n + 3) >> 2;
-        if (tid < 4 * n4) B.nf[tid] = key0;
-        if (tid + NT < 4 * n4) B.nf[tid + NT] = key1;
-        sync();
-        const uint4 *k4 = reinterpret_cast<const uint4 *>(B.nf);
-        for (int q = 0; q < n4; q++) {
-            const uint4 v = k4[q];
-            r0 += (v.x < key0) + (v.y < key0) + (v.z < key0) + (v.w < key0);
-            r1 += (v.x < key1) + (v.y < key1) + (v.z < key1) + (v.w < key1);
-            m += (v.x != 0xFFFFFFFFu) + (v.y != 0xFFFFFFFFu) + (v.z != 0xFFFFFFFFu) + (v.w != 0xFFFFFFFFu);
-        }
     }
     sync();
     if (f0) { B.lf[r0] = f0; B.rsym[r0] = (uint16_t)tid; }
     if (f1) { B.lf[r1] = f1; B.rsym[r1] = (uint16_t)(tid + NT); }
     sync();
-    PROF_MARK(WAVE ? 8 : 3);
-    if (!WAVE && S.dbg == 31) return;   // tools/stage_time.py cut-off: after the sort
+    if (S.dbg == 31) return;   // tools/stage_time.py cut-off: after the sort
     if (m <= 1) {   // degenerate: keep the code complete with two 1-bit codes
         if (tid == 0) {
             int sym = m ? B.rsym[0] : 0;
@@ -190,7 +151,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
         sync();
         return;
     }
-    if (WAVE || wave_id() == 0) {
+    if (wave_id() == 0) {
       // direction of every butterfly step as a per-lane constant: the upper lane of a pair keeps the max (med3 with ~0), the lower the min
       const uint32_t dir32 = (lane_id() & 32) ? ~0u : 0u, dir16 = (lane_id() & 16) ? ~0u : 0u, dir8 = (lane_id() & 8) ? ~0u : 0u;
       const uint32_t dir4 = (lane_id() & 4) ? ~0u : 0u, dir2 = (lane_id() & 2) ? ~0u : 0u, dir1 = (lane_id() & 1) ? ~0u : 0u;
@@ -200,8 +161,8 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
       // EVERY item not larger than T = X0 + X1 at once — no node created in this round can be smaller than T, so the pairs
       // are exactly the ones the serial algorithm would form.  The smallest remaining weight at least doubles per round:
       // ~12 rounds for a 210-symbol alphabet (m-1 rounds only for Fibonacci-like weights).  While more than 32 leaves or 32
-      // nodes are pending the window is 64 + 64 keys in two registers; after that (about half of the rounds, and always for
-      // small alphabets) 32 + 32 keys in one register.
+      // nodes are pending the window is 64 + 64 keys in two registers; after that (about half of the rounds, and
+      // always when fewer than 33 symbols are in use) 32 + 32 keys in one register.
       const int lane = lane_id();
       const uint32_t INF = 0xFFFFFFFFu;
       int i = 0, j = 0, k = 0;
@@ -270,8 +231,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
       }
     }
     sync();
-    PROF_MARK(WAVE ? 14 : 4);
-    if (!WAVE && S.dbg == 32) return;   // cut-off: after the merge
+    if (S.dbg == 32) return;   // cut-off: after the merge
     // Depth of every internal node by a parallel parent walk (root = node m-2, depth 0).  Leaves at
     // depth L = 2 * I[L-1] - I[L]; sorted order makes depth monotone in rank, so counts are enough.
     for (int q = tid; q < m - 1; q += NTH) {
@@ -280,7 +240,7 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
         atomicAdd(&icount[min(d, maxbits)], 1u);
     }
     sync();
-    if (WAVE || wave_id() == 0) {
+    if (wave_id() == 0) {
         // leaves per depth from the internal-node counts, one depth per lane; the clamp bucket takes the rest
         const int L = lane_id();
         uint32_t c = 0;
@@ -308,7 +268,6 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
         lens[B.rsym[r]] = (uint8_t)L;
     }
     sync();
-    PROF_MARK(WAVE ? 15 : 5);
 }
 
 // ---- canonical codes from lengths (wave 0; S.blcount must match lens) ----
@@ -445,7 +404,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         __syncthreads();
         return;
     }
-    PROF_DECL
     // A lane owns K contiguous bytes.  Big blocks (64-bit masks: the HBM-staged path and fused payloads over 8 KiB) run at low
     // occupancy and are LDS-latency bound: there K is a multiple of 4 and every group of four positions is ONE aligned LDS
     // dword (buf is 4-byte aligned) — measured +28 % on 100 k-sample reads.  Small blocks (32-bit masks, 8 workgroups per CU)
@@ -547,7 +505,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         nextb = up >= 0 ? (int)(S.code[up] & 0xFFFFu) : len;
         lastb = dn >= 0 ? (int)(S.code[dn] >> 16) : -1;
     }   // S.ws / S.code are next written behind later barriers
-    PROF_MARK(1);
     if (dbg == 22) { z.bitpos += (uint32_t)brk + a_sum + b_sum + lastb + nextb; return; }
 
     // Positions inside a run (no break bit) are the only ones that need the run analysis.  Most of them belong to runs of
@@ -652,14 +609,12 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     }
     if (tid == 0) atomicAdd(&S.freq[256], 1u);
     __syncthreads();
-    PROF_MARK(2);
     if (dbg == 2) { z.bitpos += S.freq[tid] + S.red[0]; return; }   // tools/stage_time.py cut-off
 
     // ---- B: codes ----
     if (tid == 0) S.dbg = dbg;   // ordered before its first use by the barriers inside build_lengths
     build_lengths(S, B, &B.sort, S.freq, NLIT, 15, S.lens, S.blcount, S.icount);
     if (dbg == 3 || dbg == 31 || dbg == 32) { z.bitpos += S.lens[tid] + B.lf[tid] + B.nf[tid]; return; }
-    PROF_RESET
     if (MODE != 0) {   // B is dead from here on: its storage becomes the bit buffer
         for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
         __syncthreads();
@@ -742,7 +697,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             if (lane == 63) S.ncl = incl;
         }
         wave_sync();
-        PROF_MARK(7);
         {
             // The 19-symbol code-length code is not built per read: it is picked from two static prefix codes by cost.
             // Its lengths travel in the block header (HCLEN x 3 bits), so any complete code is valid DEFLATE.  Code A is the
@@ -762,7 +716,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             if (lane < 19) { const uint32_t c = useA ? ca : cb; S.clcode[lane] = c; S.cllens[lane] = (uint8_t)(c >> 16); }
             if (lane == 0) { S.red[6] = useA ? costA : costB; S.hclen = useA ? 18u : 19u; }   // A: trailing zero length of symbol 15 is not sent
         }
-        PROF_MARK(6);
     } else if (wave_id() == 1) {
         assign_codes_wave(S.blcount, S.lens, NLIT, S.code);   // canonical lit/len codes, concurrently with wave 0
     } else {
@@ -777,7 +730,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         if (lane_id() == 0) { atomicAdd(&S.red[4], dynb); atomicAdd(&S.red[5], fixb); }
     }
     __syncthreads();
-    PROF_MARK(9);
     if (dbg == 4 || dbg == 41) { z.bitpos += S.red[4] + S.red[6] + S.code[tid]; return; }
     const uint32_t matches = S.red[0], extra = S.red[1];
     const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
@@ -842,8 +794,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         pos0 = z.bitpos + hdr_dyn;
         dist_bits = 1;
     }
-
-    PROF_MARK(10);
     // ---- per-lane bit totals (code-length entries and tokens share ONE prefix scan: the two sums are packed
     // into one word, 13 bits for the <= 320 * 14 header bits, 19 for the <= 16384 * 15 token bits) ----
     // (sym, extra bits, extra value) of the match token at chunk position j: from the lane's cache, else recomputed
@@ -889,7 +839,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         if (clnb[0]) put_bits(obuf, z, p, clv[0], clnb[0]);
         if (clnb[1]) put_bits(obuf, z, p + clnb[0], clv[1], clnb[1]);
     }
-    PROF_MARK(11);
     if (dbg == 5) { z.bitpos += start; return; }
     {
         // The lane's tokens go straight into the LDS bit buffer, four byte positions at a time: positions without a token
@@ -982,7 +931,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     if (tid == 0) put_bits(obuf, z, pos0 + total_bits, eob & 0xFFFF, eob >> 16);
     z.bitpos = pos0 + total_bits + (eob >> 16);
     __syncthreads();
-    PROF_MARK(12);
 }
 
 // Fused path: zlib-frame a payload of at most DEFL_BLK bytes that sits in LDS (`pay`) as ONE DEFLATE block.

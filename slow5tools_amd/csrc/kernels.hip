@@ -162,11 +162,6 @@ __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
     const s5gpu_read_desc_t d = p.a.desc[r];
-#ifdef S5_PROFILE
-    if (threadIdx.x < 16) S.prof[threadIdx.x] = 0;
-    __syncthreads();
-#endif
-    PROF_DECL
     const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
     if (plen == OVF) {
         if (threadIdx.x == 0) {
@@ -176,7 +171,6 @@ __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
         return;
     }
     __syncthreads();
-    PROF_MARK(0);
     if (p.dbg == 1) {   // stage-timing aid: svb-zd + pack only
         if (threadIdx.x == 0) p.a.out_len[r] = plen + pay[plen - 1];
         return;
@@ -184,13 +178,6 @@ __global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
     uint8_t *out = p.a.slots + d.out_off;
     const uint32_t total = zlib_compress_fused<M>(S, obuf, p.obuf_words, pay, plen, out, p.dbg);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
-    PROF_MARK(13);
-#ifdef S5_PROFILE
-    if (threadIdx.x == 0) {
-        for (int k = 0; k < 16; k++) atomicAdd(&g_prof[k], S.prof[k]);
-        atomicAdd(&g_prof[31], 1ull);
-    }
-#endif
 }
 
 // The same with ORDERED SINGLE-PASS OUTPUT: no slots, no compaction pass.  Reads are taken in ticket (start) order;
@@ -645,16 +632,6 @@ __global__ __launch_bounds__(NT) void k_synth_hdr(uint8_t *hdr, uint64_t n_reads
     }
 }
 
-#ifdef S5_PROFILE
-extern "C" int s5gpu_prof_read(unsigned long long *out, int reset) {
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32));
-    if (reset) {
-        unsigned long long z[32] = {0};
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z));
-    }
-    return 0;
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // launchers (C ABI)
