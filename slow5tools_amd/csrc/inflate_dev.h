@@ -95,6 +95,16 @@ __device__ __forceinline__ void infl_load_window(uint32_t *win, const uint8_t *s
     wave_sync();
 }
 
+// Slide the window forward.  The bits still buffered in b stay inside the new window (it starts at the dword that holds the
+// first unread bit), so a bit address relative to the window — 32 * wpos - cnt — is valid at all times.
+__device__ __forceinline__ void infl_reload(uint32_t *win, const uint8_t *src, uint32_t total, BitIn &b) {
+    const uint32_t back = ((uint32_t)b.cnt + 31u) >> 5;            // window dwords the buffered bits came from (<= 2)
+    const uint32_t from = b.wbase + 4 * (b.wpos - back);
+    infl_load_window(win, src, from, total);
+    b.wbase = from;
+    b.wpos = back;
+}
+
 // Build canonical tables + LUT for one alphabet from lens[0..n).  All 64 lanes of the wave.
 // Returns nonzero if over-subscribed (incomplete codes are tolerated like zlib does for single-code
 // distance trees; a code that does not exist simply never matches and reports INF_ERR_DATA).
@@ -227,9 +237,7 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
     while (!last && status == INF_OK) {
         // ---- block header ----
         if (b.wpos > INF_IW / 4 - 3) {   // window nearly used up: reload first
-            const uint32_t from = b.wbase + 4 * b.wpos;
-            infl_load_window(T.win, src, from, total);
-            b.wbase = from; b.wpos = 0;
+            infl_reload(T.win, src, total, b);
             continue;
         }
         bi_need32_u(b, T.win);
@@ -281,9 +289,7 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
         } else {
             // the whole dynamic header is at most 14 + 57 + 316 * 14 bits = 562 bytes: make sure it is in the window
             if (b.wpos > INF_IW / 4 - 160) {
-                const uint32_t from = b.wbase + 4 * b.wpos;
-                infl_load_window(T.win, src, from, total);
-                b.wbase = from; b.wpos = 0;
+                infl_reload(T.win, src, total, b);
             }
             bi_need32_u(b, T.win);
             const uint32_t hd = bi_get(b, 14);
@@ -350,32 +356,36 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
                     if (b.wpos > INF_IW / 4 - 3) { st = 4; break; }
                     if (o - flushed >= INF_FLUSH) { st = 5; break; }
                     bi_need32_u(b, T.win);
-                    // A run of literals out of the bits in hand, in one round: lane L looks up the code that WOULD start at
-                    // bit offset L (one LDS read for all 64 offsets); the scalar unit then hops from code to code through
-                    // those results (v_readlane with a scalar index: a few cycles per symbol instead of an LDS round trip),
-                    // and the lanes at the visited offsets store their literals side by side.  Stops at the first symbol
-                    // that is not a LUT-resolved literal (match, end of block, long code) or when the bits run out; that
-                    // symbol takes the one-at-a-time route below.
+                    // A run of literals in one round: lane L looks up the code that WOULD start L bits ahead of the reader (its
+                    // bits come straight from the LDS window, so all 64 offsets are live; one LUT read for the whole wave); the
+                    // scalar unit then hops from code to code through those results (v_readlane with a scalar index: a few
+                    // cycles per symbol instead of an LDS round trip each), and the lanes at the visited offsets store their
+                    // literals side by side.  Stops at the first symbol that is not a LUT-resolved literal (match, end of
+                    // block, long code); that symbol takes the one-at-a-time route below.
                     {
-                        const uint32_t ev = T.llut[(uint32_t)(b.buf >> lane) & ((1 << INF_LBITS) - 1)];
+                        const uint32_t abit = 32u * b.wpos - (uint32_t)b.cnt + (uint32_t)lane;   // window bit address of my offset
+                        const uint32_t w0 = T.win[abit >> 5], w1 = T.win[(abit >> 5) + 1];
+                        const uint32_t ev = T.llut[(uint32_t)((((uint64_t)w1 << 32) | w0) >> (abit & 31)) & ((1 << INF_LBITS) - 1)];
                         // per lane: is the code at my offset a LUT-resolved literal, and where would the next code start
                         const uint64_t lit_at = __ballot((ev >> 9) != 0 && (ev & 511u) < 256u);
                         const uint32_t nxt = (uint32_t)lane + (ev >> 9);
                         uint32_t off = 0;
                         uint64_t visited = 0;
                         while ((lit_at >> off) & 1) {
-                            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)off);
-                            if (n2 > (uint32_t)b.cnt) break;            // the code runs past the bits in hand
                             visited |= 1ull << off;
-                            off = n2;
+                            off = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)off);
                             if (off >= 64) break;
                         }
                         if (visited) {
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(visited >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)visited, 0u));
                             if ((visited >> lane) & 1) T.ring[(o + rank) & (INF_OW - 1)] = (uint8_t)ev;
                             o += (uint32_t)__popcll(visited);
-                            b.buf = off < 64 ? b.buf >> off : 0ull;
-                            b.cnt -= (int)off;
+                            while (off) {                       // advance the scalar reader by `off` (<= 78) bits
+                                bi_need32_u(b, T.win);
+                                const uint32_t t = off < 32u ? off : 32u;
+                                bi_get(b, (int)t);
+                                off -= t;
+                            }
                             continue;
                         }
                     }
@@ -404,9 +414,7 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
             if (st == 2 || st == 3) { status = st == 2 ? INF_ERR_DATA : INF_ERR_TRUNC; break; }
             if (st == 1) break;
             if (st == 4) {
-                const uint32_t from = b.wbase + 4 * b.wpos;
-                infl_load_window(T.win, src, from, total);
-                b.wbase = from; b.wpos = 0;
+                infl_reload(T.win, src, total, b);
                 continue;
             }
             if (st == 5) {
