@@ -347,6 +347,30 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
         if (type == 2 && ll[256] == 0) { status = INF_ERR_DATA; break; }
         if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, INF_LBITS, 9)) { status = INF_ERR_DATA; break; }
         if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, INF_DBITS, 5)) { status = INF_ERR_DATA; break; }
+        // Codes longer than the LUT: every length tested at once.  Lane L (1..15) holds limit = first[L] + count[L] and
+        // base = offs[L] - first[L] of the canonical lit/len code; the code of length L is the top L bits of the bit-reversed
+        // peek, the true length is the smallest L with code < limit (one ballot), the symbol is lsym[code + base].
+        uint32_t ll_lim = 0;
+        int ll_base = 0;
+        {
+            uint32_t first = 0, offs = 0;
+            for (int l = 1; l <= 15; l++) {
+                const uint32_t c = T.lcount[l];
+                if (lane == l) { ll_lim = first + c; ll_base = (int)offs - (int)first; }
+                offs += c;
+                first = (first + c) << 1;
+            }
+        }
+        auto long_code = [&](BitIn &bb) -> int {   // needs >= 15 buffered bits; returns the symbol or -1, consumes the code
+            const uint32_t rev = __brev((uint32_t)bb.buf & 0x7FFFu);
+            const uint32_t c = (lane >= 1 && lane <= 15) ? rev >> (32 - lane) : 0xFFFFFFFFu;
+            const uint64_t hit = __ballot(lane >= 1 && lane <= 15 && c < ll_lim);
+            if (!hit) return -1;
+            const int L = __ffsll((long long)hit) - 1;
+            const int idx = __builtin_amdgcn_readlane((int)c + ll_base, L);
+            bi_get(bb, L);
+            return (int)__builtin_amdgcn_readfirstlane((uint32_t)T.lsym[idx]);
+        };
         // ---- symbols: lane 0 decodes out of LDS; the wave refills / flushes / replicates matches ----
         for (;;) {
             // st: 0 match, 1 end of block, 2 data error, 3 truncated, 4 input window low, 5 ring needs a flush
@@ -392,7 +416,7 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
                     int sym;
                     const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.llut[(uint32_t)b.buf & ((1 << INF_LBITS) - 1)]);
                     if (e >> 9) { sym = e & 511; bi_get(b, e >> 9); }
-                    else sym = __builtin_amdgcn_readfirstlane(infl_slow(b, T.lcount, T.lsym));
+                    else sym = long_code(b);
                     if (sym < 0) { st = 2; break; }
                     if (sym < 256) { if (lane == 0) T.ring[o & (INF_OW - 1)] = (uint8_t)sym; o++; continue; }
                     if (sym == 256) { st = 1; break; }
