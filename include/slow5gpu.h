@@ -118,7 +118,7 @@ void s5gpu_shutdown(void);
 const char *s5gpu_last_error(void);
 int s5gpu_device_count(void);
 /* tuning knobs.  "inflate_simt_min": batches with at least this many zlib records use the lane-per-record
- * inflate kernel (throughput), smaller ones the wave-per-record kernel (latency); default 16384. */
+ * inflate kernel (throughput), smaller ones the wave-per-record kernel (latency); default 24576. */
 int s5gpu_set_option(const char *key, long value);
 
 /* ---- device-resident entry points (asynchronous on `hip_stream`, a hipStream_t; NULL = default) ---- */
