@@ -162,7 +162,7 @@ __device__ __forceinline__ uint32_t exzd_encode_wg(const int16_t *__restrict__ x
         uint32_t rb = rb_run + (uint32_t)(16 * tid) - (e - e_run);   // positions before me in the tile minus exceptions before me
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            if (k >= valid) break;
+            if (k >= valid) continue;
             if ((exm >> k) & 1u) {
                 const uint32_t gap = (uint32_t)(p0 + k - lastp - 1), v = z[k] - 256u;
                 const uint32_t lg = svb32_len(gap), lv = svb32_len(v);
