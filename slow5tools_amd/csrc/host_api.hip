@@ -229,11 +229,42 @@ int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_
 
 // The whole batch in one call: H2D of signals/headers, one launch, D2H of the slots, one malloc per
 // record (the ownership contract of slow5_rec_to_mem: caller frees each buffer, src/view.c:298).
+static int encode_batch_one(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                            const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                            int sig_method, void **out, size_t *out_len);
+
 extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
                                   const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
                                   int sig_method, void **out, size_t *out_len) {
     if (n == 0) return S5GPU_OK;
     if (!sig || !n_samples || !hdr || !hdr_len || !out || !out_len) { s5gpu_set_error("s5gpu_encode_batch: NULL argument"); return S5GPU_ERR_ARG; }
+    // A big batch is cut in two halves that run on two contexts at once: one half's H2D overlaps the other's kernels and
+    // D2H (PCIe is full duplex, and the host-side packing of one half hides behind the copies of the other).
+    const char *e = getenv("S5GPU_SPLIT");
+    const bool split = n >= 16384 && (!e || atoi(e) != 0);
+    if (!split) return encode_batch_one(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
+    const uint32_t h = n / 2;
+    int rc2 = S5GPU_OK;
+    char err2[512] = "";
+    std::thread t([&]() {
+        rc2 = encode_batch_one(n - h, sig + h, n_samples + h, hdr + h, hdr_len + h, aux ? aux + h : nullptr, aux_len ? aux_len + h : nullptr,
+                               rec_method, sig_method, out + h, out_len + h);
+        if (rc2) snprintf(err2, sizeof err2, "%s", s5gpu_last_error());   // the message lives in that thread
+    });
+    const int rc1 = encode_batch_one(h, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
+    t.join();
+    if (rc1 || rc2) {
+        for (uint32_t i = 0; i < n; i++) { free(out[i]); out[i] = NULL; }
+        if (!rc1) s5gpu_set_error("%s", err2);
+        return rc1 ? rc1 : rc2;
+    }
+    return S5GPU_OK;
+}
+
+static int encode_batch_one(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                            const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                            int sig_method, void **out, size_t *out_len) {
+    for (uint32_t i = 0; i < n; i++) out[i] = NULL;
     s5host::CtxHold hold;
     int rc = hold.acquire();
     if (rc) return rc;

@@ -372,3 +372,19 @@ def test_decode_fuzzed_streams_terminate_and_never_pass_wrong_data(press, inflat
             n_ok += 1
             assert np.array_equal(g["signal"], sig[k]), "a damaged record decoded to different data with status 0"
     assert n_ok < len(bad) // 10          # almost every damage is caught (a flip in the unused tail of a byte may survive)
+
+
+def test_big_host_batch_split_over_two_contexts_equals_one_context(press, monkeypatch):
+    """s5gpu_encode_batch cuts batches of >= 16384 reads in two halves that run concurrently: same records, same order"""
+    rng = np.random.default_rng(77)
+    n = 20001
+    sigs = [(500 + rng.integers(-30, 30, int(rng.integers(1, 120)))).astype(np.int16) for _ in range(n)]
+    hdrs = [press.pack_hdr(b"r%d" % i, i % 5, 8192.0, 1.0, 1400.0, 4000.0) for i in range(n)]
+    monkeypatch.setenv("S5GPU_SPLIT", "0")
+    one = press.encode_records(sigs, hdrs)
+    monkeypatch.setenv("S5GPU_SPLIT", "1")
+    two = press.encode_records(sigs, hdrs)
+    assert one == two
+    for i in (0, n // 2 - 1, n // 2, n - 1):
+        payload, _ = _oracle_payload(hdrs[i], sigs[i], b"", 1)
+        assert zlib.decompress(two[i][8:]) == payload
