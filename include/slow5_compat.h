@@ -37,7 +37,7 @@ enum slow5_press_method {
     SLOW5_COMPRESS_NONE = 0,
     SLOW5_COMPRESS_ZLIB = 1,
     SLOW5_COMPRESS_SVB_ZD = 2,
-    SLOW5_COMPRESS_ZSTD = 3,   /* not implemented: SURVEY §8(f) row 4 */
+    SLOW5_COMPRESS_ZSTD = 3,
     SLOW5_COMPRESS_EX_ZD = 4   /* signal press only (the `degrade` default, src/degrade.c:302); layout pinned on the reference's fixtures */
 };
 typedef struct {

@@ -29,7 +29,7 @@ extern "C" {
 
 /* on-disk method codes, identical to slow5lib's enum slow5_press_method values used by
  * /root/reference/src/misc.c:253-263 (SLOW5_COMPRESS_NONE/ZLIB, SLOW5_COMPRESS_NONE/SVB_ZD) */
-enum { S5GPU_REC_NONE = 0, S5GPU_REC_ZLIB = 1 };
+enum { S5GPU_REC_NONE = 0, S5GPU_REC_ZLIB = 1, S5GPU_REC_ZSTD = 2 };   /* zstd: decode only */
 enum { S5GPU_SIG_NONE = 0, S5GPU_SIG_SVB_ZD = 1, S5GPU_SIG_EX_ZD = 2 };
 
 enum {
@@ -180,7 +180,7 @@ int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec
 
 /* ---- one-stage host-buffer calls behind slow5_ptr_compress_solo / slow5_ptr_depress_solo ----
  * stage: 0 zlib compress, 1 zlib inflate, 2 svb-zd encode (in = int16 samples, in_len in bytes),
- * 3 svb-zd decode.  out[i] malloc'd, caller frees.  status[i] per record (0 ok), may be NULL. */
+ * 3 svb-zd decode, 4 zstd decompress (whole frames).  out[i] malloc'd, caller frees.  status[i] per record (0 ok), may be NULL. */
 int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t *in_len, void **out, size_t *out_len,
                      int32_t *status);
 

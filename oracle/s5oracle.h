@@ -95,6 +95,9 @@ size_t s5o_exzd_bound(uint64_t n);
 size_t s5o_exzd_encode(const int16_t *x, uint64_t n, uint8_t *out);                        /* returns bytes, 0 on allocation failure */
 int s5o_exzd_decode(const uint8_t *in, size_t len, int16_t *out, uint64_t *n_out);          /* out = NULL: query n */
 
+/* ---- §8f row 4: zstd record press — restated frame decoder (zstd_dec.c; pinned against libzstd itself) ---- */
+size_t s5o_zstd_restated_decompress(const uint8_t *in, size_t len, uint8_t *out, size_t cap);   /* (size_t)-1 on error */
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,4 +5,4 @@ Only what the hot path needs lives here:
   _lib.py    ctypes binding (fails loudly without the built library / a GPU; no CPU fallback)
   press.py   host-side mirror: batch encode / decode, device-resident batches for bench.py
 """
-from ._lib import REC_NONE, REC_ZLIB, SIG_NONE, SIG_SVB_ZD, S5GpuError  # noqa: F401
+from ._lib import REC_NONE, REC_ZLIB, REC_ZSTD, SIG_NONE, SIG_SVB_ZD, S5GpuError  # noqa: F401

@@ -12,7 +12,7 @@ from . import build as _build
 
 _LIB = None
 
-REC_NONE, REC_ZLIB = 0, 1
+REC_NONE, REC_ZLIB, REC_ZSTD = 0, 1, 2
 SIG_NONE, SIG_SVB_ZD, SIG_EX_ZD = 0, 1, 2
 
 # numpy mirrors of the C structs (same field order / padding as include/slow5gpu.h)

@@ -148,7 +148,7 @@ slow5_file_t *slow5_open(const char *pathname, const char *mode) {
     s->header = hd;
     s->meta.pathname = strdup(pathname);
     s->meta.start_rec_offset = 68ull + hl;
-    s->compress = slow5_press_init(m);   /* NULL (SLOW5_ERR_PRESS) for zstd-compressed files: not built yet */
+    s->compress = slow5_press_init(m);
     if (!s->compress) { slow5_close(s); slow5_errno = SLOW5_ERR_PRESS; return NULL; }
     if (aux_meta_build(hd) != 0) { slow5_close(s); slow5_errno = SLOW5_ERR_OTH; return NULL; }
     return s;

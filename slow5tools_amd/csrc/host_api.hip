@@ -318,6 +318,26 @@ static int encode_batch_one(uint32_t n, const int16_t *const *sig, const uint64_
     return encode_and_collect(c, n, desc, a, oo, out, out_len);
 }
 
+// first guess at a record's uncompressed size: a zstd frame says it in its header, zlib does not
+static uint64_t payload_guess(int rec_method, const void *rec, size_t len) {
+    if (rec_method == S5GPU_REC_ZLIB) return 4ull * len + 4096;
+    if (rec_method == S5GPU_REC_ZSTD) {
+        const uint8_t *p = (const uint8_t *)rec;
+        if (len >= 6 && p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD) {
+            const unsigned fhd = p[4], flag = fhd >> 6, single = (fhd >> 5) & 1;
+            const unsigned nb = flag == 0 ? single : flag == 1 ? 2 : flag == 2 ? 4 : 8;
+            const size_t at = 5 + (single ? 0 : 1);
+            if (nb && at + nb <= len) {
+                uint64_t v = 0;
+                for (unsigned i = 0; i < nb; i++) v |= (uint64_t)p[at + i] << (8 * i);
+                return flag == 1 ? v + 256 : v;
+            }
+        }
+        return 8ull * len + 4096;
+    }
+    return len;
+}
+
 extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int rec_method, int sig_method,
                                   void **payload, int16_t **sig, s5gpu_rec_fields_t *fields) {
     if (n == 0) return S5GPU_OK;
@@ -333,7 +353,7 @@ extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size
     std::vector<uint32_t> pcap(n), scap(n);
     for (uint32_t i = 0; i < n; i++) {
         if (rec_len[i] > 0xFFFFFF00ull) { s5gpu_set_error("record %u larger than 4 GiB", i); return S5GPU_ERR_ARG; }
-        const uint64_t g = rec_method == S5GPU_REC_ZLIB ? 4ull * rec_len[i] + 4096 : rec_len[i];
+        const uint64_t g = payload_guess(rec_method, rec[i], rec_len[i]);
         pcap[i] = (uint32_t)(g > 0xFFFFFF00ull ? 0xFFFFFF00ull : g);
         scap[i] = pcap[i];   // >= 1 byte per sample in either signal format... refined below
     }
@@ -378,7 +398,7 @@ extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size
         for (uint32_t k = 0; k < m; k++) {
             const uint32_t i = idx[k];
             const s5gpu_rec_fields_t &f = ff[k];
-            if (f.status == 5 && attempt < 2) { pcap[i] = f.payload_len; if (scap[i] < f.payload_len) scap[i] = f.payload_len; continue; }
+            if (f.status == 5 && attempt < 2) { pcap[i] = f.payload_len ? f.payload_len : (pcap[i] < 0x10000000u ? 8 * pcap[i] + 65536 : 0xFFFFFF00u); if (scap[i] < f.payload_len) scap[i] = f.payload_len; continue; }
             if (f.status == 6 && attempt < 2) { scap[i] = f.n_samples; continue; }
             fields[i] = f;
             done[i] = 1;
@@ -398,7 +418,7 @@ extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size
 extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t *in_len, void **out, size_t *out_len,
                                 int32_t *status) {
     if (n == 0) return S5GPU_OK;
-    if (!in || !in_len || !out || !out_len || stage < 0 || stage > 3) { s5gpu_set_error("s5gpu_solo_batch: bad argument"); return S5GPU_ERR_ARG; }
+    if (!in || !in_len || !out || !out_len || stage < 0 || stage > 4) { s5gpu_set_error("s5gpu_solo_batch: bad argument"); return S5GPU_ERR_ARG; }
     s5host::CtxHold hold;
     int rc = hold.acquire();
     if (rc) return rc;
@@ -476,10 +496,11 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
         return S5GPU_OK;
     }
     // decode side: REC_DESC
+    const bool infl = stage == 1 || stage == 4;   // 4: zstd frames
     std::vector<uint32_t> pcap(n), scap(n);
     std::vector<uint8_t> done(n, 0);
     for (uint32_t i = 0; i < n; i++) {
-        if (stage == 1) { pcap[i] = (uint32_t)(4 * in_len[i] + 4096); scap[i] = 0; }
+        if (infl) { const uint64_t g = payload_guess(stage == 4 ? S5GPU_REC_ZSTD : S5GPU_REC_ZLIB, in[i], in_len[i]); pcap[i] = (uint32_t)(g > 0xFFFFFF00ull ? 0xFFFFFF00ull : g); scap[i] = 0; }
         else {
             uint32_t ns = 0;
             if (in_len[i] >= 4) memcpy(&ns, in[i], 4);
@@ -515,28 +536,28 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
         HIP_TRY(hipMemsetAsync(c->d_fields.p, 0, sizeof(s5gpu_rec_fields_t) * m, c->st));
         s5gpu_decode_args_t a;
         memset(&a, 0, sizeof a);
-        a.n_recs = m; a.rec_method = S5GPU_REC_ZLIB; a.sig_method = S5GPU_SIG_SVB_ZD;
+        a.n_recs = m; a.rec_method = stage == 4 ? S5GPU_REC_ZSTD : S5GPU_REC_ZLIB; a.sig_method = S5GPU_SIG_SVB_ZD;
         a.desc = (const s5gpu_rec_desc_t *)c->d_desc.p; a.in = (const uint8_t *)c->d_in.p;
         a.payload = (uint8_t *)c->d_pay.p; a.sig_out = (int16_t *)c->d_sig.p; a.fields = (s5gpu_rec_fields_t *)c->d_fields.p;
-        if ((rc = stage == 1 ? s5gpu_inflate_dev(&a, c->st) : s5gpu_svbzd_decode_dev(&a, c->st))) return rc;
+        if ((rc = infl ? s5gpu_inflate_dev(&a, c->st) : s5gpu_svbzd_decode_dev(&a, c->st))) return rc;
         uint8_t *hp = (uint8_t *)c->h_out.p, *hsg = hp + up(po + 64, 64), *hf = hsg + up(so * 2 + 64, 64);
         HIP_TRY(hipMemcpyAsync(hf, c->d_fields.p, sizeof(s5gpu_rec_fields_t) * m, hipMemcpyDeviceToHost, c->st));
-        if (stage == 1) HIP_TRY(hipMemcpyAsync(hp, c->d_pay.p, po, hipMemcpyDeviceToHost, c->st));
+        if (infl) HIP_TRY(hipMemcpyAsync(hp, c->d_pay.p, po, hipMemcpyDeviceToHost, c->st));
         else HIP_TRY(hipMemcpyAsync(hsg, c->d_sig.p, so * 2, hipMemcpyDeviceToHost, c->st));
         HIP_TRY(hipStreamSynchronize(c->st));
         const s5gpu_rec_fields_t *ff = (const s5gpu_rec_fields_t *)hf;
         for (uint32_t k = 0; k < m; k++) {
             const uint32_t i = idx[k];
             const s5gpu_rec_fields_t &f = ff[k];
-            if (f.status == 5 && attempt < 2) { pcap[i] = f.payload_len; continue; }
+            if (f.status == 5 && attempt < 2) { pcap[i] = f.payload_len ? f.payload_len : (pcap[i] < 0x10000000u ? 8 * pcap[i] + 65536 : 0xFFFFFF00u); continue; }
             if (f.status == 6 && attempt < 2) { scap[i] = f.n_samples; continue; }
             done[i] = 1;
             if (status) status[i] = f.status;
             if (f.status != 0) { overall = S5GPU_ERR_DATA; continue; }
-            out_len[i] = stage == 1 ? f.payload_len : 2ull * f.n_samples;
+            out_len[i] = infl ? f.payload_len : 2ull * f.n_samples;
             out[i] = malloc(out_len[i] ? out_len[i] : 1);
             if (!out[i]) return S5GPU_ERR_NOMEM;
-            memcpy(out[i], stage == 1 ? hp + desc[k].pay_off : hsg + 2 * desc[k].sig_off, out_len[i]);
+            memcpy(out[i], infl ? hp + desc[k].pay_off : hsg + 2 * desc[k].sig_off, out_len[i]);
         }
     }
     if (overall) s5gpu_set_error("s5gpu_solo_batch: at least one input is corrupt (see status[i])");
@@ -552,7 +573,7 @@ int s5host::decode_resident(Ctx *c, uint32_t n, const void *const *rec, const si
     std::vector<uint32_t> pcap(n), scap(n);
     for (uint32_t i = 0; i < n; i++) {
         if (rec_len[i] > 0xFFFFFF00ull / 8) { s5gpu_set_error("record %u too large", i); return S5GPU_ERR_ARG; }
-        pcap[i] = (uint32_t)(from_rec == S5GPU_REC_ZLIB ? 4ull * rec_len[i] + 4096 : rec_len[i]);
+        { const uint64_t g = payload_guess(from_rec, rec[i], rec_len[i]); pcap[i] = (uint32_t)(g > 0xFFFFFF00ull ? 0xFFFFFF00ull : g); }
         scap[i] = pcap[i];   // a sample takes at least one payload byte in either signal format
     }
     rd.resize(n);
@@ -587,7 +608,7 @@ int s5host::decode_resident(Ctx *c, uint32_t n, const void *const *rec, const si
         HIP_TRY(hipStreamSynchronize(c->st));
         bool retry = false, bad = false;
         for (uint32_t i = 0; i < n; i++) {
-            if (ff[i].status == 5 && attempt < 2) { pcap[i] = ff[i].payload_len; if (scap[i] < pcap[i]) scap[i] = pcap[i]; retry = true; }
+            if (ff[i].status == 5 && attempt < 2) { pcap[i] = ff[i].payload_len ? ff[i].payload_len : (pcap[i] < 0x10000000u ? 8 * pcap[i] + 65536 : 0xFFFFFF00u); if (scap[i] < pcap[i]) scap[i] = pcap[i]; retry = true; }
             else if (ff[i].status == 6 && attempt < 2) { scap[i] = ff[i].n_samples; retry = true; }
             else if (ff[i].status != 0) { bad = true; if (status) status[i] = ff[i].status; }
         }

@@ -11,6 +11,7 @@
 #include "deflate_dev.h"
 #include "inflate_dev.h"
 #include "inflate_simt_dev.h"
+#include "zstd_dev.h"
 #include "svb_dev.h"
 #include "exzd_dev.h"
 
@@ -380,6 +381,19 @@ __global__ __launch_bounds__(64) void k_inflate(s5gpu_decode_args_t a) {
         status = zlib_inflate_wave(T, in, d.in_len, out, d.pay_cap, &olen);   // Adler-32 verified inside
     }
     if (lane == 0) {
+        a.fields[r].status = status;
+        a.fields[r].payload_len = olen;
+    }
+}
+
+// K4 for the zstd record press: one frame per wave64 (zstd_dev.h)
+__global__ __launch_bounds__(64) void k_zstd_inflate(s5gpu_decode_args_t a) {
+    __shared__ ZstdShared T;
+    const uint32_t r = blockIdx.x;
+    const s5gpu_rec_desc_t d = a.desc[r];
+    uint32_t olen = 0;
+    const int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+    if (lane_id() == 0) {
         a.fields[r].status = status;
         a.fields[r].payload_len = olen;
     }
@@ -799,7 +813,9 @@ extern "C" int s5gpu_set_option(const char *key, long value) {
     return S5GPU_ERR_ARG;
 }
 static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st) {
-    if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
+    if (a->rec_method == S5GPU_REC_ZSTD) {
+        hipLaunchKernelGGL(k_zstd_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
+    } else if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
         static bool attr = false;
         if (!attr) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate_simt), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -853,7 +869,7 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         s5gpu_set_error("s5gpu_decode_dev: bad arguments");
         return S5GPU_ERR_ARG;
     }
-    if ((a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB) ||
+    if ((a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB && a->rec_method != S5GPU_REC_ZSTD) ||
         (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD && a->sig_method != S5GPU_SIG_EX_ZD)) {
         s5gpu_set_error("s5gpu_decode_dev: unsupported method");
         return S5GPU_ERR_ARG;

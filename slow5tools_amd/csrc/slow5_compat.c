@@ -17,14 +17,16 @@
 
 __thread int slow5_errno = 0;
 
-static int rec_code(enum slow5_press_method m) { return m == SLOW5_COMPRESS_NONE ? S5GPU_REC_NONE : m == SLOW5_COMPRESS_ZLIB ? S5GPU_REC_ZLIB : -1; }
+static int rec_code(enum slow5_press_method m) {
+    return m == SLOW5_COMPRESS_NONE ? S5GPU_REC_NONE : m == SLOW5_COMPRESS_ZLIB ? S5GPU_REC_ZLIB : m == SLOW5_COMPRESS_ZSTD ? S5GPU_REC_ZSTD : -1;
+}
 static int sig_code(enum slow5_press_method m) {
     return m == SLOW5_COMPRESS_NONE ? S5GPU_SIG_NONE : m == SLOW5_COMPRESS_SVB_ZD ? S5GPU_SIG_SVB_ZD : m == SLOW5_COMPRESS_EX_ZD ? S5GPU_SIG_EX_ZD : -1;
 }
 
 struct slow5_press *slow5_press_init(slow5_press_method_t method) {
     if (rec_code(method.record_method) < 0 || sig_code(method.signal_method) < 0) {
-        slow5_errno = SLOW5_ERR_PRESS;   /* zstd: SURVEY §8(f) row 4 */
+        slow5_errno = SLOW5_ERR_PRESS;
         return NULL;
     }
     struct slow5_press *p = (struct slow5_press *)calloc(1, sizeof *p);
@@ -71,7 +73,7 @@ void *slow5_ptr_depress_solo(enum slow5_press_method method, const void *ptr, si
         memcpy(out, ptr, count);
         len = count;
     } else {
-        const int stage = method == SLOW5_COMPRESS_ZLIB ? 1 : method == SLOW5_COMPRESS_SVB_ZD ? 3 : -1;
+        const int stage = method == SLOW5_COMPRESS_ZLIB ? 1 : method == SLOW5_COMPRESS_SVB_ZD ? 3 : method == SLOW5_COMPRESS_ZSTD ? 4 : -1;
         const void *in[1] = {ptr};
         if (stage < 0 || s5gpu_solo_batch(stage, 1, in, &count, &out, &len, NULL) != S5GPU_OK) { free(out); slow5_errno = SLOW5_ERR_PRESS; return NULL; }
     }

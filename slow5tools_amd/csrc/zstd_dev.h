@@ -1,0 +1,513 @@
+// zstd_dev.h — Zstandard frame decoder, one record per wave64 (the zstd record press).
+//
+// slow5lib's third record method is libzstd's ZSTD_decompress on the whole record
+// (/root/reference/src/misc.c:259 names the method; test/data/exp/one_fast5/exp_1_lossless_zstd*_v0.2.0.blow5 are its fixtures).
+// A frame is a chain of blocks; a compressed block is (a) a literals section — raw, RLE or Huffman-coded in 1 or 4
+// backward bit streams — and (b) a sequences section: (literal run, match length, offset) triples whose codes come
+// out of three interleaved FSE (tANS) state machines.  What the format leaves parallel is little, and this is how
+// the wave uses it:
+//   - the 4 Huffman streams of a literals section are decoded by 4 lanes, each with its own 64-bit bit container;
+//     the decoded literals are parked at the END of the record's own payload slot (the frame's output can never
+//     catch up with them: bytes still to come >= literals still unread), so no side buffer exists;
+//   - the Huffman decode table (<= 2^11 entries) is filled by all 64 lanes, symbol by symbol;
+//   - the FSE state machines are inherently serial: lane 0 walks them, one sequence per step, and hands
+//     (literal run, match length, offset) to the wave, which copies with all 64 lanes (matches replicate as
+//     out[o+k] = out[o-d + k mod d], sources precede o);
+//   - table descriptions (normalised counts, weights) are tiny and decoded by lane 0.
+// The CPU twin of this file is oracle/zstd_dec.c (same structure, checked against libzstd itself).
+// Not verified: the optional content checksum (XXH64; slow5lib's one-shot ZSTD_compress never writes it).
+// Rejected: dictionaries, skippable frames, reserved bits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dev_common.h"
+#include "inflate_dev.h"   // INF_* status codes
+
+namespace s5 {
+
+struct ZstdShared {                  // per wave
+    uint16_t huf[2048];              // symbol | bits << 8
+    uint32_t ll[512], ml[512], of[256];   // symbol | bits << 8 | baseline << 16
+    uint32_t llsym[36], mlsym[53];   // extra bits | base << 8
+    uint8_t w[256];                  // Huffman weights
+    uint16_t start[256];             // first table cell of each symbol / FSE spread cells (as bytes)
+    uint16_t next[64];
+    int16_t norm[64];
+    uint32_t wt[64];                 // FSE table of the Huffman weights
+    uint32_t x[8];                   // lane 0 -> wave mailbox
+};
+
+typedef uint64_t __attribute__((aligned(1))) z_u64u;
+typedef uint32_t __attribute__((aligned(1))) z_u32u;
+
+__device__ __forceinline__ int z_highbit(uint32_t v) { return 31 - __clz((int)v); }   // v != 0
+
+// backward bit reader: a 64-bit container over the bytes [ptr, ptr + 8) of the stream, `used` bits of it consumed from the top
+struct ZBits {
+    const uint8_t *base;
+    uint32_t ptr, used;
+    uint64_t c;
+    __device__ __forceinline__ bool init(const uint8_t *p, uint32_t len) {
+        base = p; ptr = 0; used = 64; c = 0;
+        if (len == 0) return false;
+        const uint32_t last = p[len - 1];
+        if (last == 0) return false;
+        if (len >= 8) { ptr = len - 8; c = *(const z_u64u *)(p + ptr); used = 8 - (uint32_t)z_highbit(last); }
+        else {
+            for (uint32_t i = 0; i < len; i++) c |= (uint64_t)p[i] << (8 * i);
+            used = 64 - 8 * len + 8 - (uint32_t)z_highbit(last);
+        }
+        return true;
+    }
+    __device__ __forceinline__ void reload() {
+        if (ptr == 0) return;
+        uint32_t nb = used >> 3;
+        if (nb > ptr) nb = ptr;
+        ptr -= nb; used -= 8 * nb;
+        c = *(const z_u64u *)(base + ptr);
+    }
+    __device__ __forceinline__ void need(uint32_t n) { if (used + n > 64) reload(); }
+    // n <= 32 bits at the read position; bits before the start of the stream read as zero
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return used < 64 ? (uint32_t)(((c << used) >> 1) >> (63 - n)) : 0u; }
+    __device__ __forceinline__ uint32_t get(uint32_t n) { const uint32_t v = peek(n); used += n; return v; }
+    __device__ __forceinline__ uint32_t left() const { return 8 * ptr + 64 - used; }     // may wrap when overrun: check overrun() first
+    __device__ __forceinline__ bool overrun() const { return used > 64; }
+    __device__ __forceinline__ bool done() const { return ptr == 0 && used == 64; }
+};
+
+// forward bits of an FSE table description (lane 0)
+__device__ __forceinline__ uint32_t z_fpeek(const uint8_t *p, uint32_t len, uint32_t pos, int n) {
+    uint64_t v = 0;
+    const uint32_t b = pos >> 3;
+    for (uint32_t i = 0; i < 5; i++) if (b + i < len) v |= (uint64_t)p[b + i] << (8 * i);
+    return (uint32_t)(v >> (pos & 7)) & ((1u << n) - 1);
+}
+
+// normalised counts of an FSE table; bytes consumed, 0 on error (oracle/zstd_dec.c fse_read_ncount)
+__device__ __noinline__ uint32_t z_ncount(const uint8_t *p, uint32_t len, int16_t *norm, int *maxsym, int *log, int max_log, int max_sym) {
+    uint32_t pos = 4;
+    const int al = (int)z_fpeek(p, len, 0, 4) + 5;
+    if (al > max_log) return 0;
+    *log = al;
+    int remaining = (1 << al) + 1, threshold = 1 << al, nbits = al + 1, sym = 0, prev0 = 0;
+    while (remaining > 1 && sym <= max_sym) {
+        if (prev0) {
+            int n0 = 0;
+            for (;;) {
+                const int rep = (int)z_fpeek(p, len, pos, 2);
+                pos += 2;
+                n0 += rep;
+                if (rep != 3 || pos > 8 * len) break;
+            }
+            if (sym + n0 > max_sym + 1) return 0;
+            while (n0-- > 0) norm[sym++] = 0;
+            prev0 = 0;
+            if (sym > max_sym) break;
+        }
+        const int maxv = (2 * threshold - 1) - remaining;
+        int count;
+        const uint32_t bits = z_fpeek(p, len, pos, nbits);
+        if ((int)(bits & (uint32_t)(threshold - 1)) < maxv) { count = (int)(bits & (uint32_t)(threshold - 1)); pos += (uint32_t)(nbits - 1); }
+        else {
+            count = (int)(bits & (uint32_t)(2 * threshold - 1));
+            if (count >= threshold) count -= maxv;
+            pos += (uint32_t)nbits;
+        }
+        count--;
+        remaining -= count < 0 ? -count : count;
+        norm[sym++] = (int16_t)count;
+        prev0 = count == 0;
+        while (remaining < threshold) { nbits--; threshold >>= 1; }
+    }
+    if (remaining != 1 || sym > max_sym + 1) return 0;
+    *maxsym = sym - 1;
+    const uint32_t used = (pos + 7) >> 3;
+    return used <= len ? used : 0;
+}
+
+// decode table of an FSE distribution (lane 0); cell[] holds one byte per table cell
+__device__ __noinline__ int z_fse_build(uint32_t *t, const int16_t *norm, int maxsym, int log, uint8_t *cell, uint16_t *next) {
+    const int size = 1 << log;
+    int high = size - 1;
+    for (int s = 0; s <= maxsym; s++) {
+        if (norm[s] == -1) { cell[high--] = (uint8_t)s; next[s] = 1; }
+        else next[s] = (uint16_t)norm[s];
+    }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s <= maxsym; s++)
+        for (int i = 0; i < norm[s]; i++) {
+            cell[pos] = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    if (pos != 0) return -1;
+    for (int i = 0; i < size; i++) {
+        const int s = cell[i];
+        const uint32_t ns = next[s]++;
+        const int nb = log - z_highbit(ns);
+        t[i] = (uint32_t)s | ((uint32_t)nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xFFFFu) << 16);
+    }
+    return 0;
+}
+
+__device__ const int16_t Z_LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__device__ const int16_t Z_ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                         1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__device__ const int16_t Z_OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+// extra bits | base << 8 of the literal-length / match-length codes (RFC 8878 3.1.1.3.2.1.1)
+__device__ __forceinline__ uint32_t z_ll_sym(uint32_t c) {
+    if (c < 16) return c << 8;
+    if (c < 20) return 1u | ((16 + 2 * (c - 16)) << 8);
+    if (c < 22) return 2u | ((24 + 4 * (c - 20)) << 8);
+    if (c < 24) return 3u | ((32 + 8 * (c - 22)) << 8);
+    if (c == 24) return 4u | (48u << 8);
+    return (c - 19) | ((1u << (c - 19)) << 8);                    // 25: 6 bits, base 64 ... 35: 16 bits, base 65536
+}
+__device__ __forceinline__ uint32_t z_ml_sym(uint32_t c) {
+    if (c < 32) return (c + 3) << 8;
+    if (c < 36) return 1u | ((35 + 2 * (c - 32)) << 8);
+    if (c < 38) return 2u | ((43 + 4 * (c - 36)) << 8);
+    if (c < 40) return 3u | ((51 + 8 * (c - 38)) << 8);
+    if (c < 42) return 4u | ((67 + 16 * (c - 40)) << 8);
+    if (c == 42) return 5u | (99u << 8);
+    return (c - 36) | (((1u << (c - 36)) + 3) << 8);              // 43: 7 bits, base 131 ... 52: 16 bits, base 65539
+}
+
+// one of the three sequence tables (lane 0): bytes of description consumed, -1 on error
+__device__ __noinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_t *p, uint32_t len, uint32_t *t, int *log, const int16_t *def,
+                                        int def_n, int def_log, int max_log, int max_sym) {
+    if (mode == 0) {
+        for (int i = 0; i < def_n; i++) T.norm[i] = def[i];
+        if (z_fse_build(t, T.norm, def_n - 1, def_log, reinterpret_cast<uint8_t *>(T.start), T.next)) return -1;
+        *log = def_log;
+        return 0;
+    }
+    if (mode == 1) {
+        if (len < 1 || p[0] > max_sym) return -1;
+        t[0] = p[0];
+        *log = 0;
+        return 1;
+    }
+    if (mode == 2) {
+        int maxsym, l;
+        const uint32_t h = z_ncount(p, len, T.norm, &maxsym, &l, max_log, max_sym);
+        if (!h) return -1;
+        if (z_fse_build(t, T.norm, maxsym, l, reinterpret_cast<uint8_t *>(T.start), T.next)) return -1;
+        *log = l;
+        return (int)h;
+    }
+    return *log < 0 ? -1 : 0;
+}
+
+// Huffman weights of a tree description (lane 0): bytes consumed (0 on error); T.w[0..nsym), *nsym_out, *maxbits_out
+__device__ __noinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *p, uint32_t len, int *nsym_out, int *maxbits_out) {
+    if (len < 1) return 0;
+    const int hb = p[0];
+    int nsym;
+    uint32_t used;
+    if (hb >= 128) {
+        nsym = hb - 127;
+        used = 1 + (uint32_t)(nsym + 1) / 2;
+        if (used > len) return 0;
+        for (int i = 0; i < nsym; i++) T.w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
+    } else {
+        used = 1 + (uint32_t)hb;
+        if (used > len || hb < 1) return 0;
+        int maxsym, log;
+        const uint32_t h = z_ncount(p + 1, (uint32_t)hb, T.norm, &maxsym, &log, 6, 12);
+        if (!h || h >= (uint32_t)hb) return 0;
+        if (z_fse_build(T.wt, T.norm, maxsym, log, reinterpret_cast<uint8_t *>(T.start), T.next)) return 0;
+        ZBits b;
+        if (!b.init(p + 1 + h, (uint32_t)hb - h)) return 0;
+        uint32_t s1 = b.get((uint32_t)log);
+        uint32_t s2 = b.get((uint32_t)log);
+        nsym = 0;
+        for (;;) {                                                // two interleaved states
+            if (nsym >= 254) return 0;
+            const uint32_t e1 = T.wt[s1], e2 = T.wt[s2];
+            T.w[nsym++] = (uint8_t)e1;
+            b.need(8);
+            if (b.overrun() || b.left() < ((e1 >> 8) & 255)) { T.w[nsym++] = (uint8_t)e2; break; }
+            s1 = (e1 >> 16) + b.get((e1 >> 8) & 255);
+            T.w[nsym++] = (uint8_t)e2;
+            b.need(8);
+            if (b.left() < ((e2 >> 8) & 255)) { T.w[nsym++] = (uint8_t)T.wt[s1]; break; }
+            s2 = (e2 >> 16) + b.get((e2 >> 8) & 255);
+        }
+        if (nsym > 255) return 0;
+    }
+    uint32_t sum = 0;
+    for (int i = 0; i < nsym; i++) { if (T.w[i] > 11) return 0; if (T.w[i]) sum += 1u << (T.w[i] - 1); }
+    if (sum == 0) return 0;
+    const int maxbits = z_highbit(sum) + 1;
+    if (maxbits > 11) return 0;
+    const uint32_t rest = (1u << maxbits) - sum;
+    if (rest & (rest - 1)) return 0;
+    T.w[nsym++] = (uint8_t)(z_highbit(rest) + 1);
+    uint32_t cnt[12], at[12];
+    for (int r = 0; r < 12; r++) cnt[r] = 0;
+    for (int i = 0; i < nsym; i++) {
+        const int r = T.w[i];
+#pragma unroll
+        for (int q = 0; q < 12; q++) cnt[q] += q == r;            // static indices: no scratch
+    }
+    if (cnt[1] < 2 || (cnt[1] & 1)) return 0;
+    uint32_t a = 0;
+#pragma unroll
+    for (int r = 1; r < 12; r++) { at[r] = a; a += cnt[r] << (r - 1); }
+    at[0] = 0;
+    for (int i = 0; i < nsym; i++) {
+        const int r = T.w[i];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 1; q < 12; q++) if (q == r) { mine = at[q]; at[q] += 1u << (q - 1); }
+        T.start[i] = (uint16_t)mine;
+    }
+    *nsym_out = nsym;
+    *maxbits_out = maxbits;
+    return used;
+}
+
+// one Huffman stream on the calling lane: n symbols to dst; false on a malformed stream
+__device__ __forceinline__ bool z_huf_stream(const uint16_t *huf, uint32_t L, const uint8_t *p, uint32_t len, uint8_t *dst, uint32_t n) {
+    ZBits b;
+    if (!b.init(p, len)) return false;
+    uint32_t i = 0;
+    for (; i + 4 <= n; i += 4) {                                   // 4 symbols <= 44 bits per refill
+        b.need(44);
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t e = huf[b.peek(L)];
+            b.used += e >> 8;
+            v |= (e & 255u) << (8 * q);
+        }
+        *(z_u32u *)(dst + i) = v;
+    }
+    for (; i < n; i++) {
+        b.need(11);
+        const uint32_t e = huf[b.peek(L)];
+        b.used += e >> 8;
+        dst[i] = (uint8_t)e;
+    }
+    return !b.overrun() && b.done();
+}
+
+// One frame -> out (olen bytes).  INF_OK, or INF_ERR_HEADER / DATA / TRUNC / OVERFLOW (olen = bytes needed when the frame says).
+__device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out) {
+    const int lane = lane_id();
+    *olen_out = 0;
+    if (len < 6) return INF_ERR_TRUNC;
+    if (in[0] != 0x28 || in[1] != 0xB5 || in[2] != 0x2F || in[3] != 0xFD) return INF_ERR_HEADER;
+    uint32_t p = 5;
+    const uint32_t fhd = in[4];
+    const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1;
+    if ((fhd & 8) || (fhd & 3)) return INF_ERR_HEADER;            // reserved bit / dictionary
+    if (!single) p++;
+    const uint32_t fcs_bytes = fcs_flag == 0 ? single : fcs_flag == 1 ? 2u : fcs_flag == 2 ? 4u : 8u;
+    if (p + fcs_bytes > len) return INF_ERR_TRUNC;
+    uint64_t fcs = 0;
+    for (uint32_t i = 0; i < fcs_bytes; i++) fcs |= (uint64_t)in[p + i] << (8 * i);
+    if (fcs_flag == 1) fcs += 256;
+    p += fcs_bytes;
+    if (fcs_bytes && fcs > cap) { *olen_out = fcs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)fcs; return INF_ERR_OVERFLOW; }
+    const uint32_t E = fcs_bytes ? (uint32_t)fcs : cap;           // end of the output region: Huffman literals park below it
+    if (lane < 36) T.llsym[lane] = z_ll_sym((uint32_t)lane);
+    if (lane < 53) T.mlsym[lane] = z_ml_sym((uint32_t)lane);
+    int huf_log = 0, ll_log = -1, of_log = -1, ml_log = -1;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                        // lane 0's copy is the live one
+    uint32_t o = 0;
+    int status = INF_OK;
+    bool last = false;
+    while (!last) {
+        if (p + 3 > len) { status = INF_ERR_TRUNC; break; }
+        const uint32_t bh = in[p] | (in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16);
+        p += 3;
+        last = bh & 1;
+        const uint32_t type = (bh >> 1) & 3, bsize = bh >> 3;
+        if (type == 3 || bsize > 128 * 1024) { status = INF_ERR_DATA; break; }
+        if (type < 2) {                                           // raw / RLE block
+            const uint32_t nin = type == 0 ? bsize : 1u;
+            if (p + nin > len) { status = INF_ERR_TRUNC; break; }
+            if (o + bsize > E) { status = fcs_bytes ? INF_ERR_DATA : INF_ERR_OVERFLOW; break; }
+            for (uint32_t k = lane; k < bsize; k += 64) out[o + k] = in[p + (type == 0 ? k : 0u)];
+            o += bsize; p += nin;
+            wave_sync();
+            continue;
+        }
+        if (p + bsize > len) { status = INF_ERR_TRUNC; break; }
+        if (bsize < 2) { status = INF_ERR_DATA; break; }
+        const uint8_t *b = in + p;
+        const uint32_t bend = bsize;                              // offsets below are relative to b
+        p += bsize;
+        // ---- literals section ----
+        const uint32_t ltype = b[0] & 3, sf = (b[0] >> 2) & 3;
+        uint32_t lsize, csize = 0, q, streams = 1;
+        if (ltype < 2) {
+            if (sf == 0 || sf == 2) { lsize = b[0] >> 3; q = 1; }
+            else if (sf == 1) { lsize = (b[0] >> 4) | ((uint32_t)b[1] << 4); q = 2; }
+            else { if (bsize < 3) { status = INF_ERR_DATA; break; } lsize = (b[0] >> 4) | ((uint32_t)b[1] << 4) | ((uint32_t)b[2] << 12); q = 3; }
+        } else {
+            if (bsize < 5) { status = INF_ERR_DATA; break; }
+            const uint64_t v = (uint64_t)b[0] | ((uint64_t)b[1] << 8) | ((uint64_t)b[2] << 16) | ((uint64_t)b[3] << 24) | ((uint64_t)b[4] << 32);
+            if (sf < 2) { lsize = (uint32_t)(v >> 4) & 0x3FF; csize = (uint32_t)(v >> 14) & 0x3FF; q = 3; streams = sf ? 4 : 1; }
+            else if (sf == 2) { lsize = (uint32_t)(v >> 4) & 0x3FFF; csize = (uint32_t)(v >> 18) & 0x3FFF; q = 4; streams = 4; }
+            else { lsize = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; q = 5; streams = 4; }
+        }
+        if (lsize > 128 * 1024) { status = INF_ERR_DATA; break; }
+        const uint8_t *lit = nullptr;                             // where literal li lives (raw: in the input; Huffman: parked in `out`)
+        uint32_t lit_fill = 0;
+        bool lit_parked = false;
+        if (ltype == 0) { if (q + lsize > bend) { status = INF_ERR_DATA; break; } lit = b + q; q += lsize; }
+        else if (ltype == 1) { if (q + 1 > bend) { status = INF_ERR_DATA; break; } lit_fill = b[q]; q += 1; }
+        else {
+            if (q + csize > bend) { status = INF_ERR_DATA; break; }
+            if (lsize > E || o > E - lsize) { status = fcs_bytes ? INF_ERR_DATA : INF_ERR_OVERFLOW; break; }
+            uint32_t c = q;
+            const uint32_t cend = q + csize;
+            q = cend;
+            if (ltype == 2) {
+                if (lane == 0) {
+                    int nsym = 0, maxbits = 0;
+                    const uint32_t u = z_huf_weights(T, b + c, cend - c, &nsym, &maxbits);
+                    T.x[0] = u; T.x[1] = (uint32_t)nsym; T.x[2] = (uint32_t)maxbits;
+                }
+                wave_sync();
+                const uint32_t u = T.x[0], nsym = T.x[1];
+                if (!u) { status = INF_ERR_DATA; break; }
+                huf_log = (int)T.x[2];
+                c += u;
+                for (uint32_t i = 0; i < nsym; i++) {             // all lanes fill symbol i's cells
+                    const uint32_t wgt = T.w[i];
+                    if (!wgt) continue;
+                    const uint32_t span = 1u << (wgt - 1), at = T.start[i], e = i | ((uint32_t)(huf_log + 1 - (int)wgt) << 8);
+                    for (uint32_t k = lane; k < span; k += 64) T.huf[at + k] = (uint16_t)e;
+                }
+                wave_sync();
+            } else if (!huf_log) { status = INF_ERR_DATA; break; }
+            uint8_t *park = out + (E - lsize);
+            bool ok = true;
+            if (streams == 1) {
+                if (lane == 0) ok = z_huf_stream(T.huf, (uint32_t)huf_log, b + c, cend - c, park, lsize);
+            } else {
+                if (cend - c < 6) { status = INF_ERR_DATA; break; }
+                const uint32_t s1 = b[c] | (b[c + 1] << 8), s2 = b[c + 2] | (b[c + 3] << 8), s3 = b[c + 4] | (b[c + 5] << 8);
+                c += 6;
+                const uint32_t per = (lsize + 3) / 4;
+                if (s1 + s2 + s3 > cend - c || 3 * per > lsize) { status = INF_ERR_DATA; break; }
+                if (lane < 4) {
+                    const uint32_t from = lane == 0 ? 0 : lane == 1 ? s1 : lane == 2 ? s1 + s2 : s1 + s2 + s3;
+                    const uint32_t sl = lane == 0 ? s1 : lane == 1 ? s2 : lane == 2 ? s3 : cend - c - s1 - s2 - s3;
+                    ok = z_huf_stream(T.huf, (uint32_t)huf_log, b + c + from, sl, park + (uint32_t)lane * per, lane == 3 ? lsize - 3 * per : per);
+                }
+            }
+            if (__ballot(!ok)) { status = INF_ERR_DATA; break; }
+            wave_sync();
+            lit = park;
+            lit_parked = true;
+        }
+        // ---- sequences section ----
+        if (q >= bend) { status = INF_ERR_DATA; break; }
+        uint32_t nseq = b[q++];
+        if (nseq >= 128) {
+            if (nseq == 255) { if (q + 2 > bend) { status = INF_ERR_DATA; break; } nseq = b[q] + (b[q + 1] << 8) + 0x7F00; q += 2; }
+            else { if (q + 1 > bend) { status = INF_ERR_DATA; break; } nseq = ((nseq - 128) << 8) + b[q]; q += 1; }
+        }
+        uint32_t li = 0;
+        if (nseq) {
+            if (q >= bend) { status = INF_ERR_DATA; break; }
+            const uint32_t modes = b[q++];
+            if (modes & 3) { status = INF_ERR_DATA; break; }
+            if (lane == 0) {
+                int u, bad = 0;
+                uint32_t qq = q;
+                if ((u = z_seq_table(T, (int)(modes >> 6), b + qq, bend - qq, T.ll, &ll_log, Z_LL_DEF, 36, 6, 9, 35)) < 0) bad = 1; else qq += (uint32_t)u;
+                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 4) & 3), b + qq, bend - qq, T.of, &of_log, Z_OF_DEF, 29, 5, 8, 31)) < 0) bad = 1; else qq += (uint32_t)u; }
+                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 2) & 3), b + qq, bend - qq, T.ml, &ml_log, Z_ML_DEF, 53, 6, 9, 52)) < 0) bad = 1; else qq += (uint32_t)u; }
+                T.x[0] = (uint32_t)bad; T.x[1] = qq;
+            }
+            wave_sync();
+            if (T.x[0]) { status = INF_ERR_DATA; break; }
+            q = T.x[1];
+            ll_log = __shfl(ll_log, 0); of_log = __shfl(of_log, 0); ml_log = __shfl(ml_log, 0);
+            ZBits br;
+            br.base = b; br.ptr = 0; br.used = 64; br.c = 0;
+            uint32_t sl = 0, so = 0, sm = 0;
+            bool ok = true;
+            if (lane == 0) {
+                ok = q < bend && br.init(b + q, bend - q);
+                if (ok) {
+                    sl = br.get((uint32_t)ll_log);
+                    br.need(32);
+                    so = br.get((uint32_t)of_log);
+                    sm = br.get((uint32_t)ml_log);
+                }
+            }
+            if (__shfl((int)ok, 0) == 0) { status = INF_ERR_DATA; break; }
+            for (uint32_t s = 0; s < nseq; s++) {
+                uint32_t llen = 0, mlen = 0, offset = 0;
+                if (lane == 0) {
+                    const uint32_t eo = T.of[so], em = T.ml[sm], el = T.ll[sl];
+                    const uint32_t ofc = eo & 255, mls = T.mlsym[em & 255], lls = T.llsym[el & 255];
+                    br.need(ofc);
+                    const uint32_t ofv = (1u << ofc) + br.get(ofc);
+                    br.need(32);
+                    mlen = (mls >> 8) + br.get(mls & 255);
+                    llen = (lls >> 8) + br.get(lls & 255);
+                    if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+                    else {
+                        const uint32_t idx = ofv - 1 + (llen == 0);
+                        if (idx == 0) offset = rep0;
+                        else {
+                            offset = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
+                            if (idx > 1) rep2 = rep1;
+                            rep1 = rep0;
+                            rep0 = offset;
+                        }
+                    }
+                    if (s + 1 < nseq) {
+                        br.need(27);
+                        sl = (el >> 16) + br.get((el >> 8) & 255);
+                        sm = (em >> 16) + br.get((em >> 8) & 255);
+                        so = (eo >> 16) + br.get((eo >> 8) & 255);
+                    }
+                    if (br.overrun()) offset = 0;                  // reported as corrupt below
+                }
+                llen = (uint32_t)__builtin_amdgcn_readfirstlane((int)llen);
+                mlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)mlen);
+                offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)offset);
+                if (li + llen > lsize || offset == 0 || (uint64_t)offset > (uint64_t)o + llen) { status = INF_ERR_DATA; break; }
+                // room: the output may not run into the parked literals still unread, nor past the end of the slot
+                const uint32_t lim = lit_parked ? E - lsize + li + llen : E;
+                if ((uint64_t)o + llen + mlen > lim) { status = fcs_bytes ? INF_ERR_DATA : INF_ERR_OVERFLOW; break; }
+                if (lit) { for (uint32_t k = lane; k < llen; k += 64) out[o + k] = lit[li + k]; }
+                else { for (uint32_t k = lane; k < llen; k += 64) out[o + k] = (uint8_t)lit_fill; }
+                o += llen; li += llen;
+                wave_sync();
+                const uint8_t *src = out + (o - offset);
+                if (offset >= mlen) { for (uint32_t k = lane; k < mlen; k += 64) out[o + k] = src[k]; }
+                else { for (uint32_t k = lane; k < mlen; k += 64) out[o + k] = src[k % offset]; }
+                o += mlen;
+                wave_sync();
+            }
+            if (status != INF_OK) break;
+            if (__shfl((int)(br.done() && !br.overrun()), 0) == 0) { status = INF_ERR_DATA; break; }
+        }
+        const uint32_t restl = lsize - li;
+        if ((uint64_t)o + restl > E) { status = fcs_bytes ? INF_ERR_DATA : INF_ERR_OVERFLOW; break; }
+        if (lit) { for (uint32_t k = lane; k < restl; k += 64) out[o + k] = lit[li + k]; }
+        else { for (uint32_t k = lane; k < restl; k += 64) out[o + k] = (uint8_t)lit_fill; }
+        o += restl;
+        wave_sync();
+    }
+    if (status != INF_OK) return status;
+    if (checksum) { if (p + 4 > len) return INF_ERR_TRUNC; p += 4; }
+    if (p != len) return INF_ERR_DATA;
+    if (fcs_bytes && fcs != o) return INF_ERR_DATA;
+    *olen_out = o;
+    return INF_OK;
+}
+
+}   // namespace s5

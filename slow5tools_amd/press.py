@@ -13,7 +13,7 @@ import struct
 import numpy as np
 
 from . import _lib
-from ._lib import REC_NONE, REC_ZLIB, SIG_EX_ZD, SIG_NONE, SIG_SVB_ZD, S5GpuError, check  # noqa: F401
+from ._lib import REC_NONE, REC_ZLIB, REC_ZSTD, SIG_EX_ZD, SIG_NONE, SIG_SVB_ZD, S5GpuError, check  # noqa: F401
 
 
 def pack_hdr(read_id, read_group, digitisation, offset, rng, sampling_rate):

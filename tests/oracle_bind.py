@@ -278,3 +278,63 @@ def exzd_decode(blob):
     if lib().s5o_exzd_decode(_ptr(b), len(b), _ptr(out), C.byref(n)) != 0:
         return None
     return out
+
+
+# ---- §8f row 4: zstd record press ----
+# The reference calls libzstd (a dependency, not vendored).  The real library is the oracle where the image has it
+# (libzstd.so.1, no headers needed); oracle/zstd_dec.c is a restatement of the frame decoder that is pinned against it.
+REC_ZSTD = 2
+_ZSTD = None
+
+
+def zstd_ref():
+    """the real libzstd through ctypes, or None when the image has none"""
+    global _ZSTD
+    if _ZSTD is None:
+        try:
+            Z = C.CDLL("libzstd.so.1")
+        except OSError:
+            _ZSTD = False
+            return None
+        Z.ZSTD_compressBound.restype = C.c_size_t
+        Z.ZSTD_compressBound.argtypes = [C.c_size_t]
+        Z.ZSTD_compress.restype = C.c_size_t
+        Z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        Z.ZSTD_decompress.restype = C.c_size_t
+        Z.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        Z.ZSTD_isError.restype = C.c_uint
+        Z.ZSTD_isError.argtypes = [C.c_size_t]
+        Z.ZSTD_getFrameContentSize.restype = C.c_ulonglong
+        Z.ZSTD_getFrameContentSize.argtypes = [C.c_void_p, C.c_size_t]
+        _ZSTD = Z
+    return _ZSTD or None
+
+
+def zstd_compress(data, level=1):
+    Z = zstd_ref()
+    cap = Z.ZSTD_compressBound(len(data))
+    out = C.create_string_buffer(cap)
+    n = Z.ZSTD_compress(out, cap, data, len(data), level)
+    assert not Z.ZSTD_isError(n)
+    return out.raw[:n]
+
+
+def zstd_decompress(frame, cap=None):
+    """libzstd's answer; None when it rejects the frame"""
+    Z = zstd_ref()
+    if cap is None:
+        cap = Z.ZSTD_getFrameContentSize(frame, len(frame))
+        if cap >= 2**63:
+            return None
+    out = C.create_string_buffer(cap + 1)
+    n = Z.ZSTD_decompress(out, cap, frame, len(frame))
+    return None if Z.ZSTD_isError(n) else out.raw[:n]
+
+
+def zstd_restated_decompress(frame, cap):
+    L = lib()
+    L.s5o_zstd_restated_decompress.restype = C.c_size_t
+    L.s5o_zstd_restated_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    out = C.create_string_buffer(cap + 1)
+    n = L.s5o_zstd_restated_decompress(frame, len(frame), out, cap)
+    return None if n == 2**64 - 1 else out.raw[:n]

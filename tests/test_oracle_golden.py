@@ -323,3 +323,81 @@ def test_exzd_round_trip_edge_cases():
         assert y is not None and np.array_equal(x, y), x[:8]
     for bad in (b"", b"\x01" + bytes(9), ob.exzd_encode(cases[5])[:-1], ob.exzd_encode(cases[5]) + b"\x00"):
         assert ob.exzd_decode(bad) is None
+
+
+# ---- §8f row 4: zstd record press — libzstd is the oracle; oracle/zstd_dec.c restates the decoder and is pinned on it ----
+ZSTD_FIXTURES = [("exp_1_lossless_zstd_v0.2.0.blow5", 0, "exp_1_lossless_v0.2.0.blow5"),
+                 ("exp_1_lossless_zstd_svb_v0.2.0.blow5", 1, "exp_1_lossless_zlib_svb_v0.2.0.blow5"),
+                 ("example_multi_rg_v0.2.0_zstd_svb-zd.blow5", 1, "example_multi_rg_v0.2.0.blow5")]
+needs_zstd = pytest.mark.skipif(ob.zstd_ref() is None, reason="no libzstd.so.1 in this image")
+
+
+def zstd_test_inputs(rng, sizes=(10, 100, 1000, 5000, 40000, 150000, 300000)):
+    yield b""
+    yield b"a"
+    yield b"a" * 1000
+    yield bytes(rng.integers(0, 256, 100000, dtype=np.uint8))
+    for n in sizes:
+        yield np.cumsum(rng.integers(-20, 21, n)).astype(np.int16).tobytes()
+        yield bytes(rng.integers(0, 4, n, dtype=np.uint8))
+        yield bytes(rng.choice(np.array([0, 1, 2, 3, 50, 200], dtype=np.uint8), n, p=[.5, .2, .1, .1, .05, .05]))
+        t = (b"the quick brown fox jumps over the lazy dog " * (n // 40 + 1))[:n]
+        yield t
+        a = bytearray(t)
+        for k in rng.integers(0, max(1, n), n // 20):
+            a[k] = rng.integers(0, 256)
+        yield bytes(a)
+
+
+@needs_zstd
+@pytest.mark.parametrize("name,sig,twin", ZSTD_FIXTURES)
+def test_zstd_fixture_records_decode_to_the_twin_payloads(name, sig, twin):
+    """the reference's zstd files hold the same payloads as their zlib / uncompressed twins; both decoders agree on them"""
+    b5, tw = Blow5(golden(name)), Blow5(golden(twin))
+    assert (b5.rec_method, b5.sig_method) == (2, sig) and len(b5.records) == len(tw.records)
+    for r, t in zip(b5.records, tw.records):
+        want = zlib.decompress(t) if tw.rec_method == 1 else t
+        got = ob.zstd_decompress(r)
+        assert got is not None
+        assert ob.zstd_restated_decompress(r, len(got)) == got
+        assert ob.rec_parse(got, sig)["signal"].tobytes() == ob.rec_parse(want, tw.sig_method)["signal"].tobytes()
+        if tw.sig_method == sig:
+            assert got == want
+
+
+@needs_zstd
+def test_zstd_level_1_reproduces_the_reference_frames():
+    """slow5lib compresses records with ZSTD_compress at level 1: same bytes out of libzstd 1.4.8 for the plain-signal file"""
+    b5 = Blow5(golden("exp_1_lossless_zstd_v0.2.0.blow5"))
+    for r in b5.records:
+        assert ob.zstd_compress(ob.zstd_decompress(r), 1) == r
+
+
+@needs_zstd
+def test_zstd_restated_decoder_matches_libzstd():
+    rng = np.random.default_rng(11)
+    n = 0
+    for d in zstd_test_inputs(rng):
+        for level in (1, 3, 5, 9, 15, 19, -5):
+            f = ob.zstd_compress(d, level)
+            assert ob.zstd_restated_decompress(f, len(d)) == d
+            n += 1
+    assert n > 200
+
+
+@needs_zstd
+def test_zstd_restated_decoder_rejects_or_agrees_on_damaged_frames():
+    rng = np.random.default_rng(12)
+    for d in list(zstd_test_inputs(rng, sizes=(1000, 40000)))[:12]:
+        f = ob.zstd_compress(d, 1)
+        for _ in range(60):
+            g = bytearray(f)
+            for k in rng.integers(0, len(g), 3):
+                g[k] = rng.integers(0, 256)
+            mine, ref = ob.zstd_restated_decompress(bytes(g), len(d)), ob.zstd_decompress(bytes(g), len(d))
+            if ref is not None and mine is not None:
+                assert mine == ref                       # no checksum in these frames: some damage still decodes
+            # (libzstd's double-symbol Huffman decoder clamps an overrun on the last literal of a stream, so it accepts a few
+            #  damaged frames that the restatement rejects; never the other way round on valid data)
+        for cut in range(0, len(f), max(1, len(f) // 25)):
+            assert ob.zstd_restated_decompress(f[:cut], len(d)) is None

@@ -1,0 +1,120 @@
+"""zstd record press on the GPU (decode side: csrc/zstd_dev.h) against libzstd itself, against the
+restated decoder (oracle/zstd_dec.c) and against the reference's zstd fixtures."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+from blow5_fixture import Blow5, golden
+from test_oracle_golden import ZSTD_FIXTURES, zstd_test_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def press():
+    from slow5tools_amd import _lib, press as p
+    _lib.check(_lib.lib().s5gpu_init(0), "s5gpu_init")
+    return p
+
+
+def zstd_solo(frames):
+    """s5gpu_solo_batch(stage 4): whole frames in, payloads (or None) and per-frame status out"""
+    from slow5tools_amd import _lib
+    L = _lib.lib()
+    n = len(frames)
+    bufs = [C.create_string_buffer(f, len(f)) if len(f) else C.create_string_buffer(1) for f in frames]
+    inp = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    lens = (C.c_size_t * n)(*[len(f) for f in frames])
+    out, olen, st = (C.c_void_p * n)(), (C.c_size_t * n)(), (C.c_int32 * n)()
+    rc = L.s5gpu_solo_batch(4, n, inp, lens, out, olen, st)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    res = []
+    for i in range(n):
+        res.append(C.string_at(out[i], olen[i]) if out[i] else None)
+        if out[i]:
+            libc.free(out[i])
+    return rc, res, list(st)
+
+
+@pytest.mark.parametrize("name,sig,twin", ZSTD_FIXTURES)
+def test_decode_reference_zstd_files(press, name, sig, twin):
+    b5, tw = Blow5(golden(name)), Blow5(golden(twin))
+    got = press.decode_records(b5.records, press.REC_ZSTD, sig)
+    for g, r, t in zip(got, b5.records, tw.records):
+        want = ob.rec_parse(zlib.decompress(t) if tw.rec_method == 1 else t, tw.sig_method)
+        assert g["status"] == 0 and g["read_id"] == want["read_id"] and np.array_equal(g["signal"], want["signal"])
+        if ob.zstd_ref() is not None:
+            assert g["payload"] == ob.zstd_decompress(r)
+
+
+def test_frames_from_every_level_match_libzstd(press):
+    if ob.zstd_ref() is None:
+        pytest.skip("no libzstd.so.1 in this image")
+    rng = np.random.default_rng(21)
+    data, frames = [], []
+    for d in zstd_test_inputs(rng):
+        for level in (1, 3, 5, 9, 15, 19, -5):
+            data.append(d)
+            frames.append(ob.zstd_compress(d, level))
+    rc, res, st = zstd_solo(frames)
+    assert rc == 0 and all(s == 0 for s in st)
+    for d, r in zip(data, res):
+        assert r == d
+
+
+def test_damaged_frames_never_hang_and_agree_when_accepted(press):
+    if ob.zstd_ref() is None:
+        pytest.skip("no libzstd.so.1 in this image")
+    rng = np.random.default_rng(22)
+    frames, caps = [], []
+    for d in list(zstd_test_inputs(rng, sizes=(1000, 40000)))[:14]:
+        f = ob.zstd_compress(d, 1)
+        for _ in range(40):
+            g = bytearray(f)
+            for k in rng.integers(0, len(g), 3):
+                g[k] = rng.integers(0, 256)
+            frames.append(bytes(g))
+            caps.append(len(d))
+        for cut in range(1, len(f), max(1, len(f) // 10)):
+            frames.append(f[:cut])
+            caps.append(len(d))
+    rc, res, st = zstd_solo(frames)
+    n_ok = 0
+    for f, cap, r, s in zip(frames, caps, res, st):
+        if s == 0:
+            n_ok += 1
+            assert r == ob.zstd_restated_decompress(f, len(r))   # the device decoder and its CPU twin decode the same bytes
+    assert 0 < n_ok < len(frames)
+
+
+def test_payload_slot_too_small_is_retried_with_the_frame_size(press):
+    """a frame says its content size: the host sizes the slot from it, the kernel reports 5 when a caller's slot is smaller"""
+    if ob.zstd_ref() is None:
+        pytest.skip("no libzstd.so.1 in this image")
+    import torch
+    from slow5tools_amd import _lib
+    L = _lib.lib()
+    d = bytes(np.random.default_rng(3).integers(0, 7, 50000, dtype=np.uint8))
+    f = ob.zstd_compress(d, 1)
+    dev = torch.device("cuda:0")
+    t_in = torch.zeros(len(f) + 64, dtype=torch.uint8, device=dev)
+    t_in[:len(f)] = torch.frombuffer(bytearray(f), dtype=torch.uint8).to(dev)
+    pay = torch.zeros(60000, dtype=torch.uint8, device=dev)
+    for cap, want in ((1000, 5), (49999, 5), (50000, 0), (60000 - 16, 0)):
+        desc = np.zeros(1, dtype=_lib.REC_DESC)
+        desc["in_len"], desc["pay_cap"] = len(f), cap
+        t_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+        fields = torch.zeros(_lib.REC_FIELDS.itemsize, dtype=torch.uint8, device=dev)
+        a = _lib.DecodeArgs()
+        a.n_recs, a.rec_method, a.sig_method = 1, press.REC_ZSTD, 0
+        a.desc, a.in_, a.payload, a.fields = t_desc.data_ptr(), t_in.data_ptr(), pay.data_ptr(), fields.data_ptr()
+        _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "s5gpu_inflate_dev")
+        torch.cuda.synchronize()
+        got = fields.cpu().numpy().view(_lib.REC_FIELDS)[0]
+        assert got["status"] == want and got["payload_len"] == 50000
+        if want == 0:
+            assert bytes(pay[:50000].cpu().numpy()) == d
