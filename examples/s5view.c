@@ -5,7 +5,7 @@
  * work_db() call at src/view.c:292 replaced by ONE slow5_gpu_convert_batch() per batch, written against
  * include/slow5_compat.h only.  It doubles as the end-to-end harness of tests/test_container.py.
  *
- *   s5view in.[b|s]low5 out.[b|s]low5 [record: none|zlib] [signal: none|svb-zd|ex-zd] [batch K]   (defaults zlib svb-zd 4096,
+ *   s5view in.[b|s]low5 out.[b|s]low5 [record: none|zlib|zstd] [signal: none|svb-zd|ex-zd] [batch K]   (defaults zlib svb-zd 4096,
  *        src/misc.c:54-58, src/cmd.h:8; the input format is sniffed, the output format follows the extension as in
  *        src/view.c:170-190; press methods are ignored for a .slow5 output).  A 6th argument sets the number of GPU worker
  *        threads of the read || GPU || write pipeline (default 1: the reader is the bottleneck); 0 runs the reference's serial read / compute / write phases.
@@ -135,11 +135,11 @@ int main(int argc, char **argv) {
         return EXIT_SUCCESS;
     }
     if (argc < 3) {
-        fprintf(stderr, "usage: s5view in.blow5 out.blow5 [none|zlib] [none|svb-zd|ex-zd] [K]\n");
+        fprintf(stderr, "usage: s5view in.blow5 out.blow5 [none|zlib|zstd] [none|svb-zd|ex-zd] [K]\n");
         return EXIT_FAILURE;
     }
     slow5_press_method_t to = {SLOW5_COMPRESS_ZLIB, SLOW5_COMPRESS_SVB_ZD};
-    if (argc > 3) to.record_method = strcmp(argv[3], "none") == 0 ? SLOW5_COMPRESS_NONE : SLOW5_COMPRESS_ZLIB;
+    if (argc > 3) to.record_method = strcmp(argv[3], "none") == 0 ? SLOW5_COMPRESS_NONE : strcmp(argv[3], "zstd") == 0 ? SLOW5_COMPRESS_ZSTD : SLOW5_COMPRESS_ZLIB;
     if (argc > 4) to.signal_method = strcmp(argv[4], "none") == 0 ? SLOW5_COMPRESS_NONE : strcmp(argv[4], "ex-zd") == 0 ? SLOW5_COMPRESS_EX_ZD : SLOW5_COMPRESS_SVB_ZD;
     const int64_t K = argc > 5 ? atoll(argv[5]) : 4096;
 

@@ -139,7 +139,7 @@ int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *args, uint8_t *stream_out
  *    and the framed length on return; works in place (see DESIGN.md "staged path").
  *  inflate: zlib streams -> payload slots, fields[i].status / payload_len (Adler-32 verified)
  *  svbzd_decode: svb-zd blobs (desc.in_off/in_len) -> sig_out, fields[i].status / n_samples */
-int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *args, void *hip_stream);
+int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *args, void *hip_stream);   /* rec_method zstd: the zstd twin */
 int s5gpu_inflate_dev(const s5gpu_decode_args_t *args, void *hip_stream);
 int s5gpu_svbzd_decode_dev(const s5gpu_decode_args_t *args, void *hip_stream);
 /* Gather the slots into one contiguous BLOW5 record stream (what the ordered fwrite loop emits):
@@ -180,7 +180,7 @@ int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec
 
 /* ---- one-stage host-buffer calls behind slow5_ptr_compress_solo / slow5_ptr_depress_solo ----
  * stage: 0 zlib compress, 1 zlib inflate, 2 svb-zd encode (in = int16 samples, in_len in bytes),
- * 3 svb-zd decode, 4 zstd decompress (whole frames).  out[i] malloc'd, caller frees.  status[i] per record (0 ok), may be NULL. */
+ * 3 svb-zd decode, 4 zstd decompress (whole frames), 5 zstd compress.  out[i] malloc'd, caller frees.  status[i] per record (0 ok), may be NULL. */
 int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t *in_len, void **out, size_t *out_len,
                      int32_t *status);
 

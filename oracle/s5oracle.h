@@ -97,6 +97,9 @@ int s5o_exzd_decode(const uint8_t *in, size_t len, int16_t *out, uint64_t *n_out
 
 /* ---- §8f row 4: zstd record press — restated frame decoder (zstd_dec.c; pinned against libzstd itself) ---- */
 size_t s5o_zstd_restated_decompress(const uint8_t *in, size_t len, uint8_t *out, size_t cap);   /* (size_t)-1 on error */
+/* the frame layout of the device encoder (zstd_enc.c): literals-only blocks of <= 16 KiB */
+size_t s5o_zstd_literals_bound(size_t n);
+size_t s5o_zstd_literals_compress(const uint8_t *in, size_t n, uint8_t *out);
 
 #ifdef __cplusplus
 }

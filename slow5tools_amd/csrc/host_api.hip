@@ -418,7 +418,7 @@ extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size
 extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t *in_len, void **out, size_t *out_len,
                                 int32_t *status) {
     if (n == 0) return S5GPU_OK;
-    if (!in || !in_len || !out || !out_len || stage < 0 || stage > 4) { s5gpu_set_error("s5gpu_solo_batch: bad argument"); return S5GPU_ERR_ARG; }
+    if (!in || !in_len || !out || !out_len || stage < 0 || stage > 5) { s5gpu_set_error("s5gpu_solo_batch: bad argument"); return S5GPU_ERR_ARG; }
     s5host::CtxHold hold;
     int rc = hold.acquire();
     if (rc) return rc;
@@ -427,7 +427,9 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
     for (uint32_t i = 0; i < n; i++)
         if (in_len[i] > 0xFFFFFF00ull / 4) { s5gpu_set_error("item %u too large", i); return S5GPU_ERR_ARG; }
     int overall = S5GPU_OK;
-    if (stage == 0 || stage == 2) {
+    const bool park_in = stage == 0 || stage == 5;   // whole buffers through a record press (5: zstd)
+    const int park_rec = stage == 5 ? S5GPU_REC_ZSTD : S5GPU_REC_ZLIB;
+    if (park_in || stage == 2) {
         // encode side: READ_DESC slots
         std::vector<s5gpu_read_desc_t> desc(n);
         std::vector<uint32_t> park(n, 0), lens(n);
@@ -436,10 +438,10 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
             s5gpu_read_desc_t &d = desc[i];
             memset(&d, 0, sizeof d);
             d.out_off = oo;
-            if (stage == 0) {
+            if (park_in) {
                 const uint32_t len = (uint32_t)in_len[i];
                 d.hdr_len = (len > 8 ? len : 8) - 8;
-                d.slot_cap = (uint32_t)s5gpu_slot_bound(0, d.hdr_len, 0, S5GPU_REC_ZLIB, S5GPU_SIG_NONE);
+                d.slot_cap = (uint32_t)s5gpu_slot_bound(0, d.hdr_len, 0, park_rec, S5GPU_SIG_NONE);
                 park[i] = (d.slot_cap - (d.hdr_len + 8)) & ~15u;
                 lens[i] = len;
             } else {
@@ -451,33 +453,33 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
             }
             oo += d.slot_cap;
         }
-        const size_t hin = up(stage == 0 ? oo : so * 2, 64) + 64 + sizeof(s5gpu_read_desc_t) * n + 4ull * n;
+        const size_t hin = up(park_in ? oo : so * 2, 64) + 64 + sizeof(s5gpu_read_desc_t) * n + 4ull * n;
         if ((rc = c->h_in.reserve(hin)) || (rc = c->d_slots.reserve(oo + 64)) || (rc = c->d_sig.reserve(so * 2 + 64)) ||
             (rc = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * n)) || (rc = c->d_len.reserve(4ull * n)) ||
             (rc = c->d_hdr.reserve(64)) || (rc = c->h_out.reserve(oo + 64 + 4ull * n)))
             return rc;
         uint8_t *h0 = (uint8_t *)c->h_in.p;
-        uint8_t *hd = h0 + up(stage == 0 ? oo : so * 2, 64) + 64, *hl = hd + sizeof(s5gpu_read_desc_t) * n;
+        uint8_t *hd = h0 + up(park_in ? oo : so * 2, 64) + 64, *hl = hd + sizeof(s5gpu_read_desc_t) * n;
         for (uint32_t i = 0; i < n; i++) {
             if (!in_len[i]) continue;
-            if (stage == 0) memcpy(h0 + desc[i].out_off + park[i], in[i], in_len[i]);
+            if (park_in) memcpy(h0 + desc[i].out_off + park[i], in[i], in_len[i]);
             else memcpy(h0 + 2 * desc[i].sig_off, in[i], in_len[i]);
         }
         memcpy(hd, desc.data(), sizeof(s5gpu_read_desc_t) * n);
         memcpy(hl, lens.data(), 4ull * n);
-        if (stage == 0) HIP_TRY(hipMemcpyAsync(c->d_slots.p, h0, oo, hipMemcpyHostToDevice, c->st));
+        if (park_in) HIP_TRY(hipMemcpyAsync(c->d_slots.p, h0, oo, hipMemcpyHostToDevice, c->st));
         else if (so) HIP_TRY(hipMemcpyAsync(c->d_sig.p, h0, so * 2, hipMemcpyHostToDevice, c->st));
         HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_read_desc_t) * n, hipMemcpyHostToDevice, c->st));
         HIP_TRY(hipMemcpyAsync(c->d_len.p, hl, 4ull * n, hipMemcpyHostToDevice, c->st));
         s5gpu_encode_args_t a;
         memset(&a, 0, sizeof a);
         a.n_reads = n;
-        a.rec_method = stage == 0 ? S5GPU_REC_ZLIB : S5GPU_REC_NONE;
-        a.sig_method = stage == 0 ? S5GPU_SIG_NONE : S5GPU_SIG_SVB_ZD;
+        a.rec_method = park_in ? park_rec : S5GPU_REC_NONE;
+        a.sig_method = park_in ? S5GPU_SIG_NONE : S5GPU_SIG_SVB_ZD;
         a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
         a.sig = (const int16_t *)c->d_sig.p; a.hdr = (const uint8_t *)c->d_hdr.p;
         a.slots = (uint8_t *)c->d_slots.p; a.out_len = (uint32_t *)c->d_len.p;
-        if ((rc = stage == 0 ? s5gpu_deflate_parked_dev(&a, c->st) : s5gpu_svbzd_encode_dev(&a, c->st))) return rc;
+        if ((rc = park_in ? s5gpu_deflate_parked_dev(&a, c->st) : s5gpu_svbzd_encode_dev(&a, c->st))) return rc;
         uint8_t *ho_len = (uint8_t *)c->h_out.p, *ho_slots = ho_len + up(4ull * n, 64);
         if ((rc = c->h_out.reserve(up(4ull * n, 64) + oo + 64))) return rc;
         ho_len = (uint8_t *)c->h_out.p; ho_slots = ho_len + up(4ull * n, 64);
@@ -486,7 +488,7 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
         HIP_TRY(hipStreamSynchronize(c->st));
         const uint32_t *ol = (const uint32_t *)ho_len;
         for (uint32_t i = 0; i < n; i++) {
-            const uint32_t skip = stage == 0 ? 8 : 0;   // the solo call returns the bare zlib stream, no u64 prefix
+            const uint32_t skip = park_in ? 8 : 0;   // the solo call returns the bare zlib stream / zstd frame, no u64 prefix
             if (ol[i] < skip || ol[i] > desc[i].slot_cap) { s5gpu_set_error("item %u: impossible device length %u", i, ol[i]); return S5GPU_ERR_HIP; }
             out_len[i] = ol[i] - skip;
             out[i] = malloc(out_len[i] ? out_len[i] : 1);

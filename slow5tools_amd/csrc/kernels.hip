@@ -12,6 +12,7 @@
 #include "inflate_dev.h"
 #include "inflate_simt_dev.h"
 #include "zstd_dev.h"
+#include "zstd_enc_dev.h"
 #include "svb_dev.h"
 #include "exzd_dev.h"
 
@@ -308,6 +309,43 @@ __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list
             *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
             p.a.out_len[r] = total;
         }
+    }
+}
+
+// zstd record press, fused: payload in LDS -> literals-only zstd frame (zstd_enc_dev.h).  Same shape as k_encode_fused.
+template <bool EXZD>
+__global__ __launch_bounds__(NT) void k_zstd_fused(EncParams p) {
+    const uint32_t r = blockIdx.x;
+    DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
+    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
+    uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
+    const s5gpu_read_desc_t d = p.a.desc[r];
+    const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
+    if (plen == OVF) {
+        if (threadIdx.x == 0) {
+            const uint32_t at = atomicAdd(&p.a.ovf[0], 1u);
+            p.a.ovf[1 + at] = r;
+        }
+        return;
+    }
+    __syncthreads();
+    const uint32_t total = zstd_record<false>(S, obuf, p.obuf_words, pay, nullptr, plen, p.a.slots + d.out_off);
+    if (threadIdx.x == 0) p.a.out_len[r] = total;
+}
+// ... and staged: a parked payload, 16 KiB block at a time through LDS (k_deflate_staged's twin)
+__global__ __launch_bounds__(NT) void k_zstd_staged(EncParams p, int use_list) {
+    DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
+    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
+    uint8_t *stage = smem + S_BYTES + 4u * p.obuf_words;
+    const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const uint32_t r = use_list ? p.a.ovf[1 + it] : it;
+        const s5gpu_read_desc_t d = p.a.desc[r];
+        uint8_t *out = p.a.slots + d.out_off;
+        const uint32_t plen = p.a.out_len[r];
+        __syncthreads();
+        const uint32_t total = zstd_record<true>(S, obuf, p.obuf_words, out + park_offset(d, p.a.sig_method), stage, plen, out);
+        if (threadIdx.x == 0) p.a.out_len[r] = total;
     }
 }
 
@@ -658,13 +696,14 @@ extern "C" uint64_t s5gpu_payload_bound(uint32_t n, uint32_t hdr_len, uint32_t a
 extern "C" uint64_t s5gpu_slot_bound(uint32_t n, uint32_t hdr_len, uint32_t aux_len, int rec_method, int sig_method) {
     const uint64_t p = s5gpu_payload_bound(n, hdr_len, aux_len, sig_method);
     // stored blocks: 5 bytes + <1 byte of alignment per 16 KiB block; 8 prefix + 2 header + 4 adler; word slack
-    const uint64_t z = rec_method == S5GPU_REC_ZLIB ? p + 6 * (p / DEFL_BLK + 1) + 14 : p + 8;
+    // zstd: 8 prefix + 9 frame header + 3 per <= 16 KiB block (raw at worst) + the word flush
+    const uint64_t z = rec_method == S5GPU_REC_ZLIB ? p + 6 * (p / DEFL_BLK + 1) + 14 : rec_method == S5GPU_REC_ZSTD ? p + 4 * (p / DEFL_BLK + 1) + 24 : p + 8;
     return (z + 16 + 15) & ~15ull;
 }
 
 static int enc_check(const s5gpu_encode_args_t *a) {
     if (!a || (a->n_reads && (!a->desc || !a->sig || !a->hdr || !a->slots || !a->out_len))) return S5GPU_ERR_ARG;
-    if (a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB) return S5GPU_ERR_ARG;
+    if (a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB && a->rec_method != S5GPU_REC_ZSTD) return S5GPU_ERR_ARG;
     if (a->sig_method != S5GPU_SIG_NONE && a->sig_method != S5GPU_SIG_SVB_ZD && a->sig_method != S5GPU_SIG_EX_ZD) return S5GPU_ERR_ARG;
     return S5GPU_OK;
 }
@@ -681,6 +720,9 @@ static int set_lds_attrs() {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svbzd_encode), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     g_attr_done = true;
     return S5GPU_OK;
@@ -727,18 +769,21 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         p.obuf_words = (cap + 64 > B_BYTES ? cap + 64 : B_BYTES) / 4;
         const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
         // a lane owns ceil(len / 256) bytes: payloads up to 8 KiB need 32-bit position masks only
-        const bool xz = a->sig_method == S5GPU_SIG_EX_ZD;
-        if (cap <= 8192) { if (xz) hipLaunchKernelGGL((k_encode_fused<uint32_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_encode_fused<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p); }
+        const bool xz = a->sig_method == S5GPU_SIG_EX_ZD, zs = a->rec_method == S5GPU_REC_ZSTD;
+        if (zs) { if (xz) hipLaunchKernelGGL(k_zstd_fused<true>, dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_zstd_fused<false>, dim3(a->n_reads), dim3(NT), lds, st, p); }
+        else if (cap <= 8192) { if (xz) hipLaunchKernelGGL((k_encode_fused<uint32_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_encode_fused<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p); }
         else { if (xz) hipLaunchKernelGGL((k_encode_fused<uint64_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_encode_fused<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p); }
         // overflow reads (usually none: the two launches below then exit at once)
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
         const uint32_t g = a->n_reads < 8192 ? a->n_reads : 8192;   // persistent loops over the list; enough workgroups for the CUs to balance
         hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2);
-        hipLaunchKernelGGL(k_deflate_staged, dim3(g), dim3(NT), st_lds, st, p, 1);
+        if (zs) hipLaunchKernelGGL(k_zstd_staged, dim3(g), dim3(NT), st_lds, st, p, 1);
+        else hipLaunchKernelGGL(k_deflate_staged, dim3(g), dim3(NT), st_lds, st, p, 1);
     } else {
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
         hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
-        hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0);
+        if (a->rec_method == S5GPU_REC_ZSTD) hipLaunchKernelGGL(k_zstd_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0);
+        else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0);
     }
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
@@ -799,7 +844,8 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
     p.obuf_words = (DEFL_BLK + 64) / 4;
     p.pay_cap = DEFL_BLK;
     const size_t lds = S_BYTES + 4ull * p.obuf_words + DEFL_BLK;
-    hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
+    if (a->rec_method == S5GPU_REC_ZSTD) hipLaunchKernelGGL(k_zstd_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
+    else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }

@@ -56,7 +56,7 @@ void *slow5_ptr_compress_solo(enum slow5_press_method method, const void *ptr, s
         memcpy(out, ptr, count);
         len = count;
     } else {
-        const int stage = method == SLOW5_COMPRESS_ZLIB ? 0 : method == SLOW5_COMPRESS_SVB_ZD ? 2 : -1;
+        const int stage = method == SLOW5_COMPRESS_ZLIB ? 0 : method == SLOW5_COMPRESS_SVB_ZD ? 2 : method == SLOW5_COMPRESS_ZSTD ? 5 : -1;
         const void *in[1] = {ptr};
         if (stage < 0 || s5gpu_solo_batch(stage, 1, in, &count, &out, &len, NULL) != S5GPU_OK) { slow5_errno = SLOW5_ERR_PRESS; return NULL; }
     }

@@ -128,6 +128,8 @@ def make_read_desc(n_samples, hdr_len, aux_len, rec_method, sig_method):
     pay = hdr_len + 8 + sigb + aux_len
     if rec_method == REC_ZLIB:
         slot = pay + 6 * (pay // 16384 + 1) + 14
+    elif rec_method == REC_ZSTD:
+        slot = pay + 4 * (pay // 16384 + 1) + 24
     else:
         slot = pay + 8
     slot = (slot + 16 + 15) // 16 * 16

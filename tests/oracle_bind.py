@@ -338,3 +338,15 @@ def zstd_restated_decompress(frame, cap):
     out = C.create_string_buffer(cap + 1)
     n = L.s5o_zstd_restated_decompress(frame, len(frame), out, cap)
     return None if n == 2**64 - 1 else out.raw[:n]
+
+
+def zstd_literals_compress(data):
+    """oracle/zstd_enc.c: the frame layout of the device encoder, stated on the CPU"""
+    L = lib()
+    L.s5o_zstd_literals_bound.restype = C.c_size_t
+    L.s5o_zstd_literals_bound.argtypes = [C.c_size_t]
+    L.s5o_zstd_literals_compress.restype = C.c_size_t
+    L.s5o_zstd_literals_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    out = C.create_string_buffer(L.s5o_zstd_literals_bound(len(data)))
+    n = L.s5o_zstd_literals_compress(data, len(data), out)
+    return out.raw[:n]

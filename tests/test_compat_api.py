@@ -77,7 +77,10 @@ def _malloc_copy(b):
 
 
 def test_press_init_rejects_unimplemented_codecs(L):
-    assert not L.slow5_press_init(PressMethod(3, 0))      # zstd record press: not built
+    assert not L.slow5_press_init(PressMethod(7, 0))      # no such method
+    z = L.slow5_press_init(PressMethod(3, SVB))           # zstd record press
+    assert z and z.contents.record_press.contents.method == 3
+    L.slow5_press_free(z)
     assert not L.slow5_press_init(PressMethod(4, 0))      # ex-zd is a signal press, not a record press
     q = L.slow5_press_init(PressMethod(ZLIB, 4))          # zlib + ex-zd: the `degrade` default
     assert q and q.contents.signal_press.contents.method == 4
@@ -150,6 +153,15 @@ def test_solo_press_calls(L):
         assert C.string_at(p, n.value) == data
         libc.free(p)
     assert not L.slow5_ptr_depress_solo(ZLIB, b"\x78\x9c\x01\x02", 4, C.byref(n))      # truncated stream -> NULL
+    for data in (b"", b"a", bytes(1000), blob, rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()):   # zstd (method 3) both ways
+        p = L.slow5_ptr_compress_solo(3, data, len(data), C.byref(n))
+        z = C.string_at(p, n.value)
+        libc.free(p)
+        assert ob.zstd_restated_decompress(z, len(data)) == data
+        p = L.slow5_ptr_depress_solo(3, z, len(z), C.byref(n))
+        assert C.string_at(p, n.value) == data
+        libc.free(p)
+    assert not L.slow5_ptr_depress_solo(3, b"\x28\xb5\x2f\xfd\x20", 5, C.byref(n))
 
 
 def test_merge_batch_rewrites_read_group(L):

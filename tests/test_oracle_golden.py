@@ -401,3 +401,32 @@ def test_zstd_restated_decoder_rejects_or_agrees_on_damaged_frames():
             #  damaged frames that the restatement rejects; never the other way round on valid data)
         for cut in range(0, len(f), max(1, len(f) // 25)):
             assert ob.zstd_restated_decompress(f[:cut], len(d)) is None
+
+
+def zstd_literal_inputs(rng):
+    """byte blocks that steer the literals-only encoder through each of its paths"""
+    yield from zstd_test_inputs(rng, sizes=(10, 100, 1000, 5000, 40000))
+    for n in (64, 100, 1000, 5000, 16383, 16384, 16385, 20000, 70000):
+        yield bytes(np.clip(rng.normal(128, 30, n), 0, 255).astype(np.uint8))                       # > 128 symbols: FSE-compressed weights
+        yield bytes(np.clip(rng.normal(10, 3, n), 0, 255).astype(np.uint8)) + bytes(range(256))     # few heavy, many rare
+        yield bytes(rng.integers(0, 256, n, dtype=np.uint8))                                        # incompressible: raw blocks
+        yield bytes((rng.integers(0, 256, n) * (rng.random(n) < 0.02)).astype(np.uint8)) + bytes(range(256))
+        yield bytes(rng.integers(0, 100, n, dtype=np.uint8))                                        # <= 128 symbols: direct weights
+        yield bytes([7]) * n                                                                        # RLE blocks
+        yield bytes(rng.choice(np.array([3, 250], dtype=np.uint8), n, p=[.97, .03]))               # two symbols
+
+
+@needs_zstd
+def test_zstd_literals_only_frames_are_valid():
+    """oracle/zstd_enc.c (the layout the device encoder writes): libzstd and the restated decoder both take its frames"""
+    rng = np.random.default_rng(13)
+    n = 0
+    for d in zstd_literal_inputs(rng):
+        f = ob.zstd_literals_compress(d)
+        assert ob.zstd_decompress(f) == d and ob.zstd_restated_decompress(f, len(d)) == d
+        assert len(f) <= len(d) + 3 * (len(d) // 16384 + 1) + 9
+        n += 1
+    assert n > 80
+    b5 = Blow5(golden("exp_1_lossless_zstd_svb_v0.2.0.blow5"))
+    p = ob.zstd_decompress(b5.records[0])
+    assert len(ob.zstd_literals_compress(p)) < 1.04 * len(b5.records[0])     # literals only: within 4 % of the reference's frame

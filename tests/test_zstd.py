@@ -118,3 +118,104 @@ def test_payload_slot_too_small_is_retried_with_the_frame_size(press):
         assert got["status"] == want and got["payload_len"] == 50000
         if want == 0:
             assert bytes(pay[:50000].cpu().numpy()) == d
+
+
+# ---- encode side (csrc/zstd_enc_dev.h): valid frames that libzstd decompresses to the identical payload ----
+def zstd_solo_compress(datas):
+    from slow5tools_amd import _lib
+    L = _lib.lib()
+    n = len(datas)
+    bufs = [C.create_string_buffer(d, len(d)) if len(d) else C.create_string_buffer(1) for d in datas]
+    inp = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    lens = (C.c_size_t * n)(*[len(d) for d in datas])
+    out, olen, st = (C.c_void_p * n)(), (C.c_size_t * n)(), (C.c_int32 * n)()
+    _lib.check(L.s5gpu_solo_batch(5, n, inp, lens, out, olen, st), "s5gpu_solo_batch(5)")
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    res = []
+    for i in range(n):
+        res.append(C.string_at(out[i], olen[i]))
+        libc.free(out[i])
+    return res
+
+
+def test_compressed_buffers_are_valid_frames(press):
+    """every block type (raw / RLE / Huffman with direct and FSE-compressed weights), block boundaries, tiny inputs"""
+    if ob.zstd_ref() is None:
+        pytest.skip("no libzstd.so.1 in this image")
+    from test_oracle_golden import zstd_literal_inputs
+    datas = list(zstd_literal_inputs(np.random.default_rng(31)))
+    frames = zstd_solo_compress(datas)
+    worst = 0.0
+    for d, f in zip(datas, frames):
+        assert ob.zstd_decompress(f) == d
+        assert len(f) <= len(d) + 3 * (len(d) // 16384 + 1) + 9
+        twin = ob.zstd_literals_compress(d)
+        if len(d) >= 1000:
+            worst = max(worst, len(f) / len(twin))
+    assert worst < 1.02                                     # same layout as the CPU statement; code lengths may differ a little
+    rc, back, st = zstd_solo(frames)                        # and the device decoder reads its own frames
+    assert rc == 0 and back == datas
+
+
+def _hdr(press, i):
+    return press.pack_hdr(b"read_%06d" % i, i % 3, 8192.0, 23.0, 1467.61, 4000.0)
+
+
+@pytest.mark.parametrize("sig_name", ["svb-zd", "none", "ex-zd"])
+def test_records_encode_to_frames_libzstd_reads(press, sig_name):
+    sm = {"svb-zd": press.SIG_SVB_ZD, "none": press.SIG_NONE, "ex-zd": press.SIG_EX_ZD}[sig_name]
+    rng = np.random.default_rng(32)
+    sigs = [(500 + np.cumsum(rng.integers(-15, 16, n)) % 300).astype(np.int16)
+            for n in (0, 1, 5, 50, 100, 400, 1000, 4000, 4000, 9000, 20000, 70000, 150000)]   # fused, overflow list and multi-block staged reads
+    sigs += [np.zeros(5000, np.int16), np.full(40000, 77, np.int16), rng.integers(-32768, 32768, 6000).astype(np.int16)]
+    sigs += [ob.synth_read(0x5105, i, 4000) for i in range(40)]
+    hdrs = [_hdr(press, i) for i in range(len(sigs))]
+    auxs = [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 40, len(sigs))]
+    out = press.encode_records(sigs, hdrs, auxs, press.REC_ZSTD, sm)
+    raw = press.encode_records(sigs, hdrs, auxs, press.REC_NONE, sm)
+    for o, r in zip(out, raw):
+        assert int.from_bytes(o[:8], "little") == len(o) - 8
+        if ob.zstd_ref() is not None:
+            assert ob.zstd_decompress(o[8:]) == r[8:]
+        assert ob.zstd_restated_decompress(o[8:], len(r)) == r[8:]
+    dec = press.decode_records([o[8:] for o in out], press.REC_ZSTD, sm)
+    for d, s, a in zip(dec, sigs, auxs):
+        assert d["status"] == 0 and np.array_equal(d["signal"], s) and d["aux"] == a
+
+
+def test_all_staged_batch_and_tiny_lds_budget(press):
+    """long reads only (every read staged) and a batch forced onto the overflow list"""
+    rng = np.random.default_rng(33)
+    sigs = [(600 + rng.integers(-50, 50, n)).astype(np.int16) for n in (120000, 90000, 100001)]
+    hdrs = [_hdr(press, i) for i in range(len(sigs))]
+    out = press.encode_records(sigs, hdrs, None, press.REC_ZSTD, press.SIG_SVB_ZD)
+    raw = press.encode_records(sigs, hdrs, None, press.REC_NONE, press.SIG_SVB_ZD)
+    for o, r in zip(out, raw):
+        assert ob.zstd_restated_decompress(o[8:], len(r)) == r[8:]
+    b = press.DeviceBatch([len(s) for s in sigs[:1]] + [4000] * 8, hdr_len=len(_hdr(press, 0)), rec_method=press.REC_ZSTD, lds_payload_cap=1024, with_stream_out=False)
+    some = [sigs[0]] + [ob.synth_read(1, i, 4000) for i in range(8)]
+    b.upload(some, [_hdr(press, i) for i in range(9)])
+    b.encode()
+    recs = b.records()
+    want = press.encode_records(some, [_hdr(press, i) for i in range(9)], None, press.REC_NONE, press.SIG_SVB_ZD)
+    for o, r in zip(recs, want):
+        assert ob.zstd_restated_decompress(o[8:], len(r)) == r[8:]
+
+
+def test_view_to_zstd_and_back_through_the_compat_api(press, tmp_path):
+    """s5view zlib -> zstd -> zlib: the payloads survive (the container path behind `view -c zstd`)"""
+    from test_container import _run
+    src = golden("exp_1_lossless_zlib_svb_v0.2.0.blow5")
+    mid, back = str(tmp_path / "z.blow5"), str(tmp_path / "back.blow5")
+    _run(src, mid, "zstd", "svb-zd")
+    b5 = Blow5(mid)
+    assert b5.rec_method == 2 and b5.sig_method == 1
+    want = [zlib.decompress(r) for r in Blow5(src).records]
+    assert [ob.zstd_restated_decompress(r, 10 ** 6) for r in b5.records] == want
+    _run(mid, back, "zlib", "svb-zd")
+    assert [zlib.decompress(r) for r in Blow5(back).records] == want
+    # and the reference's own zstd file converts to the bytes of its zlib twin's payloads
+    out2 = str(tmp_path / "ref.blow5")
+    _run(golden("exp_1_lossless_zstd_svb_v0.2.0.blow5"), out2, "none", "svb-zd")
+    assert Blow5(out2).records == want
