@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list
 
 // zstd record press, fused: payload in LDS -> literals-only zstd frame (zstd_enc_dev.h).  Same shape as k_encode_fused.
 template <bool EXZD>
-__global__ __launch_bounds__(NT) void k_zstd_fused(EncParams p) {
+__global__ __launch_bounds__(NT, 6) void k_zstd_fused(EncParams p) {
     const uint32_t r = blockIdx.x;
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
@@ -329,7 +329,8 @@ __global__ __launch_bounds__(NT) void k_zstd_fused(EncParams p) {
         return;
     }
     __syncthreads();
-    const uint32_t total = zstd_record<false>(S, obuf, p.obuf_words, pay, nullptr, plen, p.a.slots + d.out_off);
+    if (p.dbg == 9) { if (threadIdx.x == 0) p.a.out_len[r] = plen; return; }   // payload only
+    const uint32_t total = zstd_record<false>(S, obuf, p.obuf_words, pay, nullptr, plen, p.a.slots + d.out_off, p.dbg);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
 }
 // ... and staged: a parked payload, 16 KiB block at a time through LDS (k_deflate_staged's twin)

@@ -10,9 +10,11 @@
 // One record per 256-thread workgroup, one block at a time:
 //   histogram     4 per-wave sub-histograms in the (still dead) build scratch, summed into S.freq;
 //   code lengths  build_lengths<> of the DEFLATE side, capped at 11 bits (deflate_dev.h);
-//   wave 0        weights, canonical codes (longest first, symbol order), the Huffman tree description: direct nibbles for
-//                 <= 128 weights, else FSE-compressed — normalised counts by lane 0, the two interleaved state chains walked
-//                 backwards with one table cell per lane (the cell whose interval holds the next state is a ballot away);
+//   two waves     canonical codes (longest first, symbol order) on one; on another the Huffman tree description: direct
+//                 nibbles for <= 128 weights, else FSE-compressed — normalised counts in uniform code, one decode cell per
+//                 lane, the two interleaved state chains walked backwards (the cell whose interval holds the next state
+//                 is a ballot away), transition bits packed by a prefix sum.  Which two waves rotates with the workgroup
+//                 id, so the resident workgroups of a CU spread this serial work over its four SIMDs (15.0 -> 10.5 ms);
 //   streams       wave k packs stream k: a lane owns a contiguous run of bytes, a wave suffix sum of the code lengths gives
 //                 its bit offset (the LAST byte of a stream sits at bit 0: zstd reads its streams backwards);
 //   output        the same LDS bit buffer / ZOut / flush_words machinery as the DEFLATE blocks.
@@ -26,9 +28,8 @@ constexpr int ZSTD_MAXBITS = 11;
 
 // scratch of the tree description (wave 0); lives in DeflShared fields the zstd path does not otherwise use
 struct ZstdDesc {
-    uint8_t bytes[192];      // the description itself
-    uint32_t cnt[16];        // weights histogram
-    int32_t norm[16];
+    uint32_t words[48];      // the description itself (192 bytes), assembled with byte stores and word ORs
+    uint8_t state[256];      // state[k]: FSE state that emits weight k
     uint32_t cell[64];       // FSE decode cell: symbol | bits << 8 | base << 16
 };
 static_assert(sizeof(ZstdDesc) <= sizeof(DeflShared::code) + sizeof(DeflShared::clseq), "ZstdDesc overlays S.code and S.clseq");
@@ -38,27 +39,37 @@ __device__ __forceinline__ void zput_bytes(uint32_t *obuf, const ZOut &z, uint32
     if (nbytes > 4) put_bits(obuf, z, bitpos + 32, (uint32_t)(v >> 32), 8 * (nbytes - 4));
 }
 
-// Huffman tree description into D.bytes (wave 0, all 64 lanes).  Returns its length, 0 = not representable.
+// Huffman tree description into D.words (wave 0, all 64 lanes).  Returns its length in bytes, 0 = not representable.
+// Weights w[0..n) are sent (the weight of symbol n, the largest one in use, is implied).  Up to 128 weights go as nibbles.
+// More are FSE-compressed (table log 6): lane 0 normalises the 13-bin weight histogram and writes the count header; the 64
+// decode cells are then built one per lane (cell i is slot 3i mod 64 of the spread: 43 * 3 = 1 mod 64); the two interleaved
+// state chains are walked backwards — the only serial part, one ballot per weight: the cell of symbol w[k] whose interval
+// holds state[k + 2] — and the transition bits are packed by all lanes with a prefix sum of their widths.
 __device__ __forceinline__ uint32_t zstd_tree_desc(ZstdDesc &D, const uint8_t *lens, int n, int maxbits) {
     const int lane = lane_id();
-    auto weight = [&](int s) -> uint32_t { const uint32_t l = lens[s]; return l ? (uint32_t)(maxbits + 1) - l : 0u; };
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(D.words);
+    uint32_t wr[4];                                                // weights of symbols lane, lane + 64, lane + 128, lane + 192
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const uint32_t l = lens[lane + 64 * j]; wr[j] = l ? (uint32_t)(maxbits + 1) - l : 0u; }
     if (n <= 128) {
-        if (lane == 0) D.bytes[0] = (uint8_t)(127 + n);
-        const int nb = (n + 1) / 2;
-        if (lane < nb) {
-            const uint32_t hi = weight(2 * lane), lo = 2 * lane + 1 < n ? weight(2 * lane + 1) : 0u;
-            D.bytes[1 + lane] = (uint8_t)((hi << 4) | lo);
+        if (lane == 0) bytes[0] = (uint8_t)(127 + n);
+        // byte j = w[2j] << 4 | w[2j + 1]: pair up neighbouring lanes
+        const uint32_t nx0 = wave_next(wr[0], 0), nx1 = wave_next(wr[1], 0);
+        if (!(lane & 1)) {
+            if (lane < n) bytes[1 + (lane >> 1)] = (uint8_t)((wr[0] << 4) | (lane + 1 < n ? nx0 : 0u));
+            if (lane + 64 < n) bytes[1 + 32 + (lane >> 1)] = (uint8_t)((wr[1] << 4) | (lane + 65 < n ? nx1 : 0u));
         }
         wave_sync();
-        return 1u + (uint32_t)nb;
+        return 1u + (uint32_t)(n + 1) / 2;
     }
     constexpr int LOG = 6, SIZE = 64;
+    if (lane < 48) D.words[lane] = 0;
     // histogram of the weights
     uint32_t mycnt = 0;                                            // lane q < 13 ends with the count of weight q
     int maxw = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int s = base + lane;
-        const uint32_t w = s < n ? weight(s) : 99u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t w = lane + 64 * j < n ? wr[j] : 99u;
 #pragma unroll
         for (int q = 0; q < 13; q++) {
             const uint32_t c = (uint32_t)__popcll(__ballot(w == (uint32_t)q));
@@ -67,33 +78,35 @@ __device__ __forceinline__ uint32_t zstd_tree_desc(ZstdDesc &D, const uint8_t *l
         }
     }
     if (__ballot(lane < 13 && mycnt == (uint32_t)n)) return 0;     // one weight value only: an FSE stream of it cannot end
-    int v = 0;
-    if (lane < 13 && mycnt) { v = (int)(mycnt * SIZE / (uint32_t)n); if (v < 1) v = 1; }
-    if (lane < 16) { D.cnt[lane] = lane < 13 ? mycnt : 0; D.norm[lane] = v; }
-    wave_sync();
-    uint32_t dl = 0;
-    if (lane == 0) {
-        int sum = 0, big = 0;
-        for (int q = 0; q <= maxw; q++) { sum += D.norm[q]; if (D.cnt[q] > D.cnt[big]) big = q; }
-        if (sum < SIZE) D.norm[big] += SIZE - sum;
-        while (sum > SIZE) {
-            int m = 0;
-            for (int q = 1; q <= maxw; q++) if (D.norm[q] > D.norm[m]) m = q;
-            D.norm[m]--; sum--;
+    // normalise to 64 slots, every weight in use at least one; lane q holds norm[q].  Uniform code: no lane-0 section.
+    uint32_t v = 0;
+    if (lane < 13 && mycnt) { v = mycnt * SIZE / (uint32_t)n; if (v < 1) v = 1; }
+    {
+        uint32_t sum = wave_sum(v);
+        const int kbig = __builtin_amdgcn_readlane(wave_incl_max(lane < 13 ? (int)((mycnt << 4) | (uint32_t)(15 - lane)) : 0), 63);
+        if (sum < (uint32_t)SIZE && lane == 15 - (kbig & 15)) v += (uint32_t)SIZE - sum;
+        while (sum > (uint32_t)SIZE) {                             // take from the largest entries
+            const int km = __builtin_amdgcn_readlane(wave_incl_max(lane < 13 ? (int)((v << 4) | (uint32_t)(15 - lane)) : 0), 63);
+            if (lane == 15 - (km & 15)) v--;
+            sum--;
         }
-        // normalised counts (writer side of z_ncount / oracle fse_read_ncount)
-        uint64_t acc = (uint64_t)(LOG - 5);
-        int nacc = 4;
-        uint32_t o = 1;
-        int remaining = SIZE + 1, threshold = SIZE, nbits = LOG + 1, prev0 = 0, s = 0;
-        while (s <= maxw && remaining > 1) {
+    }
+    // normalised counts (writer side of z_ncount / oracle fse_read_ncount); bits 0-7 are the header byte, filled in last
+    uint32_t dl;
+    {
+        uint64_t acc = (uint64_t)(LOG - 5) << 8;
+        int nacc = 12;
+        uint32_t ow = 0;
+        int remaining = SIZE + 1, threshold = SIZE, nbits = LOG + 1, prev0 = 0, sy = 0;
+        while (sy <= maxw && remaining > 1) {
             if (prev0) {
-                int start = s;
-                while (!D.norm[s]) s++;
-                while (s >= start + 3) { start += 3; acc |= 3ull << nacc; nacc += 2; }
-                acc |= (uint64_t)(s - start) << nacc; nacc += 2;
+                int start = sy;
+                while (!__builtin_amdgcn_readlane((int)v, sy)) sy++;
+                while (sy >= start + 3) { start += 3; acc |= 3ull << nacc; nacc += 2; }
+                acc |= (uint64_t)(sy - start) << nacc; nacc += 2;
             }
-            int count = D.norm[s++];
+            int count = __builtin_amdgcn_readlane((int)v, sy);
+            sy++;
             const int maxv = (2 * threshold - 1) - remaining;
             remaining -= count;
             count++;
@@ -102,67 +115,89 @@ __device__ __forceinline__ uint32_t zstd_tree_desc(ZstdDesc &D, const uint8_t *l
             nacc += nbits - (count < maxv);
             prev0 = count == 1;
             while (remaining < threshold) { nbits--; threshold >>= 1; }
-            while (nacc >= 8) { D.bytes[o++] = (uint8_t)acc; acc >>= 8; nacc -= 8; }
+            if (nacc >= 32) { if (lane == 0) D.words[ow] = (uint32_t)acc; ow++; acc >>= 32; nacc -= 32; }
         }
-        if (nacc) D.bytes[o++] = (uint8_t)acc;
-        dl = o;
-        // the decoder's table for this distribution (z_fse_build), one cell per entry of D.cell
-        uint32_t next[13];
-        uint8_t *spread = reinterpret_cast<uint8_t *>(D.cnt);       // 64 bytes: cnt is dead
-        for (int q = 0; q < 13; q++) next[q] = q <= maxw ? (uint32_t)D.norm[q] : 0u;
-        const int step = (SIZE >> 1) + (SIZE >> 3) + 3, mask = SIZE - 1;
-        int pos = 0;
-        for (int q = 0; q <= maxw; q++)
-            for (int i = 0; i < D.norm[q]; i++) { spread[pos] = (uint8_t)q; pos = (pos + step) & mask; }
-        for (int i = 0; i < SIZE; i++) {
-            const int q = spread[i];
-            uint32_t ns = 0;
-#pragma unroll
-            for (int t = 0; t < 13; t++) if (t == q) { ns = next[t]; next[t]++; }
-            const int nb = LOG - (31 - __clz((int)ns));
-            D.cell[i] = (uint32_t)q | ((uint32_t)nb << 8) | (((ns << nb) - (uint32_t)SIZE) << 16);
-        }
+        if (nacc && lane == 0) D.words[ow] = (uint32_t)acc;
+        dl = 4 * ow + (uint32_t)((nacc + 7) >> 3);
     }
     wave_sync();
-    dl = (uint32_t)__builtin_amdgcn_readfirstlane((int)dl);
-    const uint32_t cell = D.cell[lane];
-    const uint32_t csym = cell & 255u, cnb = (cell >> 8) & 255u, cbase = cell >> 16;
-    auto first_cell = [&](uint32_t w) -> uint32_t { return (uint32_t)__ffsll((long long)__ballot(csym == w)) - 1u; };   // its costliest state
-    uint32_t st0, st1;
+    // my decode cell: slot j of the spread holds the symbol whose cumulative count covers j; its k-th cell (in cell order) is
+    // the decoder's "next state" count + k
+    uint32_t csym = 0, cnb, cbase;
     {
-        const uint32_t a = first_cell(weight(n - 1)), b = first_cell(weight(n - 2));
-        if ((n - 1) & 1) { st1 = a; st0 = b; } else { st0 = a; st1 = b; }
-    }
-    uint64_t acc = 0;
-    int nacc = 0;
-    uint32_t o = dl;
-    for (int k = n - 3; k >= 0; k--) {
-        const uint32_t next = (k & 1) ? st1 : st0, wk = weight(k);
-        const uint64_t m = __ballot(csym == wk && next >= cbase && next < cbase + (1u << cnb));
-        const int found = __ffsll((long long)m) - 1;               // exactly one cell of a symbol covers a state
-        const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)cbase, found), fn = (uint32_t)__builtin_amdgcn_readlane((int)cnb, found);
-        acc |= (uint64_t)(next - fb) << nacc;
-        nacc += (int)fn;
-        if (k & 1) st1 = (uint32_t)found; else st0 = (uint32_t)found;
-        if (nacc >= 32) {
-            if (lane == 0) { D.bytes[o] = (uint8_t)acc; D.bytes[o + 1] = (uint8_t)(acc >> 8); D.bytes[o + 2] = (uint8_t)(acc >> 16); D.bytes[o + 3] = (uint8_t)(acc >> 24); }
-            o += 4; acc >>= 32; nacc -= 32;
-            if (o > 180) return 0;
+        const uint32_t slot = (3u * (uint32_t)lane) & 63u;
+        uint32_t cum = 0, mynorm = 0;
+#pragma unroll
+        for (int q = 0; q < 13; q++) {
+            const uint32_t nq = (uint32_t)__builtin_amdgcn_readlane((int)v, q);
+            if (slot >= cum && slot < cum + nq) { csym = (uint32_t)q; mynorm = nq; }
+            cum += nq;
         }
+        uint32_t ns = 0;
+#pragma unroll
+        for (int q = 0; q < 13; q++) {
+            const uint64_t m = __ballot(csym == (uint32_t)q);
+            if (csym == (uint32_t)q) ns = mynorm + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        }
+        cnb = (uint32_t)LOG - (uint32_t)(31 - __clz((int)ns));
+        cbase = (ns << cnb) - (uint32_t)SIZE;
+        D.cell[lane] = csym | (cnb << 8) | (cbase << 16);
     }
-    acc |= (uint64_t)st1 << nacc; nacc += LOG;
-    acc |= (uint64_t)st0 << nacc; nacc += LOG;
-    acc |= 1ull << nacc; nacc += 1;
-    while (nacc > 0) { if (lane == 0) D.bytes[o] = (uint8_t)acc; o++; acc >>= 8; nacc -= 8; }
+    auto wget = [&](int k) -> uint32_t {                           // w[k], uniform
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)wr[0], k & 63), b = (uint32_t)__builtin_amdgcn_readlane((int)wr[1], k & 63);
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)wr[2], k & 63), d = (uint32_t)__builtin_amdgcn_readlane((int)wr[3], k & 63);
+        return k < 64 ? a : k < 128 ? b : k < 192 ? c : d;
+    };
+    auto first_cell = [&](uint32_t w) -> uint32_t { return (uint32_t)__ffsll((long long)__ballot(csym == w)) - 1u; };   // its costliest state (>= 1 bit)
+    auto prev_state = [&](uint32_t w, uint32_t next) -> uint32_t {   // exactly one cell of a symbol covers a state
+        return (uint32_t)__ffsll((long long)__ballot(csym == w && next >= cbase && next < cbase + (1u << cnb))) - 1u;
+    };
+    {
+        uint32_t sa = first_cell(wget(n - 1)), sb = first_cell(wget(n - 2));   // chains of k = n-1, n-3, ... and k = n-2, n-4, ...
+        if (lane == 0) { D.state[n - 1] = (uint8_t)sa; D.state[n - 2] = (uint8_t)sb; }
+        int k = n - 3;
+        for (; k >= 1; k -= 2) {                                   // two independent recurrences per trip
+            sa = prev_state(wget(k), sa);
+            sb = prev_state(wget(k - 1), sb);
+            if (lane == 0) { D.state[k] = (uint8_t)sa; D.state[k - 1] = (uint8_t)sb; }
+        }
+        if (k == 0) { sa = prev_state(wget(0), sa); if (lane == 0) D.state[0] = (uint8_t)sa; }
+    }
+    wave_sync();
+    // transition k (k = n-3 first, at the lowest bits): value state[k+2] - base(state[k]), width bits(state[k])
+    uint32_t run = 8 * dl;                                          // bit position in D.words
+    for (int t0 = 0; t0 < n - 2; t0 += 64) {
+        const int t = t0 + lane, k = n - 3 - t;
+        uint32_t nb = 0, val = 0;
+        if (t < n - 2) {
+            const uint32_t cell = D.cell[D.state[k]];
+            nb = (cell >> 8) & 255u;
+            val = (uint32_t)D.state[k + 2] - (cell >> 16);
+        }
+        const uint32_t incl = wave_incl_add(nb);
+        const uint32_t pos = run + incl - nb;
+        if (nb) {
+            atomicOr(&D.words[pos >> 5], val << (pos & 31));
+            if ((pos & 31) + nb > 32) atomicOr(&D.words[(pos >> 5) + 1], val >> (32 - (pos & 31)));
+        }
+        run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (run > 8 * 150) return 0;                                // cannot end below 128 bytes
+    }
+    if (lane == 0) {                                                // the two final states and the end mark
+        const uint32_t tail = (uint32_t)D.state[1] | ((uint32_t)D.state[0] << LOG) | (1u << (2 * LOG));
+        atomicOr(&D.words[run >> 5], tail << (run & 31));
+        if ((run & 31) + 13 > 32) atomicOr(&D.words[(run >> 5) + 1], tail >> (32 - (run & 31)));
+    }
+    const uint32_t o = (run + 13 + 7) >> 3;
     if (o - 1 >= 128) return 0;
-    if (lane == 0) D.bytes[0] = (uint8_t)(o - 1);
+    if (lane == 0) bytes[0] = (uint8_t)(o - 1);
     wave_sync();
     return o;
 }
 
 // One zstd block of blen <= DEFL_BLK bytes at LDS `stage` into the bit buffer (B overlays obuf, as deflate_block MODE 2).
 __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words, const uint8_t *stage,
-                                           uint32_t blen, bool last, ZOut &z) {
+                                           uint32_t blen, bool last, ZOut &z, uint32_t dbg = 0) {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     ZstdDesc &D = *reinterpret_cast<ZstdDesc *>(S.code);
     // ---- histogram: one sub-histogram per wave, in scratch that is dead until build_lengths ----
@@ -190,6 +225,7 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
     }
     __syncthreads();
     const uint32_t distinct = S.red[0], maxsym = S.red[1];
+    if (dbg == 1) { z.bitpos += distinct; return; }   // tools/ cut-offs (S5GPU_DEBUG_STAGE)
     int type = 0;                                                   // 0 raw, 1 RLE, 2 compressed
     uint32_t dl = 0, hl = 0, csize = 0, sbytes[4] = {0, 0, 0, 0};
     const uint32_t per = (blen + 3) >> 2;
@@ -199,45 +235,53 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
     else if (blen >= 64) {
         if (tid == 0) S.dbg = 0;
         build_lengths(S, B, &B.sort, S.freq, 256, ZSTD_MAXBITS, S.lens, S.blcount, S.icount);
+        if (dbg == 2) { z.bitpos += S.lens[tid]; return; }
         // ---- stream k on wave k: bits of my run, then (wave 0) codes and the tree description ----
         const uint32_t sfrom = (uint32_t)wv * per, sto = wv == 3 ? blen : sfrom + per;
         const uint32_t count = sto - sfrom;
         cs = (count + 63) >> 6;
         c0 = min(sfrom + (uint32_t)lane * cs, sto); c1 = min(c0 + cs, sto);
-        for (uint32_t i = c0; i < c1; i++) mybits += S.lens[stage[i]];
+        if (dbg != 33) for (uint32_t i = c0; i < c1; i++) mybits += S.lens[stage[i]];
         mytotal = wave_sum(mybits);
         if (lane == 0) S.ws[wv] = mytotal;
-        if (wv == 0) {
+        // the two serial jobs go to different waves, and to a different pair from one workgroup to the next: the waves of
+        // the workgroups resident on a CU then spread this work over its four SIMDs instead of piling it on one
+        const int role = (wv + (int)blockIdx.x) & 3;
+        if (role < 2) {
             int maxbits = 0;
 #pragma unroll
             for (int L = 1; L <= ZSTD_MAXBITS; L++) if (__builtin_amdgcn_readfirstlane((int)S.blcount[L])) maxbits = L;
-            // canonical codes: the longest codes take the smallest values, symbol order inside a length
-            uint32_t next[ZSTD_MAXBITS + 2];
-            next[ZSTD_MAXBITS + 1] = 0;
+            if (role == 1 && dbg != 32) {
+                // canonical codes: the longest codes take the smallest values, symbol order inside a length
+                uint32_t next[ZSTD_MAXBITS + 2];
+                next[ZSTD_MAXBITS + 1] = 0;
 #pragma unroll
-            for (int L = ZSTD_MAXBITS; L >= 1; L--) {
-                const uint32_t above = L < ZSTD_MAXBITS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)S.blcount[L + 1]) : 0u;
-                next[L] = L >= maxbits ? 0u : (next[L + 1] + above) >> 1;
-            }
-            for (int base = 0; base < 256; base += 64) {
-                const int s = base + lane;
-                const int l = S.lens[s];
-                uint32_t mine = 0;
-#pragma unroll
-                for (int b = 1; b <= ZSTD_MAXBITS; b++) {
-                    const uint64_t mask = __ballot(l == b);
-                    if (mask == 0) continue;
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (l == b) mine = next[b] + below;
-                    next[b] += (uint32_t)__popcll(mask);
+                for (int L = ZSTD_MAXBITS; L >= 1; L--) {
+                    const uint32_t above = L < ZSTD_MAXBITS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)S.blcount[L + 1]) : 0u;
+                    next[L] = L >= maxbits ? 0u : (next[L + 1] + above) >> 1;
                 }
-                S.freq[s] = l ? mine | ((uint32_t)l << 16) : 0u;     // the histogram is dead: S.freq now holds the codes
+                for (int base = 0; base < 256; base += 64) {
+                    const int s = base + lane;
+                    const int l = S.lens[s];
+                    uint32_t mine = 0;
+#pragma unroll
+                    for (int b = 1; b <= ZSTD_MAXBITS; b++) {
+                        const uint64_t mask = __ballot(l == b);
+                        if (mask == 0) continue;
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        if (l == b) mine = next[b] + below;
+                        next[b] += (uint32_t)__popcll(mask);
+                    }
+                    S.freq[s] = l ? mine | ((uint32_t)l << 16) : 0u;     // the histogram is dead: S.freq now holds the codes
+                }
+            } else if (role == 0) {
+                const uint32_t d = dbg == 31 ? 1u : zstd_tree_desc(D, S.lens, (int)maxsym, maxbits);
+                if (lane == 0) S.red[2] = d;
             }
-            const uint32_t d = zstd_tree_desc(D, S.lens, (int)maxsym, maxbits);
-            if (lane == 0) S.red[2] = d;
         }
         __syncthreads();
         dl = S.red[2];
+        if (dbg == 3 || dbg > 30) { z.bitpos += dl + S.ws[0]; return; }
         if (dl && 3 * per <= blen) {
 #pragma unroll
             for (int k = 0; k < 4; k++) sbytes[k] = (S.ws[k] >> 3) + 1;   // + the end mark
@@ -271,7 +315,7 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
             put_bits(obuf, z, jt, sbytes[0] | (sbytes[1] << 16), 32);
             put_bits(obuf, z, jt + 32, sbytes[2], 16);
         }
-        for (uint32_t i = tid; i < dl; i += NT) put_bits(obuf, z, lit0 + 8 * (hl + i), D.bytes[i], 8);
+        for (uint32_t i = tid; i < dl; i += NT) put_bits(obuf, z, lit0 + 8 * (hl + i), reinterpret_cast<const uint8_t *>(D.words)[i], 8);
         // my stream starts after the tree, the jump table and the streams before it; my run's bits sit above those of the lanes after me
         uint32_t sb = lit0 + 8 * (hl + dl + 6);
 #pragma unroll
@@ -279,6 +323,7 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
         const uint32_t incl = wave_incl_add(mybits);
         uint32_t pos = sb + (mytotal - incl);
         if (lane == 0) put_bits(obuf, z, sb + mytotal, 1u, 1);      // end mark
+        if (dbg == 4) { z.bitpos += pos; return; }
         uint32_t w = (pos >> 5) - z.flushed;
         uint64_t acc = 0;
         uint32_t nacc = pos & 31u;
@@ -301,7 +346,7 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
 // Returns the record length (prefix included).
 template <bool STAGED>
 __device__ __forceinline__ uint32_t zstd_record(DeflShared &S, uint32_t *obuf, uint32_t obuf_words, const uint8_t *src, uint8_t *stage,
-                                                uint32_t plen, uint8_t *out) {
+                                                uint32_t plen, uint8_t *out, uint32_t dbg = 0) {
     const int tid = threadIdx.x;
     BuildScratch &B = *reinterpret_cast<BuildScratch *>(obuf);
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
@@ -326,7 +371,8 @@ __device__ __forceinline__ uint32_t zstd_record(DeflShared &S, uint32_t *obuf, u
             blk = stage;
             __syncthreads();
         }
-        zstd_block(S, B, obuf, obuf_words, blk, blen, last, z);
+        zstd_block(S, B, obuf, obuf_words, blk, blen, last, z, dbg);
+        if (dbg) return z.bitpos >> 3;
         done += blen;
         if (!last) {
             flush_words(obuf, out32, z, false);
