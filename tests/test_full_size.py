@@ -141,3 +141,57 @@ def test_one_million_reads_svbzd_stage_bit_exact_sample_and_full_round_trip():
     for i in range(0, N_READS, 997):
         blob = b.slots[int(slot_off[i]): int(slot_off[i]) + int(lens[i])].cpu().numpy().tobytes()
         assert blob == ob.svbzd_encode(ob.synth_read(0x5105, i, N)), i
+
+
+@pytest.mark.gpu
+def test_zstd_full_size_round_trip_checksum():
+    """BASELINE configs[2] through the zstd record press: 1 M reads encode -> compact -> decode; every signal comes back (checksum
+    of checksums against the synthetic source), every record carries a frame whose declared content size is the payload length"""
+    import ctypes as C
+    import torch
+    from slow5tools_amd import _lib, press
+    L = _lib.lib()
+    _lib.check(L.s5gpu_init(0), "s5gpu_init")
+    n_reads, n_samp = 1_000_000, 4000
+    b = press.DeviceBatch([n_samp] * n_reads, rec_method=press.REC_ZSTD, with_stream_out=True)
+    b.synth()
+    b.encode()
+    b.compact()
+    torch.cuda.synchronize()
+    off = b.rec_off.cpu().numpy()
+    lens = (off[1:] - off[:-1]).astype(np.int64)
+    assert lens.min() > 17 and lens.max() < 8 + s5_slot(press, n_samp)
+    # frame headers: magic + single-segment descriptor + 4-byte content size
+    heads = b.stream_out[torch.from_numpy(off[:-1].astype(np.int64)).to(b.dev)[:, None] + torch.arange(8, 17, device=b.dev)[None, :]].cpu().numpy()
+    assert (heads[:, :5] == np.frombuffer(b"\x28\xb5\x2f\xfd\xa0", np.uint8)).all()
+    declared = heads[:, 5:9].copy().view('<u4')[:, 0]
+    dev = b.dev
+    desc = np.zeros(n_reads, dtype=_lib.REC_DESC)
+    desc["in_off"] = off[:-1] + 8
+    desc["in_len"] = (lens - 8).astype(np.uint32)
+    pcap = (b.tot["max_payload"] + 31) // 16 * 16
+    stride = (n_samp + 7) // 8 * 8
+    desc["pay_off"] = np.arange(n_reads, dtype=np.uint64) * pcap
+    desc["pay_cap"] = pcap - 16
+    desc["sig_off"] = np.arange(n_reads, dtype=np.uint64) * stride
+    desc["sig_cap"] = n_samp
+    t_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    pay = torch.empty(n_reads * pcap + 64, dtype=torch.uint8, device=dev)
+    sig = torch.empty(n_reads * stride + 64, dtype=torch.int16, device=dev)
+    fields = torch.zeros(n_reads * _lib.REC_FIELDS.itemsize, dtype=torch.uint8, device=dev)
+    a = _lib.DecodeArgs()
+    a.n_recs, a.rec_method, a.sig_method = n_reads, press.REC_ZSTD, press.SIG_SVB_ZD
+    a.desc, a.in_, a.payload, a.sig_out, a.fields = t_desc.data_ptr(), b.stream_out.data_ptr(), pay.data_ptr(), sig.data_ptr(), fields.data_ptr()
+    _lib.check(L.s5gpu_decode_dev(C.byref(a), None), "s5gpu_decode_dev")
+    torch.cuda.synchronize()
+    f = fields.cpu().numpy().view(_lib.REC_FIELDS)
+    assert (f["status"] == 0).all() and (f["n_samples"] == n_samp).all()
+    assert (f["payload_len"] == declared).all()                 # every frame header names its payload's length
+    got = sig[: n_reads * stride].view(n_reads, stride)[:, :n_samp]
+    want = b.sig[: n_reads * stride].view(n_reads, stride)[:, :n_samp]
+    assert torch.equal(got, want)
+
+
+def s5_slot(press, n_samp):
+    from slow5tools_amd import _lib
+    return _lib.lib().s5gpu_slot_bound(n_samp, 74, 0, press.REC_ZSTD, press.SIG_SVB_ZD)
