@@ -332,6 +332,23 @@ static uint64_t payload_guess(int rec_method, const void *rec, size_t len) {
                 for (unsigned i = 0; i < nb; i++) v |= (uint64_t)p[at + i] << (8 * i);
                 return flag == 1 ? v + 256 : v;
             }
+            if (!nb && at <= len) {
+                // no content size in the header (streaming writers): walk the block headers — a raw / RLE block says its size,
+                // a compressed one regenerates at most 128 KiB (Block_Maximum_Size)
+                uint64_t bound = 0;
+                size_t q = at;
+                for (;;) {
+                    if (q + 3 > len) break;
+                    const uint32_t bh = p[q] | (p[q + 1] << 8) | ((uint32_t)p[q + 2] << 16);
+                    const uint32_t type = (bh >> 1) & 3, bs = bh >> 3;
+                    q += 3;
+                    if (type == 0) { bound += bs; q += bs; }
+                    else if (type == 1) { bound += bs; q += 1; }
+                    else { bound += 128 * 1024; q += bs; }
+                    if ((bh & 1) || type == 3) break;
+                }
+                return bound + 16;
+            }
         }
         return 8ull * len + 4096;
     }

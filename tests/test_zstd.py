@@ -219,3 +219,31 @@ def test_view_to_zstd_and_back_through_the_compat_api(press, tmp_path):
     out2 = str(tmp_path / "ref.blow5")
     _run(golden("exp_1_lossless_zstd_svb_v0.2.0.blow5"), out2, "none", "svb-zd")
     assert Blow5(out2).records == want
+
+
+def test_frames_without_a_content_size_field(press):
+    """streaming writers may leave the content size out of the frame header (window descriptor instead): the slot is then a
+    guess, a frame that does not fit reports 5 and is retried with a larger one"""
+    if ob.zstd_ref() is None:
+        pytest.skip("no libzstd.so.1 in this image")
+    rng = np.random.default_rng(41)
+    datas, frames = [], []
+    for n in (0, 10, 3000, 50000, 300000):
+        d = bytes(rng.integers(0, 6, n, dtype=np.uint8))                  # compresses ~3x: beyond the first slot guess for the big ones
+        f = ob.zstd_compress(d, 3)
+        fhd = f[4]
+        flag, single = fhd >> 6, (fhd >> 5) & 1
+        nb = {0: single, 1: 2, 2: 4, 3: 8}[flag]
+        body = f[5 + (0 if single else 1) + nb:]
+        g = f[:4] + bytes([0x00, 0x70]) + body                             # no content size, window log 24: same blocks
+        assert ob.zstd_decompress(g, len(d)) == d
+        datas.append(d)
+        frames.append(g)
+    highly = bytes(1 << 20)                                               # 1 MiB of zeros in a ~50-byte frame: far beyond any guess
+    f = ob.zstd_compress(highly, 1)
+    nb = {0: (f[4] >> 5) & 1, 1: 2, 2: 4, 3: 8}[f[4] >> 6]
+    frames.append(f[:4] + bytes([0x00, 0x70]) + f[5 + (0 if (f[4] >> 5) & 1 else 1) + nb:])
+    datas.append(highly)
+    rc, res, st = zstd_solo(frames)
+    assert rc == 0 and all(s == 0 for s in st)
+    assert res == datas
