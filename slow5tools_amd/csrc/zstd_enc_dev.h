@@ -39,13 +39,15 @@ __device__ __forceinline__ void zput_bytes(uint32_t *obuf, const ZOut &z, uint32
     if (nbytes > 4) put_bits(obuf, z, bitpos + 32, (uint32_t)(v >> 32), 8 * (nbytes - 4));
 }
 
-// Huffman tree description into D.words (wave 0, all 64 lanes).  Returns its length in bytes, 0 = not representable.
+// Huffman tree description into D.words, in three steps so that the one serial part can run on two waves at once.
 // Weights w[0..n) are sent (the weight of symbol n, the largest one in use, is implied).  Up to 128 weights go as nibbles.
-// More are FSE-compressed (table log 6): lane 0 normalises the 13-bin weight histogram and writes the count header; the 64
-// decode cells are then built one per lane (cell i is slot 3i mod 64 of the spread: 43 * 3 = 1 mod 64); the two interleaved
-// state chains are walked backwards — the only serial part, one ballot per weight: the cell of symbol w[k] whose interval
-// holds state[k + 2] — and the transition bits are packed by all lanes with a prefix sum of their widths.
-__device__ __forceinline__ uint32_t zstd_tree_desc(ZstdDesc &D, const uint8_t *lens, int n, int maxbits) {
+// More are FSE-compressed (table log 6).  zstd_desc_head (one wave): the 13-bin weight histogram is normalised and written as
+// the count header in uniform code; the 64 decode cells are built one per lane (cell i is slot 3i mod 64 of the spread:
+// 43 * 3 = 1 mod 64).  zstd_desc_chain: the two interleaved state chains are walked backwards, one chain per wave — one
+// ballot per weight finds the cell of symbol w[k] whose interval holds state[k + 2].  zstd_desc_pack (one wave): the
+// transition bits are packed by all lanes with a prefix sum of their widths.
+// zstd_desc_head returns 0 = not representable, the finished length for the nibble form, (count header bytes | 1 << 31) for FSE.
+__device__ __forceinline__ uint32_t zstd_desc_head(ZstdDesc &D, const uint8_t *lens, int n, int maxbits) {
     const int lane = lane_id();
     uint8_t *bytes = reinterpret_cast<uint8_t *>(D.words);
     uint32_t wr[4];                                                // weights of symbols lane, lane + 64, lane + 128, lane + 192
@@ -143,27 +145,46 @@ __device__ __forceinline__ uint32_t zstd_tree_desc(ZstdDesc &D, const uint8_t *l
         cbase = (ns << cnb) - (uint32_t)SIZE;
         D.cell[lane] = csym | (cnb << 8) | (cbase << 16);
     }
-    auto wget = [&](int k) -> uint32_t {                           // w[k], uniform
-        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)wr[0], k & 63), b = (uint32_t)__builtin_amdgcn_readlane((int)wr[1], k & 63);
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)wr[2], k & 63), d = (uint32_t)__builtin_amdgcn_readlane((int)wr[3], k & 63);
-        return k < 64 ? a : k < 128 ? b : k < 192 ? c : d;
-    };
-    auto first_cell = [&](uint32_t w) -> uint32_t { return (uint32_t)__ffsll((long long)__ballot(csym == w)) - 1u; };   // its costliest state (>= 1 bit)
-    auto prev_state = [&](uint32_t w, uint32_t next) -> uint32_t {   // exactly one cell of a symbol covers a state
-        return (uint32_t)__ffsll((long long)__ballot(csym == w && next >= cbase && next < cbase + (1u << cnb))) - 1u;
-    };
-    {
-        uint32_t sa = first_cell(wget(n - 1)), sb = first_cell(wget(n - 2));   // chains of k = n-1, n-3, ... and k = n-2, n-4, ...
-        if (lane == 0) { D.state[n - 1] = (uint8_t)sa; D.state[n - 2] = (uint8_t)sb; }
-        int k = n - 3;
-        for (; k >= 1; k -= 2) {                                   // two independent recurrences per trip
-            sa = prev_state(wget(k), sa);
-            sb = prev_state(wget(k - 1), sb);
-            if (lane == 0) { D.state[k] = (uint8_t)sa; D.state[k - 1] = (uint8_t)sb; }
+    wave_sync();
+    return dl | 0x80000000u;                                        // FSE: the chains and the packing follow
+}
+
+// One of the two interleaved state chains, backwards: par 0 walks k = n-1, n-3, ..., par 1 walks k = n-2, n-4, ...
+// (any wave; the cells come from D.cell).  state[k] = the cell of weight w[k] whose interval holds state[k + 2].
+__device__ __forceinline__ void zstd_desc_chain(ZstdDesc &D, const uint8_t *lens, int n, int maxbits, int par) {
+    const int lane = lane_id();
+    // lanes 0..31 hold 8 weights each, 4 bits apiece: w[k] is one v_readlane and a bit-field extract away
+    uint32_t wp = 0;
+    if (lane < 32) {
+        const uint32_t *l32 = reinterpret_cast<const uint32_t *>(lens);   // S.lens is 16-byte aligned
+        const uint32_t lo = l32[2 * lane], hi = l32[2 * lane + 1];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t l = ((i < 4 ? lo : hi) >> (8 * (i & 3))) & 255u;
+            wp |= (l ? (uint32_t)(maxbits + 1) - l : 0u) << (4 * i);
         }
-        if (k == 0) { sa = prev_state(wget(0), sa); if (lane == 0) D.state[0] = (uint8_t)sa; }
+    }
+    const uint32_t cell = D.cell[lane];
+    const uint32_t csym = cell & 255u, cnb = (cell >> 8) & 255u, cbase = cell >> 16;
+    const uint32_t cend = cbase + (1u << cnb);
+    auto wget = [&](int k) -> uint32_t { return ((uint32_t)__builtin_amdgcn_readlane((int)wp, k >> 3) >> ((k & 7) * 4)) & 15u; };   // uniform
+    int k = n - 1 - par;
+    uint32_t st = (uint32_t)__ffsll((long long)__ballot(csym == wget(k))) - 1u;   // the last symbol of a chain: its costliest state (>= 1 bit)
+    D.state[k] = (uint8_t)st;                                       // every lane stores the same byte: no exec juggling in the loop
+    for (k -= 2; k >= 0; k -= 2) {
+        const uint32_t w = wget(k);
+        st = (uint32_t)__ffsll((long long)__ballot(csym == w && st >= cbase && st < cend)) - 1u;   // exactly one cell of a symbol covers a state
+        D.state[k] = (uint8_t)st;
     }
     wave_sync();
+}
+
+// The transition bits, the two first states and the end mark behind the count header of dl bytes.  Returns the length of the
+// whole description, 0 if it would not fit the 127 bytes its header byte can say.
+__device__ __forceinline__ uint32_t zstd_desc_pack(ZstdDesc &D, int n, uint32_t dl) {
+    const int lane = lane_id();
+    constexpr int LOG = 6;
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(D.words);
     // transition k (k = n-3 first, at the lowest bits): value state[k+2] - base(state[k]), width bits(state[k])
     uint32_t run = 8 * dl;                                          // bit position in D.words
     for (int t0 = 0; t0 < n - 2; t0 += 64) {
@@ -244,42 +265,53 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
         if (dbg != 33) for (uint32_t i = c0; i < c1; i++) mybits += S.lens[stage[i]];
         mytotal = wave_sum(mybits);
         if (lane == 0) S.ws[wv] = mytotal;
-        // the two serial jobs go to different waves, and to a different pair from one workgroup to the next: the waves of
-        // the workgroups resident on a CU then spread this work over its four SIMDs instead of piling it on one
+        // The serial jobs go to different waves, and to different ones from one workgroup to the next: the waves of the
+        // workgroups resident on a CU then spread this work over its four SIMDs instead of piling it on one.
+        // role 0: tree description (head, chain of the odd-from-the-end weights, packing); role 1: canonical codes;
+        // role 2: the other chain.
         const int role = (wv + (int)blockIdx.x) & 3;
-        if (role < 2) {
-            int maxbits = 0;
+        int maxbits = 0;
 #pragma unroll
-            for (int L = 1; L <= ZSTD_MAXBITS; L++) if (__builtin_amdgcn_readfirstlane((int)S.blcount[L])) maxbits = L;
-            if (role == 1 && dbg != 32) {
-                // canonical codes: the longest codes take the smallest values, symbol order inside a length
-                uint32_t next[ZSTD_MAXBITS + 2];
-                next[ZSTD_MAXBITS + 1] = 0;
+        for (int L = 1; L <= ZSTD_MAXBITS; L++) if (__builtin_amdgcn_readfirstlane((int)S.blcount[L])) maxbits = L;
+        if (role == 1 && dbg != 32) {
+            // canonical codes: the longest codes take the smallest values, symbol order inside a length
+            uint32_t next[ZSTD_MAXBITS + 2];
+            next[ZSTD_MAXBITS + 1] = 0;
 #pragma unroll
-                for (int L = ZSTD_MAXBITS; L >= 1; L--) {
-                    const uint32_t above = L < ZSTD_MAXBITS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)S.blcount[L + 1]) : 0u;
-                    next[L] = L >= maxbits ? 0u : (next[L + 1] + above) >> 1;
-                }
-                for (int base = 0; base < 256; base += 64) {
-                    const int s = base + lane;
-                    const int l = S.lens[s];
-                    uint32_t mine = 0;
-#pragma unroll
-                    for (int b = 1; b <= ZSTD_MAXBITS; b++) {
-                        const uint64_t mask = __ballot(l == b);
-                        if (mask == 0) continue;
-                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                        if (l == b) mine = next[b] + below;
-                        next[b] += (uint32_t)__popcll(mask);
-                    }
-                    S.freq[s] = l ? mine | ((uint32_t)l << 16) : 0u;     // the histogram is dead: S.freq now holds the codes
-                }
-            } else if (role == 0) {
-                const uint32_t d = dbg == 31 ? 1u : zstd_tree_desc(D, S.lens, (int)maxsym, maxbits);
-                if (lane == 0) S.red[2] = d;
+            for (int L = ZSTD_MAXBITS; L >= 1; L--) {
+                const uint32_t above = L < ZSTD_MAXBITS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)S.blcount[L + 1]) : 0u;
+                next[L] = L >= maxbits ? 0u : (next[L + 1] + above) >> 1;
             }
+            for (int base = 0; base < 256; base += 64) {
+                const int s = base + lane;
+                const int l = S.lens[s];
+                uint32_t mine = 0;
+#pragma unroll
+                for (int b = 1; b <= ZSTD_MAXBITS; b++) {
+                    const uint64_t mask = __ballot(l == b);
+                    if (mask == 0) continue;
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (l == b) mine = next[b] + below;
+                    next[b] += (uint32_t)__popcll(mask);
+                }
+                S.freq[s] = l ? mine | ((uint32_t)l << 16) : 0u;     // the histogram is dead: S.freq now holds the codes
+            }
+        } else if (role == 0) {
+            const uint32_t h = dbg == 31 ? 1u : zstd_desc_head(D, S.lens, (int)maxsym, maxbits);
+            if (lane == 0) S.red[2] = h;
         }
         __syncthreads();
+        const uint32_t h = S.red[2];
+        if (h >> 31) {                                              // FSE-compressed weights: one state chain on each of two waves
+            if (role == 0) zstd_desc_chain(D, S.lens, (int)maxsym, maxbits, 0);
+            else if (role == 2) zstd_desc_chain(D, S.lens, (int)maxsym, maxbits, 1);
+            __syncthreads();
+            if (role == 0) {
+                const uint32_t o = zstd_desc_pack(D, (int)maxsym, h & 0x7FFFFFFFu);
+                if (lane == 0) S.red[2] = o;
+            }
+            __syncthreads();
+        }
         dl = S.red[2];
         if (dbg == 3 || dbg > 30) { z.bitpos += dl + S.ws[0]; return; }
         if (dl && 3 * per <= blen) {

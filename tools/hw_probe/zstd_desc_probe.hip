@@ -1,4 +1,4 @@
-// Probe for zstd_tree_desc (csrc/zstd_enc_dev.h): runs the tree description for random sets of code lengths on one wave and
+// Probe for the tree description of csrc/zstd_enc_dev.h (zstd_desc_head / _chain / _pack): runs the tree description for random sets of code lengths on one wave and
 // checks the FSE state chain on the host (state[k] is a cell of weight w[k] whose interval holds state[k+2]).
 // Lesson it was written for: LDS is NOT zero in a busy kernel — a variant that packed table bytes of rows it had not
 // written passed here (fresh LDS) and failed in the encoder until the bytes were masked.
@@ -14,7 +14,12 @@ __global__ void k_probe(const uint8_t *lens_in, int n, int maxbits, uint8_t *out
     ZstdDesc &D = *reinterpret_cast<ZstdDesc *>(S.code);
     for (int i = threadIdx.x; i < 320; i += 64) S.lens[i] = i < 256 ? lens_in[i] : 0;
     __syncthreads();
-    const uint32_t d = zstd_tree_desc(D, S.lens, n, maxbits);
+    uint32_t d = zstd_desc_head(D, S.lens, n, maxbits);
+    if (d >> 31) {
+        zstd_desc_chain(D, S.lens, n, maxbits, 0);
+        zstd_desc_chain(D, S.lens, n, maxbits, 1);
+        d = zstd_desc_pack(D, n, d & 0x7FFFFFFFu);
+    }
     __syncthreads();
     if (threadIdx.x == 0) *dl_out = d;
     const uint8_t *p = reinterpret_cast<const uint8_t *>(&D);
