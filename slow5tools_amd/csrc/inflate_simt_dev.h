@@ -1,26 +1,39 @@
 // inflate_simt_dev.h — zlib (RFC 1950/1951) decoder, ONE RECORD PER LANE.
 //
-// DEFLATE decoding is bit-serial inside a stream, and serial code costs a GPU wave ~7 cycles per instruction
+// DEFLATE decoding is bit-serial inside a stream, and serial code costs a GPU wave ~5 cycles per instruction
 // whether 1 or 64 lanes are active.  So the throughput design is SIMT across records: each lane of a wave64
-// walks its own stream with its own tables (8-bit lookup + canonical fallback, 1.2 KiB of LDS per lane),
-// and one VALU instruction advances 64 records.  Records of a batch have the same structure (header, keys,
-// data), so the lanes stay largely convergent.  Same contract and status codes as inflate_dev.h (the
-// wave-per-record decoder, kept for records this one hands back: none — any conforming stream is accepted).
+// walks its own stream with its own tables, and one VALU instruction advances 64 records.
+//
+// What bounds this kernel was measured, not guessed (tools/simt_probe.py, rocprofv3 PMC):
+//   - throughput is linear in resident waves per CU (1 wave 4.2 M records/s, 2 waves 8.05 M): every wave sits alone on
+//     its SIMD, and the per-lane tables in LDS decide how many waves fit;
+//   - 64 DIFFERENT records per wave execute 2.58x the instructions of 64 identical ones (130 vs 50 VALU per symbol): the
+//     lanes disagree on which path a symbol takes, above all on "lookup table hit" vs "walk the canonical code", and the
+//     wave runs the union.  Input addresses being scattered costs nothing (copies of one record at 4096 addresses run as
+//     fast as one address), nor does HBM latency (L2-hot input: no change).
+// Hence this form: NO lookup table.  A symbol's length comes from comparing the next 15 bits (MSB-first) against the 15
+// left-justified canonical limits, which live in registers — the same ~30 VALU instructions for every lane and every code
+// length, no divergence — and the tables shrink from 1284 to 612 bytes per lane: symbols as bytes plus a 288-bit plane
+// for the ninth bit, code lengths as nibbles while the tables are built.  Four waves per CU instead of two.
+// Same contract and status codes as inflate_dev.h (the wave-per-record decoder).
 #pragma once
 #include "dev_common.h"
 #include "inflate_dev.h"
 
 namespace s5 {
 
-constexpr int SL_LBITS = 8;
 struct LaneTables {                    // per lane, in LDS
-    uint16_t llut[1 << SL_LBITS];      // sym | len << 9 (0 = long code); doubles as the code-length array while tables are built
-    uint16_t lsym[288];                // canonical order
-    uint16_t lcount[16], dcount[16];
-    uint16_t dsym[32];
-    uint32_t lstate;                   // canonical-walk state after SL_LBITS bits: first << 16 | index (also makes the dword stride odd, 305)
+    uint8_t lsym[288];                 // lit/len symbols in canonical order, low 8 bits
+    uint32_t lhi[9];                   // ... and their bit 8 (length codes and end-of-block), one bit per entry
+    uint8_t lens4[160];                // code lengths of the block header, 4 bits each (<= 316 of them), while the tables are built
+    int16_t ladj[16];                  // canonical index - first code, per length
+    uint16_t tmp[16];                  // counts, then next free index per length, while building
+    uint16_t dcount[16];               // distance code (and, before it, the code-length code): counts per length
+    uint8_t dsym[32];                  // ... symbols in canonical order
 };
-static_assert(sizeof(LaneTables) == 512 + 576 + 64 + 64 + 4, "LaneTables layout");
+static_assert(sizeof(LaneTables) == 612 && (sizeof(LaneTables) / 4) % 2 == 1, "LaneTables layout: odd dword stride spreads the lanes over the banks");
+
+struct LaneLimits { uint32_t v[15]; };   // v[l-1] = (first code of length l + codes of length l) << (15 - l): registers
 
 struct LaneBits {
     const uint32_t *p;    // next aligned dword to fetch
@@ -58,8 +71,14 @@ __device__ __forceinline__ uint32_t lb_get(LaneBits &b, int n) {
 }
 __device__ __forceinline__ uint64_t lb_consumed(const LaneBits &b) { return b.taken - (uint64_t)b.cnt; }
 
-// canonical decode (count / syms), needs cnt >= 15
-__device__ __forceinline__ int lane_slow(LaneBits &b, const uint16_t *count, const uint16_t *syms) {
+__device__ __forceinline__ uint32_t nib_get(const uint8_t *a, int i) { return (a[i >> 1] >> ((i & 1) * 4)) & 15u; }
+__device__ __forceinline__ void nib_set(uint8_t *a, int i, uint32_t v) {   // the other nibble of the byte is kept
+    const uint32_t sh = (uint32_t)(i & 1) * 4;
+    a[i >> 1] = (uint8_t)((a[i >> 1] & ~(15u << sh)) | (v << sh));
+}
+
+// canonical decode by walking the lengths (count / syms): the code-length code and the distance code (rare symbols).  cnt >= 15.
+__device__ __forceinline__ int lane_slow(LaneBits &b, const uint16_t *count, const uint8_t *syms) {
     int code = 0, first = 0, index = 0;
     for (int len = 1; len <= 15; len++) {
         code |= (int)lb_get(b, 1);
@@ -72,49 +91,60 @@ __device__ __forceinline__ int lane_slow(LaneBits &b, const uint16_t *count, con
     }
     return -1;
 }
-
-// Build count/syms (+ LUT when lut != nullptr) from lens[0..n) (uint16 per length, any storage).  Returns nonzero if over-subscribed.
-__device__ __forceinline__ int lane_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *syms) {
+// count / syms of a small alphabet (n <= 32) from lengths get(s).  Nonzero if over-subscribed.
+template <typename F>
+__device__ __forceinline__ int lane_build_small(F get, int n, uint16_t *count, uint8_t *syms) {
     for (int i = 0; i < 16; i++) count[i] = 0;
-    for (int s = 0; s < n; s++) count[lens[s]]++;
+    for (int s = 0; s < n; s++) count[get(s)]++;
     count[0] = 0;
     int left = 1;
     for (int l = 1; l <= 15; l++) { left = (left << 1) - count[l]; if (left < 0) return 1; }
     uint16_t offs[16];
     offs[1] = 0;
     for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
-    for (int s = 0; s < n; s++) { const int l = lens[s]; if (l) syms[offs[l]++] = (uint16_t)s; }
+    for (int s = 0; s < n; s++) { const int l = (int)get(s); if (l) syms[offs[l]++] = (uint8_t)s; }
     return 0;
 }
-// canonical walk resumed after the LUT missed: the first SL_LBITS bits (LSB-first, already consumed) are `bits`
-__device__ __forceinline__ int lane_slow_resume(LaneBits &b, const uint16_t *count, const uint16_t *syms, uint32_t bits, uint32_t state) {
-    int code = (int)(__brev(bits) >> (32 - SL_LBITS)) << 1;
-    int first = (int)(state >> 16), index = (int)(state & 0xFFFF);
-    for (int len = SL_LBITS + 1; len <= 15; len++) {
-        code |= (int)lb_get(b, 1);
-        const int c = count[len];
-        if (code - c < first) return syms[index + (code - first)];
+// lit/len tables from the nibbles lens4[0..n): symbols in canonical order (T.lsym / T.lhi), T.ladj, and the limits.
+__device__ __forceinline__ int lane_build_litlen(LaneTables &T, int n, LaneLimits &lim) {
+    for (int i = 0; i < 16; i++) T.tmp[i] = 0;
+    for (int i = 0; i < 9; i++) T.lhi[i] = 0;
+    for (int s = 0; s < n; s++) T.tmp[nib_get(T.lens4, s)]++;
+    T.tmp[0] = 0;
+    int left = 1;
+    uint32_t first = 0, index = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; l++) {
+        const uint32_t c = T.tmp[l];
+        left = (left << 1) - (int)c;
+        if (left < 0) return 1;
+        lim.v[l - 1] = (first + c) << (15 - l);
+        T.ladj[l] = (int16_t)((int)index - (int)first);
+        T.tmp[l] = (uint16_t)index;          // next free canonical index of this length
         index += c;
-        first += c;
-        first <<= 1;
-        code <<= 1;
+        first = (first + c) << 1;
     }
-    return -1;
-}
-
-// LUT from the canonical order: walking syms by increasing length enumerates the codes in increasing order
-__device__ __forceinline__ void lane_fill_lut(const uint16_t *count, const uint16_t *syms, uint16_t *lut, int lutbits, int lenshift) {
-    for (int i = 0; i < (1 << lutbits); i++) lut[i] = 0;
-    uint32_t code = 0;
-    int idx = 0;
-    for (int l = 1; l <= lutbits; l++) {
-        for (int k = 0; k < count[l]; k++, idx++, code++) {
-            const uint32_t rev = __brev(code) >> (32 - l);
-            const uint16_t ent = (uint16_t)(syms[idx] | (l << lenshift));
-            for (uint32_t e = rev; e < (1u << lutbits); e += (1u << l)) lut[e] = ent;
+    for (int s = 0; s < n; s++) {
+        const uint32_t l = nib_get(T.lens4, s);
+        if (l) {
+            const uint32_t at = T.tmp[l]++;
+            T.lsym[at] = (uint8_t)s;
+            if (s >= 256) T.lhi[at >> 5] |= 1u << (at & 31);
         }
-        code <<= 1;
     }
+    return 0;
+}
+// one lit/len symbol: -1 = no such code.  cnt >= 15.
+__device__ __forceinline__ int lane_litlen(LaneBits &b, const LaneTables &T, const LaneLimits &lim) {
+    const uint32_t v = __brev((uint32_t)b.buf) >> 17;      // the next 15 bits, first bit of the code on top
+    uint32_t len = 1;
+#pragma unroll
+    for (int l = 0; l < 15; l++) len += v >= lim.v[l] ? 1u : 0u;
+    if (len > 15) return -1;
+    const uint32_t idx = (uint32_t)((int)T.ladj[len] + (int)(v >> (15 - len)));
+    b.buf >>= len;
+    b.cnt -= (int)len;
+    return (int)((uint32_t)T.lsym[idx] | (((T.lhi[idx >> 5] >> (idx & 31)) & 1u) << 8));
 }
 
 // Inflate one zlib stream with ONE lane.  `in` needs 16 readable bytes of padding after in + in_len.
@@ -157,6 +187,7 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
     auto flush_pending = [&]() {   // make bytes [o & ~3, o) visible in memory (before a match reads them back)
         for (uint32_t q = o & ~3u; q < o; q++) if (q < cap) out[q] = (uint8_t)(pend >> (8 * (q & 3)));
     };
+    LaneLimits lim;
     int last = 0;
     while (!last) {
         lb_need32(b);
@@ -178,14 +209,11 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
             continue;
         }
         int nl, nd;
-        uint8_t *lens = reinterpret_cast<uint8_t *>(T.llut);   // the LUT storage (512 B) holds the <= 316 code lengths until the tables are built
         if (type == 1) {
-            for (int s = 0; s < 288; s++) lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+            for (int s = 0; s < 288; s++) nib_set(T.lens4, s, s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u);
             nl = 288;
             nd = 30;
-            if (lane_build(lens, nl, T.lcount, T.lsym)) return INF_ERR_DATA;
-            for (int s = 0; s < 30; s++) lens[s] = 5;
-            if (lane_build(lens, nd, T.dcount, T.dsym)) return INF_ERR_DATA;
+            if (lane_build_small([](int) { return 5u; }, nd, T.dcount, T.dsym)) return INF_ERR_DATA;
         } else {
             lb_need32(b);
             const uint32_t hd = lb_get(b, 14);
@@ -193,52 +221,43 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
             nd = (int)((hd >> 5) & 31) + 1;
             const int ncl = (int)(hd >> 10) + 4;
             if (nl > 286 || nd > 30) return INF_ERR_DATA;
-            // code-length code: 19 lengths -> canonical tables in the distance table storage
-            uint8_t *cl = reinterpret_cast<uint8_t *>(T.lsym);   // scratch for the 19 lengths (lsym is free until the lit/len tables are built)
+            // code-length code: its 19 lengths are parked in the (still unused) symbol table, its canonical tables in the
+            // distance tables' storage
+            uint8_t *cl = T.lsym;
             for (int i = 0; i < 19; i++) cl[i] = 0;
             {
                 const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
                 for (int i = 0; i < ncl; i++) { lb_need32(b); cl[order[i]] = (uint8_t)lb_get(b, 3); }
             }
-            if (lane_build(cl, 19, T.dcount, T.dsym)) return INF_ERR_DATA;
-            uint8_t prev = 0;
+            if (lane_build_small([&](int s) { return (uint32_t)cl[s]; }, 19, T.dcount, T.dsym)) return INF_ERR_DATA;
+            uint32_t prev = 0;
             int idx = 0;
             const int tot = nl + nd;
             while (idx < tot) {
                 lb_need32(b);
                 const int sym = lane_slow(b, T.dcount, T.dsym);
                 if (sym < 0) return INF_ERR_DATA;
-                if (sym < 16) { prev = (uint8_t)sym; lens[idx++] = prev; }
+                if (sym < 16) { prev = (uint32_t)sym; nib_set(T.lens4, idx++, prev); }
                 else {
                     int rep;
-                    uint8_t v = 0;
+                    uint32_t v = 0;
                     if (sym == 16) { if (idx == 0) return INF_ERR_DATA; v = prev; rep = 3 + (int)lb_get(b, 2); }
                     else if (sym == 17) rep = 3 + (int)lb_get(b, 3);
                     else rep = 11 + (int)lb_get(b, 7);
                     if (idx + rep > tot) return INF_ERR_DATA;
-                    while (rep--) lens[idx++] = v;
+                    while (rep--) nib_set(T.lens4, idx++, v);
                     if (sym != 16) prev = 0;
                 }
             }
             if (lb_consumed(b) > total_bits) return INF_ERR_TRUNC;
-            if (lens[256] == 0) return INF_ERR_DATA;
-            // distance tables first (their lengths sit behind the lit/len ones), then lit/len
-            if (lane_build(lens + nl, nd, T.dcount, T.dsym)) return INF_ERR_DATA;
-            if (lane_build(lens, nl, T.lcount, T.lsym)) return INF_ERR_DATA;
+            if (nib_get(T.lens4, 256) == 0) return INF_ERR_DATA;
+            // distance tables (their lengths sit behind the lit/len ones)
+            if (lane_build_small([&](int s) { return nib_get(T.lens4, nl + s); }, nd, T.dcount, T.dsym)) return INF_ERR_DATA;
         }
-        lane_fill_lut(T.lcount, T.lsym, T.llut, SL_LBITS, 9);   // overwrites the code lengths: no longer needed
-        {
-            uint32_t first = 0, index = 0;
-            for (int l = 1; l <= SL_LBITS; l++) { index += T.lcount[l]; first += T.lcount[l]; first <<= 1; }
-            T.lstate = (first << 16) | index;
-        }
-        const uint32_t lstate = T.lstate;
+        if (lane_build_litlen(T, nl, lim)) return INF_ERR_DATA;
         for (;;) {
             lb_need32(b);
-            int sym;
-            const uint32_t e = T.llut[b.buf & ((1 << SL_LBITS) - 1)];
-            if (e >> 9) { sym = e & 511; lb_get(b, e >> 9); }
-            else { const uint32_t bits = lb_get(b, SL_LBITS); sym = lane_slow_resume(b, T.lcount, T.lsym, bits, lstate); }
+            int sym = lane_litlen(b, T, lim);
             if (sym < 0) return INF_ERR_DATA;
             if (sym < 256) { put((uint32_t)sym); if (lb_consumed(b) > total_bits) return INF_ERR_TRUNC; continue; }
             if (lb_consumed(b) > total_bits) return INF_ERR_TRUNC;
