@@ -33,10 +33,15 @@ struct LaneTables {                    // per lane, in LDS
 };
 static_assert(sizeof(LaneTables) == 612 && (sizeof(LaneTables) / 4) % 2 == 1, "LaneTables layout: odd dword stride spreads the lanes over the banks");
 
-struct LaneLimits { uint32_t v[15]; };   // v[l-1] = (first code of length l + codes of length l) << (15 - l): registers
+typedef short lane_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short lane_u2 __attribute__((ext_vector_type(2)));
+// limit of length l = (first code of length l + codes of length l) << (15 - l), left-justified in 15 bits; kept minus one, two per
+// register (lengths 2k+1 | 2k+2), so that sixteen 16-bit subtractions in eight packed instructions compare them all
+struct LaneLimits { lane_s2 m1[8]; };
 
+typedef const uint32_t __attribute__((address_space(1))) *lane_gptr32;   // input words: global_load, not flat (a flat access also waits on the LDS counter)
 struct LaneBits {
-    const uint32_t *p;    // next aligned dword to fetch
+    lane_gptr32 p;        // next aligned dword to fetch
     uint32_t ahead;       // dword already fetched (software prefetch: its HBM/L2 latency overlaps ~4 symbols of decoding)
     uint64_t buf;
     int cnt;
@@ -46,7 +51,7 @@ __device__ __forceinline__ void lb_init(LaneBits &b, const uint8_t *src) {
     b.buf = 0; b.cnt = 0; b.taken = 0;
     const uintptr_t a = reinterpret_cast<uintptr_t>(src);
     const int mis = (int)(a & 3);
-    b.p = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    b.p = (lane_gptr32)(a & ~(uintptr_t)3);
     if (mis) {   // first partial dword
         const uint32_t w = *b.p++;
         b.buf = w >> (8 * mis);
@@ -118,7 +123,10 @@ __device__ __forceinline__ int lane_build_litlen(LaneTables &T, int n, LaneLimit
         const uint32_t c = T.tmp[l];
         left = (left << 1) - (int)c;
         if (left < 0) return 1;
-        lim.v[l - 1] = (first + c) << (15 - l);
+        {
+            const short m1 = (short)(int)(((first + c) << (15 - l)) - 1u);
+            if ((l - 1) & 1) lim.m1[(l - 1) >> 1].y = m1; else lim.m1[(l - 1) >> 1].x = m1;
+        }
         T.ladj[l] = (int16_t)((int)index - (int)first);
         T.tmp[l] = (uint16_t)index;          // next free canonical index of this length
         index += c;
@@ -137,9 +145,11 @@ __device__ __forceinline__ int lane_build_litlen(LaneTables &T, int n, LaneLimit
 // one lit/len symbol: -1 = no such code.  cnt >= 15.
 __device__ __forceinline__ int lane_litlen(LaneBits &b, const LaneTables &T, const LaneLimits &lim) {
     const uint32_t v = __brev((uint32_t)b.buf) >> 17;      // the next 15 bits, first bit of the code on top
-    uint32_t len = 1;
+    const lane_s2 vv = {(short)v, (short)v};
+    lane_u2 acc = {0, 0};
 #pragma unroll
-    for (int l = 0; l < 15; l++) len += v >= lim.v[l] ? 1u : 0u;
+    for (int k = 0; k < 8; k++) acc += __builtin_bit_cast(lane_u2, (lane_s2)(lim.m1[k] - vv)) >> (unsigned short)15;   // sign bit: v >= limit
+    const uint32_t len = 1u + acc.x + acc.y;
     if (len > 15) return -1;
     const uint32_t idx = (uint32_t)((int)T.ladj[len] + (int)(v >> (15 - len)));
     b.buf >>= len;
@@ -150,10 +160,6 @@ __device__ __forceinline__ int lane_litlen(LaneBits &b, const LaneTables &T, con
 // Inflate one zlib stream with ONE lane.  `in` needs 16 readable bytes of padding after in + in_len.
 __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap,
                                                  uint32_t *out_len) {
-    const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     *out_len = 0;
     if (in_len < 6) return INF_ERR_TRUNC;
     {
@@ -188,6 +194,7 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
         for (uint32_t q = o & ~3u; q < o; q++) if (q < cap) out[q] = (uint8_t)(pend >> (8 * (q & 3)));
     };
     LaneLimits lim;
+    lim.m1[7].y = 0x7FFF;                                          // there is no sixteenth length: never counted
     int last = 0;
     while (!last) {
         lb_need32(b);
@@ -264,11 +271,14 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
             if (sym == 256) break;
             sym -= 257;
             if (sym >= 29) return INF_ERR_DATA;
-            const uint32_t mlen = lbase[sym] + lb_get(b, lext[sym]);
+            // length code: 3..10 one each, then 4 codes per extra-bit count, 258 on its own — arithmetic, no table in memory
+            const uint32_t le = sym < 8 || sym == 28 ? 0u : (uint32_t)(sym >> 2) - 1u;
+            const uint32_t mlen = (sym == 28 ? 258u : sym < 8 ? 3u + (uint32_t)sym : 3u + ((4u + ((uint32_t)sym & 3u)) << le)) + lb_get(b, (int)le);
             lb_need32(b);
             const int ds = lane_slow(b, T.dcount, T.dsym);
             if (ds < 0 || ds >= 30) return INF_ERR_DATA;
-            const uint32_t mdist = dbase[ds] + lb_get(b, dext[ds]);
+            const uint32_t de = ds < 4 ? 0u : (uint32_t)(ds >> 1) - 1u;
+            const uint32_t mdist = (ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + lb_get(b, (int)de);
             if (mdist > o) return INF_ERR_DATA;
             if (lb_consumed(b) > total_bits) return INF_ERR_TRUNC;
             if (mdist == 1) {
