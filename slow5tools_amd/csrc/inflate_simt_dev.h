@@ -13,8 +13,9 @@
 //     fast as one address), nor does HBM latency (L2-hot input: no change).
 // Hence this form: NO lookup table.  A symbol's length comes from comparing the next 15 bits (MSB-first) against the 15
 // left-justified canonical limits, which live in registers — the same ~30 VALU instructions for every lane and every code
-// length, no divergence — and the tables shrink from 1284 to 612 bytes per lane: symbols as bytes plus a 288-bit plane
-// for the ninth bit, code lengths as nibbles while the tables are built.  Four waves per CU instead of two.
+// length, no divergence — and the tables shrink from 1284 to 420 bytes of LDS per lane: symbols as bytes plus a 288-bit plane
+// for the ninth bit; what only the table construction needs (code lengths as nibbles, counters) sits in private memory.
+// Six waves per CU instead of two.
 // Same contract and status codes as inflate_dev.h (the wave-per-record decoder).
 #pragma once
 #include "dev_common.h"
@@ -25,13 +26,18 @@ namespace s5 {
 struct LaneTables {                    // per lane, in LDS
     uint8_t lsym[288];                 // lit/len symbols in canonical order, low 8 bits
     uint32_t lhi[9];                   // ... and their bit 8 (length codes and end-of-block), one bit per entry
-    uint8_t lens4[160];                // code lengths of the block header, 4 bits each (<= 316 of them), while the tables are built
     int16_t ladj[16];                  // canonical index - first code, per length
-    uint16_t tmp[16];                  // counts, then next free index per length, while building
     uint16_t dcount[16];               // distance code (and, before it, the code-length code): counts per length
     uint8_t dsym[32];                  // ... symbols in canonical order
 };
-static_assert(sizeof(LaneTables) == 612 && (sizeof(LaneTables) / 4) % 2 == 1, "LaneTables layout: odd dword stride spreads the lanes over the banks");
+static_assert(sizeof(LaneTables) == 420 && (sizeof(LaneTables) / 4) % 2 == 1, "LaneTables layout: odd dword stride spreads the lanes over the banks");
+
+// What only the table construction needs lives in PRIVATE memory (scratch: per-lane, swizzled so that the 64 lanes' copies of one
+// element are contiguous), not in LDS: the LDS footprint per lane is what decides how many waves a CU holds.
+struct LaneBuild {
+    uint8_t lens4[160];                // code lengths of the block header, 4 bits each (<= 316 of them)
+    uint16_t tmp[16];                  // counts, then next free index per length
+};
 
 typedef short lane_s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short lane_u2 __attribute__((ext_vector_type(2)));
@@ -111,16 +117,16 @@ __device__ __forceinline__ int lane_build_small(F get, int n, uint16_t *count, u
     return 0;
 }
 // lit/len tables from the nibbles lens4[0..n): symbols in canonical order (T.lsym / T.lhi), T.ladj, and the limits.
-__device__ __forceinline__ int lane_build_litlen(LaneTables &T, int n, LaneLimits &lim) {
-    for (int i = 0; i < 16; i++) T.tmp[i] = 0;
+__device__ __forceinline__ int lane_build_litlen(LaneTables &T, LaneBuild &B, int n, LaneLimits &lim) {
+    for (int i = 0; i < 16; i++) B.tmp[i] = 0;
     for (int i = 0; i < 9; i++) T.lhi[i] = 0;
-    for (int s = 0; s < n; s++) T.tmp[nib_get(T.lens4, s)]++;
-    T.tmp[0] = 0;
+    for (int s = 0; s < n; s++) B.tmp[nib_get(B.lens4, s)]++;
+    B.tmp[0] = 0;
     int left = 1;
     uint32_t first = 0, index = 0;
 #pragma unroll
     for (int l = 1; l <= 15; l++) {
-        const uint32_t c = T.tmp[l];
+        const uint32_t c = B.tmp[l];
         left = (left << 1) - (int)c;
         if (left < 0) return 1;
         {
@@ -128,14 +134,14 @@ __device__ __forceinline__ int lane_build_litlen(LaneTables &T, int n, LaneLimit
             if ((l - 1) & 1) lim.m1[(l - 1) >> 1].y = m1; else lim.m1[(l - 1) >> 1].x = m1;
         }
         T.ladj[l] = (int16_t)((int)index - (int)first);
-        T.tmp[l] = (uint16_t)index;          // next free canonical index of this length
+        B.tmp[l] = (uint16_t)index;          // next free canonical index of this length
         index += c;
         first = (first + c) << 1;
     }
     for (int s = 0; s < n; s++) {
-        const uint32_t l = nib_get(T.lens4, s);
+        const uint32_t l = nib_get(B.lens4, s);
         if (l) {
-            const uint32_t at = T.tmp[l]++;
+            const uint32_t at = B.tmp[l]++;
             T.lsym[at] = (uint8_t)s;
             if (s >= 256) T.lhi[at >> 5] |= 1u << (at & 31);
         }
@@ -193,6 +199,7 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
     auto flush_pending = [&]() {   // make bytes [o & ~3, o) visible in memory (before a match reads them back)
         for (uint32_t q = o & ~3u; q < o; q++) if (q < cap) out[q] = (uint8_t)(pend >> (8 * (q & 3)));
     };
+    LaneBuild B;
     LaneLimits lim;
     lim.m1[7].y = 0x7FFF;                                          // there is no sixteenth length: never counted
     int last = 0;
@@ -217,7 +224,7 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
         }
         int nl, nd;
         if (type == 1) {
-            for (int s = 0; s < 288; s++) nib_set(T.lens4, s, s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u);
+            for (int s = 0; s < 288; s++) nib_set(B.lens4, s, s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u);
             nl = 288;
             nd = 30;
             if (lane_build_small([](int) { return 5u; }, nd, T.dcount, T.dsym)) return INF_ERR_DATA;
@@ -244,7 +251,7 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
                 lb_need32(b);
                 const int sym = lane_slow(b, T.dcount, T.dsym);
                 if (sym < 0) return INF_ERR_DATA;
-                if (sym < 16) { prev = (uint32_t)sym; nib_set(T.lens4, idx++, prev); }
+                if (sym < 16) { prev = (uint32_t)sym; nib_set(B.lens4, idx++, prev); }
                 else {
                     int rep;
                     uint32_t v = 0;
@@ -252,16 +259,16 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
                     else if (sym == 17) rep = 3 + (int)lb_get(b, 3);
                     else rep = 11 + (int)lb_get(b, 7);
                     if (idx + rep > tot) return INF_ERR_DATA;
-                    while (rep--) nib_set(T.lens4, idx++, v);
+                    while (rep--) nib_set(B.lens4, idx++, v);
                     if (sym != 16) prev = 0;
                 }
             }
             if (lb_consumed(b) > total_bits) return INF_ERR_TRUNC;
-            if (nib_get(T.lens4, 256) == 0) return INF_ERR_DATA;
+            if (nib_get(B.lens4, 256) == 0) return INF_ERR_DATA;
             // distance tables (their lengths sit behind the lit/len ones)
-            if (lane_build_small([&](int s) { return nib_get(T.lens4, nl + s); }, nd, T.dcount, T.dsym)) return INF_ERR_DATA;
+            if (lane_build_small([&](int s) { return nib_get(B.lens4, nl + s); }, nd, T.dcount, T.dsym)) return INF_ERR_DATA;
         }
-        if (lane_build_litlen(T, nl, lim)) return INF_ERR_DATA;
+        if (lane_build_litlen(T, B, nl, lim)) return INF_ERR_DATA;
         for (;;) {
             lb_need32(b);
             int sym = lane_litlen(b, T, lim);
