@@ -276,6 +276,42 @@ def bench_decode(args):
         got = sig[: k * sig_cap].view(k, sig_cap)[:, :n]
         want = b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[torch.from_numpy(sel).to(dev)][:, :n]
         ok &= bool((st == 0).all().item()) and bool((got == want).all().item())
+    # pass 3: the whole index in one call (what `view` / `merge` decode per batch when the batch is large): device time of
+    # inflate + unpack by HIP events, every signal compared afterwards
+    del payload, sig, fields, desc_dev
+    torch.cuda.empty_cache()
+    bulk = None
+    try:
+        d = np.zeros(n_reads, dtype=_lib.REC_DESC)
+        d["in_off"] = rec_off[:-1] + 8
+        d["in_len"] = rec_off[1:] - rec_off[:-1] - 8
+        d["pay_off"] = np.arange(n_reads, dtype=np.uint64) * pay_cap
+        d["pay_cap"] = pay_cap
+        d["sig_off"] = np.arange(n_reads, dtype=np.uint64) * sig_cap
+        d["sig_cap"] = sig_cap
+        big_desc = torch.from_numpy(d.view(np.uint8)).to(dev)
+        big_pay = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device=dev)
+        big_sig = torch.empty(n_reads * sig_cap + 64, dtype=torch.int16, device=dev)
+        big_fields = torch.zeros(n_reads * 64, dtype=torch.uint8, device=dev)
+        a.n_recs = n_reads
+        a.desc, a.payload, a.sig_out, a.fields = big_desc.data_ptr(), big_pay.data_ptr(), big_sig.data_ptr(), big_fields.data_ptr()
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(L.s5gpu_decode_dev(C.byref(a), b._stream()), "s5gpu_decode_dev")
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms = min(ts[1:])
+        st = big_fields.view(torch.int32).view(n_reads, 16)[:, 0]
+        same = bool((st == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n],
+                                                                  b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]))
+        bulk = {"reads": n_reads, "ms": round(ms, 2), "reads_per_s": round(n_reads / ms * 1e3, 1),
+                "raw_signal_GB_per_s": round(n_reads * 2 * n / ms / 1e6, 2), "roundtrip_identical": same}
+        ok &= same
+    except torch.OutOfMemoryError:
+        bulk = None
     wall = time.perf_counter() - t_all
     lat_ms = np.array(lat[2:]) * 1e3
     busy = float(np.sum(lat[2:]))
@@ -284,6 +320,7 @@ def bench_decode(args):
             "config": {"workload": "BASELINE configs[4]: random get decode (inflate + svb-zd unpack), %d ids (seed 1) over a %d-read index, batches of %d, %d samples/read" % (len(ids), n_reads, K, n)},
             "reads_per_s": round(done / busy, 1), "batch_latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p99": round(float(np.percentile(lat_ms, 99)), 3)},
             "per_read_latency_us_p50": round(float(np.percentile(lat_ms, 50)) * 1e3 / K, 3),
+            "bulk_decode_one_call": bulk,
             "roundtrip_identical": bool(ok), "wall_s_including_verification": round(wall, 2)}
     print(json.dumps(line))
 
