@@ -118,7 +118,10 @@ void s5gpu_shutdown(void);
 const char *s5gpu_last_error(void);
 int s5gpu_device_count(void);
 /* tuning knobs.  "inflate_simt_min": batches with at least this many zlib records use the lane-per-record
- * inflate kernel (throughput), smaller ones the wave-per-record kernel (latency); default 24576. */
+ * inflate kernel (throughput), smaller ones the wave-per-record kernel (latency); default 24576.
+ * "inflate_route" (0/1, default 1): such batches are first counting-sorted by compressed length on the device, and records
+ * of >= 32 KiB go to the wave-per-record kernel beside the lane kernel (real runs have read lengths spread over two decades).
+ * In inflate-only calls fields[i].reserved / read_group are then left holding routing scratch. */
 int s5gpu_set_option(const char *key, long value);
 
 /* ---- device-resident entry points (asynchronous on `hip_stream`, a hipStream_t; NULL = default) ---- */

@@ -438,16 +438,88 @@ __global__ __launch_bounds__(64) void k_zstd_inflate(s5gpu_decode_args_t a) {
     }
 }
 
-// K4, throughput form: one record per LANE (inflate_simt_dev.h); 64 records per workgroup, tables in dynamic LDS
+// K4, throughput form: one record per LANE (inflate_simt_dev.h); 64 records per workgroup, tables in dynamic LDS.
+// ROUTED: the records come through the length-sorted list built by the k_route_* kernels below (longest first), and only the
+// part of the list behind the n_long longest records is this kernel's.
+template <bool ROUTED>
 __global__ __launch_bounds__(64) void k_inflate_simt(s5gpu_decode_args_t a) {
-    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= a.n_recs) return;
+    uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (ROUTED) {
+        const uint32_t n_long = a.fields[128].read_group;
+        if (r >= a.n_recs - n_long) return;
+        r = a.fields[n_long + r].reserved;
+    } else if (r >= a.n_recs) return;
     LaneTables &T = reinterpret_cast<LaneTables *>(smem)[threadIdx.x];
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
     const int status = zlib_inflate_lane(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
     a.fields[r].status = status;
     a.fields[r].payload_len = olen;
+}
+// ... and the wave-per-record kernel over the n_long longest records of the same list (persistent blocks)
+__global__ __launch_bounds__(64) void k_inflate_long(s5gpu_decode_args_t a) {
+    __shared__ InflShared T;
+    const uint32_t n_long = a.fields[128].read_group;
+    for (uint32_t i = blockIdx.x; i < n_long; i += gridDim.x) {
+        const uint32_t r = a.fields[i].reserved;
+        const s5gpu_rec_desc_t d = a.desc[r];
+        uint32_t olen = 0;
+        const int status = zlib_inflate_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+        if (lane_id() == 0) {
+            a.fields[r].status = status;
+            a.fields[r].payload_len = olen;
+        }
+        wave_sync();
+    }
+}
+
+// Routing of a big zlib batch.  One lane decodes one record, so a wave takes as long as its longest record and the batch as
+// long as its longest wave: with the read lengths of a real run (log-normal, a tail of 100x the median) the lane kernel alone
+// loses to the wave kernel (tools/mixed_lengths.py).  So the records are counting-sorted by compressed length (128 buckets, four
+// per octave, longest first): a wave then holds records of one bucket, the longest waves start first, and records of 32 KiB
+// and more (a lane would need > 30 ms for one) go to the wave-per-record kernel, which runs beside the lane kernel.
+// Scratch: fields[b].read_group (b < 128) bucket counts then cursors, fields[128].read_group = n_long, fields[i].reserved = the
+// sorted list.  All of it is overwritten or reset by the kernels that follow.
+__device__ __forceinline__ uint32_t route_bucket(uint32_t len) {
+    if (len < 4) return len;
+    const uint32_t hb = 31u - (uint32_t)__clz((int)len);
+    return hb * 4 + ((len >> (hb - 2)) & 3u);
+}
+constexpr uint32_t ROUTE_LONG_BUCKET = 15 * 4;   // compressed records of >= 32 KiB
+__global__ __launch_bounds__(NT) void k_route_zero(s5gpu_decode_args_t a) {
+    if (threadIdx.x < 129) a.fields[threadIdx.x].read_group = 0;
+}
+__global__ __launch_bounds__(NT) void k_route_count(s5gpu_decode_args_t a) {   // workgroup histogram in LDS, one global add per bucket in use
+    __shared__ uint32_t h[128];
+    if (threadIdx.x < 128) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * NT + threadIdx.x;
+    if (i < a.n_recs) atomicAdd(&h[route_bucket(a.desc[i].in_len)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 128 && h[threadIdx.x]) atomicAdd(&a.fields[threadIdx.x].read_group, h[threadIdx.x]);
+}
+__global__ __launch_bounds__(128) void k_route_scan(s5gpu_decode_args_t a) {   // one workgroup of 128: thread t owns bucket 127 - t
+    __shared__ uint32_t ws[2];
+    const uint32_t b = 127u - threadIdx.x;
+    const uint32_t c = a.fields[b].read_group;
+    const uint32_t incl = wave_incl_add(c);
+    if (lane_id() == 63) ws[wave_id()] = incl;
+    __syncthreads();
+    const uint32_t start = incl - c + (wave_id() ? ws[0] : 0u);
+    a.fields[b].read_group = start;                                           // cursor of the bucket in the descending list
+    if (b == ROUTE_LONG_BUCKET) a.fields[128].read_group = start + c;         // everything in front of the shorter buckets
+}
+__global__ __launch_bounds__(NT) void k_route_scatter(s5gpu_decode_args_t a) {   // a workgroup reserves one range per bucket
+    __shared__ uint32_t h[128], base[128];
+    if (threadIdx.x < 128) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * NT + threadIdx.x;
+    uint32_t b = 0, rank = 0;
+    if (i < a.n_recs) { b = route_bucket(a.desc[i].in_len); rank = atomicAdd(&h[b], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 128 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&a.fields[threadIdx.x].read_group, h[threadIdx.x]);
+    __syncthreads();
+    if (i < a.n_recs) a.fields[base[b] + rank].reserved = i;
 }
 
 // K2 + field parse: payload -> primary fields + int16 raw_signal (slow5_rec_depress_parse, a7/a8)
@@ -517,6 +589,7 @@ __global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
         f.sampling_rate = __longlong_as_double((long long)v[3]);
         f.aux_off = hl + 8 + sig_bytes;
         f.aux_len = plen - (hl + 8 + sig_bytes);
+        f.reserved = 0;   // scratch of the routing kernels
     }
 }
 
@@ -853,22 +926,52 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
 
 // Small batches (a single slow5_get) take the wave-per-record decoder (lowest latency); from
 // g_inflate_simt_min records on, the lane-per-record decoder (highest throughput).
+static uint32_t g_inflate_route = 1;           // big zlib batches: sort by length, long records to the wave kernel (below)
 static uint32_t g_inflate_simt_min = 24576;   // measured crossover on 4000-sample reads: 16384 wave 3.0 ms vs lane 4.2 ms, 32768 wave 5.8 vs lane 4.5
 extern "C" int s5gpu_set_option(const char *key, long value) {
     if (key && strcmp(key, "inflate_simt_min") == 0 && value >= 0) { g_inflate_simt_min = (uint32_t)value; return S5GPU_OK; }
+    if (key && strcmp(key, "inflate_route") == 0 && (value == 0 || value == 1)) { g_inflate_route = (uint32_t)value; return S5GPU_OK; }
     s5gpu_set_error("s5gpu_set_option: unknown option");
     return S5GPU_ERR_ARG;
 }
+struct AuxStream {   // one per host thread: the batch API runs calls from several threads
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static thread_local AuxStream t_aux;
+
 static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st) {
     if (a->rec_method == S5GPU_REC_ZSTD) {
         hipLaunchKernelGGL(k_zstd_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
         static bool attr = false;
         if (!attr) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate_simt), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate_simt<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate_simt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
             attr = true;
         }
-        hipLaunchKernelGGL(k_inflate_simt, dim3((a->n_recs + 63) / 64), dim3(64), 64 * sizeof(LaneTables), st, *a);
+        const uint32_t nb64 = (a->n_recs + 63) / 64;
+        if (a->n_recs < 1024 || !g_inflate_route) {   // tiny batches (tests force the lane kernel on them): no routing
+            hipLaunchKernelGGL(k_inflate_simt<false>, dim3(nb64), dim3(64), 64 * sizeof(LaneTables), st, *a);
+        } else {
+            if (!t_aux.st) {
+                HIP_TRY(hipStreamCreateWithFlags(&t_aux.st, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&t_aux.fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&t_aux.join, hipEventDisableTiming));
+            }
+            const uint32_t nbt = (a->n_recs + NT - 1) / NT;
+            hipLaunchKernelGGL(k_route_zero, dim3(1), dim3(NT), 0, st, *a);
+            hipLaunchKernelGGL(k_route_count, dim3(nbt), dim3(NT), 0, st, *a);
+            hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(128), 0, st, *a);
+            hipLaunchKernelGGL(k_route_scatter, dim3(nbt), dim3(NT), 0, st, *a);
+            // the longest records first, on a second stream, beside the lane kernel
+            HIP_TRY(hipEventRecord(t_aux.fork, st));
+            HIP_TRY(hipStreamWaitEvent(t_aux.st, t_aux.fork, 0));
+            hipLaunchKernelGGL(k_inflate_long, dim3(a->n_recs < 16384 ? a->n_recs : 16384), dim3(64), 0, t_aux.st, *a);
+            HIP_TRY(hipEventRecord(t_aux.join, t_aux.st));
+            hipLaunchKernelGGL(k_inflate_simt<true>, dim3(nb64), dim3(64), 64 * sizeof(LaneTables), st, *a);
+            HIP_TRY(hipStreamWaitEvent(st, t_aux.join, 0));
+        }
     } else {
         hipLaunchKernelGGL(k_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
     }

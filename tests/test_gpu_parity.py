@@ -244,7 +244,7 @@ def inflate_kernel(request, press):
     L = _lib.lib()
     _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 1 if request.param == "lane-per-record" else 1 << 30))
     yield request.param
-    _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 16384))
+    _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 24576))
 
 
 @pytest.mark.parametrize("name", ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES + NONE_NONE_FIXTURES)
@@ -388,3 +388,29 @@ def test_big_host_batch_split_over_two_contexts_equals_one_context(press, monkey
     for i in (0, n // 2 - 1, n // 2, n - 1):
         payload, _ = _oracle_payload(hdrs[i], sigs[i], b"", 1)
         assert zlib.decompress(two[i][8:]) == payload
+
+
+def test_big_mixed_length_batch_is_routed_by_length(press):
+    """a batch of >= 1024 zlib records with very different lengths: the lane kernel takes them counting-sorted by compressed length
+    and hands records of >= 32 KiB to the wave kernel; the result is the one the unrouted kernels give"""
+    from slow5tools_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(17)
+    ns = np.clip(np.exp(rng.normal(np.log(1500), 1.0, 1400)), 1, 90000).astype(int)
+    ns[:4] = (0, 1, 90000, 60000)
+    sigs = [ob.synth_read(0x77, i, int(n)) for i, n in enumerate(ns)]
+    hdrs = [_hdr(press, i) for i in range(len(sigs))]
+    recs = [r[8:] for r in press.encode_records(sigs, hdrs)]
+    assert sum(len(r) >= 32768 for r in recs) >= 2 and sum(len(r) < 32768 for r in recs) > 1024
+    _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 1), "set_option")
+    try:
+        outs = []
+        for route in (1, 0):
+            _lib.check(L.s5gpu_set_option(b"inflate_route", route), "set_option")
+            outs.append(press.decode_records(recs))
+    finally:
+        _lib.check(L.s5gpu_set_option(b"inflate_route", 1), "set_option")
+        _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 24576), "set_option")
+    for g, h, s in zip(outs[0], outs[1], sigs):
+        assert g["status"] == 0 and h["status"] == 0 and np.array_equal(g["signal"], s) and g["payload"] == h["payload"]
