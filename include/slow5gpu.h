@@ -71,7 +71,10 @@ typedef struct s5gpu_encode_args {
     uint32_t max_payload;            /* max over reads of s5gpu_payload_bound()                      */
     uint32_t lds_payload_cap;        /* 0 = auto.  LDS bytes the one-workgroup-per-read kernel keeps */
                                      /*   for a payload; reads that need more (long or incompressible*/
-                                     /*   signals) are re-run through the HBM-staged kernels          */
+                                     /*   signals) are re-run through the HBM-staged kernels.  With 0 and */
+                                     /*   a longest read far over the budget the whole batch is staged;   */
+                                     /*   name a budget (8192 is a good one) for batches that mix short   */
+                                     /*   and long reads: the host batch calls do so from the lengths     */
     uint32_t *ovf;                   /* device, n_reads + 1 words of scratch (list of such reads)    */
 } s5gpu_encode_args_t;
 

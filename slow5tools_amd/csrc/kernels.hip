@@ -832,7 +832,9 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     if (cap > (uint32_t)DEFL_BLK) cap = DEFL_BLK;
     cap = (cap + 15u) & ~15u;
     // every read certainly longer than the fused budget?  (min payload ~ 1.25 B/sample of a 3.25 B/sample bound)
-    const bool all_staged = a->sig_method == S5GPU_SIG_EX_ZD ? (uint64_t)a->max_payload * 100 / 950 > 4ull * DEFL_BLK
+    // (a caller that names an LDS budget knows its batch is mixed: short reads fused, the rest through the overflow list)
+    const bool all_staged = a->lds_payload_cap ? false
+                          : a->sig_method == S5GPU_SIG_EX_ZD ? (uint64_t)a->max_payload * 100 / 950 > 4ull * DEFL_BLK
                           : a->sig_method == S5GPU_SIG_SVB_ZD ? (uint64_t)a->max_payload * 100 / 325 > 4ull * DEFL_BLK
                                                               : a->max_payload > 4u * DEFL_BLK;
     const uint32_t st_obuf = (DEFL_BLK + 64) / 4;

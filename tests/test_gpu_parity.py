@@ -414,3 +414,15 @@ def test_big_mixed_length_batch_is_routed_by_length(press):
         _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 24576), "set_option")
     for g, h, s in zip(outs[0], outs[1], sigs):
         assert g["status"] == 0 and h["status"] == 0 and np.array_equal(g["signal"], s) and g["payload"] == h["payload"]
+
+
+def test_host_batch_with_one_very_long_read_keeps_the_short_reads_fused(press):
+    """a batch the device entry point would stage as a whole (longest read >> the LDS budget): the host call names an 8 KiB fused
+    budget from the lengths it sees — short reads fused, the long ones through the overflow list; same records either way"""
+    rng = np.random.default_rng(23)
+    sigs = [ob.synth_read(0x99, 0, 230000)] + [ob.synth_read(0x99, 1 + i, int(n)) for i, n in enumerate(rng.integers(1, 9000, 40))]
+    hdrs = [_hdr(press, i) for i in range(len(sigs))]
+    recs = press.encode_records(sigs, hdrs)
+    for r, h, s in zip(recs, hdrs, sigs):
+        payload, _ = _oracle_payload(h, s, b"", 1)
+        assert zlib.decompress(r[8:]) == payload
