@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64) void k_zstd_inflate(s5gpu_decode_args_t a) {
 template <bool ROUTED>
 __global__ __launch_bounds__(64) void k_inflate_simt(s5gpu_decode_args_t a) {
     uint32_t r = blockIdx.x * 64 + threadIdx.x;
-    if (ROUTED) {
+    if (ROUTED && !a.fields[128].aux_len) {           // aux_len != 0: one length class, the list was not built (file order)
         const uint32_t n_long = a.fields[128].read_group;
         if (r >= a.n_recs - n_long) return;
         r = a.fields[n_long + r].reserved;
@@ -508,9 +508,25 @@ __global__ __launch_bounds__(128) void k_route_scan(s5gpu_decode_args_t a) {   /
     const uint32_t start = incl - c + (wave_id() ? ws[0] : 0u);
     a.fields[b].read_group = start;                                           // cursor of the bucket in the descending list
     if (b == ROUTE_LONG_BUCKET) a.fields[128].read_group = start + c;         // everything in front of the shorter buckets
+    // a batch of one length class (<= 3 neighbouring buckets in use, none of them long) needs no list: file order is as good
+    const uint64_t used = __ballot(c != 0);
+    __shared__ uint64_t su[2];
+    if (lane_id() == 0) su[wave_id()] = used;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // thread t owns bucket 127 - t: su[0] bit i = bucket 127 - i, su[1] bit i = bucket 63 - i
+        const uint64_t hi = su[0], lo = su[1];
+        bool uniform = false;
+        if (hi == 0 && lo != 0) {
+            const int first = __ffsll((long long)lo) - 1, last = 63 - __clzll((long long)lo);
+            uniform = last - first <= 2 && 63 - first < (int)ROUTE_LONG_BUCKET;
+        }
+        a.fields[128].aux_len = uniform ? 1u : 0u;
+    }
 }
 __global__ __launch_bounds__(NT) void k_route_scatter(s5gpu_decode_args_t a) {   // a workgroup reserves one range per bucket
     __shared__ uint32_t h[128], base[128];
+    if (a.fields[128].aux_len) return;                                             // one length class: no list
     if (threadIdx.x < 128) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * NT + threadIdx.x;
