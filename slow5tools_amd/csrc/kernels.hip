@@ -541,6 +541,7 @@ __global__ __launch_bounds__(NT) void k_route_scatter(s5gpu_decode_args_t a) {  
 // K2 + field parse: payload -> primary fields + int16 raw_signal (slow5_rec_depress_parse, a7/a8)
 __global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
     __shared__ uint32_t ws[16];
+    __shared__ __attribute__((aligned(16))) uint8_t svb_stage[SVB_STAGE];
     __shared__ int s_err;
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
         uint32_t total = 0;
         int carry = 0, err = 0;
         for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE)
-            total += svb_decode_tile(keys + (t0 >> 2), data + total, dend, n, t0, out, carry, err, ws);
+            total += svb_decode_tile(keys + (t0 >> 2), data + total, dend, n, t0, out, carry, err, ws, svb_stage);
         if (err) s_err = 1;
         __syncthreads();
         if (s_err || 4 + nk + total != L) { if (tid == 0) f.status = 7; return; }
@@ -612,6 +613,7 @@ __global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
 // K2 alone: svb-zd blob -> int16 (slow5_ptr_depress_solo(SVB_ZD)); in = blobs, fields.n_samples/status out
 __global__ __launch_bounds__(NT) void k_svbzd_decode(s5gpu_decode_args_t a) {
     __shared__ uint32_t ws[16];
+    __shared__ __attribute__((aligned(16))) uint8_t svb_stage[SVB_STAGE];
     __shared__ int s_err;
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(NT) void k_svbzd_decode(s5gpu_decode_args_t a) {
     uint32_t total = 0;
     int carry = 0, err = 0;
     for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE)
-        total += svb_decode_tile(keys + (t0 >> 2), data + total, dend, n, t0, out, carry, err, ws);
+        total += svb_decode_tile(keys + (t0 >> 2), data + total, dend, n, t0, out, carry, err, ws, svb_stage);
     if (err) s_err = 1;
     __syncthreads();
     if (tid == 0) {

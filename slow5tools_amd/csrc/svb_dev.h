@@ -102,9 +102,12 @@ __device__ __forceinline__ uint32_t svb_encode_tile(const int16_t *__restrict__ 
 // data: first data byte of this tile; data_end: end of blob.  `carry` = x[t0-1] (0 for the first tile).
 // Writes int16 samples to out[t0..].  Returns the tile's data byte count; updates carry (uniform).
 // err is set (not cleared) if a value would read past data_end.
+// stage: LDS, SVB_STAGE bytes, 16-byte aligned.  The data bytes of the tile are brought in with 16-byte loads and the lanes
+// pick their bytes out of LDS: byte-granular loads straight from HBM cost ~20 vector-memory instructions per lane and tile.
+constexpr uint32_t SVB_STAGE = 4u * SVB_TILE + 16u;
 __device__ __forceinline__ uint32_t svb_decode_tile(const uint8_t *keys, const uint8_t *data, const uint8_t *data_end,
                                                     uint32_t n, uint32_t t0, int16_t *__restrict__ out, int &carry,
-                                                    int &err, uint32_t *ws) {
+                                                    int &err, uint32_t *ws, uint8_t *stage) {
     const int tid = threadIdx.x;
     const uint32_t i0 = t0 + 16u * tid;
     const int valid = i0 >= n ? 0 : (int)min(16u, n - i0);
@@ -119,11 +122,21 @@ __device__ __forceinline__ uint32_t svb_decode_tile(const uint8_t *keys, const u
         if (q < valid) nbytes += ((key >> (2 * q)) & 3) + 1;
     uint32_t total;
     const uint32_t off = block_excl_add(nbytes, ws, total);
-    const uint8_t *dp = data + off;
-    if (valid > 0 && dp + nbytes > data_end) { err = 1; }
+    {   // data[0 .. min(total, bytes left)) -> stage (total <= 4 * SVB_TILE)
+        const uint32_t have = (uint32_t)min((uint64_t)total, (uint64_t)(data_end - data));
+        typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(1)));
+        typedef uint32_t v4a __attribute__((ext_vector_type(4)));
+        for (uint32_t k = 16u * tid; k < have; k += 16u * NT) {
+            if (k + 16 <= have) *reinterpret_cast<v4a *>(stage + k) = *reinterpret_cast<const v4u *>(data + k);
+            else for (uint32_t j = k; j < have; j++) stage[j] = data[j];
+        }
+        __syncthreads();
+    }
+    const uint8_t *dp = stage + off;
+    const bool ok = !(valid > 0 && data + off + nbytes > data_end);
+    if (!ok) { err = 1; }
     int d[16];
     int sum = 0;
-    const bool ok = !(valid > 0 && dp + nbytes > data_end);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         d[q] = 0;
