@@ -330,7 +330,12 @@ __global__ __launch_bounds__(NT, 6) void k_zstd_fused(EncParams p) {
     }
     __syncthreads();
     if (p.dbg == 9) { if (threadIdx.x == 0) p.a.out_len[r] = plen; return; }   // payload only
-    const uint32_t total = zstd_record<false>(S, obuf, p.obuf_words, pay, nullptr, plen, p.a.slots + d.out_off, p.dbg);
+    uint32_t split = 0;   // svb-zd: head + key bytes in a block of their own
+    if (!EXZD && p.a.sig_method == S5GPU_SIG_SVB_ZD) {
+        const uint32_t at = d.hdr_len + 12 + ((d.n_samples + 3) >> 2);
+        if (at >= 256 && at + 256 <= plen && at <= (uint32_t)DEFL_BLK) split = at;
+    }
+    const uint32_t total = zstd_record<false>(S, obuf, p.obuf_words, pay, nullptr, plen, p.a.slots + d.out_off, p.dbg, split, split ? d.hdr_len + 12 : 0u);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
 }
 // ... and staged: a parked payload, 16 KiB block at a time through LDS (k_deflate_staged's twin)

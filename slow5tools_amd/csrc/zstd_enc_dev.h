@@ -4,8 +4,9 @@
 // match finder is a serial hash chain over the record; like the DEFLATE side this encoder does not reproduce its bytes but
 // writes a VALID frame that libzstd decompresses to the identical payload.  The frame is "literals only": blocks of at most
 // 16 KiB (the LDS stage of the staged path), each raw, RLE, or compressed = Huffman literals in 4 streams + an empty
-// sequences section.  On nanopore records that is within ~2 % of libzstd level 1 (75 370 B svb-zd payload: 51 047 B here,
-// 49 895 B libzstd 1.4.8, 50 766 B zlib): the svb-zd bytes hold little for a match finder to find.
+// sequences section; the fused kernel cuts an svb-zd record at its own seams (head raw | key bytes | data bytes).  On nanopore
+// records that is within ~2 % of libzstd level 1 (75 370 B svb-zd payload: 51 047 B here, 49 895 B libzstd 1.4.8, 50 766 B zlib):
+// the svb-zd bytes hold little for a match finder to find.
 //
 // One record per 256-thread workgroup, one block at a time:
 //   histogram     4 per-wave sub-histograms in the (still dead) build scratch, summed into S.freq;
@@ -218,7 +219,7 @@ __device__ __forceinline__ uint32_t zstd_desc_pack(ZstdDesc &D, int n, uint32_t 
 
 // One zstd block of blen <= DEFL_BLK bytes at LDS `stage` into the bit buffer (B overlays obuf, as deflate_block MODE 2).
 __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words, const uint8_t *stage,
-                                           uint32_t blen, bool last, ZOut &z, uint32_t dbg = 0) {
+                                           uint32_t blen, bool last, ZOut &z, uint32_t dbg = 0, bool force_raw = false) {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     ZstdDesc &D = *reinterpret_cast<ZstdDesc *>(S.code);
     // ---- histogram: one sub-histogram per wave, in scratch that is dead until build_lengths ----
@@ -227,13 +228,17 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
     if (tid < 16) S.red[tid & 7] = 0;
     wave_sync();
     {
-        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(stage);
-        const uint32_t nw = blen >> 2;
+        // the block may start anywhere in the payload (the key | data split): bytes up to the first aligned dword, dwords, tail
+        const uint32_t head = min(blen, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(stage) & 3)) & 3));
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(stage + head);
+        const uint32_t nw = (blen - head) >> 2;
         for (uint32_t i = tid; i < nw; i += NT) {
             const uint32_t x = s32[i];
             atomicAdd(&sub[x & 255u], 1u); atomicAdd(&sub[(x >> 8) & 255u], 1u); atomicAdd(&sub[(x >> 16) & 255u], 1u); atomicAdd(&sub[x >> 24], 1u);
         }
-        if ((uint32_t)tid < (blen & 3u)) atomicAdd(&sub[stage[4 * nw + tid]], 1u);
+        if ((uint32_t)tid < head) atomicAdd(&sub[stage[tid]], 1u);
+        const uint32_t tail0 = head + 4 * nw;
+        if ((uint32_t)tid < blen - tail0) atomicAdd(&sub[stage[tail0 + tid]], 1u);
     }
     __syncthreads();
     const uint32_t f = S.freq[tid] + B.lf[tid] + B.nf[tid] + B.sort.bm[tid];
@@ -252,8 +257,8 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
     const uint32_t per = (blen + 3) >> 2;
     uint32_t mybits = 0, mytotal = 0;
     uint32_t cs = 0, c0 = 0, c1 = 0;                                // my run of stream wv: bytes [c0, c1) of the block
-    if (blen >= 64 && distinct == 1) type = 1;
-    else if (blen >= 64) {
+    if (blen >= 64 && distinct == 1 && !force_raw) type = 1;
+    else if (blen >= 64 && !force_raw) {
         if (tid == 0) S.dbg = 0;
         build_lengths(S, B, &B.sort, S.freq, 256, ZSTD_MAXBITS, S.lens, S.blcount, S.icount);
         if (dbg == 2) { z.bitpos += S.lens[tid]; return; }
@@ -332,10 +337,12 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
     const uint32_t p0 = z.bitpos;
     if (tid == 0) zput_bytes(obuf, z, p0, (last ? 1u : 0u) | ((uint32_t)type << 1) | ((type == 2 ? bsize : blen) << 3), 3);
     if (type == 0) {
-        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(stage);
-        const uint32_t nw = blen >> 2;
-        for (uint32_t i = tid; i < nw; i += NT) put_bits(obuf, z, p0 + 24 + 32 * i, s32[i], 32);
-        if ((uint32_t)tid < (blen & 3u)) put_bits(obuf, z, p0 + 24 + 32 * nw + 8 * tid, stage[4 * nw + tid], 8);
+        const uint32_t head = min(blen, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(stage) & 3)) & 3));
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(stage + head);
+        const uint32_t nw = (blen - head) >> 2, tail0 = head + 4 * nw;
+        for (uint32_t i = tid; i < nw; i += NT) put_bits(obuf, z, p0 + 24 + 8 * head + 32 * i, s32[i], 32);
+        if ((uint32_t)tid < head) put_bits(obuf, z, p0 + 24 + 8 * tid, stage[tid], 8);
+        if ((uint32_t)tid < blen - tail0) put_bits(obuf, z, p0 + 24 + 8 * (tail0 + tid), stage[tail0 + tid], 8);
     } else if (type == 1) {
         if (tid == 0) put_bits(obuf, z, p0 + 24, stage[0], 8);
     } else {
@@ -378,7 +385,10 @@ __device__ __forceinline__ void zstd_block(DeflShared &S, BuildScratch &B, uint3
 // Returns the record length (prefix included).
 template <bool STAGED>
 __device__ __forceinline__ uint32_t zstd_record(DeflShared &S, uint32_t *obuf, uint32_t obuf_words, const uint8_t *src, uint8_t *stage,
-                                                uint32_t plen, uint8_t *out, uint32_t dbg = 0) {
+                                                uint32_t plen, uint8_t *out, uint32_t dbg = 0, uint32_t split = 0, uint32_t head = 0) {
+    // split != 0 (payload in LDS only): the first block ends there.  An svb-zd payload is `head | key bytes | data bytes`; the key
+    // bytes are ~94 % zeros and share nothing with the data bytes, and one Huffman table over both costs 6.6 % of the record
+    // (0.9466 -> 0.8838 B/sample on the bench reads: what libzstd's match finder gets out of the key area, 0.878)
     const int tid = threadIdx.x;
     BuildScratch &B = *reinterpret_cast<BuildScratch *>(obuf);
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
@@ -392,7 +402,10 @@ __device__ __forceinline__ uint32_t zstd_record(DeflShared &S, uint32_t *obuf, u
     z.carry = plen >> 24;
     uint32_t done = 0;
     do {
-        const uint32_t blen = min(plen - done, (uint32_t)DEFL_BLK);
+        // head != 0: the record head in front of the key bytes goes as a raw block (its doubles would push the key block's
+        // alphabet past 128 symbols, i.e. into FSE-compressed weights, for nothing)
+        const bool raw_head = !STAGED && split && head && done == 0;
+        const uint32_t blen = raw_head ? head : !STAGED && split && done < split ? split - done : min(plen - done, (uint32_t)DEFL_BLK);
         const bool last = done + blen == plen;
         const uint8_t *blk = src + done;
         if (STAGED) {
@@ -403,7 +416,7 @@ __device__ __forceinline__ uint32_t zstd_record(DeflShared &S, uint32_t *obuf, u
             blk = stage;
             __syncthreads();
         }
-        zstd_block(S, B, obuf, obuf_words, blk, blen, last, z, dbg);
+        zstd_block(S, B, obuf, obuf_words, blk, blen, last, z, dbg, raw_head);
         if (dbg) return z.bitpos >> 3;
         done += blen;
         if (!last) {
