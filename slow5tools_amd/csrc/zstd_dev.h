@@ -238,36 +238,56 @@ __device__ __noinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *p, 
         }
         if (nsym > 255) return 0;
     }
-    uint32_t sum = 0;
-    for (int i = 0; i < nsym; i++) { if (T.w[i] > 11) return 0; if (T.w[i]) sum += 1u << (T.w[i] - 1); }
+    *nsym_out = nsym;
+    *maxbits_out = 0;
+    return used;
+}
+
+// From the weights T.w[0..nsym) to the table layout, all 64 lanes: the implied last weight, the code length limit, and
+// T.start[i] = first cell of symbol i (cells ascend by weight, symbol order inside a weight).  Lane l looks after symbols
+// l, l + 64, l + 128, l + 192; counts per weight are ballots, ranks inside a weight the set bits below the lane.
+// Returns the number of symbols (0: not a valid description); *maxbits_out = longest code.
+__device__ __forceinline__ uint32_t z_huf_ranks(ZstdShared &T, uint32_t nsym, int *maxbits_out) {
+    const int lane = lane_id();
+    uint32_t w[4], part = 0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = (uint32_t)lane + 64u * j;
+        w[j] = i < nsym ? T.w[i] : 0u;
+        if (w[j] > 11) { bad = true; w[j] = 0; }
+        if (w[j]) part += 1u << (w[j] - 1);
+    }
+    if (__ballot(bad)) return 0;
+    const uint32_t sum = wave_sum(part);
     if (sum == 0) return 0;
     const int maxbits = z_highbit(sum) + 1;
     if (maxbits > 11) return 0;
     const uint32_t rest = (1u << maxbits) - sum;
     if (rest & (rest - 1)) return 0;
-    T.w[nsym++] = (uint8_t)(z_highbit(rest) + 1);
-    uint32_t cnt[12], at[12];
-    for (int r = 0; r < 12; r++) cnt[r] = 0;
-    for (int i = 0; i < nsym; i++) {
-        const int r = T.w[i];
+    const uint32_t wl = (uint32_t)z_highbit(rest) + 1;             // the weight of the last symbol is implied
 #pragma unroll
-        for (int q = 0; q < 12; q++) cnt[q] += q == r;            // static indices: no scratch
+    for (int j = 0; j < 4; j++) if ((uint32_t)lane + 64u * j == nsym) { w[j] = wl; T.w[nsym] = (uint8_t)wl; }
+    nsym++;
+    uint32_t at = 0;                                               // first cell of the weight class at hand
+#pragma unroll
+    for (uint32_t r = 1; r <= 11; r++) {
+        uint32_t seen = 0;                                         // symbols of this weight in the slices before
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t m = __ballot(w[j] == r);
+            if (w[j] == r) {
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                T.start[lane + 64 * j] = (uint16_t)(at + ((seen + below) << (r - 1)));
+            }
+            seen += (uint32_t)__popcll(m);
+        }
+        if (r == 1 && (seen < 2 || (seen & 1))) return 0;
+        at += seen << (r - 1);
     }
-    if (cnt[1] < 2 || (cnt[1] & 1)) return 0;
-    uint32_t a = 0;
-#pragma unroll
-    for (int r = 1; r < 12; r++) { at[r] = a; a += cnt[r] << (r - 1); }
-    at[0] = 0;
-    for (int i = 0; i < nsym; i++) {
-        const int r = T.w[i];
-        uint32_t mine = 0;
-#pragma unroll
-        for (int q = 1; q < 12; q++) if (q == r) { mine = at[q]; at[q] += 1u << (q - 1); }
-        T.start[i] = (uint16_t)mine;
-    }
-    *nsym_out = nsym;
+    wave_sync();
     *maxbits_out = maxbits;
-    return used;
+    return nsym;
 }
 
 // one Huffman stream on the calling lane: n symbols to dst; false on a malformed stream
@@ -296,7 +316,7 @@ __device__ __forceinline__ bool z_huf_stream(const uint16_t *huf, uint32_t L, co
 }
 
 // One frame -> out (olen bytes).  INF_OK, or INF_ERR_HEADER / DATA / TRUNC / OVERFLOW (olen = bytes needed when the frame says).
-__device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out) {
+__device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out, int dbg = 0) {
     const int lane = lane_id();
     *olen_out = 0;
     if (len < 6) return INF_ERR_TRUNC;
@@ -370,14 +390,15 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             q = cend;
             if (ltype == 2) {
                 if (lane == 0) {
-                    int nsym = 0, maxbits = 0;
-                    const uint32_t u = z_huf_weights(T, b + c, cend - c, &nsym, &maxbits);
-                    T.x[0] = u; T.x[1] = (uint32_t)nsym; T.x[2] = (uint32_t)maxbits;
+                    int nw = 0, unused = 0;
+                    const uint32_t u = z_huf_weights(T, b + c, cend - c, &nw, &unused);
+                    T.x[0] = u; T.x[1] = (uint32_t)nw;
                 }
                 wave_sync();
-                const uint32_t u = T.x[0], nsym = T.x[1];
+                const uint32_t u = T.x[0];
                 if (!u) { status = INF_ERR_DATA; break; }
-                huf_log = (int)T.x[2];
+                const uint32_t nsym = z_huf_ranks(T, T.x[1], &huf_log);
+                if (!nsym) { huf_log = 0; status = INF_ERR_DATA; break; }
                 c += u;
                 for (uint32_t i = 0; i < nsym; i++) {             // all lanes fill symbol i's cells
                     const uint32_t wgt = T.w[i];
@@ -387,6 +408,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 }
                 wave_sync();
             } else if (!huf_log) { status = INF_ERR_DATA; break; }
+            if (dbg == 1) return 9;
             uint8_t *park = out + (E - lsize);
             bool ok = true;
             if (streams == 1) {
@@ -404,6 +426,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 }
             }
             if (__ballot(!ok)) { status = INF_ERR_DATA; break; }
+            if (dbg == 2) return 9;
             wave_sync();
             lit = park;
             lit_parked = true;
@@ -430,6 +453,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             }
             wave_sync();
             if (T.x[0]) { status = INF_ERR_DATA; break; }
+            if (dbg == 3) return 9;
             q = T.x[1];
             ll_log = __shfl(ll_log, 0); of_log = __shfl(of_log, 0); ml_log = __shfl(ml_log, 0);
             ZBits br;
