@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64) void k_zstd_inflate(s5gpu_decode_args_t a) {
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
-    const int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, a.sig_method >> 8);
+    const int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
     if (lane_id() == 0) {
         a.fields[r].status = status;
         a.fields[r].payload_len = olen;

@@ -35,6 +35,7 @@ struct ZstdShared {                  // per wave
     uint16_t next[64];
     int16_t norm[64];
     uint32_t wt[64];                 // FSE table of the Huffman weights
+    uint8_t slot[512];               // FSE build: symbol of every spread slot
     uint32_t x[8];                   // lane 0 -> wave mailbox
 };
 
@@ -151,6 +152,58 @@ __device__ __noinline__ int z_fse_build(uint32_t *t, const int16_t *norm, int ma
     return 0;
 }
 
+// The same table, built by the whole wave (norm[0..maxsym] in LDS, maxsym < 64).  Lane s looks after symbol s: the symbols
+// with probability "less than one" take the top cells, every other symbol writes itself over its run of spread slots; then
+// a lane per spread step t places slot k(t) (= accepted steps before t: a prefix count) at cell (t * step) mod size; and the
+// rank of a cell among the cells of its symbol — the decoder's "next state" counter — comes from one ballot per distinct
+// symbol of a 64-cell slice, the running counts living in the symbol lanes.  Was ~150 k cycles of lane-0 code per 512-cell table.
+__device__ __forceinline__ int z_fse_build_wave(ZstdShared &T, uint32_t *t, int maxsym, int log) {
+    const int lane = lane_id();
+    const int size = 1 << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint8_t *cell = reinterpret_cast<uint8_t *>(T.start);
+    const int mine = lane <= maxsym ? (int)T.norm[lane] : 0;
+    const uint64_t lowm = __ballot(mine == -1);
+    const int nlow = __popcll(lowm), high = size - 1 - nlow;
+    if (mine == -1) cell[size - 1 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lowm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lowm, 0u))] = (uint8_t)lane;
+    const uint32_t cntp = mine > 0 ? (uint32_t)mine : 0u;
+    const uint32_t incl = wave_incl_add(cntp);
+    if ((int)__builtin_amdgcn_readlane((int)incl, 63) != size - nlow) return -1;
+    for (uint32_t k = incl - cntp; k < incl; k++) T.slot[k] = (uint8_t)lane;
+    wave_sync();
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < size; t0 += 64) {
+        const int tt = t0 + lane;
+        const int pos = (tt * step) & mask;
+        const bool acc = tt < size && pos <= high;
+        const uint64_t m = __ballot(acc);
+        if (acc) cell[pos] = T.slot[carry + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))];
+        carry += (uint32_t)__popcll(m);
+    }
+    wave_sync();
+    uint32_t nextc = mine == -1 ? 1u : cntp;                          // lane s: next state counter of symbol s
+    for (int c0 = 0; c0 < size; c0 += 64) {
+        const int ci = c0 + lane;
+        const uint32_t sym = ci < size ? cell[ci] : 0xFFu;
+        uint64_t todo = __ballot(ci < size);
+        uint32_t ns = 0;
+        while (todo) {
+            const int first = __ffsll((long long)todo) - 1;
+            const uint32_t sy = (uint32_t)__builtin_amdgcn_readlane((int)sym, first);
+            const uint64_t m = __ballot(sym == sy) & todo;
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)nextc, (int)sy);
+            if (sym == sy) ns = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if ((uint32_t)lane == sy) nextc += (uint32_t)__popcll(m);
+            todo &= ~m;
+        }
+        if (ci < size) {
+            const int nb = log - z_highbit(ns);
+            t[ci] = sym | ((uint32_t)nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xFFFFu) << 16);
+        }
+    }
+    wave_sync();
+    return 0;
+}
+
 __device__ const int16_t Z_LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
 __device__ const int16_t Z_ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
                                          1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
@@ -175,27 +228,35 @@ __device__ __forceinline__ uint32_t z_ml_sym(uint32_t c) {
     return (c - 36) | (((1u << (c - 36)) + 3) << 8);              // 43: 7 bits, base 131 ... 52: 16 bits, base 65539
 }
 
-// one of the three sequence tables (lane 0): bytes of description consumed, -1 on error
-__device__ __noinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_t *p, uint32_t len, uint32_t *t, int *log, const int16_t *def,
-                                        int def_n, int def_log, int max_log, int max_sym) {
+// one of the three sequence tables (all lanes; the count header is read by lane 0): bytes of description consumed, -1 on error
+__device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_t *p, uint32_t len, uint32_t *t, int *log, const int16_t *def,
+                                           int def_n, int def_log, int max_log, int max_sym) {
+    const int lane = lane_id();
     if (mode == 0) {
-        for (int i = 0; i < def_n; i++) T.norm[i] = def[i];
-        if (z_fse_build(t, T.norm, def_n - 1, def_log, reinterpret_cast<uint8_t *>(T.start), T.next)) return -1;
+        if (lane < def_n) T.norm[lane] = def[lane];
+        wave_sync();
+        if (z_fse_build_wave(T, t, def_n - 1, def_log)) return -1;
         *log = def_log;
         return 0;
     }
     if (mode == 1) {
         if (len < 1 || p[0] > max_sym) return -1;
-        t[0] = p[0];
+        if (lane == 0) t[0] = p[0];
+        wave_sync();
         *log = 0;
         return 1;
     }
     if (mode == 2) {
-        int maxsym, l;
-        const uint32_t h = z_ncount(p, len, T.norm, &maxsym, &l, max_log, max_sym);
+        if (lane == 0) {
+            int maxsym = 0, l = 0;
+            const uint32_t h = z_ncount(p, len, T.norm, &maxsym, &l, max_log, max_sym);
+            T.x[4] = h; T.x[5] = (uint32_t)maxsym; T.x[6] = (uint32_t)l;
+        }
+        wave_sync();
+        const uint32_t h = T.x[4];
         if (!h) return -1;
-        if (z_fse_build(t, T.norm, maxsym, l, reinterpret_cast<uint8_t *>(T.start), T.next)) return -1;
-        *log = l;
+        if (z_fse_build_wave(T, t, (int)T.x[5], (int)T.x[6])) return -1;
+        *log = (int)T.x[6];
         return (int)h;
     }
     return *log < 0 ? -1 : 0;
@@ -316,7 +377,7 @@ __device__ __forceinline__ bool z_huf_stream(const uint16_t *huf, uint32_t L, co
 }
 
 // One frame -> out (olen bytes).  INF_OK, or INF_ERR_HEADER / DATA / TRUNC / OVERFLOW (olen = bytes needed when the frame says).
-__device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out, int dbg = 0) {
+__device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out) {
     const int lane = lane_id();
     *olen_out = 0;
     if (len < 6) return INF_ERR_TRUNC;
@@ -408,7 +469,6 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 }
                 wave_sync();
             } else if (!huf_log) { status = INF_ERR_DATA; break; }
-            if (dbg == 1) return 9;
             uint8_t *park = out + (E - lsize);
             bool ok = true;
             if (streams == 1) {
@@ -426,7 +486,6 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 }
             }
             if (__ballot(!ok)) { status = INF_ERR_DATA; break; }
-            if (dbg == 2) return 9;
             wave_sync();
             lit = park;
             lit_parked = true;
@@ -443,19 +502,17 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             if (q >= bend) { status = INF_ERR_DATA; break; }
             const uint32_t modes = b[q++];
             if (modes & 3) { status = INF_ERR_DATA; break; }
-            if (lane == 0) {
+            {
                 int u, bad = 0;
                 uint32_t qq = q;
                 if ((u = z_seq_table(T, (int)(modes >> 6), b + qq, bend - qq, T.ll, &ll_log, Z_LL_DEF, 36, 6, 9, 35)) < 0) bad = 1; else qq += (uint32_t)u;
                 if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 4) & 3), b + qq, bend - qq, T.of, &of_log, Z_OF_DEF, 29, 5, 8, 31)) < 0) bad = 1; else qq += (uint32_t)u; }
                 if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 2) & 3), b + qq, bend - qq, T.ml, &ml_log, Z_ML_DEF, 53, 6, 9, 52)) < 0) bad = 1; else qq += (uint32_t)u; }
-                T.x[0] = (uint32_t)bad; T.x[1] = qq;
+                if (lane == 0) { T.x[0] = (uint32_t)bad; T.x[1] = qq; }
             }
             wave_sync();
             if (T.x[0]) { status = INF_ERR_DATA; break; }
-            if (dbg == 3) return 9;
             q = T.x[1];
-            ll_log = __shfl(ll_log, 0); of_log = __shfl(of_log, 0); ml_log = __shfl(ml_log, 0);
             ZBits br;
             br.base = b; br.ptr = 0; br.used = 64; br.c = 0;
             uint32_t sl = 0, so = 0, sm = 0;
