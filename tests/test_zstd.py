@@ -247,3 +247,27 @@ def test_frames_without_a_content_size_field(press):
     rc, res, st = zstd_solo(frames)
     assert rc == 0 and all(s == 0 for s in st)
     assert res == datas
+
+
+def test_random_buffers_round_trip_through_both_directions(press):
+    """300 random buffers (random length 0..40000, random alphabet size and skew, runs, boundaries around 16 KiB): the device
+    encoder's frames are read back by libzstd (when present), by the restated decoder and by the device decoder"""
+    rng = np.random.default_rng(51)
+    datas = []
+    for _ in range(300):
+        n = int(rng.choice([rng.integers(0, 300), rng.integers(300, 5000), rng.integers(5000, 40000), 16384 + rng.integers(-3, 4)]))
+        k = int(rng.choice([1, 2, 3, 8, 40, 129, 200, 256]))
+        alphabet = rng.choice(256, size=k, replace=False).astype(np.uint8)
+        p = rng.dirichlet(np.full(k, rng.choice([0.05, 0.3, 1.0, 5.0])))
+        d = alphabet[rng.choice(k, size=n, p=p)]
+        if n > 50 and rng.random() < 0.3:                       # a run in the middle
+            a = int(rng.integers(0, n - 20))
+            d[a:a + int(rng.integers(5, min(3000, n - a)))] = alphabet[0]
+        datas.append(d.tobytes())
+    frames = zstd_solo_compress(datas)
+    for d, f in zip(datas, frames):
+        assert ob.zstd_restated_decompress(f, len(d)) == d
+        if ob.zstd_ref() is not None:
+            assert ob.zstd_decompress(f, len(d)) == d
+    rc, back, st = zstd_solo(frames)
+    assert rc == 0 and back == datas
