@@ -271,3 +271,19 @@ def test_random_buffers_round_trip_through_both_directions(press):
             assert ob.zstd_decompress(f, len(d)) == d
     rc, back, st = zstd_solo(frames)
     assert rc == 0 and back == datas
+
+
+def test_random_length_records_through_the_split_encoder(press):
+    """200 reads of random length (0 .. 12000 samples: with and without a key | data split, one- and two-tile payloads) with
+    random aux tails: every frame holds the uncompressed record"""
+    rng = np.random.default_rng(52)
+    ns = rng.integers(0, 12000, 200)
+    sigs = [(rng.integers(200, 900) + np.cumsum(rng.integers(-25, 26, int(n))) % 400).astype(np.int16) for n in ns]
+    hdrs = [_hdr(press, i) for i in range(len(sigs))]
+    auxs = [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 300, len(sigs))]
+    out = press.encode_records(sigs, hdrs, auxs, press.REC_ZSTD, press.SIG_SVB_ZD)
+    raw = press.encode_records(sigs, hdrs, auxs, press.REC_NONE, press.SIG_SVB_ZD)
+    for o, r in zip(out, raw):
+        assert ob.zstd_restated_decompress(o[8:], len(r)) == r[8:]
+    dec = press.decode_records([o[8:] for o in out], press.REC_ZSTD, press.SIG_SVB_ZD)
+    assert all(d["status"] == 0 and np.array_equal(d["signal"], s) and d["aux"] == a for d, s, a in zip(dec, sigs, auxs))
