@@ -356,15 +356,22 @@ __device__ __forceinline__ bool z_huf_stream(const uint16_t *huf, uint32_t L, co
     ZBits b;
     if (!b.init(p, len)) return false;
     uint32_t i = 0;
+    const uint32_t sh = 64u - L;
     for (; i + 4 <= n; i += 4) {                                   // 4 symbols <= 44 bits per refill
         b.need(44);
-        uint32_t v = 0;
+        // the unread bits on top of one 64-bit word: a symbol is a shift for the index and a shift to drop its code
+        // (bits before the start of the stream read as zero, as peek() has it)
+        uint64_t w = b.used < 64 ? b.c << b.used : 0ull;
+        uint32_t v = 0, took = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint32_t e = huf[b.peek(L)];
-            b.used += e >> 8;
+            const uint32_t e = huf[(uint32_t)(w >> sh)];
+            const uint32_t nb = e >> 8;
+            w <<= nb;
+            took += nb;
             v |= (e & 255u) << (8 * q);
         }
+        b.used += took;
         *(z_u32u *)(dst + i) = v;
     }
     for (; i < n; i++) {
