@@ -468,11 +468,23 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 const uint32_t nsym = z_huf_ranks(T, T.x[1], &huf_log);
                 if (!nsym) { huf_log = 0; status = INF_ERR_DATA; break; }
                 c += u;
-                for (uint32_t i = 0; i < nsym; i++) {             // all lanes fill symbol i's cells
-                    const uint32_t wgt = T.w[i];
-                    if (!wgt) continue;
-                    const uint32_t span = 1u << (wgt - 1), at = T.start[i], e = i | ((uint32_t)(huf_log + 1 - (int)wgt) << 8);
-                    for (uint32_t k = lane; k < span; k += 64) T.huf[at + k] = (uint16_t)e;
+                // the table: a lane fills the cells of its own symbols when they are few (weights up to 5: at most 16 cells);
+                // the handful of frequent symbols with hundreds of cells each are filled by the whole wave, one after the other
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t i = (uint32_t)lane + 64u * j;
+                    const uint32_t wgt = i < nsym ? T.w[i] : 0u;
+                    const uint32_t at = i < nsym ? T.start[i] : 0u;
+                    const uint32_t e = i | ((uint32_t)(huf_log + 1 - (int)wgt) << 8);
+                    if (wgt && wgt <= 5) { const uint32_t span = 1u << (wgt - 1); for (uint32_t k = 0; k < span; k++) T.huf[at + k] = (uint16_t)e; }
+                    uint64_t big = __ballot(wgt >= 6);
+                    while (big) {
+                        const int l = __ffsll((long long)big) - 1;
+                        const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)wgt, l), ba = (uint32_t)__builtin_amdgcn_readlane((int)at, l);
+                        const uint32_t be = (uint32_t)__builtin_amdgcn_readlane((int)e, l), span = 1u << (bw - 1);
+                        for (uint32_t k = lane; k < span; k += 64) T.huf[ba + k] = (uint16_t)be;
+                        big &= big - 1;
+                    }
                 }
                 wave_sync();
             } else if (!huf_log) { status = INF_ERR_DATA; break; }
