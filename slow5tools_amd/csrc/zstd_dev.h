@@ -32,7 +32,6 @@ struct ZstdShared {                  // per wave
     uint32_t llsym[36], mlsym[53];   // extra bits | base << 8
     uint8_t w[256];                  // Huffman weights
     uint16_t start[256];             // first table cell of each symbol / FSE spread cells (as bytes)
-    uint16_t next[64];
     int16_t norm[64];
     uint32_t wt[64];                 // FSE table of the Huffman weights
     uint8_t slot[512];               // FSE build: symbol of every spread slot
@@ -127,32 +126,8 @@ __device__ __noinline__ uint32_t z_ncount(const uint8_t *p, uint32_t len, int16_
     return used <= len ? used : 0;
 }
 
-// decode table of an FSE distribution (lane 0); cell[] holds one byte per table cell
-__device__ __noinline__ int z_fse_build(uint32_t *t, const int16_t *norm, int maxsym, int log, uint8_t *cell, uint16_t *next) {
-    const int size = 1 << log;
-    int high = size - 1;
-    for (int s = 0; s <= maxsym; s++) {
-        if (norm[s] == -1) { cell[high--] = (uint8_t)s; next[s] = 1; }
-        else next[s] = (uint16_t)norm[s];
-    }
-    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
-    int pos = 0;
-    for (int s = 0; s <= maxsym; s++)
-        for (int i = 0; i < norm[s]; i++) {
-            cell[pos] = (uint8_t)s;
-            do { pos = (pos + step) & mask; } while (pos > high);
-        }
-    if (pos != 0) return -1;
-    for (int i = 0; i < size; i++) {
-        const int s = cell[i];
-        const uint32_t ns = next[s]++;
-        const int nb = log - z_highbit(ns);
-        t[i] = (uint32_t)s | ((uint32_t)nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xFFFFu) << 16);
-    }
-    return 0;
-}
-
-// The same table, built by the whole wave (norm[0..maxsym] in LDS, maxsym < 64).  Lane s looks after symbol s: the symbols
+// Decode table of an FSE distribution (oracle/zstd_dec.c fse_build is the serial statement of it).
+// Built by the whole wave (norm[0..maxsym] in LDS, maxsym < 64).  Lane s looks after symbol s: the symbols
 // with probability "less than one" take the top cells, every other symbol writes itself over its run of spread slots; then
 // a lane per spread step t places slot k(t) (= accepted steps before t: a prefix count) at cell (t * step) mod size; and the
 // rank of a cell among the cells of its symbol — the decoder's "next state" counter — comes from one ballot per distinct
@@ -262,45 +237,57 @@ __device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_
     return *log < 0 ? -1 : 0;
 }
 
-// Huffman weights of a tree description (lane 0): bytes consumed (0 on error); T.w[0..nsym), *nsym_out, *maxbits_out
-__device__ __noinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *p, uint32_t len, int *nsym_out, int *maxbits_out) {
+// Huffman weights of a tree description: bytes consumed (0 on error); T.w[0..*nsym_out)
+__device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *p, uint32_t len, uint32_t *nsym_out) {   // all lanes
+    const int lane = lane_id();
     if (len < 1) return 0;
-    const int hb = p[0];
-    int nsym;
-    uint32_t used;
-    if (hb >= 128) {
-        nsym = hb - 127;
-        used = 1 + (uint32_t)(nsym + 1) / 2;
+    const uint32_t hb = p[0];
+    if (hb >= 128) {                                              // nibbles, two per byte
+        const uint32_t nsym = hb - 127, used = 1 + (nsym + 1) / 2;
         if (used > len) return 0;
-        for (int i = 0; i < nsym; i++) T.w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
-    } else {
-        used = 1 + (uint32_t)hb;
-        if (used > len || hb < 1) return 0;
-        int maxsym, log;
-        const uint32_t h = z_ncount(p + 1, (uint32_t)hb, T.norm, &maxsym, &log, 6, 12);
-        if (!h || h >= (uint32_t)hb) return 0;
-        if (z_fse_build(T.wt, T.norm, maxsym, log, reinterpret_cast<uint8_t *>(T.start), T.next)) return 0;
-        ZBits b;
-        if (!b.init(p + 1 + h, (uint32_t)hb - h)) return 0;
-        uint32_t s1 = b.get((uint32_t)log);
-        uint32_t s2 = b.get((uint32_t)log);
-        nsym = 0;
-        for (;;) {                                                // two interleaved states
-            if (nsym >= 254) return 0;
-            const uint32_t e1 = T.wt[s1], e2 = T.wt[s2];
-            T.w[nsym++] = (uint8_t)e1;
-            b.need(8);
-            if (b.overrun() || b.left() < ((e1 >> 8) & 255)) { T.w[nsym++] = (uint8_t)e2; break; }
-            s1 = (e1 >> 16) + b.get((e1 >> 8) & 255);
-            T.w[nsym++] = (uint8_t)e2;
-            b.need(8);
-            if (b.left() < ((e2 >> 8) & 255)) { T.w[nsym++] = (uint8_t)T.wt[s1]; break; }
-            s2 = (e2 >> 16) + b.get((e2 >> 8) & 255);
-        }
-        if (nsym > 255) return 0;
+        for (uint32_t i = lane; i < nsym; i += 64) T.w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
+        wave_sync();
+        *nsym_out = nsym;
+        return used;
     }
-    *nsym_out = nsym;
-    *maxbits_out = 0;
+    // FSE-compressed: count header by lane 0, table by the wave, the two interleaved states walked by lane 0
+    const uint32_t used = 1 + hb;
+    if (used > len || hb < 1) return 0;
+    if (lane == 0) {
+        int maxsym = 0, log = 0;
+        const uint32_t h = z_ncount(p + 1, hb, T.norm, &maxsym, &log, 6, 12);
+        T.x[4] = (h && h < hb) ? h : 0u; T.x[5] = (uint32_t)maxsym; T.x[6] = (uint32_t)log;
+    }
+    wave_sync();
+    const uint32_t h = T.x[4];
+    const int log = (int)T.x[6];
+    if (!h) return 0;
+    if (z_fse_build_wave(T, T.wt, (int)T.x[5], log)) return 0;
+    if (lane == 0) {
+        uint32_t nsym = 0;
+        ZBits b;
+        if (b.init(p + 1 + h, hb - h)) {
+            uint32_t s1 = b.get((uint32_t)log);
+            uint32_t s2 = b.get((uint32_t)log);
+            for (;;) {                                            // two interleaved states
+                if (nsym >= 254) { nsym = 0; break; }
+                const uint32_t e1 = T.wt[s1], e2 = T.wt[s2];
+                T.w[nsym++] = (uint8_t)e1;
+                b.need(8);
+                if (b.overrun() || b.left() < ((e1 >> 8) & 255)) { T.w[nsym++] = (uint8_t)e2; break; }
+                s1 = (e1 >> 16) + b.get((e1 >> 8) & 255);
+                T.w[nsym++] = (uint8_t)e2;
+                b.need(8);
+                if (b.left() < ((e2 >> 8) & 255)) { T.w[nsym++] = (uint8_t)T.wt[s1]; break; }
+                s2 = (e2 >> 16) + b.get((e2 >> 8) & 255);
+            }
+            if (nsym > 255) nsym = 0;
+        }
+        T.x[4] = nsym;
+    }
+    wave_sync();
+    if (!T.x[4]) return 0;
+    *nsym_out = T.x[4];
     return used;
 }
 
@@ -457,15 +444,10 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             const uint32_t cend = q + csize;
             q = cend;
             if (ltype == 2) {
-                if (lane == 0) {
-                    int nw = 0, unused = 0;
-                    const uint32_t u = z_huf_weights(T, b + c, cend - c, &nw, &unused);
-                    T.x[0] = u; T.x[1] = (uint32_t)nw;
-                }
-                wave_sync();
-                const uint32_t u = T.x[0];
+                uint32_t nw = 0;
+                const uint32_t u = z_huf_weights(T, b + c, cend - c, &nw);
                 if (!u) { status = INF_ERR_DATA; break; }
-                const uint32_t nsym = z_huf_ranks(T, T.x[1], &huf_log);
+                const uint32_t nsym = z_huf_ranks(T, nw, &huf_log);
                 if (!nsym) { huf_log = 0; status = INF_ERR_DATA; break; }
                 c += u;
                 // the table: a lane fills the cells of its own symbols when they are few (weights up to 5: at most 16 cells);
