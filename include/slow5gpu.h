@@ -124,7 +124,8 @@ int s5gpu_device_count(void);
  * inflate kernel (throughput), smaller ones the wave-per-record kernel (latency); default 24576.
  * "inflate_route" (0/1, default 1): such batches are first counting-sorted by compressed length on the device, and records
  * of >= 32 KiB go to the wave-per-record kernel beside the lane kernel (real runs have read lengths spread over two decades).
- * In inflate-only calls fields[i].reserved / read_group are then left holding routing scratch. */
+ * In inflate-only calls fields[i].reserved, fields[0..128].read_group and fields[128].aux_len are then left holding routing
+ * scratch (s5gpu_decode_dev overwrites all of them with the parsed fields). */
 int s5gpu_set_option(const char *key, long value);
 
 /* ---- device-resident entry points (asynchronous on `hip_stream`, a hipStream_t; NULL = default) ---- */
