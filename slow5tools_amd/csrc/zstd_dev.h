@@ -28,15 +28,25 @@ namespace s5 {
 
 struct ZstdShared {                  // per wave
     uint16_t huf[2048];              // symbol | bits << 8
-    uint32_t ll[512], ml[512], of[256];   // symbol | bits << 8 | baseline << 16
+    // FSE decode tables, 3 bytes per cell (bits | baseline << 4 in 16 bits, the symbol in 8): the footprint of these tables and
+    // of the Huffman table decides how many waves a CU holds, and the decoder is latency bound (13 -> 16 waves per CU)
+    uint16_t ll_e[512], ml_e[512], of_e[256];
+    uint8_t ll_s[512], ml_s[512], of_s[256];
     uint32_t llsym[36], mlsym[53];   // extra bits | base << 8
     uint8_t w[256];                  // Huffman weights
     uint16_t start[256];             // first table cell of each symbol / FSE spread cells (as bytes)
     int16_t norm[64];
-    uint32_t wt[64];                 // FSE table of the Huffman weights
+    uint16_t wt_e[64];               // FSE table of the Huffman weights
+    uint8_t wt_s[64];
     uint8_t slot[512];               // FSE build: symbol of every spread slot
     uint32_t x[8];                   // lane 0 -> wave mailbox
 };
+
+struct ZFse { uint16_t *e; uint8_t *s; };                       // one FSE decode table
+__device__ __forceinline__ uint32_t zfse_get(const ZFse &t, uint32_t i) {   // symbol | bits << 8 | baseline << 16
+    const uint32_t e = t.e[i];
+    return (uint32_t)t.s[i] | ((e & 15u) << 8) | ((e >> 4) << 16);
+}
 
 typedef uint64_t __attribute__((aligned(1))) z_u64u;
 typedef uint32_t __attribute__((aligned(1))) z_u32u;
@@ -132,7 +142,7 @@ __device__ __noinline__ uint32_t z_ncount(const uint8_t *p, uint32_t len, int16_
 // a lane per spread step t places slot k(t) (= accepted steps before t: a prefix count) at cell (t * step) mod size; and the
 // rank of a cell among the cells of its symbol — the decoder's "next state" counter — comes from one ballot per distinct
 // symbol of a 64-cell slice, the running counts living in the symbol lanes.  Was ~150 k cycles of lane-0 code per 512-cell table.
-__device__ __forceinline__ int z_fse_build_wave(ZstdShared &T, uint32_t *t, int maxsym, int log) {
+__device__ __forceinline__ int z_fse_build_wave(ZstdShared &T, const ZFse &t, int maxsym, int log) {
     const int lane = lane_id();
     const int size = 1 << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
     uint8_t *cell = reinterpret_cast<uint8_t *>(T.start);
@@ -172,7 +182,8 @@ __device__ __forceinline__ int z_fse_build_wave(ZstdShared &T, uint32_t *t, int 
         }
         if (ci < size) {
             const int nb = log - z_highbit(ns);
-            t[ci] = sym | ((uint32_t)nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xFFFFu) << 16);
+            t.s[ci] = (uint8_t)sym;
+            t.e[ci] = (uint16_t)((uint32_t)nb | ((((ns << nb) - (uint32_t)size) & 0xFFFu) << 4));
         }
     }
     wave_sync();
@@ -204,7 +215,7 @@ __device__ __forceinline__ uint32_t z_ml_sym(uint32_t c) {
 }
 
 // one of the three sequence tables (all lanes; the count header is read by lane 0): bytes of description consumed, -1 on error
-__device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_t *p, uint32_t len, uint32_t *t, int *log, const int16_t *def,
+__device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_t *p, uint32_t len, const ZFse &t, int *log, const int16_t *def,
                                            int def_n, int def_log, int max_log, int max_sym) {
     const int lane = lane_id();
     if (mode == 0) {
@@ -216,7 +227,7 @@ __device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_
     }
     if (mode == 1) {
         if (len < 1 || p[0] > max_sym) return -1;
-        if (lane == 0) t[0] = p[0];
+        if (lane == 0) { t.s[0] = p[0]; t.e[0] = 0; }
         wave_sync();
         *log = 0;
         return 1;
@@ -262,7 +273,8 @@ __device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *
     const uint32_t h = T.x[4];
     const int log = (int)T.x[6];
     if (!h) return 0;
-    if (z_fse_build_wave(T, T.wt, (int)T.x[5], log)) return 0;
+    const ZFse wt = {T.wt_e, T.wt_s};
+    if (z_fse_build_wave(T, wt, (int)T.x[5], log)) return 0;
     if (lane == 0) {
         uint32_t nsym = 0;
         ZBits b;
@@ -271,14 +283,14 @@ __device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *
             uint32_t s2 = b.get((uint32_t)log);
             for (;;) {                                            // two interleaved states
                 if (nsym >= 254) { nsym = 0; break; }
-                const uint32_t e1 = T.wt[s1], e2 = T.wt[s2];
+                const uint32_t e1 = zfse_get(wt, s1), e2 = zfse_get(wt, s2);
                 T.w[nsym++] = (uint8_t)e1;
                 b.need(8);
                 if (b.overrun() || b.left() < ((e1 >> 8) & 255)) { T.w[nsym++] = (uint8_t)e2; break; }
                 s1 = (e1 >> 16) + b.get((e1 >> 8) & 255);
                 T.w[nsym++] = (uint8_t)e2;
                 b.need(8);
-                if (b.left() < ((e2 >> 8) & 255)) { T.w[nsym++] = (uint8_t)T.wt[s1]; break; }
+                if (b.left() < ((e2 >> 8) & 255)) { T.w[nsym++] = T.wt_s[s1]; break; }
                 s2 = (e2 >> 16) + b.get((e2 >> 8) & 255);
             }
             if (nsym > 255) nsym = 0;
@@ -391,6 +403,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
     const uint32_t E = fcs_bytes ? (uint32_t)fcs : cap;           // end of the output region: Huffman literals park below it
     if (lane < 36) T.llsym[lane] = z_ll_sym((uint32_t)lane);
     if (lane < 53) T.mlsym[lane] = z_ml_sym((uint32_t)lane);
+    const ZFse tll = {T.ll_e, T.ll_s}, tml = {T.ml_e, T.ml_s}, tof = {T.of_e, T.of_s};
     int huf_log = 0, ll_log = -1, of_log = -1, ml_log = -1;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                        // lane 0's copy is the live one
     uint32_t o = 0;
@@ -506,9 +519,9 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             {
                 int u, bad = 0;
                 uint32_t qq = q;
-                if ((u = z_seq_table(T, (int)(modes >> 6), b + qq, bend - qq, T.ll, &ll_log, Z_LL_DEF, 36, 6, 9, 35)) < 0) bad = 1; else qq += (uint32_t)u;
-                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 4) & 3), b + qq, bend - qq, T.of, &of_log, Z_OF_DEF, 29, 5, 8, 31)) < 0) bad = 1; else qq += (uint32_t)u; }
-                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 2) & 3), b + qq, bend - qq, T.ml, &ml_log, Z_ML_DEF, 53, 6, 9, 52)) < 0) bad = 1; else qq += (uint32_t)u; }
+                if ((u = z_seq_table(T, (int)(modes >> 6), b + qq, bend - qq, tll, &ll_log, Z_LL_DEF, 36, 6, 9, 35)) < 0) bad = 1; else qq += (uint32_t)u;
+                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 4) & 3), b + qq, bend - qq, tof, &of_log, Z_OF_DEF, 29, 5, 8, 31)) < 0) bad = 1; else qq += (uint32_t)u; }
+                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 2) & 3), b + qq, bend - qq, tml, &ml_log, Z_ML_DEF, 53, 6, 9, 52)) < 0) bad = 1; else qq += (uint32_t)u; }
                 if (lane == 0) { T.x[0] = (uint32_t)bad; T.x[1] = qq; }
             }
             wave_sync();
@@ -531,7 +544,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             for (uint32_t s = 0; s < nseq; s++) {
                 uint32_t llen = 0, mlen = 0, offset = 0;
                 if (lane == 0) {
-                    const uint32_t eo = T.of[so], em = T.ml[sm], el = T.ll[sl];
+                    const uint32_t eo = zfse_get(tof, so), em = zfse_get(tml, sm), el = zfse_get(tll, sl);
                     const uint32_t ofc = eo & 255, mls = T.mlsym[em & 255], lls = T.llsym[el & 255];
                     br.need(ofc);
                     const uint32_t ofv = (1u << ofc) + br.get(ofc);
