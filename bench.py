@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — BLOW5 encode throughput (svb-zd + DEFLATE, BASELINE.json config 3) on N MI355X.
+"""bench.py — BLOW5 record press throughput on N MI355X (BASELINE.json's metric: raw-signal GB/s and reads/s).
 
-A step = one pass of the hot path over one resident batch of synthetic reads, ending in the contiguous BLOW5
-record stream the ordered fwrite loop emits:
+Default run = BASELINE configs[2] as the headline value (1 M reads x 4000 samples per GPU, full encode svb-zd + DEFLATE,
+weak scaling) PLUS a configs[3] leg in the same JSON line under "configs3" (100 k-sample reads, a fixed read-index space
+sharded over the ranks with shard.shard_range: strong scaling).
+
+A step = one pass of the hot path over one resident batch of synthetic reads, ending in the contiguous BLOW5 record
+stream the ordered fwrite loop emits:
     k_encode_stream (svb-zd -> pack -> DEFLATE -> zlib frame, one read per workgroup, records placed by a
                      decoupled look-back: one launch)                                   [default]
-    or k_encode_fused into worst-case slots + s5gpu_compact (--two-pass, long reads, --svb-only)
+    or k_encode_fused / k_pack + k_deflate_staged into worst-case slots + s5gpu_compact (--two-pass, long reads, --svb-only)
 Inputs (int16 signals, 74-byte record heads) are already in HBM when the timed region starts.
-Reads shard across ranks with no collective (weak scaling: every rank encodes its own batch).
-Prints ONE JSON line on rank 0.
+Reads shard across ranks with no collective.  Prints ONE JSON line on rank 0.
+
+Other modes (one line each, for profiles/):  --svb-only (configs[1]), --long (configs[3] alone), --mixed (read lengths of a
+real run), --decode (configs[4]), --samples / --reads (any uniform shape).
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -21,6 +29,176 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+PEAK_HBM_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md chip table (6290 measured copy ceiling quoted beside it)
+LONG_TOTAL_READS_FULL = 10_000_000   # BASELINE configs[3]: 10 M reads x 100 k samples = 2 TB raw: run on a stated fraction
+
+
+def csrc_sha256():
+    """content hash of the kernel sources: PMC traffic figures are only valid for the build they were collected on
+    (the GPU box has no .git, so a content hash stands in for the commit id)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "slow5tools_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, samples, n_reads):
+    """HBM bytes per launch from the committed PMC pass (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc.sh), or None when the
+    kernel sources changed since it was collected (profiles/pmc_traffic.json carries the hash)"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        entries = t if isinstance(t, list) else [t]
+        now = csrc_sha256()
+        for e in entries:
+            if e.get("kernel") == kernel and e.get("samples_per_read") == samples and e.get("csrc_sha256") == now:
+                return int(e["hbm_bytes_per_read"] * n_reads), {"file": e.get("source"), "csrc_sha256": now}
+    except Exception:
+        pass
+    return None, None
+
+
+def make_events(L, _lib, count):
+    evs = []
+    for _ in range(count):
+        e = C.c_void_p()
+        _lib.check(L.s5gpu_event_create(C.byref(e)))
+        evs.append(e)
+    return evs
+
+
+def cpu_encode_baseline(ob, sig2d, first, n, ref_seconds, sweep_seconds):
+    """The oracle's reference-shaped pthread batch encode on this box's host cores.  `value` is the reference's own shape
+    (view -t <all cores> -K 4096: threads created and joined per batch, 16 records per thread on a 256-core box, so it is
+    thread-spawn bound); `best_of` is a sweep over -t and -K (still per-record deflateInit, src/view.c:43-54) — the fair CPU
+    configuration.  Each point runs until >= its share of seconds."""
+    cores = os.cpu_count() or 1
+    m = sig2d.shape[0]
+
+    def run(t, K, secs_target):
+        reads = 0
+        secs = 0.0
+        out_bytes = 0
+        while secs < secs_target:
+            tot, s, _ = ob.encode_batch_mt(sig2d, first, t, K)
+            reads += m
+            secs += s
+            out_bytes += tot
+        return reads, secs, out_bytes
+
+    reads, secs, out_bytes = run(cores, 4096, ref_seconds)
+    cpu = {"value": round(reads * 2 * n / secs / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
+           "reads_per_s": round(reads / secs, 1), "bytes_per_sample": round(out_bytes / (reads * n), 4),
+           "shape": "view -t %d -K 4096 (the reference's defaults on this box; thread create/join per batch, src/thread.c:100-110)" % cores,
+           "sample": "first %d reads of the same batch (%d samples each), compute phase only (svb-zd + zlib-1.2.11 level 6, per-record "
+                     "deflateInit), repeated for %.1f s" % (m, n, secs)}
+    if sweep_seconds > 0:
+        sweep = []
+        for t in sorted({min(32, cores), min(64, cores), min(128, cores), cores}):
+            for K in (4096, 65536):
+                if t == cores and K == 4096:
+                    r, s = reads, secs
+                else:
+                    r, s, _ = run(t, K, sweep_seconds)
+                sweep.append({"t": t, "K": K, "GB_per_s": round(r * 2 * n / s / 1e9, 3), "seconds": round(s, 1)})
+        best = max(sweep, key=lambda x: x["GB_per_s"])
+        cpu["best_of"] = {"value": best["GB_per_s"], "unit": "GB/s", "t": best["t"], "K": best["K"]}
+        cpu["sweep"] = sweep
+    return cpu
+
+
+def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
+    """BASELINE configs[3]: record-sharded encode of 100 k-sample reads.  The job is a FIXED read-index space
+    [0, --long-reads) (a stated fraction of the 10 M reads: 2 TB of raw signal does not fit anywhere at once), rank g of G
+    takes shard_range(total, g, G) — strong scaling — and works through its shard in chunks of <= --long-chunk reads
+    (16384 reads = 3.3 GB of signal per launch), signals generated on the device and resident before the timed region.
+    Per chunk: k_pack (svb-zd tiles -> parked payload) + k_deflate_staged (16 KiB blocks through LDS, in place) + the
+    compaction into the contiguous record stream."""
+    import numpy as np
+    import torch
+
+    n = args.long_samples
+    total = args.long_reads
+    lo, hi = shard.shard_range(total, rank, world)
+    mine = hi - lo
+    chunk = max(1, min(args.long_chunk, mine))
+    chunks = []
+    first_b = None
+    for c0 in range(lo, hi, chunk):
+        cn = min(chunk, hi - c0)
+        b = press.DeviceBatch(np.full(cn, n, dtype=np.uint64), device=dev, share=first_b)
+        if first_b is None:
+            first_b = b
+        b.synth(seed=0x5105, first=c0)
+        chunks.append((c0, b))
+    torch.cuda.synchronize()
+    st = first_b._stream()
+
+    def step(evs=None, k=0):
+        for ci, (_, b) in enumerate(chunks):
+            if evs is not None:
+                L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3], st)
+            b.encode()
+            if evs is not None:
+                L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3 + 1], st)
+            b.compact()
+            if evs is not None:
+                L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3 + 2], st)
+
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    evs = make_events(L, _lib, 3 * K * len(chunks))
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(evs, k)
+    torch.cuda.synchronize()
+    shard.barrier()
+    dt = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+    ms = C.c_float()
+    enc_ms = cmp_ms = 0.0
+    for i in range(K * len(chunks)):
+        _lib.check(L.s5gpu_event_elapsed_ms(evs[3 * i], evs[3 * i + 1], C.byref(ms)))
+        enc_ms += ms.value
+        _lib.check(L.s5gpu_event_elapsed_ms(evs[3 * i + 1], evs[3 * i + 2], C.byref(ms)))
+        cmp_ms += ms.value
+    for e in evs:
+        L.s5gpu_event_destroy(e)
+    enc_ms /= K
+    cmp_ms /= K
+    if rank != 0:
+        return None
+    # the last chunk's output is still in the shared buffers; sizes of every chunk are in its own out_len
+    z_bytes = sum(int(b.out_len[: b.n].sum().item()) for _, b in chunks)
+    import zlib
+
+    c0, b = chunks[-1]
+    idx = sorted({0, b.n // 2, b.n - 1})
+    parity = True
+    for i, rec in zip(idx, b.stream_records(idx)):
+        sig = ob.synth_read(0x5105, c0 + i, n)
+        r, keep = ob.make_rec(ob.synth_read_id(c0 + i), 0, 8192.0, 23.0, 1467.61, 4000.0, sig)
+        parity &= zlib.decompress(rec[8:]) == ob.rec_pack(r, ob.SIG_SVB_ZD)
+    alg = 2 * n * mine + 74 * mine + z_bytes          # 2N + H + Z per read (SURVEY 8d), this rank's shard per step
+    achieved = alg / (enc_ms / 1e3) / 1e9
+    reads_per_s = total * K / dt
+    return {
+        "workload": "BASELINE configs[3] shape: record-sharded full BLOW5 encode, %d reads x %d int16 samples = %.1f GB raw signal per step "
+                    "(a 1/%.1f fraction of the 10 M-read job), read-index space split over %d rank(s) with shard_range, chunks of <= %d reads "
+                    "(%.2f GB of signal per launch), generated on device" % (total, n, total * 2 * n / 1e9, LONG_TOTAL_READS_FULL / total, world, chunk, chunk * 2 * n / 1e9),
+        "value": round(reads_per_s * 2 * n / 1e9, 3), "unit": "GB/s", "reads_per_s": round(reads_per_s, 1), "scaling": "strong",
+        "n_gpus": world, "steps": K, "ms_per_step": round(dt / K * 1e3, 3), "reads_total": total, "reads_rank0": mine, "chunks_rank0": len(chunks),
+        "scale_factor_vs_10M_reads": round(LONG_TOTAL_READS_FULL / total, 3),
+        "bytes_per_sample": round(z_bytes / (mine * n), 4), "parity_spot_check": bool(parity),
+        "kernel_ms": {"pack+deflate_staged": round(enc_ms, 3), "compact": round(cmp_ms, 3)},
+        "roofline": {"bound": "hbm", "kernel": "k_pack+k_deflate_staged", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": alg,
+                     "note": "rank 0's shard per step; launch = the chunk loop of one step (k_pack + k_deflate_staged per chunk)"},
+    }
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -29,10 +207,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
     ap.add_argument("--samples", type=int, default=4000, help="int16 samples per read")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
-    ap.add_argument("--svb-only", action="store_true", help="config 2: svb-zd stage alone")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline, reference-shaped point: seconds (0 = skip)")
+    ap.add_argument("--cpu-sweep-seconds", type=float, default=5.0, help="CPU baseline: seconds per point of the -t / -K sweep (0 = skip)")
+    ap.add_argument("--svb-only", action="store_true", help="configs[1]: svb-zd stage alone")
     ap.add_argument("--two-pass", action="store_true", help="encode into worst-case slots + compaction pass instead of the ordered single-pass stream")
-    ap.add_argument("--decode", action="store_true", help="config 5: random get-style decode (inflate + svb-zd unpack)")
+    ap.add_argument("--mixed", action="store_true", help="read lengths of a real run: log-normal, median 6000 samples (--reads reads, default 262144)")
+    ap.add_argument("--long", action="store_true", help="configs[3] alone (the long-read leg as the whole line)")
+    ap.add_argument("--no-long", action="store_true", help="skip the configs[3] leg of the default run")
+    ap.add_argument("--long-reads", type=int, default=65536, help="configs[3] leg: size of the read-index space (all ranks together)")
+    ap.add_argument("--long-samples", type=int, default=100_000)
+    ap.add_argument("--long-chunk", type=int, default=16384, help="configs[3] leg: reads per launch")
+    ap.add_argument("--decode", action="store_true", help="configs[4]: random get-style decode (inflate + svb-zd unpack)")
     ap.add_argument("--get-reads", type=int, default=100_000, help="--decode: random read ids to fetch (seed 1)")
     ap.add_argument("--get-batch", type=int, default=4096, help="--decode: ids per batch (-K)")
     args = ap.parse_args()
@@ -53,21 +238,57 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
+    import oracle_bind as ob
     from slow5tools_amd import _lib, press, shard
 
     L = _lib.lib()
     _lib.check(L.s5gpu_init(local_rank), "s5gpu_init")
+    K = args.steps
 
-    n_reads, n = args.reads, args.samples
-    first = rank * n_reads                      # each rank encodes its own shard of the read index space
-    b = press.DeviceBatch(np.full(n_reads, n, dtype=np.uint64), device=dev)
-    b.synth(seed=0x5105, first=first)
+    def finish(line):
+        print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+
+    if args.long:
+        leg = long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, args.warmup)
+        if rank != 0:
+            if world > 1:
+                dist.destroy_process_group()
+            return
+        line = {"metric": "blow5_encode_raw_signal_throughput", "value": leg["value"], "unit": "GB/s", "n_gpus": world, "steps": K,
+                "warmup": args.warmup, "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "int16->u8", "data": "synthetic", "config": {"workload": leg["workload"], "record_press": "zlib", "signal_press": "svb-zd",
+                                                                      "parallelism": "read-index space sharded over %d GPU(s), no collective" % world}}
+        line.update({k: leg[k] for k in ("reads_per_s", "bytes_per_sample", "parity_spot_check", "kernel_ms", "roofline", "scale_factor_vs_10M_reads")})
+        line["cpu_baseline"] = None
+        return finish(line)
+
+    n = args.samples
+    if args.mixed:
+        n_reads = args.reads if args.reads != 1_000_000 else 262144
+        rng = np.random.default_rng(5)
+        ns = np.clip(np.exp(rng.normal(np.log(6000), 0.9, n_reads)), 200, 400000).astype(np.uint64)
+        # the device entry point only knows the longest read; the host batch calls name this budget from the lengths themselves
+        b = press.DeviceBatch(ns, device=dev, lds_payload_cap=8192)
+        tot = b.sig.numel()
+        # one long synthetic trace cut into the reads (the event model is position-keyed)
+        _lib.check(L.s5gpu_synth_dev(b.sig.data_ptr(), 1, tot - 64, tot, 0x5105 + rank, 0, b._stream()), "synth")
+        _lib.check(L.s5gpu_synth_hdr_dev(b.hdr.data_ptr(), n_reads, rank * n_reads, b._stream()), "hdr")
+        raw_bytes = int(2 * ns.sum())
+    else:
+        n_reads = args.reads
+        ns = None
+        first = rank * n_reads                      # each rank encodes its own shard of the read index space
+        b = press.DeviceBatch(np.full(n_reads, n, dtype=np.uint64), device=dev)
+        b.synth(seed=0x5105, first=first)
+        raw_bytes = 2 * n * n_reads
     torch.cuda.synchronize()
 
     # Full encode, default: ONE launch per step — k_encode_stream writes every record straight to its place in the
     # contiguous BLOW5 record stream (ordered single pass, decoupled look-back).  It needs every read to fit the LDS
-    # budget (true for 4000-sample reads); long reads, --two-pass and --svb-only use slots + the compaction pass.
-    single_pass = not args.svb_only and not args.two_pass and b.tot["max_payload"] * 100 // 325 <= 16384
+    # budget (true for 4000-sample reads); long reads, --two-pass, --mixed and --svb-only use slots + the compaction pass.
+    single_pass = not args.svb_only and not args.two_pass and not args.mixed and b.tot["max_payload"] * 100 // 325 <= 16384
 
     def run_step():
         if single_pass:
@@ -80,9 +301,6 @@ def main():
             b.compact()
 
     st = b._stream()
-
-    barrier = shard.barrier
-
     for _ in range(args.warmup):
         run_step()
         second_half()
@@ -92,13 +310,8 @@ def main():
         run_step(); second_half()
         torch.cuda.synchronize()
 
-    K = args.steps
-    evs = []
-    for _ in range(3 * K):
-        e = C.c_void_p()
-        _lib.check(L.s5gpu_event_create(C.byref(e)))
-        evs.append(e)
-    barrier()
+    evs = make_events(L, _lib, 3 * K)
+    shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(K):
@@ -108,7 +321,7 @@ def main():
         second_half()
         L.s5gpu_event_record(evs[3 * k + 2], st)
     torch.cuda.synchronize()
-    barrier()
+    shard.barrier()
     dt = time.perf_counter() - t0
     dt = shard.max_over_ranks(dt, device=dev)
 
@@ -122,90 +335,110 @@ def main():
     for e in evs:
         L.s5gpu_event_destroy(e)
 
+    # ---- the configs[3] leg of the default run (every rank takes part: its shard of the fixed index space) ----
+    leg = None
+    default_shape = not (args.svb_only or args.mixed or args.two_pass) and n == 4000
+    if default_shape and not args.no_long:
+        main_out_len = b.out_len[:n_reads].cpu().numpy().astype(np.int64)
+        main_recs = None
+        if rank == 0:
+            idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
+            main_recs = (idx, b.stream_records(idx) if single_pass else b.records(idx), b.stream_ok() if single_pass else True)
+        sig_cpu_t = None
+        if rank == 0 and (args.cpu_seconds > 0):
+            stride = (n + 7) // 8 * 8
+            m = min(n_reads, 262144)
+            sig_cpu_t = b.sig[: m * stride].cpu().numpy().reshape(m, stride)[:, :n].copy()
+        del b                                   # free the 1 M-read batch before the long leg allocates
+        torch.cuda.empty_cache()
+        leg = long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, args.warmup)
+    else:
+        main_out_len = b.out_len[:n_reads].cpu().numpy().astype(np.int64)
+        main_recs = None
+        sig_cpu_t = None
+        if rank == 0:
+            idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
+            main_recs = (idx, b.stream_records(idx) if single_pass else b.records(idx), b.stream_ok() if single_pass else True)
+            if args.cpu_seconds > 0 and not args.svb_only and not args.mixed:
+                stride = (n + 7) // 8 * 8
+                m = min(n_reads, 262144)
+                sig_cpu_t = b.sig[: m * stride].cpu().numpy().reshape(m, stride)[:, :n].copy()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
     # ---- results, rank 0 ----
-    out_len = b.out_len[:n_reads].cpu().numpy().astype(np.int64)
-    z_bytes = int(out_len.sum())
-    raw_bytes = 2 * n * n_reads
+    z_bytes = int(main_out_len.sum())
     total_reads = n_reads * world
     reads_per_s = total_reads * K / dt
-    value = reads_per_s * 2 * n / 1e9
+    value = raw_bytes * world * K / dt / 1e9
     # algorithmic HBM bytes of the dominant kernel per launch:
     #   full encode: 2N + H (74-byte head) + Z (record incl. 8-byte prefix), per read; svb only: 2N + S
     alg_bytes = raw_bytes + (0 if args.svb_only else 74 * n_reads) + z_bytes
     kern_s = float(np.mean(enc_ms)) / 1e3
     achieved = alg_bytes / kern_s / 1e9
-    peak = 8000.0
-    # HBM traffic per launch from the committed PMC pass (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc.sh); only valid
-    # for the kernel/config it was collected on
-    traffic = None
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if not args.svb_only and t.get("samples_per_read") == n and t.get("kernel") == ("k_encode_stream" if single_pass else "k_encode_fused"):
-            traffic = int(t["hbm_bytes_per_read"] * n_reads)
-    except Exception:
-        pass
+    if args.svb_only:
+        kernel = "k_svbzd_encode"
+    elif single_pass:
+        kernel = "k_encode_stream"
+    elif args.mixed:
+        kernel = "k_encode_fused+k_pack+k_deflate_staged"
+    elif main_recs is not None and (n * 13 // 4) * 100 // 325 <= 4 * 16384:
+        kernel = "k_encode_fused"
+    else:
+        kernel = "k_pack+k_deflate_staged"
+    traffic, traffic_src = (None, None) if args.mixed else pmc_traffic(kernel, n, n_reads)
 
     # parity spot check of this very run (outside the timed region)
     import zlib
 
-    import oracle_bind as ob
+    idx, recs, parity = main_recs
+    if not args.mixed:
+        for i, rec in zip(idx, recs):
+            sig = ob.synth_read(0x5105, rank * n_reads + i, n)
+            if args.svb_only:
+                parity &= rec == ob.svbzd_encode(sig)
+            else:
+                r, keep = ob.make_rec(ob.synth_read_id(rank * n_reads + i), 0, 8192.0, 23.0, 1467.61, 4000.0, sig)
+                parity &= zlib.decompress(rec[8:]) == ob.rec_pack(r, ob.SIG_SVB_ZD)
+    else:
+        for i, rec in zip(idx, recs):          # mixed lengths: stock zlib must inflate every sampled record to a payload of the right shape
+            pay = zlib.decompress(rec[8:])
+            parity &= len(pay) > 82 and int.from_bytes(pay[82:86], "little") == int(ns[i])
 
-    idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
-    recs = b.stream_records(idx) if single_pass else b.records(idx)
-    parity = b.stream_ok() if single_pass else True
-    for i, rec in zip(idx, recs):
-        sig = ob.synth_read(0x5105, first + i, n)
-        if args.svb_only:
-            parity &= rec == ob.svbzd_encode(sig)
-        else:
-            r, keep = ob.make_rec(ob.synth_read_id(first + i), 0, 8192.0, 23.0, 1467.61, 4000.0, sig)
-            parity &= zlib.decompress(rec[8:]) == ob.rec_pack(r, ob.SIG_SVB_ZD)
-
-    # ---- CPU baseline: the oracle's reference-shaped pthread batch encode on this box's host cores ----
     cpu = None
-    if args.cpu_seconds > 0 and not args.svb_only:
-        cores = os.cpu_count() or 1
-        stride = (n + 7) // 8 * 8
-        probe_reads = min(n_reads, 256 * cores)
-        sig_probe = b.sig[: probe_reads * stride].cpu().numpy().reshape(probe_reads, stride)[:, :n]
-        _, secs, _ = ob.encode_batch_mt(sig_probe, first, cores, 4096)
-        rate = probe_reads / max(secs, 1e-6)
-        m = int(min(n_reads, max(probe_reads, rate * args.cpu_seconds)))
-        sig_cpu = b.sig[: m * stride].cpu().numpy().reshape(m, stride)[:, :n]
-        tot, secs, _ = ob.encode_batch_mt(sig_cpu, first, cores, 4096)
-        cpu = {"value": round(m * 2 * n / secs / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
-               "reads_per_s": round(m / secs, 1), "bytes_per_sample": round(tot / (m * n), 4),
-               "sample": "first %d reads of the same batch (%d samples each), compute phase of view -t %d -K 4096 "
-                         "(svb-zd + zlib-1.2.11 level 6, per-record deflateInit), %.1f s" % (m, n, cores, secs)}
+    if sig_cpu_t is not None:
+        cpu = cpu_encode_baseline(ob, sig_cpu_t, 0, n, args.cpu_seconds, args.cpu_sweep_seconds)
 
+    if args.mixed:
+        workload = "read lengths of a real run: %d reads, log-normal lengths (median %d, max %d samples, %.2f G samples), full BLOW5 encode, 8 KiB fused budget" % (
+            n_reads, int(np.median(ns)), int(ns.max()), ns.sum() / 1e9)
+    else:
+        workload = "BASELINE configs[%d]: %s, %d reads x %d int16 samples per GPU" % (
+            1 if args.svb_only else 2, "svb-zd only" if args.svb_only else "full BLOW5 encode (svb-zd + DEFLATE, zlib framing)", n_reads, n)
     line = {
         "metric": "blow5_encode_raw_signal_throughput" if not args.svb_only else "svbzd_encode_raw_signal_throughput",
         "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int16->u8", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[%d]: %s, %d reads x %d int16 samples per GPU"
-                               % (1 if args.svb_only else 2, "svb-zd only" if args.svb_only else "full BLOW5 encode (svb-zd + DEFLATE, zlib framing)", n_reads, n),
-                   "reads_per_gpu": n_reads, "samples_per_read": n, "record_press": "none" if args.svb_only else "zlib",
+        "config": {"workload": workload, "reads_per_gpu": n_reads, "samples_per_read": n if not args.mixed else "mixed",
+                   "record_press": "none" if args.svb_only else "zlib",
                    "signal_press": "svb-zd", "parallelism": "reads sharded over %d GPU(s), no collective" % world},
         "reads_per_s": round(reads_per_s, 1),
-        "bytes_per_sample": round(z_bytes / (n_reads * n), 4),
+        "bytes_per_sample": round(z_bytes / (raw_bytes / 2), 4),
         "parity_spot_check": bool(parity),
         "kernel_ms": {"encode": round(float(np.mean(enc_ms)), 3), "compact": round(float(np.mean(cmp_ms)), 3) if not single_pass else 0.0},
         "output": "ordered single-pass record stream (k_encode_stream)" if single_pass else "worst-case slots + compaction pass",
-        "roofline": {"bound": "hbm", "kernel": "k_svbzd_encode" if args.svb_only else ("k_encode_stream" if single_pass else "k_encode_fused" if b.tot["max_payload"] * 100 // 325 <= 4 * 16384 else "k_pack+k_deflate_staged"),
-                     "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
-                     "frac": round(achieved / peak, 5), "traffic": traffic,
+        "roofline": {"bound": "hbm", "kernel": kernel,
+                     "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes},
         "cpu_baseline": cpu,
+        "configs3": leg,
     }
-    print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    finish(line)
 
 
 def bench_decode(args):
@@ -216,6 +449,7 @@ def bench_decode(args):
     import numpy as np
     import torch
 
+    import oracle_bind as ob
     from slow5tools_amd import _lib, press
 
     L = _lib.lib()
@@ -228,6 +462,7 @@ def bench_decode(args):
     b.compact()
     torch.cuda.synchronize()
     rec_off = b.rec_off.cpu().numpy().astype(np.int64)          # the "index": offset/size per read (Appendix A.5)
+    z_total = int(rec_off[n_reads])
     rng = np.random.default_rng(1)
     ids = rng.integers(0, n_reads, args.get_reads)
     K = args.get_batch
@@ -242,8 +477,11 @@ def bench_decode(args):
     a.desc, a.in_, a.payload, a.sig_out, a.fields = desc_dev.data_ptr(), b.stream_out.data_ptr(), payload.data_ptr(), sig.data_ptr(), fields.data_ptr()
     lat, ok, done = [], True, 0
     t_all = time.perf_counter()
+    st = b._stream()
+    ev = make_events(L, _lib, 2)
+    kern_ms = []
 
-    def run_batch(sel):
+    def run_batch(sel, timed=False):
         k = len(sel)
         d = np.zeros(k, dtype=_lib.REC_DESC)
         d["in_off"] = rec_off[sel] + 8
@@ -256,8 +494,16 @@ def bench_decode(args):
         # batches on this stack — measured, tools note in DESIGN.md — which has nothing to do with the decode)
         desc_dev[: d.nbytes].copy_(torch.from_numpy(d.view(np.uint8)))
         a.n_recs = k
-        _lib.check(L.s5gpu_decode_dev(C.byref(a), b._stream()), "s5gpu_decode_dev")
+        if timed:
+            L.s5gpu_event_record(ev[0], st)
+        _lib.check(L.s5gpu_decode_dev(C.byref(a), st), "s5gpu_decode_dev")
+        if timed:
+            L.s5gpu_event_record(ev[1], st)
         torch.cuda.synchronize()
+        if timed:
+            ms = C.c_float()
+            _lib.check(L.s5gpu_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
+            kern_ms.append((ms.value, int(d["in_len"].sum()) + 8 * k))
 
     # pass 1: latency, nothing but the decode between the clock reads (the first two batches are warm-up)
     for lo in range(0, len(ids), K):
@@ -267,15 +513,16 @@ def bench_decode(args):
         lat.append(time.perf_counter() - t0)
         if lo >= 2 * K:
             done += len(sel)
-    # pass 2: the same batches again, every decoded signal compared with the generator (untimed: the comparison allocates)
+    # pass 2: the same batches again, kernel time by HIP events on the launch stream, every decoded signal compared with
+    # the generator (untimed: the comparison allocates)
     for lo in range(0, len(ids), K):
         sel = ids[lo:lo + K]
         k = len(sel)
-        run_batch(sel)
-        st = fields[: k * 64].view(torch.int32).view(k, 16)[:, 0]
+        run_batch(sel, timed=True)
+        stt = fields[: k * 64].view(torch.int32).view(k, 16)[:, 0]
         got = sig[: k * sig_cap].view(k, sig_cap)[:, :n]
         want = b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[torch.from_numpy(sel).to(dev)][:, :n]
-        ok &= bool((st == 0).all().item()) and bool((got == want).all().item())
+        ok &= bool((stt == 0).all().item()) and bool((got == want).all().item())
     # pass 3: the whole index in one call (what `view` / `merge` decode per batch when the batch is large): device time of
     # inflate + unpack by HIP events, every signal compared afterwards
     del payload, sig, fields, desc_dev
@@ -297,30 +544,68 @@ def bench_decode(args):
         a.desc, a.payload, a.sig_out, a.fields = big_desc.data_ptr(), big_pay.data_ptr(), big_sig.data_ptr(), big_fields.data_ptr()
         ts = []
         for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.check(L.s5gpu_decode_dev(C.byref(a), b._stream()), "s5gpu_decode_dev")
-            e1.record()
+            L.s5gpu_event_record(ev[0], st)
+            _lib.check(L.s5gpu_decode_dev(C.byref(a), st), "s5gpu_decode_dev")
+            L.s5gpu_event_record(ev[1], st)
             torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
+            ms = C.c_float()
+            _lib.check(L.s5gpu_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
+            ts.append(ms.value)
         ms = min(ts[1:])
-        st = big_fields.view(torch.int32).view(n_reads, 16)[:, 0]
-        same = bool((st == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n],
-                                                                  b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]))
+        stt = big_fields.view(torch.int32).view(n_reads, 16)[:, 0]
+        same = bool((stt == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n],
+                                                                   b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]))
+        alg = z_total + 2 * n * n_reads                         # Z + 2N per record (decode)
         bulk = {"reads": n_reads, "ms": round(ms, 2), "reads_per_s": round(n_reads / ms * 1e3, 1),
-                "raw_signal_GB_per_s": round(n_reads * 2 * n / ms / 1e6, 2), "roundtrip_identical": same}
+                "raw_signal_GB_per_s": round(n_reads * 2 * n / ms / 1e6, 2), "roundtrip_identical": same,
+                "roofline": {"bound": "hbm", "kernel": "k_inflate_simt+k_unpack (routed)", "achieved": round(alg / ms / 1e6, 2), "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": round(alg / ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": alg}}
         ok &= same
+        del big_desc, big_pay, big_sig, big_fields
     except torch.OutOfMemoryError:
         bulk = None
     wall = time.perf_counter() - t_all
     lat_ms = np.array(lat[2:]) * 1e3
     busy = float(np.sum(lat[2:]))
+    # roofline of the K-record batches: (Z + 2N) of the batch / kernel time of k_inflate + k_unpack (HIP events on the launch stream)
+    full = [(m, z) for m, z in kern_ms[2:] if True]
+    k_ms = float(np.mean([m for m, _ in full])) if full else None
+    k_alg = float(np.mean([z for _, z in full])) + 2 * n * K if full else None
+
+    # ---- CPU baseline beside it: the oracle's pthread get --benchmark shape (inflate + svb-zd decode per id), thread sweep
+    # as /root/reference/test/bench/simple_bench.sh:75-104 ----
+    cpu = None
+    if args.cpu_seconds > 0:
+        cores = os.cpu_count() or 1
+        stream_h = b.stream_out[:z_total].cpu().numpy()
+        off_h = rec_off[:-1].astype(np.uint64)
+        ids32 = ids.astype(np.uint32)
+        sweep = []
+        for t in sorted({1, min(8, cores), min(32, cores), min(64, cores), min(128, cores), cores}):
+            got, secs, reps = 0, 0.0, 0
+            while secs < max(2.0, args.cpu_seconds / 3):
+                tot, s, _ = ob.decode_batch_mt(stream_h, off_h, ids32, t, K)
+                assert tot == len(ids32) * n, "CPU decode failed"
+                got += len(ids32); secs += s; reps += 1
+            sweep.append({"t": t, "reads_per_s": round(got / secs, 1), "GB_per_s": round(got * 2 * n / secs / 1e9, 3), "seconds": round(secs, 1)})
+        ref = [x for x in sweep if x["t"] == cores][0]
+        best = max(sweep, key=lambda x: x["reads_per_s"])
+        cpu = {"value": ref["GB_per_s"], "unit": "GB/s", "cores": cores, "kind": "port", "reads_per_s": ref["reads_per_s"],
+               "shape": "get --benchmark -t %d -K %d: per id inflate (per-record inflateInit) + parse + svb-zd decode, threads created per batch; preads excluded" % (cores, K),
+               "best_of": {"value": best["GB_per_s"], "unit": "GB/s", "t": best["t"], "reads_per_s": best["reads_per_s"]},
+               "sweep": sweep,
+               "sample": "the same %d random ids (seed 1) over the same %d-read index, repeated until each point ran >= %.1f s" % (len(ids), n_reads, max(2.0, args.cpu_seconds / 3))}
+
     line = {"metric": "blow5_get_decode_throughput", "value": round(done * 2 * n / busy / 1e9, 3), "unit": "GB/s",
             "n_gpus": 1, "higher_is_better": True, "dtype": "u8->int16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: random get decode (inflate + svb-zd unpack), %d ids (seed 1) over a %d-read index, batches of %d, %d samples/read" % (len(ids), n_reads, K, n)},
             "reads_per_s": round(done / busy, 1), "batch_latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p99": round(float(np.percentile(lat_ms, 99)), 3)},
             "per_read_latency_us_p50": round(float(np.percentile(lat_ms, 50)) * 1e3 / K, 3),
+            "kernel_ms_per_batch": round(k_ms, 4) if k_ms else None,
+            "roofline": {"bound": "hbm", "kernel": "k_inflate+k_unpack (K = %d)" % K, "achieved": round(k_alg / k_ms / 1e6, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(k_alg / k_ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(k_alg)} if k_ms else None,
             "bulk_decode_one_call": bulk,
+            "cpu_baseline": cpu,
             "roundtrip_identical": bool(ok), "wall_s_including_verification": round(wall, 2)}
     print(json.dumps(line))
 

@@ -97,16 +97,30 @@ struct slow5_file {                           /* fields read at src/stats.c:98-1
 typedef struct slow5_file slow5_file_t;
 
 extern __thread int slow5_errno;              /* thread-local like slow5lib's (workers run concurrently) */
-enum { SLOW5_ERR_OK = 0, SLOW5_ERR_EOF = -1, SLOW5_ERR_ARG = -2, SLOW5_ERR_TRUNC = -3, SLOW5_ERR_IO = -5, SLOW5_ERR_NOIDX = -6,
-       SLOW5_ERR_NOTFOUND = -7, SLOW5_ERR_MEM = -10, SLOW5_ERR_PRESS = -13, SLOW5_ERR_MAGIC = -14, SLOW5_ERR_RECPARSE = -15,
-       SLOW5_ERR_OTH = -20 };
+/* slow5lib's numbering (slow5_error.h), so that a caller comparing against slow5lib's codes reads failures right */
+enum { SLOW5_ERR_OK = 0, SLOW5_ERR_EOF = -1, SLOW5_ERR_ARG = -2, SLOW5_ERR_TRUNC = -3, SLOW5_ERR_RECPARSE = -4, SLOW5_ERR_IO = -5,
+       SLOW5_ERR_NOIDX = -6, SLOW5_ERR_NOTFOUND = -7, SLOW5_ERR_OTH = -8, SLOW5_ERR_UNK = -9, SLOW5_ERR_MEM = -10, SLOW5_ERR_NOAUX = -11,
+       SLOW5_ERR_NOFLD = -12, SLOW5_ERR_PRESS = -13, SLOW5_ERR_MAGIC = -14, SLOW5_ERR_VERSION = -15, SLOW5_ERR_HDRPARSE = -16,
+       SLOW5_ERR_TYPE = -17 };
+
+/* process-wide switches slow5tools sets once at start-up: /root/reference/src/main.c:246-247, src/get.c:194 */
+enum slow5_log_level_opt { SLOW5_LOG_OFF = 0, SLOW5_LOG_ERR, SLOW5_LOG_WARN, SLOW5_LOG_INFO, SLOW5_LOG_VERB, SLOW5_LOG_DBUG };
+enum slow5_exit_condition_opt { SLOW5_EXIT_OFF = 0, SLOW5_EXIT_ON_ERR, SLOW5_EXIT_ON_WARN };
+void slow5_set_log_level(enum slow5_log_level_opt log_level);          /* what this layer prints to stderr (default: INFO) */
+void slow5_set_exit_condition(enum slow5_exit_condition_opt exit_condition);   /* exit(EXIT_FAILURE) after an error / a warning (default: off) */
+void slow5_set_skip_rid(void);            /* slow5_get of an unknown read id is no longer an error message, only SLOW5_ERR_NOTFOUND */
 
 struct slow5_press *slow5_press_init(slow5_press_method_t method);
 void slow5_press_free(struct slow5_press *comp);
 
-/* one-shot (de)compression of a byte range; returns a malloc'd buffer, NULL on error */
+/* one-shot (de)compression of a byte range; returns a malloc'd buffer, NULL on error.  Methods: zlib, zstd (bytes),
+ * svb-zd, ex-zd (ptr = int16 samples, count in bytes). */
 void *slow5_ptr_compress_solo(enum slow5_press_method method, const void *ptr, size_t count, size_t *n);
 void *slow5_ptr_depress_solo(enum slow5_press_method method, const void *ptr, size_t count, size_t *n);
+/* the stateful forms (SURVEY 8b last row): the method comes from one half of a slow5_press_t (comp->record_press or
+ * comp->signal_press); codec state lives on the device, so `comp` only names the method */
+void *slow5_ptr_compress(struct __slow5_press *comp, const void *ptr, size_t count, size_t *n);
+void *slow5_ptr_depress(struct __slow5_press *comp, const void *ptr, size_t count, size_t *n);
 
 /* BLOW5: returns malloc'd [u64 size][press_record(payload)], *n = total length; NULL on error.
  * aux_meta == NULL drops the aux fields (lossy, src/merge.c:58-62). */
@@ -116,6 +130,12 @@ void *slow5_rec_to_mem(struct slow5_rec *read, struct slow5_aux_meta *aux_meta, 
  * the uncompressed record; allocates *read if NULL.  0 on success. */
 int slow5_rec_depress_parse(char **mem, size_t *bytes, const char *read_id, struct slow5_rec **read,
                             struct slow5_file *s5p);
+/* the same without the read id argument (/root/reference/src/skim.c:320); < 0 on error */
+int slow5_decode(char **mem, size_t *bytes, struct slow5_rec **read, struct slow5_file *s5p);
+/* slow5_rec_to_mem + fwrite (/root/reference/src/get.c:89, src/read_fast5.c:177): bytes written, -1 on error.  format ASCII
+ * prints the record line (raw_signal column formatted on the GPU), aux_meta then names the aux column types. */
+int slow5_rec_fwrite(FILE *fp, struct slow5_rec *read, struct slow5_aux_meta *aux_meta, enum slow5_fmt format,
+                     struct slow5_press *compress);
 struct slow5_rec *slow5_rec_init(void);
 void slow5_rec_free(struct slow5_rec *read);
 
@@ -124,11 +144,16 @@ void slow5_rec_free(struct slow5_rec *read);
  * EOF writers, and the read_id index.  slow5_open tells BLOW5 from SLOW5 ASCII by the file's first bytes; for ASCII,
  * slow5_get_next_mem returns one record line (without its newline) and slow5_hdr_fwrite prints the two '#' version lines
  * followed by the same header text.  The index calls are BLOW5 only. */
-slow5_file_t *slow5_open(const char *pathname, const char *mode);                 /* src/view.c:192, "r" only */
+slow5_file_t *slow5_open(const char *pathname, const char *mode);                 /* "r" only */
+/* the same with the format the caller parsed from --from / the extension (/root/reference/src/view.c:192, src/degrade.c:423):
+ * SLOW5_FORMAT_UNKNOWN = look at the file; a named format must match what the file's first bytes say */
+slow5_file_t *slow5_open_with(const char *pathname, const char *mode, enum slow5_fmt format);
 int slow5_close(slow5_file_t *s5p);
 /* next record's bytes without the u64 size prefix, malloc'd; NULL + slow5_errno = SLOW5_ERR_EOF at the end
  * marker (src/view.c:265-278) */
 void *slow5_get_next_mem(size_t *n, const slow5_file_t *s5p);
+/* the same through out-parameters (/root/reference/src/skim.c:385): 0 and *mem / *bytes set, or slow5_errno (< 0) */
+int slow5_get_next_bytes(char **mem, size_t *bytes, slow5_file_t *s5p);
 /* 64-byte binary header + u32 length + header text; the version is raised to 0.2.0 when a signal press is set
  * (fixture exp_1_lossless_zlib_svb_v0.2.0.blow5 vs exp_1_lossless_zlib.blow5).  Returns bytes written or -1. */
 int slow5_hdr_fwrite(FILE *fp, struct slow5_hdr *header, enum slow5_fmt format, slow5_press_method_t comp);

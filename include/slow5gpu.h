@@ -117,6 +117,14 @@ typedef struct s5gpu_decode_args {
 
 /* ---- lifetime ---- */
 int s5gpu_init(int device);              /* select device; S5GPU_ERR_NODEV if it is not a gfx950 GPU */
+/* Several GPUs of one node behind the host-buffer batch calls: bit d of dev_mask = HIP device d.  A host batch is
+ * then cut into one contiguous index range per device — device g of G takes records [g*n/G, (g+1)*n/G), exactly how work_db
+ * cuts a batch per thread (/root/reference/src/thread.c:76-90) — each range goes through its own pinned H2D -> kernels -> D2H on
+ * its device's stream, concurrently, and every result lands in the caller's out[i]: the ordered write loop
+ * (/root/reference/src/view.c:296-299) does not change.  No collective, no peer traffic.  The *_dev entry points are not
+ * affected: their caller picks the device (hipSetDevice) and passes buffers of that device. */
+int s5gpu_init_mask(uint64_t dev_mask);
+int s5gpu_devices_in_use(void);          /* devices the batch calls run on (0 before initialisation) */
 void s5gpu_shutdown(void);
 const char *s5gpu_last_error(void);
 int s5gpu_device_count(void);
@@ -125,7 +133,8 @@ int s5gpu_device_count(void);
  * "inflate_route" (0/1, default 1): such batches are first counting-sorted by compressed length on the device, and records
  * of >= 32 KiB go to the wave-per-record kernel beside the lane kernel (real runs have read lengths spread over two decades).
  * In inflate-only calls fields[i].reserved, fields[0..128].read_group and fields[128].aux_len are then left holding routing
- * scratch (s5gpu_decode_dev overwrites all of them with the parsed fields). */
+ * scratch (s5gpu_decode_dev overwrites all of them with the parsed fields).
+ * "multi_min_per_device" (default 1024): a host batch of fewer than this many records per device stays on the first device. */
 int s5gpu_set_option(const char *key, long value);
 
 /* ---- device-resident entry points (asynchronous on `hip_stream`, a hipStream_t; NULL = default) ---- */
@@ -187,7 +196,8 @@ int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec
 
 /* ---- one-stage host-buffer calls behind slow5_ptr_compress_solo / slow5_ptr_depress_solo ----
  * stage: 0 zlib compress, 1 zlib inflate, 2 svb-zd encode (in = int16 samples, in_len in bytes),
- * 3 svb-zd decode, 4 zstd decompress (whole frames), 5 zstd compress.  out[i] malloc'd, caller frees.  status[i] per record (0 ok), may be NULL. */
+ * 3 svb-zd decode, 4 zstd decompress (whole frames), 5 zstd compress, 6 ex-zd encode (in = int16 samples), 7 ex-zd decode.
+ * out[i] malloc'd, caller frees.  status[i] per record (0 ok), may be NULL. */
 int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t *in_len, void **out, size_t *out_len,
                      int32_t *status);
 

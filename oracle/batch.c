@@ -26,6 +26,12 @@ typedef struct {
     int64_t n_batch;
     uint8_t **out;
     size_t *out_len;
+    /* decode batches (s5o_decode_batch_mt): records of a BLOW5 stream picked through an id list */
+    const uint8_t *stream;
+    const uint64_t *rec_off;
+    const uint32_t *ids;
+    int failed;
+    void (*one)(void *db, int32_t i);
 } batch_t;
 
 typedef struct worker {
@@ -36,7 +42,11 @@ typedef struct worker {
     int32_t n_threads;
 } worker_t;
 
+static void encode_one_(batch_t *db, int32_t i);
 static void encode_one(batch_t *db, int32_t i) {
+    if (db->one) db->one(db, i); else encode_one_(db, i);
+}
+static void encode_one_(batch_t *db, int32_t i) {
     s5o_rec_t r;
     char id[37];
     uint64_t ridx = db->first_idx + db->base + (uint64_t)i;
@@ -113,6 +123,7 @@ uint64_t s5o_encode_batch_mt(const int16_t *sig, uint64_t n_reads, uint64_t n_sa
                              int rec_method, int sig_method, int n_threads, int batch_size, double *secs,
                              uint64_t *checksum) {
     batch_t db;
+    memset(&db, 0, sizeof db);
     db.sig = sig;
     db.n_samples = n_samples;
     db.first_idx = first_read_idx;
@@ -139,4 +150,78 @@ uint64_t s5o_encode_batch_mt(const int16_t *sig, uint64_t n_reads, uint64_t n_sa
     if (secs) *secs = t;
     if (checksum) *checksum = ck;
     return total;
+}
+
+/* ---- decode twin: the compute phase of `slow5tools get --benchmark -t T -K B` (src/get.c:52: slow5_get only, no
+ * re-encode): per id  inflate (inflateInit/inflate/inflateEnd per record) -> parse -> svb-zd decode into a malloc'd
+ * int16 buffer that is freed after the batch, under the same work_db shape.  The preads of slow5_get are excluded
+ * (the records are in memory), which favours the CPU.  stream: BLOW5 records [u64 size][zlib stream] back to back,
+ * rec_off[i] = byte offset of record i; ids: which records to fetch, in order.  Returns the number of samples decoded. */
+static void decode_one(void *dbv, int32_t i) {
+    batch_t *db = (batch_t *)dbv;
+    const uint32_t id = db->ids[db->base + (uint64_t)i];
+    const uint8_t *rec = db->stream + db->rec_off[id];
+    uint64_t zlen;
+    memcpy(&zlen, rec, 8);
+    size_t cap = (size_t)zlen * 4 + 4096, plen = 0;
+    uint8_t *pay = NULL;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        pay = (uint8_t *)malloc(cap);
+        plen = cap;
+        if (db->rec_method == S5O_REC_ZLIB) {
+            if (s5o_zlib_decompress(rec + 8, (size_t)zlen, pay, &plen) == 0) break;
+        } else {
+            if (zlen <= cap) { memcpy(pay, rec + 8, (size_t)zlen); plen = (size_t)zlen; break; }
+        }
+        free(pay);
+        pay = NULL;
+        cap *= 4;
+    }
+    db->out[i] = NULL;
+    db->out_len[i] = 0;
+    if (!pay) { db->failed = 1; return; }
+    s5o_rec_t r;
+    if (s5o_rec_parse(pay, plen, db->sig_method, &r, NULL) != 0) { free(pay); db->failed = 1; return; }
+    int16_t *sig = (int16_t *)malloc(r.len_raw_signal ? 2 * (size_t)r.len_raw_signal : 2);
+    if (s5o_rec_parse(pay, plen, db->sig_method, &r, sig) != 0) { free(pay); free(sig); db->failed = 1; return; }
+    free(pay);
+    db->out[i] = (uint8_t *)sig;
+    db->out_len[i] = (size_t)r.len_raw_signal;
+}
+
+uint64_t s5o_decode_batch_mt(const uint8_t *stream, const uint64_t *rec_off, const uint32_t *ids, uint64_t n_ids,
+                             int rec_method, int sig_method, int n_threads, int batch_size, double *secs,
+                             uint64_t *checksum) {
+    batch_t db;
+    memset(&db, 0, sizeof db);
+    db.stream = stream;
+    db.rec_off = rec_off;
+    db.ids = ids;
+    db.rec_method = rec_method;
+    db.sig_method = sig_method;
+    db.one = decode_one;
+    db.out = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)batch_size);
+    db.out_len = (size_t *)malloc(sizeof(size_t) * (size_t)batch_size);
+    uint64_t total = 0, ck = 0;
+    double t = 0;
+    for (uint64_t base = 0; base < n_ids; base += (uint64_t)batch_size) {
+        db.base = base;
+        db.n_batch = (int64_t)(n_ids - base < (uint64_t)batch_size ? n_ids - base : (uint64_t)batch_size);
+        double t0 = now_s();
+        work_batch(&db, n_threads);
+        t += now_s() - t0;
+        for (int64_t i = 0; i < db.n_batch; i++) {
+            total += db.out_len[i];
+            if (db.out[i] && db.out_len[i]) {   /* cheap fingerprint: first, middle and last sample */
+                const int16_t *sg = (const int16_t *)db.out[i];
+                ck = ck * 1000003ull + (uint16_t)sg[0] + ((uint64_t)(uint16_t)sg[db.out_len[i] / 2] << 16) + ((uint64_t)(uint16_t)sg[db.out_len[i] - 1] << 32);
+            }
+            free(db.out[i]);
+        }
+    }
+    free(db.out);
+    free(db.out_len);
+    if (secs) *secs = t;
+    if (checksum) *checksum = ck;
+    return db.failed ? 0 : total;
 }

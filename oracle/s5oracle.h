@@ -81,6 +81,13 @@ uint64_t s5o_encode_batch_mt(const int16_t *sig, uint64_t n_reads, uint64_t n_sa
                              int rec_method, int sig_method, int n_threads, int batch_size, double *secs,
                              uint64_t *checksum);
 
+/* the decode twin: compute phase of `get --benchmark -t T -K B` (src/get.c:52) — per id inflate (per-record inflateInit) +
+ * parse + svb-zd decode into a malloc'd buffer; stream = BLOW5 records [u64 size][zlib], rec_off[i] their offsets.
+ * Returns samples decoded (0 if any record failed); *secs = compute wall time. */
+uint64_t s5o_decode_batch_mt(const uint8_t *stream, const uint64_t *rec_off, const uint32_t *ids, uint64_t n_ids,
+                             int rec_method, int sig_method, int n_threads, int batch_size, double *secs,
+                             uint64_t *checksum);
+
 /* ---- §8f row 2: SLOW5 ASCII record lines <-> uncompressed payloads (ascii.c) ---- */
 /* aux type codes: low 4 bits 0..11 = int8,int16,int32,int64,uint8,uint16,uint32,uint64,float,double,char,enum; 0x80 = array */
 int s5o_aux_types(const char *types_line, size_t len, uint8_t *types, unsigned cap);

@@ -65,6 +65,9 @@ def lib():
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     L.s5gpu_last_error.restype = C.c_char_p
     L.s5gpu_init.argtypes = [i32]
+    L.s5gpu_init_mask.argtypes = [u64]
+    L.s5gpu_devices_in_use.restype = i32
+    L.s5gpu_recompress_batch.argtypes = [u32, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     L.s5gpu_device_count.restype = i32
     L.s5gpu_slot_bound.restype = u64
     L.s5gpu_slot_bound.argtypes = [u32, u32, u32, i32, i32]
@@ -105,7 +108,7 @@ def check(rc, what=""):
 
 
 EXPORTS = [
-    "s5gpu_init", "s5gpu_shutdown", "s5gpu_last_error", "s5gpu_device_count", "s5gpu_slot_bound", "s5gpu_payload_bound",
+    "s5gpu_init", "s5gpu_init_mask", "s5gpu_devices_in_use", "s5gpu_shutdown", "s5gpu_last_error", "s5gpu_device_count", "s5gpu_slot_bound", "s5gpu_payload_bound",
     "s5gpu_encode_dev", "s5gpu_decode_dev", "s5gpu_svbzd_encode_dev", "s5gpu_compact_dev", "s5gpu_synth_dev",
     "s5gpu_synth_hdr_dev", "s5gpu_event_create", "s5gpu_event_record", "s5gpu_event_elapsed_ms", "s5gpu_event_destroy",
     "s5gpu_encode_batch", "s5gpu_decode_batch", "s5gpu_solo_batch", "s5gpu_deflate_parked_dev", "s5gpu_inflate_dev",

@@ -10,11 +10,15 @@
 #define _GNU_SOURCE
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
 
 #include "../../include/slow5_compat.h"
 #include "../../include/slow5gpu.h"
+
+void slow5_compat_error(const char *fmt, ...);   /* slow5_compat.c: printed per log level, fatal under SLOW5_EXIT_ON_ERR */
+extern int slow5_compat_skip_rid;                /* slow5_set_skip_rid() */
 
 static const char BLOW5_MAGIC[6] = {'B', 'L', 'O', 'W', '5', '\1'};
 static const char BLOW5_EOF[5] = {'5', 'W', 'O', 'L', 'B'};
@@ -154,6 +158,18 @@ slow5_file_t *slow5_open(const char *pathname, const char *mode) {
     return s;
 }
 
+slow5_file_t *slow5_open_with(const char *pathname, const char *mode, enum slow5_fmt format) {
+    if (format != SLOW5_FORMAT_UNKNOWN && format != SLOW5_FORMAT_ASCII && format != SLOW5_FORMAT_BINARY) { slow5_errno = SLOW5_ERR_ARG; return NULL; }
+    slow5_file_t *s = slow5_open(pathname, mode);
+    if (s && format != SLOW5_FORMAT_UNKNOWN && s->format != format) {   /* the file is not what the caller said it is */
+        slow5_close(s);
+        slow5_errno = SLOW5_ERR_MAGIC;
+        slow5_compat_error("'%s' is not a %s file", pathname, format == SLOW5_FORMAT_ASCII ? "SLOW5 ASCII" : "BLOW5");
+        return NULL;
+    }
+    return s;
+}
+
 int slow5_close(slow5_file_t *s) {
     if (!s) return 0;
     slow5_idx_unload(s);
@@ -198,6 +214,19 @@ void *slow5_get_next_mem(size_t *n, const slow5_file_t *s) {
     if (n) *n = sz;
     slow5_errno = SLOW5_ERR_OK;
     return mem;
+}
+
+int slow5_get_next_bytes(char **mem, size_t *bytes, slow5_file_t *s) {
+    if (!mem || !bytes) { slow5_errno = SLOW5_ERR_ARG; return SLOW5_ERR_ARG; }
+    size_t n = 0;
+    char *m = (char *)slow5_get_next_mem(&n, s);
+    if (!m) {
+        if (slow5_errno != SLOW5_ERR_EOF) slow5_compat_error("slow5_get_next_bytes: the next record could not be read (slow5_errno %d)", slow5_errno);
+        return slow5_errno ? slow5_errno : SLOW5_ERR_UNK;
+    }
+    *mem = m;
+    *bytes = n;
+    return 0;
 }
 
 int slow5_hdr_fwrite(FILE *fp, struct slow5_hdr *header, enum slow5_fmt format, slow5_press_method_t comp) {
@@ -399,6 +428,29 @@ int slow5_idx_load(slow5_file_t *s) {
     if (!p) { slow5_errno = SLOW5_ERR_MEM; return -1; }
     if (access(p, R_OK) != 0 && slow5_idx_create(s) != 0) { free(p); return -1; }
     s->index = idx_read(p);
+    if (s->index) {
+        /* an index is only as good as the file it was made from: same version, every entry inside the file (size covers the
+         * u64 prefix), and not older than the BLOW5 (a rewritten file keeps a stale .idx next to it) */
+        struct stat fs, is;
+        int stale = 0;
+        const struct slow5_version fv = s->header->version, iv = s->index->version;
+        if (iv.major != fv.major || iv.minor != fv.minor || iv.patch != fv.patch) stale = 1;
+        if (!stale && fstat(fileno(s->fp), &fs) == 0) {
+            for (uint64_t i = 0; i < s->index->n && !stale; i++) {
+                const struct idx_ent *e = &s->index->ents[i];
+                if (e->size < 8 || e->offset < s->meta.start_rec_offset || e->offset + e->size > (uint64_t)fs.st_size) stale = 1;
+            }
+            if (!stale && stat(p, &is) == 0 && is.st_mtime < fs.st_mtime) stale = 2;
+        }
+        if (stale) {
+            slow5_idx_unload(s);
+            if (stale == 2) {       /* older than the file: rebuild instead of trusting it */
+                if (slow5_idx_create(s) == 0) s->index = idx_read(p);
+            } else {
+                slow5_compat_error("index '%s' does not belong to this file (version or record extents differ); remove it", p);
+            }
+        }
+    }
     free(p);
     if (!s->index) { slow5_errno = SLOW5_ERR_NOIDX; return -1; }
     return 0;
@@ -407,7 +459,11 @@ int slow5_idx_load(slow5_file_t *s) {
 void *slow5_get_mem(const char *read_id, size_t *n, const slow5_file_t *s) {
     if (!s || !s->index || !read_id) { slow5_errno = SLOW5_ERR_NOIDX; return NULL; }
     const struct idx_ent *e = idx_find(s->index, read_id);
-    if (!e) { slow5_errno = SLOW5_ERR_NOTFOUND; return NULL; }
+    if (!e) {
+        slow5_errno = SLOW5_ERR_NOTFOUND;
+        if (!slow5_compat_skip_rid) slow5_compat_error("read id '%s' is not in the index", read_id);
+        return NULL;
+    }
     const size_t sz = (size_t)(e->size - 8);
     void *mem = malloc(sz ? sz : 1);
     if (!mem) { slow5_errno = SLOW5_ERR_MEM; return NULL; }

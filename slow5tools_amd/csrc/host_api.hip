@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -18,7 +19,6 @@
 #include "host_ctx.h"
 
 static thread_local char g_err[512] = "";
-static int g_device = -1;
 namespace s5host { std::mutex g_mu; }
 using s5host::g_mu;
 
@@ -36,40 +36,101 @@ extern "C" int s5gpu_device_count(void) {
     return n;
 }
 
-extern "C" int s5gpu_init(int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
+// ---- devices and contexts ----
+// The library runs on the devices named at initialisation (one for s5gpu_init, several for s5gpu_init_mask).  Each device
+// has a few contexts (workspaces + stream); a batch call owns one for its duration.
+static const int MAX_DEV = 16, MAX_CTX = 4;
+struct DevState {
+    int phys = -1;                 // HIP device ordinal
+    Ctx *ctx[MAX_CTX] = {nullptr, nullptr, nullptr, nullptr};
+    int nctx = 0;
+};
+static DevState g_dev[MAX_DEV];
+static int g_ndev = 0;
+static uint32_t g_multi_min = 1024;   // records per device below which a host batch is not split over devices
+uint32_t s5host_generation = 1;       // bumped by s5gpu_shutdown: per-thread helper streams of kernels.hip are stale after it
+
+static int init_devices_locked(const int *phys, int count) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         s5gpu_set_error("s5gpu_init: no HIP device visible (this library has no CPU path)");
         return S5GPU_ERR_NODEV;
     }
-    if (device < 0 || device >= n) {
-        s5gpu_set_error("s5gpu_init: device %d out of range (0..%d)", device, n - 1);
-        return S5GPU_ERR_ARG;
+    // S5GPU_ALIAS_DEVICES=1 (tests on a one-GPU box): an ordinal past the last device wraps around, so several logical
+    // devices share a physical one and the multi-device split runs as it would on a node
+    const char *al = getenv("S5GPU_ALIAS_DEVICES");
+    const bool alias = al && atoi(al) != 0;
+    int resolved[MAX_DEV];
+    for (int i = 0; i < count; i++) {
+        int d = phys[i];
+        if (d >= n && alias) d %= n;
+        if (d < 0 || d >= n) {
+            s5gpu_set_error("s5gpu_init: device %d out of range (0..%d)", phys[i], n - 1);
+            return S5GPU_ERR_ARG;
+        }
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, d));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            s5gpu_set_error("s5gpu_init: device %d is %s; kernels are built for gfx950 only", d, prop.gcnArchName);
+            return S5GPU_ERR_NODEV;
+        }
+        resolved[i] = d;
     }
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        s5gpu_set_error("s5gpu_init: device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
-        return S5GPU_ERR_NODEV;
+    if (g_ndev) {   // re-initialisation on the same devices is a no-op; on other devices it needs s5gpu_shutdown first
+        bool same = g_ndev == count;
+        for (int i = 0; same && i < count; i++) same = g_dev[i].phys == resolved[i];
+        if (same) return hipSetDevice(resolved[0]) == hipSuccess ? S5GPU_OK : S5GPU_ERR_HIP;
+        for (int i = 0; i < g_ndev; i++)
+            if (g_dev[i].nctx) { s5gpu_set_error("s5gpu_init: already initialised on other devices with live contexts; call s5gpu_shutdown first"); return S5GPU_ERR_ARG; }
     }
-    HIP_TRY(hipSetDevice(device));
-    g_device = device;
+    for (int i = 0; i < count; i++) g_dev[i].phys = resolved[i];
+    g_ndev = count;
+    HIP_TRY(hipSetDevice(resolved[0]));
     return S5GPU_OK;
 }
 
-static const int MAX_CTX = 4;
-static Ctx *g_ctxs[MAX_CTX] = {nullptr, nullptr, nullptr, nullptr};
-static int g_nctx = 0;
+extern "C" int s5gpu_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return init_devices_locked(&device, 1);
+}
 
-int s5host::CtxHold::acquire() {
-    if (g_device < 0) {
-        int rc = s5gpu_init(0);
-        if (rc) return rc;
+extern "C" int s5gpu_init_mask(uint64_t dev_mask) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int phys[MAX_DEV], count = 0;
+    for (int d = 0; d < 64 && count < MAX_DEV; d++)
+        if ((dev_mask >> d) & 1) phys[count++] = d;
+    if (count == 0) { s5gpu_set_error("s5gpu_init_mask: empty device mask"); return S5GPU_ERR_ARG; }
+    return init_devices_locked(phys, count);
+}
+
+extern "C" int s5gpu_devices_in_use(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_ndev;
+}
+
+int s5host_set_option(const char *key, long value) {
+    if (key && strcmp(key, "multi_min_per_device") == 0 && value >= 1) { g_multi_min = (uint32_t)value; return S5GPU_OK; }
+    return S5GPU_ERR_ARG;
+}
+
+int s5host::n_devices() {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_ndev) return g_ndev;
     }
+    if (s5gpu_init(0)) return 0;
+    return 1;
+}
+
+int s5host::CtxHold::acquire(int want_slot) {
+    if (s5host::n_devices() == 0) return S5GPU_ERR_NODEV;
+    DevState *D;
     {
         std::lock_guard<std::mutex> g(g_mu);
-        if (g_nctx == 0) {
+        if (want_slot < 0 || want_slot >= g_ndev) { s5gpu_set_error("no device slot %d (library runs on %d device(s))", want_slot, g_ndev); return S5GPU_ERR_ARG; }
+        D = &g_dev[want_slot];
+        if (hipSetDevice(D->phys) != hipSuccess) { s5gpu_set_error("hipSetDevice(%d) failed", D->phys); return S5GPU_ERR_HIP; }   // per host thread
+        if (D->nctx == 0) {
             const char *e = getenv("S5GPU_CONTEXTS");
             int want = e ? atoi(e) : 2;
             want = want < 1 ? 1 : want > MAX_CTX ? MAX_CTX : want;
@@ -78,42 +139,71 @@ int s5host::CtxHold::acquire() {
                 if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) {
                     delete c;
                     s5gpu_set_error("hipStreamCreate failed");
-                    if (g_nctx == 0) return S5GPU_ERR_HIP;
+                    if (D->nctx == 0) return S5GPU_ERR_HIP;
                     break;
                 }
-                g_ctxs[g_nctx++] = c;
+                D->ctx[D->nctx++] = c;
             }
         }
     }
-    if (hipSetDevice(g_device) != hipSuccess) { s5gpu_set_error("hipSetDevice(%d) failed", g_device); return S5GPU_ERR_HIP; }   // per host thread
-    for (int i = 0; i < g_nctx; i++) {
-        std::unique_lock<std::mutex> t(g_ctxs[i]->mu, std::try_to_lock);
-        if (t.owns_lock()) { lk = std::move(t); c = g_ctxs[i]; return S5GPU_OK; }
+    slot = want_slot;
+    for (int i = 0; i < D->nctx; i++) {
+        std::unique_lock<std::mutex> t(D->ctx[i]->mu, std::try_to_lock);
+        if (t.owns_lock()) { lk = std::move(t); c = D->ctx[i]; return S5GPU_OK; }
     }
-    const size_t pick = std::hash<std::thread::id>()(std::this_thread::get_id()) % (size_t)g_nctx;
-    lk = std::unique_lock<std::mutex>(g_ctxs[pick]->mu);
-    c = g_ctxs[pick];
+    const size_t pick = std::hash<std::thread::id>()(std::this_thread::get_id()) % (size_t)D->nctx;
+    lk = std::unique_lock<std::mutex>(D->ctx[pick]->mu);
+    c = D->ctx[pick];
+    return S5GPU_OK;
+}
+
+int s5host::for_each_device_range(uint32_t n, const std::function<int(int, uint32_t, uint32_t)> &fn) {
+    int G = s5host::n_devices();
+    if (G == 0) return S5GPU_ERR_NODEV;
+    if ((uint64_t)n < (uint64_t)g_multi_min * (uint64_t)G) G = 1;
+    if (G == 1) return fn(0, 0u, n);
+    std::vector<int> rcs(G, S5GPU_OK);
+    std::vector<std::string> errs(G);
+    std::vector<std::thread> th;
+    auto body = [&](int g) {
+        const uint32_t lo = (uint32_t)((uint64_t)n * g / G), hi = (uint32_t)((uint64_t)n * (g + 1) / G);
+        rcs[g] = lo < hi ? fn(g, lo, hi) : S5GPU_OK;
+        if (rcs[g]) errs[g] = s5gpu_last_error();   // the message lives in the thread that failed
+    };
+    for (int g = 1; g < G; g++) th.emplace_back(body, g);
+    body(0);
+    for (auto &t : th) t.join();
+    for (int g = 0; g < G; g++)
+        if (rcs[g]) { s5gpu_set_error("device slot %d: %s", g, errs[g].c_str()); return rcs[g]; }
     return S5GPU_OK;
 }
 
 using s5host::encode_and_collect;
+void s5kern_release_aux();   // kernels.hip
 
 extern "C" void s5gpu_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (int i = 0; i < g_nctx; i++) {
-        Ctx *c = g_ctxs[i];
-        {
-            std::lock_guard<std::mutex> own(c->mu);   // wait for a batch still running on it
-            Buf *bs[] = {&c->d_sig, &c->d_hdr, &c->d_aux, &c->d_desc, &c->d_slots, &c->d_len, &c->d_ovf, &c->d_in, &c->d_pay, &c->d_fields,
-                         &c->d_stream, &c->d_scan, &c->d_sig2, &c->d_desc2, &c->d_patch, &c->d_txt, &c->d_tdesc, &c->d_gather, &c->h_in, &c->h_out};
-            for (Buf *b : bs) b->release();
-            if (c->st) (void)hipStreamDestroy(c->st);
+    for (int d = 0; d < g_ndev; d++) {
+        DevState &D = g_dev[d];
+        if (D.nctx) (void)hipSetDevice(D.phys);
+        for (int i = 0; i < D.nctx; i++) {
+            Ctx *c = D.ctx[i];
+            {
+                std::lock_guard<std::mutex> own(c->mu);   // wait for a batch still running on it
+                Buf *bs[] = {&c->d_sig, &c->d_hdr, &c->d_aux, &c->d_desc, &c->d_slots, &c->d_len, &c->d_ovf, &c->d_in, &c->d_pay, &c->d_fields,
+                             &c->d_stream, &c->d_scan, &c->d_sig2, &c->d_desc2, &c->d_patch, &c->d_txt, &c->d_tdesc, &c->d_gather, &c->h_in, &c->h_out};
+                for (Buf *b : bs) b->release();
+                if (c->st) (void)hipStreamDestroy(c->st);
+            }
+            delete c;
+            D.ctx[i] = nullptr;
         }
-        delete c;
-        g_ctxs[i] = nullptr;
+        D.nctx = 0;
+        D.phys = -1;
     }
-    g_nctx = 0;
-    g_device = -1;
+    g_ndev = 0;
+    s5kern_release_aux();
+    s5host_generation++;
 }
 
 // ---- events (bench.py times the kernels on the stream they run on) ----
@@ -240,44 +330,57 @@ int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_
 
 // The whole batch in one call: H2D of signals/headers, one launch, D2H of the slots, one malloc per
 // record (the ownership contract of slow5_rec_to_mem: caller frees each buffer, src/view.c:298).
-static int encode_batch_one(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
                             const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
                             int sig_method, void **out, size_t *out_len);
 
-extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
-                                  const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
-                                  int sig_method, void **out, size_t *out_len) {
-    if (n == 0) return S5GPU_OK;
-    if (!sig || !n_samples || !hdr || !hdr_len || !out || !out_len) { s5gpu_set_error("s5gpu_encode_batch: NULL argument"); return S5GPU_ERR_ARG; }
+// one device's share of a batch
+static int encode_batch_dev(int slot, uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                            const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                            int sig_method, void **out, size_t *out_len) {
     // A big batch is cut in two halves that run on two contexts at once: one half's H2D overlaps the other's kernels and
     // D2H (PCIe is full duplex, and the host-side packing of one half hides behind the copies of the other).
     const char *e = getenv("S5GPU_SPLIT");
     const bool split = n >= 16384 && (!e || atoi(e) != 0);
-    if (!split) return encode_batch_one(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
+    if (!split) return encode_batch_one(slot, n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
     const uint32_t h = n / 2;
     int rc2 = S5GPU_OK;
     char err2[512] = "";
     std::thread t([&]() {
-        rc2 = encode_batch_one(n - h, sig + h, n_samples + h, hdr + h, hdr_len + h, aux ? aux + h : nullptr, aux_len ? aux_len + h : nullptr,
+        rc2 = encode_batch_one(slot, n - h, sig + h, n_samples + h, hdr + h, hdr_len + h, aux ? aux + h : nullptr, aux_len ? aux_len + h : nullptr,
                                rec_method, sig_method, out + h, out_len + h);
         if (rc2) snprintf(err2, sizeof err2, "%s", s5gpu_last_error());   // the message lives in that thread
     });
-    const int rc1 = encode_batch_one(h, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
+    const int rc1 = encode_batch_one(slot, h, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
     t.join();
     if (rc1 || rc2) {
-        for (uint32_t i = 0; i < n; i++) { free(out[i]); out[i] = NULL; }
         if (!rc1) s5gpu_set_error("%s", err2);
         return rc1 ? rc1 : rc2;
     }
     return S5GPU_OK;
 }
 
-static int encode_batch_one(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                                  const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                                  int sig_method, void **out, size_t *out_len) {
+    if (n == 0) return S5GPU_OK;
+    if (!sig || !n_samples || !hdr || !hdr_len || !out || !out_len) { s5gpu_set_error("s5gpu_encode_batch: NULL argument"); return S5GPU_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++) out[i] = NULL;
+    // contiguous index range per device (src/thread.c:76-90 does the same per thread); every record's result lands in the
+    // caller's out[i], so the ordered fwrite loop of src/view.c:296-299 is untouched
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) {
+        return encode_batch_dev(slot, hi - lo, sig + lo, n_samples + lo, hdr + lo, hdr_len + lo, aux ? aux + lo : nullptr,
+                                aux_len ? aux_len + lo : nullptr, rec_method, sig_method, out + lo, out_len + lo);
+    });
+    if (rc) for (uint32_t i = 0; i < n; i++) { free(out[i]); out[i] = NULL; }
+    return rc;
+}
+
+static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
                             const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
                             int sig_method, void **out, size_t *out_len) {
-    for (uint32_t i = 0; i < n; i++) out[i] = NULL;
     s5host::CtxHold hold;
-    int rc = hold.acquire();
+    int rc = hold.acquire(slot);
     if (rc) return rc;
     Ctx *c = hold.c;
     std::vector<s5gpu_read_desc_t> desc(n);
@@ -366,17 +469,27 @@ static uint64_t payload_guess(int rec_method, const void *rec, size_t len) {
     return len;
 }
 
+static int decode_batch_dev(int slot, uint32_t n, const void *const *rec, const size_t *rec_len, int rec_method, int sig_method,
+                            void **payload, int16_t **sig, s5gpu_rec_fields_t *fields);
+
 extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int rec_method, int sig_method,
                                   void **payload, int16_t **sig, s5gpu_rec_fields_t *fields) {
     if (n == 0) return S5GPU_OK;
     if (!rec || !rec_len || !payload || !sig || !fields) { s5gpu_set_error("s5gpu_decode_batch: NULL argument"); return S5GPU_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++) { payload[i] = NULL; sig[i] = NULL; }
+    return s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) {
+        return decode_batch_dev(slot, hi - lo, rec + lo, rec_len + lo, rec_method, sig_method, payload + lo, sig + lo, fields + lo);
+    });
+}
+
+static int decode_batch_dev(int slot, uint32_t n, const void *const *rec, const size_t *rec_len, int rec_method, int sig_method,
+                            void **payload, int16_t **sig, s5gpu_rec_fields_t *fields) {
     s5host::CtxHold hold;
-    int rc = hold.acquire();
+    int rc = hold.acquire(slot);
     if (rc) return rc;
     Ctx *c = hold.c;
     std::vector<s5gpu_rec_desc_t> desc(n);
     std::vector<uint8_t> done(n, 0);
-    for (uint32_t i = 0; i < n; i++) { payload[i] = NULL; sig[i] = NULL; }
     // capacity guesses; records that overflow report the size they need and are retried once
     std::vector<uint32_t> pcap(n), scap(n);
     for (uint32_t i = 0; i < n; i++) {
@@ -446,7 +559,7 @@ extern "C" int s5gpu_decode_batch(uint32_t n, const void *const *rec, const size
 extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t *in_len, void **out, size_t *out_len,
                                 int32_t *status) {
     if (n == 0) return S5GPU_OK;
-    if (!in || !in_len || !out || !out_len || stage < 0 || stage > 5) { s5gpu_set_error("s5gpu_solo_batch: bad argument"); return S5GPU_ERR_ARG; }
+    if (!in || !in_len || !out || !out_len || stage < 0 || stage > 7) { s5gpu_set_error("s5gpu_solo_batch: bad argument"); return S5GPU_ERR_ARG; }
     s5host::CtxHold hold;
     int rc = hold.acquire();
     if (rc) return rc;
@@ -457,8 +570,10 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
     int overall = S5GPU_OK;
     const bool park_in = stage == 0 || stage == 5;   // whole buffers through a record press (5: zstd)
     const int park_rec = stage == 5 ? S5GPU_REC_ZSTD : S5GPU_REC_ZLIB;
-    if (park_in || stage == 2) {
-        // encode side: READ_DESC slots
+    const bool exzd_enc = stage == 6, exzd_dec = stage == 7;
+    if (park_in || stage == 2 || exzd_enc) {
+        // encode side: READ_DESC slots.  ex-zd has no kernel of its own: the blob is what the record builder writes behind the
+        // u64 length of a record without head and aux (record press none): slot = [u64 size][u64 L][blob]
         std::vector<s5gpu_read_desc_t> desc(n);
         std::vector<uint32_t> park(n, 0), lens(n);
         uint64_t so = 0, oo = 0;
@@ -477,7 +592,8 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
                 d.n_samples = (uint32_t)(in_len[i] / 2);
                 d.sig_off = so;
                 so += up(d.n_samples, 8);
-                d.slot_cap = (uint32_t)up(4ull + (d.n_samples + 3ull) / 4 + 3ull * d.n_samples + 16, 16);
+                d.slot_cap = exzd_enc ? (uint32_t)s5gpu_slot_bound(d.n_samples, 0, 0, S5GPU_REC_NONE, S5GPU_SIG_EX_ZD)
+                                      : (uint32_t)up(4ull + (d.n_samples + 3ull) / 4 + 3ull * d.n_samples + 16, 16);
             }
             oo += d.slot_cap;
         }
@@ -503,11 +619,11 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
         memset(&a, 0, sizeof a);
         a.n_reads = n;
         a.rec_method = park_in ? park_rec : S5GPU_REC_NONE;
-        a.sig_method = park_in ? S5GPU_SIG_NONE : S5GPU_SIG_SVB_ZD;
+        a.sig_method = park_in ? S5GPU_SIG_NONE : exzd_enc ? S5GPU_SIG_EX_ZD : S5GPU_SIG_SVB_ZD;
         a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
         a.sig = (const int16_t *)c->d_sig.p; a.hdr = (const uint8_t *)c->d_hdr.p;
         a.slots = (uint8_t *)c->d_slots.p; a.out_len = (uint32_t *)c->d_len.p;
-        if ((rc = park_in ? s5gpu_deflate_parked_dev(&a, c->st) : s5gpu_svbzd_encode_dev(&a, c->st))) return rc;
+        if ((rc = park_in ? s5gpu_deflate_parked_dev(&a, c->st) : exzd_enc ? s5gpu_encode_dev(&a, c->st) : s5gpu_svbzd_encode_dev(&a, c->st))) return rc;
         uint8_t *ho_len = (uint8_t *)c->h_out.p, *ho_slots = ho_len + up(4ull * n, 64);
         if ((rc = c->h_out.reserve(up(4ull * n, 64) + oo + 64))) return rc;
         ho_len = (uint8_t *)c->h_out.p; ho_slots = ho_len + up(4ull * n, 64);
@@ -516,7 +632,7 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
         HIP_TRY(hipStreamSynchronize(c->st));
         const uint32_t *ol = (const uint32_t *)ho_len;
         for (uint32_t i = 0; i < n; i++) {
-            const uint32_t skip = park_in ? 8 : 0;   // the solo call returns the bare zlib stream / zstd frame, no u64 prefix
+            const uint32_t skip = park_in ? 8 : exzd_enc ? 16 : 0;   // the solo call returns the bare zlib stream / zstd frame / ex-zd blob
             if (ol[i] < skip || ol[i] > desc[i].slot_cap) { s5gpu_set_error("item %u: impossible device length %u", i, ol[i]); return S5GPU_ERR_HIP; }
             out_len[i] = ol[i] - skip;
             out[i] = malloc(out_len[i] ? out_len[i] : 1);
@@ -531,7 +647,13 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
     std::vector<uint8_t> done(n, 0);
     for (uint32_t i = 0; i < n; i++) {
         if (infl) { const uint64_t g = payload_guess(stage == 4 ? S5GPU_REC_ZSTD : S5GPU_REC_ZLIB, in[i], in_len[i]); pcap[i] = (uint32_t)(g > 0xFFFFFF00ull ? 0xFFFFFF00ull : g); scap[i] = 0; }
-        else {
+        else if (exzd_dec) {
+            // the blob goes in as the signal of a record without id and aux (EXZD_HEAD zero bytes of head + u64 L); N sits at blob + 1
+            uint64_t ns = 0;
+            if (in_len[i] >= 9) memcpy(&ns, (const uint8_t *)in[i] + 1, 8);
+            if (ns > 2ull * in_len[i] + 64) ns = 2ull * in_len[i] + 64;   // an impossible count: the kernel reports what it needs
+            scap[i] = (uint32_t)ns; pcap[i] = (uint32_t)(in_len[i] + 64);
+        } else {
             uint32_t ns = 0;
             if (in_len[i] >= 4) memcpy(&ns, in[i], 4);
             if ((uint64_t)ns > 4ull * in_len[i]) ns = 0;   // impossible count: let the kernel report it
@@ -549,8 +671,9 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
             const uint32_t i = idx[k];
             s5gpu_rec_desc_t &d = desc[k];
             d.in_off = io; d.pay_off = po; d.sig_off = so;
-            d.in_len = (uint32_t)in_len[i]; d.pay_cap = pcap[i]; d.sig_cap = scap[i]; d.reserved = 0;
-            io += up(in_len[i] + 16, 16); po += up((uint64_t)pcap[i] + 16, 16); so += up((uint64_t)scap[i] + 8, 8);
+            const uint32_t EXZD_HEAD = 2 + 4 + 32 + 8;   // u16 id_len 0 | u32 read_group | 4 x f64 | u64 L
+            d.in_len = (uint32_t)in_len[i] + (exzd_dec ? EXZD_HEAD : 0u); d.pay_cap = pcap[i]; d.sig_cap = scap[i]; d.reserved = 0;
+            io += up((uint64_t)d.in_len + 16, 16); po += up((uint64_t)pcap[i] + 16, 16); so += up((uint64_t)scap[i] + 8, 8);
         }
         const size_t hin = up(io + 64, 64) + sizeof(s5gpu_rec_desc_t) * m;
         const size_t hout = up(po + 64, 64) + up(so * 2 + 64, 64) + sizeof(s5gpu_rec_fields_t) * m;
@@ -559,17 +682,26 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
             (rc = c->h_out.reserve(hout)))
             return rc;
         uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + up(io + 64, 64);
-        for (uint32_t k = 0; k < m; k++) if (in_len[idx[k]]) memcpy(hi + desc[k].in_off, in[idx[k]], in_len[idx[k]]);
+        for (uint32_t k = 0; k < m; k++) {
+            uint8_t *dst = hi + desc[k].in_off;
+            if (exzd_dec) {
+                memset(dst, 0, 38);
+                const uint64_t L = in_len[idx[k]];
+                memcpy(dst + 38, &L, 8);
+                dst += 46;
+            }
+            if (in_len[idx[k]]) memcpy(dst, in[idx[k]], in_len[idx[k]]);
+        }
         memcpy(hd, desc.data(), sizeof(s5gpu_rec_desc_t) * m);
         HIP_TRY(hipMemcpyAsync(c->d_in.p, hi, io, hipMemcpyHostToDevice, c->st));
         HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_rec_desc_t) * m, hipMemcpyHostToDevice, c->st));
         HIP_TRY(hipMemsetAsync(c->d_fields.p, 0, sizeof(s5gpu_rec_fields_t) * m, c->st));
         s5gpu_decode_args_t a;
         memset(&a, 0, sizeof a);
-        a.n_recs = m; a.rec_method = stage == 4 ? S5GPU_REC_ZSTD : S5GPU_REC_ZLIB; a.sig_method = S5GPU_SIG_SVB_ZD;
+        a.n_recs = m; a.rec_method = exzd_dec ? S5GPU_REC_NONE : stage == 4 ? S5GPU_REC_ZSTD : S5GPU_REC_ZLIB; a.sig_method = exzd_dec ? S5GPU_SIG_EX_ZD : S5GPU_SIG_SVB_ZD;
         a.desc = (const s5gpu_rec_desc_t *)c->d_desc.p; a.in = (const uint8_t *)c->d_in.p;
         a.payload = (uint8_t *)c->d_pay.p; a.sig_out = (int16_t *)c->d_sig.p; a.fields = (s5gpu_rec_fields_t *)c->d_fields.p;
-        if ((rc = infl ? s5gpu_inflate_dev(&a, c->st) : s5gpu_svbzd_decode_dev(&a, c->st))) return rc;
+        if ((rc = infl ? s5gpu_inflate_dev(&a, c->st) : exzd_dec ? s5gpu_decode_dev(&a, c->st) : s5gpu_svbzd_decode_dev(&a, c->st))) return rc;
         uint8_t *hp = (uint8_t *)c->h_out.p, *hsg = hp + up(po + 64, 64), *hf = hsg + up(so * 2 + 64, 64);
         HIP_TRY(hipMemcpyAsync(hf, c->d_fields.p, sizeof(s5gpu_rec_fields_t) * m, hipMemcpyDeviceToHost, c->st));
         if (infl) HIP_TRY(hipMemcpyAsync(hp, c->d_pay.p, po, hipMemcpyDeviceToHost, c->st));
@@ -649,16 +781,29 @@ int s5host::decode_resident(Ctx *c, uint32_t n, const void *const *rec, const si
 }
 
 // ---- view / merge worker for a whole batch, device-resident between decode and encode ----
+static int recompress_batch_dev(int slot, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, int32_t *status);
+
 extern "C" int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
                                       int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
                                       int32_t *status) {
     if (n == 0) return S5GPU_OK;
     if (!rec || !rec_len || !out || !out_len) { s5gpu_set_error("s5gpu_recompress_batch: NULL argument"); return S5GPU_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) {
+        return recompress_batch_dev(slot, hi - lo, rec + lo, rec_len + lo, from_rec, from_sig, to_rec, to_sig,
+                                    new_read_group ? new_read_group + lo : nullptr, drop_aux, out + lo, out_len + lo, status ? status + lo : nullptr);
+    });
+    if (rc) for (uint32_t i = 0; i < n; i++) { free(out[i]); out[i] = NULL; }
+    return rc;
+}
+
+static int recompress_batch_dev(int slot, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, int32_t *status) {
     s5host::CtxHold hold;
-    int rc = hold.acquire();
+    int rc = hold.acquire(slot);
     if (rc) return rc;
     Ctx *c = hold.c;
-    for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
     std::vector<s5gpu_rec_desc_t> rd;
     std::vector<s5gpu_rec_fields_t> ff;
     if ((rc = s5host::decode_resident(c, n, rec, rec_len, from_rec, from_sig, rd, ff, status))) return rc;

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -32,7 +33,7 @@ struct Buf {
         if (n <= cap) return S5GPU_OK;
         if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = n + n / 4 + 4096;
-        hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocPortable) : hipMalloc(&p, want);
         if (e != hipSuccess) { s5gpu_set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); p = nullptr; return S5GPU_ERR_NOMEM; }
         cap = want;
         return S5GPU_OK;
@@ -52,11 +53,21 @@ namespace s5host {
 extern std::mutex g_mu;
 // A batch call owns one of a few contexts (workspaces + stream) for its duration, so host threads can run batches
 // concurrently: one batch's PCIe copies overlap another's kernels.  S5GPU_CONTEXTS (default 2, max 4).
+// slot = index into the devices the library was initialised on (s5gpu_init_mask); a host thread that holds a context has
+// that device current.
 struct CtxHold {
     Ctx *c = nullptr;
+    int slot = 0;
     std::unique_lock<std::mutex> lk;
-    int acquire();
+    int acquire(int slot = 0);
 };
+// devices in use (>= 1 once the library is initialised; initialises on device 0 if nobody has)
+int n_devices();
+// The reference splits a batch into one contiguous index range per worker thread (/root/reference/src/thread.c:76-90);
+// here per DEVICE: device g of G takes [g*n/G, (g+1)*n/G), one host thread each, results land in the caller's own
+// per-record slots, so the order is the caller's.  fn(slot, lo, hi) -> S5GPU_* code.  Batches of fewer than
+// multi_min_per_device * G records stay on device 0.
+int for_each_device_range(uint32_t n, const std::function<int(int, uint32_t, uint32_t)> &fn);
 // encode descriptors already on the device -> one malloc per record on the host (host_api.hip)
 int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
                        void **out, size_t *out_len);

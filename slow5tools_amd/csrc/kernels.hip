@@ -7,6 +7,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "../../include/slow5gpu.h"
 #include "deflate_dev.h"
 #include "inflate_dev.h"
@@ -19,6 +23,8 @@
 using namespace s5;
 
 extern "C" void s5gpu_set_error(const char *fmt, ...);
+int s5host_set_option(const char *key, long value);   // host_api.hip: options of the host layer
+extern uint32_t s5host_generation;                    // host_api.hip: bumped by s5gpu_shutdown
 
 #define HIP_TRY(x)                                                                                   \
     do {                                                                                             \
@@ -805,9 +811,17 @@ static int enc_check(const s5gpu_encode_args_t *a) {
     return S5GPU_OK;
 }
 
-static bool g_attr_done = false;
+// Function attributes are per device: done once for each device a launch is made on (the batch API runs host threads on
+// several devices at once, so the bookkeeping is a mutex-guarded bit per device ordinal).
+static std::mutex g_attr_mu;
+static std::atomic<uint64_t> g_attr_devs{0};
 static int set_lds_attrs() {
-    if (g_attr_done) return S5GPU_OK;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (g_attr_devs.load(std::memory_order_acquire) & bit) return S5GPU_OK;
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (g_attr_devs.load(std::memory_order_relaxed) & bit) return S5GPU_OK;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -821,7 +835,9 @@ static int set_lds_attrs() {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svbzd_encode), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    g_attr_done = true;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate_simt<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate_simt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    g_attr_devs.fetch_or(bit, std::memory_order_release);
     return S5GPU_OK;
 }
 
@@ -956,34 +972,66 @@ static uint32_t g_inflate_simt_min = 24576;   // measured crossover on 4000-samp
 extern "C" int s5gpu_set_option(const char *key, long value) {
     if (key && strcmp(key, "inflate_simt_min") == 0 && value >= 0) { g_inflate_simt_min = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_route") == 0 && (value == 0 || value == 1)) { g_inflate_route = (uint32_t)value; return S5GPU_OK; }
+    if (s5host_set_option(key, value) == S5GPU_OK) return S5GPU_OK;
     s5gpu_set_error("s5gpu_set_option: unknown option");
     return S5GPU_ERR_ARG;
 }
-struct AuxStream {   // one per host thread: the batch API runs calls from several threads
+// Helper stream + two events for the routed inflate (the long records run beside the lane kernel).  One per host thread and
+// device — the batch API runs calls from several threads — owned by a registry so that s5gpu_shutdown can release them; a
+// thread notices a shutdown (or a change of device) by the generation / device stamp and takes a fresh one.
+struct AuxStream {
     hipStream_t st = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    int dev = -1;
+    uint32_t gen = 0;
 };
-static thread_local AuxStream t_aux;
+static std::mutex g_aux_mu;
+static std::vector<AuxStream *> g_aux_all;
+static thread_local AuxStream *t_aux_p = nullptr;
+static int aux_stream(AuxStream **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_aux_mu);   // also orders the read of the generation against s5gpu_shutdown
+    if (t_aux_p && t_aux_p->dev == dev && t_aux_p->gen == s5host_generation) { *out = t_aux_p; return S5GPU_OK; }
+    AuxStream *a = new AuxStream();
+    a->dev = dev;
+    a->gen = s5host_generation;
+    if (hipStreamCreateWithFlags(&a->st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&a->join, hipEventDisableTiming) != hipSuccess) {
+        if (a->st) (void)hipStreamDestroy(a->st);
+        if (a->fork) (void)hipEventDestroy(a->fork);
+        delete a;
+        s5gpu_set_error("helper stream for the routed inflate could not be created");
+        return S5GPU_ERR_HIP;
+    }
+    g_aux_all.push_back(a);
+    t_aux_p = a;
+    *out = a;
+    return S5GPU_OK;
+}
+void s5kern_release_aux() {   // s5gpu_shutdown
+    std::lock_guard<std::mutex> lk(g_aux_mu);
+    for (AuxStream *a : g_aux_all) {
+        (void)hipStreamDestroy(a->st);
+        (void)hipEventDestroy(a->fork);
+        (void)hipEventDestroy(a->join);
+        a->gen = 0;       // a thread still pointing at it sees a stale stamp (generations start at 1); the struct itself stays
+    }
+    g_aux_all.clear();    // (a few dozen bytes per thread and shutdown: not freed, a thread-local may still point at it)
+}
 
 static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st) {
     if (a->rec_method == S5GPU_REC_ZSTD) {
         hipLaunchKernelGGL(k_zstd_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
-        static bool attr = false;
-        if (!attr) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate_simt<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate_simt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-            attr = true;
-        }
+        { const int rc = set_lds_attrs(); if (rc) return rc; }
         const uint32_t nb64 = (a->n_recs + 63) / 64;
         if (a->n_recs < 1024 || !g_inflate_route) {   // tiny batches (tests force the lane kernel on them): no routing
             hipLaunchKernelGGL(k_inflate_simt<false>, dim3(nb64), dim3(64), 64 * sizeof(LaneTables), st, *a);
         } else {
-            if (!t_aux.st) {
-                HIP_TRY(hipStreamCreateWithFlags(&t_aux.st, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&t_aux.fork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&t_aux.join, hipEventDisableTiming));
-            }
+            AuxStream *ax;
+            { const int rc = aux_stream(&ax); if (rc) return rc; }
+            AuxStream &t_aux = *ax;
             const uint32_t nbt = (a->n_recs + NT - 1) / NT;
             hipLaunchKernelGGL(k_route_zero, dim3(1), dim3(NT), 0, st, *a);
             hipLaunchKernelGGL(k_route_count, dim3(nbt), dim3(NT), 0, st, *a);

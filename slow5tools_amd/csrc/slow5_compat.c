@@ -17,6 +17,28 @@
 
 __thread int slow5_errno = 0;
 
+/* ---- process-wide switches (src/main.c:246-247, src/get.c:194) ---- */
+#include <stdarg.h>
+#include <stdio.h>
+static enum slow5_log_level_opt g_log_level = SLOW5_LOG_INFO;
+static enum slow5_exit_condition_opt g_exit_cond = SLOW5_EXIT_OFF;
+int slow5_compat_skip_rid = 0;   /* read by blow5_file.c */
+void slow5_set_log_level(enum slow5_log_level_opt l) { g_log_level = l; }
+void slow5_set_exit_condition(enum slow5_exit_condition_opt e) { g_exit_cond = e; }
+void slow5_set_skip_rid(void) { slow5_compat_skip_rid = 1; }
+/* error report of this layer: printed at log level >= ERR, fatal under SLOW5_EXIT_ON_ERR (the policy slow5tools selects) */
+void slow5_compat_error(const char *fmt, ...) {
+    if (g_log_level >= SLOW5_LOG_ERR) {
+        va_list ap;
+        va_start(ap, fmt);
+        fputs("[slow5gpu::ERROR] ", stderr);
+        vfprintf(stderr, fmt, ap);
+        fputc('\n', stderr);
+        va_end(ap);
+    }
+    if (g_exit_cond >= SLOW5_EXIT_ON_ERR) exit(EXIT_FAILURE);
+}
+
 static int rec_code(enum slow5_press_method m) {
     return m == SLOW5_COMPRESS_NONE ? S5GPU_REC_NONE : m == SLOW5_COMPRESS_ZLIB ? S5GPU_REC_ZLIB : m == SLOW5_COMPRESS_ZSTD ? S5GPU_REC_ZSTD : -1;
 }
@@ -56,7 +78,7 @@ void *slow5_ptr_compress_solo(enum slow5_press_method method, const void *ptr, s
         memcpy(out, ptr, count);
         len = count;
     } else {
-        const int stage = method == SLOW5_COMPRESS_ZLIB ? 0 : method == SLOW5_COMPRESS_SVB_ZD ? 2 : method == SLOW5_COMPRESS_ZSTD ? 5 : -1;
+        const int stage = method == SLOW5_COMPRESS_ZLIB ? 0 : method == SLOW5_COMPRESS_SVB_ZD ? 2 : method == SLOW5_COMPRESS_ZSTD ? 5 : method == SLOW5_COMPRESS_EX_ZD ? 6 : -1;
         const void *in[1] = {ptr};
         if (stage < 0 || s5gpu_solo_batch(stage, 1, in, &count, &out, &len, NULL) != S5GPU_OK) { slow5_errno = SLOW5_ERR_PRESS; return NULL; }
     }
@@ -73,12 +95,21 @@ void *slow5_ptr_depress_solo(enum slow5_press_method method, const void *ptr, si
         memcpy(out, ptr, count);
         len = count;
     } else {
-        const int stage = method == SLOW5_COMPRESS_ZLIB ? 1 : method == SLOW5_COMPRESS_SVB_ZD ? 3 : method == SLOW5_COMPRESS_ZSTD ? 4 : -1;
+        const int stage = method == SLOW5_COMPRESS_ZLIB ? 1 : method == SLOW5_COMPRESS_SVB_ZD ? 3 : method == SLOW5_COMPRESS_ZSTD ? 4 : method == SLOW5_COMPRESS_EX_ZD ? 7 : -1;
         const void *in[1] = {ptr};
         if (stage < 0 || s5gpu_solo_batch(stage, 1, in, &count, &out, &len, NULL) != S5GPU_OK) { free(out); slow5_errno = SLOW5_ERR_PRESS; return NULL; }
     }
     if (n) *n = len;
     return out;
+}
+
+void *slow5_ptr_compress(struct __slow5_press *comp, const void *ptr, size_t count, size_t *n) {
+    if (!comp) { slow5_errno = SLOW5_ERR_ARG; return NULL; }
+    return slow5_ptr_compress_solo(comp->method, ptr, count, n);
+}
+void *slow5_ptr_depress(struct __slow5_press *comp, const void *ptr, size_t count, size_t *n) {
+    if (!comp) { slow5_errno = SLOW5_ERR_ARG; return NULL; }
+    return slow5_ptr_depress_solo(comp->method, ptr, count, n);
 }
 
 struct slow5_rec *slow5_rec_init(void) { return (struct slow5_rec *)calloc(1, sizeof(struct slow5_rec)); }
@@ -139,14 +170,38 @@ done:
 
 void *slow5_rec_to_mem(struct slow5_rec *read, struct slow5_aux_meta *aux_meta, enum slow5_fmt format,
                        struct slow5_press *compress, size_t *n) {
-    if (!read || format != SLOW5_FORMAT_BINARY) { slow5_errno = SLOW5_ERR_ARG; return NULL; }   /* ASCII: SURVEY §8(f) row 2 */
+    if (!read || (format != SLOW5_FORMAT_BINARY && format != SLOW5_FORMAT_ASCII)) { slow5_errno = SLOW5_ERR_ARG; return NULL; }
     slow5_press_method_t m = {SLOW5_COMPRESS_NONE, SLOW5_COMPRESS_NONE};
-    if (compress) { m.record_method = compress->record_press->method; m.signal_method = compress->signal_press->method; }
+    if (compress && format == SLOW5_FORMAT_BINARY) { m.record_method = compress->record_press->method; m.signal_method = compress->signal_press->method; }
     void *out = NULL;
     size_t len = 0;
     if (slow5_gpu_rec_to_mem_batch(1, &read, aux_meta == NULL, m, &out, &len) != 0) return NULL;
+    if (format == SLOW5_FORMAT_ASCII) {
+        /* the record line: the uncompressed record goes back through the ASCII formatter, whose raw_signal
+         * column is printed on the device; the line ends in a newline like slow5lib's */
+        const void *rec = (const char *)out + 8;
+        size_t rlen = len - 8, llen = 0;
+        void *line = NULL;
+        const int rc = s5gpu_blow5_to_ascii_batch(1, &rec, &rlen, S5GPU_REC_NONE, S5GPU_SIG_NONE, aux_meta ? aux_meta->num : 0, aux_meta ? aux_meta->types : NULL, NULL, 0,
+                                                  &line, &llen, NULL);
+        free(out);
+        if (rc != S5GPU_OK) { slow5_errno = SLOW5_ERR_RECPARSE; return NULL; }
+        out = line;
+        len = llen;
+    }
     if (n) *n = len;
     return out;
+}
+
+int slow5_rec_fwrite(FILE *fp, struct slow5_rec *read, struct slow5_aux_meta *aux_meta, enum slow5_fmt format, struct slow5_press *compress) {
+    if (!fp) { slow5_errno = SLOW5_ERR_ARG; return -1; }
+    size_t n = 0;
+    void *mem = slow5_rec_to_mem(read, aux_meta, format, compress, &n);
+    if (!mem) { slow5_compat_error("slow5_rec_fwrite: the record could not be encoded (%s)", s5gpu_last_error()); return -1; }
+    const size_t w = fwrite(mem, 1, n, fp);
+    free(mem);
+    if (w != n) { slow5_errno = SLOW5_ERR_IO; slow5_compat_error("slow5_rec_fwrite: short write"); return -1; }
+    return (int)n;
 }
 
 static int fill_rec(struct slow5_rec **pr, const s5gpu_rec_fields_t *f, const uint8_t *payload, int16_t *sig) {
@@ -164,13 +219,13 @@ static int fill_rec(struct slow5_rec **pr, const s5gpu_rec_fields_t *f, const ui
     r->range = f->range;
     r->sampling_rate = f->sampling_rate;
     r->len_raw_signal = f->n_samples;
-    r->raw_signal = sig;   /* ownership moves to the record */
     r->aux_len = f->aux_len;
     if (f->aux_len) {
         r->aux_blob = (uint8_t *)malloc(f->aux_len);
-        if (!r->aux_blob) return -1;
+        if (!r->aux_blob) { r->len_raw_signal = 0; r->aux_len = 0; return -1; }   /* sig stays the caller's: nothing to free twice */
         memcpy(r->aux_blob, payload + f->aux_off, f->aux_len);
     }
+    r->raw_signal = sig;   /* ownership moves to the record only once every allocation has succeeded */
     return 0;
 }
 
@@ -207,6 +262,12 @@ int slow5_rec_depress_parse(char **mem, size_t *bytes, const char *read_id, stru
     slow5_press_method_t m = {SLOW5_COMPRESS_NONE, SLOW5_COMPRESS_NONE};
     if (s5p->compress) { m.record_method = s5p->compress->record_press->method; m.signal_method = s5p->compress->signal_press->method; }
     return slow5_gpu_depress_parse_batch(1, mem, bytes, m, read);
+}
+
+int slow5_decode(char **mem, size_t *bytes, struct slow5_rec **read, struct slow5_file *s5p) {
+    const int rc = slow5_rec_depress_parse(mem, bytes, NULL, read, s5p);
+    if (rc != 0) { slow5_compat_error("slow5_decode: the record could not be decoded (%s)", s5gpu_last_error()); return slow5_errno ? slow5_errno : SLOW5_ERR_RECPARSE; }
+    return 0;
 }
 
 int slow5_gpu_convert_batch(int64_t n, char **mem, size_t *bytes, enum slow5_fmt from_fmt, slow5_press_method_t from,

@@ -153,7 +153,9 @@ class DeviceBatch:
     """Device-resident encode batch.  torch is plumbing only: HBM allocations and the stream handle."""
 
     def __init__(self, n_samples, hdr_len=74, aux_len=0, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD, device="cuda:0",
-                 with_stream_out=True, lds_payload_cap=0):
+                 with_stream_out=True, lds_payload_cap=0, share=None):
+        """share: another DeviceBatch whose slots / stream_out (at least as large) this one reuses — chunks of a long job
+        that run one after the other need one set of output buffers, not one per chunk"""
         import torch
 
         self.torch = torch
@@ -166,12 +168,19 @@ class DeviceBatch:
         self.sig = torch.zeros(self.tot["samples"] + 64, dtype=torch.int16, device=self.dev)
         self.hdr = torch.zeros(self.tot["hdr"] + 64, dtype=u8, device=self.dev)
         self.aux = torch.zeros(self.tot["aux"] + 64, dtype=u8, device=self.dev)
-        self.slots = torch.empty(self.tot["slots"] + 64, dtype=u8, device=self.dev)
+        if share is not None:
+            assert share.slots.numel() >= self.tot["slots"] + 64
+            self.slots = share.slots
+        else:
+            self.slots = torch.empty(self.tot["slots"] + 64, dtype=u8, device=self.dev)
         self.out_len = torch.zeros(self.n + 1, dtype=torch.int32, device=self.dev)
         self.ovf = torch.zeros(self.n + 4, dtype=torch.int32, device=self.dev)
         self.rec_off = torch.zeros(self.n + 1, dtype=torch.int64, device=self.dev)
         self.tmp = torch.zeros(self.n // 1024 + 8, dtype=torch.int64, device=self.dev)
-        self.stream_out = torch.empty(self.tot["slots"] + 64, dtype=u8, device=self.dev) if with_stream_out else None
+        if share is not None and share.stream_out is not None:
+            self.stream_out = share.stream_out
+        else:
+            self.stream_out = torch.empty(self.tot["slots"] + 64, dtype=u8, device=self.dev) if with_stream_out else None
         a = _lib.EncodeArgs()
         a.n_reads, a.rec_method, a.sig_method = self.n, rec_method, sig_method
         a.desc, a.sig, a.hdr, a.aux = self.desc.data_ptr(), self.sig.data_ptr(), self.hdr.data_ptr(), self.aux.data_ptr()

@@ -71,6 +71,9 @@ def lib():
     L.s5o_encode_batch_mt.restype = C.c_uint64
     L.s5o_encode_batch_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.s5o_decode_batch_mt.restype = C.c_uint64
+    L.s5o_decode_batch_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.s5o_exzd_bound.restype = C.c_size_t
     L.s5o_exzd_bound.argtypes = [C.c_uint64]
     L.s5o_exzd_encode.restype = C.c_size_t
@@ -221,6 +224,18 @@ def encode_batch_mt(sig2d, first_idx, n_threads, batch_size=4096, rec_method=REC
     ck = C.c_uint64()
     total = lib().s5o_encode_batch_mt(_ptr(sig2d), sig2d.shape[0], sig2d.shape[1], first_idx, rec_method, sig_method,
                                       n_threads, batch_size, C.byref(secs), C.byref(ck))
+    return total, secs.value, ck.value
+
+
+def decode_batch_mt(stream, rec_off, ids, n_threads, batch_size=4096, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD):
+    """compute phase of `get --benchmark` on the CPU: returns (samples decoded, seconds, checksum)"""
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    secs = C.c_double()
+    ck = C.c_uint64()
+    total = lib().s5o_decode_batch_mt(_ptr(stream), _ptr(rec_off), _ptr(ids), ids.size, rec_method, sig_method, n_threads,
+                                      batch_size, C.byref(secs), C.byref(ck))
     return total, secs.value, ck.value
 
 

@@ -195,3 +195,70 @@ def test_zstd_full_size_round_trip_checksum():
 def s5_slot(press, n_samp):
     from slow5tools_amd import _lib
     return _lib.lib().s5gpu_slot_bound(n_samp, 74, 0, press.REC_ZSTD, press.SIG_SVB_ZD)
+
+
+def test_long_reads_configs3_shape_round_trip_and_sampled_zlib_parity():
+    """BASELINE configs[3]'s read shape (100 000 samples per read) at a chunk of 4096 reads = 0.8 GB of raw signal, through the
+    HBM-staged kernels (k_pack + k_deflate_staged, 16 KiB DEFLATE blocks) and the compaction:
+      - the record stream is well formed (u64 prefixes chain to the end);
+      - decode(encode(x)) == x for every read (GPU inflate + unpack, Adler-32 verified on the device);
+      - a 1-in-173 sample is inflated by STOCK zlib and equals the oracle's payload byte for byte;
+      - the sampled records are not larger than zlib level 6's."""
+    import torch
+    from slow5tools_amd import _lib, press
+
+    L = _lib.lib()
+    _lib.check(L.s5gpu_init(0), "s5gpu_init")
+    dev = "cuda:0"
+    n_reads, n = 4096, 100_000
+    b = press.DeviceBatch(np.full(n_reads, n, dtype=np.uint64), device=dev)
+    b.synth(seed=0x5105, first=12345)
+    b.encode()
+    b.compact()
+    torch.cuda.synchronize()
+    assert int(b.ovf[0].item()) == 0                      # the whole batch is staged: nothing goes through the overflow list
+    off = b.rec_off.cpu().numpy().astype(np.int64)
+    lens = np.diff(off)
+    assert off[0] == 0 and (lens > 8).all()
+    total = int(off[n_reads])
+    stream = b.stream_out[:total]
+    prefix_idx = torch.from_numpy(off[:-1]).to(dev)
+    pre = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    for k in range(8):
+        pre |= stream[prefix_idx + k].to(torch.int64) << (8 * k)
+    assert torch.equal(pre, torch.from_numpy(lens - 8).to(dev))
+    pay_cap = 16 * ((int(b.tot["max_payload"]) + 31) // 16)
+    sig_cap = (n + 7) // 8 * 8
+    payload = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device=dev)
+    sig = torch.empty(n_reads * sig_cap + 64, dtype=torch.int16, device=dev)
+    fields = torch.zeros(n_reads * 64, dtype=torch.uint8, device=dev)
+    d = np.zeros(n_reads, dtype=_lib.REC_DESC)
+    d["in_off"] = off[:-1] + 8
+    d["in_len"] = lens - 8
+    d["pay_off"] = np.arange(n_reads, dtype=np.uint64) * pay_cap
+    d["pay_cap"] = pay_cap
+    d["sig_off"] = np.arange(n_reads, dtype=np.uint64) * sig_cap
+    d["sig_cap"] = sig_cap
+    desc = torch.from_numpy(d.view(np.uint8).copy()).to(dev)
+    a = _lib.DecodeArgs()
+    a.n_recs, a.rec_method, a.sig_method = n_reads, 1, 1
+    a.desc, a.in_, a.payload, a.sig_out, a.fields = desc.data_ptr(), b.stream_out.data_ptr(), payload.data_ptr(), sig.data_ptr(), fields.data_ptr()
+    _lib.check(L.s5gpu_decode_dev(C.byref(a), b._stream()), "s5gpu_decode_dev")
+    torch.cuda.synchronize()
+    f32 = fields.view(torch.int32).view(n_reads, 16)
+    assert int(f32[:, 0].abs().sum().item()) == 0, "a record failed to decode (status != 0)"
+    assert bool((f32[:, 2] == n).all().item())
+    got = sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]
+    want = b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]
+    assert torch.equal(got, want), "decode(encode(x)) != x"
+    idx = list(range(0, n_reads, 173)) + [n_reads - 1]
+    gpu_bytes = ref_bytes = 0
+    for i, rec in zip(idx, b.stream_records(idx)):
+        s = ob.synth_read(0x5105, 12345 + i, n)
+        r, keep = ob.make_rec(ob.synth_read_id(12345 + i), 0, 8192.0, 23.0, 1467.61, 4000.0, s)
+        pay = ob.rec_pack(r, ob.SIG_SVB_ZD)
+        assert struct.unpack_from("<Q", rec, 0)[0] == len(rec) - 8
+        assert zlib.decompress(rec[8:]) == pay
+        gpu_bytes += len(rec) - 8
+        ref_bytes += len(zlib.compress(pay, 6))
+    assert gpu_bytes <= ref_bytes, (gpu_bytes, ref_bytes)

@@ -1,0 +1,149 @@
+"""several GPUs behind ONE host batch call.  s5gpu_init_mask names the devices; the host batch calls cut a batch
+into one contiguous index range per device (as work_db cuts it per thread, /root/reference/src/thread.c:76-90) and every
+result lands in the caller's own slot, so the ordered write loop (/root/reference/src/view.c:296-299) sees the same bytes as with
+one device.  The GPU box has one MI355X: S5GPU_ALIAS_DEVICES=1 lets device ordinals past the last one wrap around, so the split,
+the per-device contexts and the concurrent host threads run exactly as on a node (each in a fresh process: the device set is
+process state)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CODE = r"""
+import os, sys, zlib
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import oracle_bind as ob
+from slow5tools_amd import _lib, press
+L = _lib.lib()
+mask = %(mask)d
+_lib.check(L.s5gpu_init_mask(mask), "init_mask")
+assert L.s5gpu_devices_in_use() == bin(mask).count("1")
+_lib.check(L.s5gpu_set_option(b"multi_min_per_device", 8), "opt")
+rng = np.random.default_rng(11)
+n = %(n)d
+lens = rng.integers(1, 9000, n); lens[::97] = 0; lens[5] = 70000
+sigs = [ob.synth_read(0x5105, i, int(l)) if l else np.zeros(0, np.int16) for i, l in enumerate(lens)]
+hdrs = [press.pack_hdr(ob.synth_read_id(i), i %% 3, 8192.0, 23.0, 1467.61, 4000.0) for i in range(n)]
+recs = press.encode_records(sigs, hdrs)
+for i, r in enumerate(recs):
+    rec, keep = ob.make_rec(ob.synth_read_id(i), i %% 3, 8192.0, 23.0, 1467.61, 4000.0, sigs[i])
+    assert int.from_bytes(r[:8], "little") == len(r) - 8
+    assert zlib.decompress(r[8:]) == ob.rec_pack(rec, ob.SIG_SVB_ZD), i
+dec = press.decode_records([r[8:] for r in recs])
+assert all(d["status"] == 0 and np.array_equal(d["signal"], sigs[i]) and d["read_group"] == i %% 3 for i, d in enumerate(dec))
+# a corrupt record in the second device's range is reported in its own slot, the others still decode
+bad = [r[8:] for r in recs]; k = n - 3; bad[k] = bad[k][:20] + bytes([bad[k][20] ^ 0x55]) + bad[k][21:]
+dec2 = press.decode_records(bad, raise_on_error=False)
+assert dec2[k]["status"] != 0 and all(d["status"] == 0 for i, d in enumerate(dec2) if i != k)
+# the view worker (decode + re-encode, device-resident) through the same split: zlib+svb -> none+none -> back
+import ctypes as C
+vp = C.c_void_p
+def recompress(rs, f, t, rg=None):
+    m = len(rs)
+    bufs = [C.create_string_buffer(r, len(r)) for r in rs]
+    ptr = (vp * m)(*[C.addressof(b) for b in bufs]); ln = (C.c_size_t * m)(*[len(r) for r in rs])
+    out = (vp * m)(); ol = (C.c_size_t * m)(); st = (C.c_int32 * m)()
+    rgp = (C.c_uint32 * m)(*rg) if rg is not None else None
+    L.s5gpu_recompress_batch.argtypes = [C.c_uint32, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]
+    _lib.check(L.s5gpu_recompress_batch(m, ptr, ln, f[0], f[1], t[0], t[1], rgp, 0, out, ol, st), "recompress")
+    libc = C.CDLL(None); libc.free.argtypes = [vp]
+    res = [C.string_at(out[i], ol[i]) for i in range(m)]
+    for i in range(m): libc.free(out[i])
+    return res
+plain = recompress([r[8:] for r in recs], (1, 1), (0, 0), rg=[7] * n)
+for i, p in enumerate(plain):
+    rec, keep = ob.make_rec(ob.synth_read_id(i), 7, 8192.0, 23.0, 1467.61, 4000.0, sigs[i])
+    assert p[8:] == ob.rec_pack(rec, ob.SIG_NONE), i
+L.s5gpu_shutdown()
+assert L.s5gpu_devices_in_use() == 0
+print("multi ok", len(b"".join(recs)))
+"""
+
+
+def _run(mask, n, alias):
+    env = dict(os.environ)
+    if alias:
+        env["S5GPU_ALIAS_DEVICES"] = "1"
+    r = subprocess.run([sys.executable, "-c", CODE % dict(root=ROOT, mask=mask, n=n)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "multi ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout.strip().splitlines()[-1]
+
+
+def test_batch_split_over_three_logical_devices_matches_one_device():
+    one = _run(0b1, 301, alias=False)
+    three = _run(0b111, 301, alias=True)
+    assert one == three          # same total bytes: the records are the same whichever device made them
+
+
+def test_mask_naming_a_missing_device_fails_without_alias():
+    import torch
+
+    if torch.cuda.device_count() > 3:
+        pytest.skip("box has the devices")
+    code = ("import sys; sys.path.insert(0, %r)\nfrom slow5tools_amd import _lib\nL = _lib.lib()\n"
+            "rc = L.s5gpu_init_mask(0b1001)\nassert rc != 0 and b'out of range' in L.s5gpu_last_error(), (rc, L.s5gpu_last_error())\n"
+            "assert L.s5gpu_init_mask(0) != 0\nprint('ok')\n" % ROOT)
+    env = dict(os.environ)
+    env.pop("S5GPU_ALIAS_DEVICES", None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+# ---- one process per GPU (the bench / torchrun shape): two gloo ranks, each runs the HIP path on its shard ----
+WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch, torch.distributed as dist
+from slow5tools_amd import _lib, press, shard
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+L = _lib.lib()
+_lib.check(L.s5gpu_init(rank %% torch.cuda.device_count()), "init")
+n_total, n = int(sys.argv[4]), int(sys.argv[5])
+lo, hi = shard.shard_range(n_total, rank, world)
+b = press.DeviceBatch(np.full(hi - lo, n, dtype=np.uint64), device="cuda:%%d" %% (rank %% torch.cuda.device_count()))
+b.synth(seed=0x5105, first=lo)
+shard.barrier()
+b.encode_stream(); torch.cuda.synchronize()
+assert b.stream_ok()
+blob, off = b.stream_bytes()
+shard.barrier()
+open(os.path.join(sys.argv[6], "shard%%d.bin" %% rank), "wb").write(blob)
+dist.destroy_process_group()
+"""
+
+
+def test_two_gloo_ranks_run_the_hip_path_on_their_shards(tmp_path):
+    import zlib
+
+    import numpy as np
+
+    import oracle_bind as ob
+
+    n_total, n, world = 1001, 4000, 2
+    port = str(29700 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, "-c", WORKER % dict(root=ROOT), str(r), str(world), port, str(n_total), str(n), str(tmp_path)],
+                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
+    stream = b"".join(open(tmp_path / ("shard%d.bin" % r), "rb").read() for r in range(world))
+    # the concatenation in rank order is the record stream of the whole index space: walk it, inflate every record with stock
+    # zlib, compare a sample with the oracle's payload and every read id with its index
+    pos, i = 0, 0
+    while pos < len(stream):
+        size = int.from_bytes(stream[pos:pos + 8], "little")
+        pay = zlib.decompress(stream[pos + 8:pos + 8 + size])
+        assert pay[2:38] == ob.synth_read_id(i)
+        if i % 97 == 0 or i == n_total - 1:
+            rec, keep = ob.make_rec(ob.synth_read_id(i), 0, 8192.0, 23.0, 1467.61, 4000.0, ob.synth_read(0x5105, i, n))
+            assert pay == ob.rec_pack(rec, ob.SIG_SVB_ZD)
+        pos += 8 + size
+        i += 1
+    assert i == n_total and pos == len(stream)
