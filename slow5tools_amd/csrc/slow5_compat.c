@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include "../../include/slow5gpu.h"
+#include "../../include/slow5gpu_hooks.h"
 
 __thread int slow5_errno = 0;
 
@@ -324,4 +325,96 @@ int slow5_gpu_recompress_batch(int64_t n, char **mem, size_t *bytes, slow5_press
     }
     for (int64_t i = 0; i < n; i++) { free(mem[i]); mem[i] = NULL; }   /* the reference's worker frees the input record (src/view.c:41) */
     return 0;
+}
+
+
+/* ---- slow5gpu_hooks.h: the hooks without any slow5lib type in their signatures (a patched slow5tools includes that header
+ * next to <slow5/slow5.h>).  Methods and formats arrive as ints holding slow5lib's enum values. ---- */
+static int hook_method_ok(int rec, int sig) {
+    return rec_code((enum slow5_press_method)rec) >= 0 && sig_code((enum slow5_press_method)sig) >= 0;
+}
+int slow5_gpu_hook_init(uint64_t dev_mask) { return s5gpu_init_mask(dev_mask) == S5GPU_OK ? 0 : -1; }
+void slow5_gpu_hook_shutdown(void) { s5gpu_shutdown(); }
+const char *slow5_gpu_hook_error(void) { return s5gpu_last_error(); }
+
+int slow5_gpu_hook_recompress(int64_t n, char **mem, size_t *bytes, int from_record_method, int from_signal_method, int to_record_method,
+                              int to_signal_method, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len) {
+    slow5_press_method_t from = {(enum slow5_press_method)from_record_method, (enum slow5_press_method)from_signal_method};
+    slow5_press_method_t to = {(enum slow5_press_method)to_record_method, (enum slow5_press_method)to_signal_method};
+    return slow5_gpu_recompress_batch(n, mem, bytes, from, to, new_read_group, drop_aux, out, out_len);
+}
+
+int slow5_gpu_hook_convert(int64_t n, char **mem, size_t *bytes, int from_fmt, int from_record_method, int from_signal_method,
+                           const char *aux_types_line, int to_fmt, int to_record_method, int to_signal_method,
+                           const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len) {
+    slow5_press_method_t from = {(enum slow5_press_method)from_record_method, (enum slow5_press_method)from_signal_method};
+    slow5_press_method_t to = {(enum slow5_press_method)to_record_method, (enum slow5_press_method)to_signal_method};
+    uint8_t types[1024];
+    struct slow5_aux_meta am = {0, types};
+    if (aux_types_line) {
+        const int k = s5gpu_aux_types_parse(aux_types_line, strlen(aux_types_line), types, sizeof types);
+        if (k < 0) { slow5_errno = SLOW5_ERR_TYPE; return -1; }
+        am.num = (uint32_t)k;
+    }
+    return slow5_gpu_convert_batch(n, mem, bytes, (enum slow5_fmt)from_fmt, from, am.num ? &am : NULL, (enum slow5_fmt)to_fmt, to, new_read_group,
+                                   drop_aux, out, out_len);
+}
+
+int slow5_gpu_hook_depress_parse(int64_t n, char **mem, size_t *bytes, int from_record_method, int from_signal_method, slow5_gpu_read_t *reads) {
+    if (n < 0 || !hook_method_ok(from_record_method, from_signal_method)) { slow5_errno = SLOW5_ERR_PRESS; return -1; }
+    if (n == 0) return 0;
+    void **pay = (void **)calloc((size_t)n, sizeof(void *));
+    int16_t **sig = (int16_t **)calloc((size_t)n, sizeof(void *));
+    s5gpu_rec_fields_t *f = (s5gpu_rec_fields_t *)calloc((size_t)n, sizeof *f);
+    int ret = -1;
+    if (!pay || !sig || !f) { slow5_errno = SLOW5_ERR_MEM; goto done; }
+    if (s5gpu_decode_batch((uint32_t)n, (const void *const *)mem, bytes, rec_code((enum slow5_press_method)from_record_method),
+                           sig_code((enum slow5_press_method)from_signal_method), pay, sig, f) != S5GPU_OK) { slow5_errno = SLOW5_ERR_RECPARSE; goto done; }
+    for (int64_t i = 0; i < n; i++) {
+        slow5_gpu_read_t *r = &reads[i];
+        free(mem[i]);
+        mem[i] = (char *)pay[i];           /* the uncompressed record; read_id / aux below point into it */
+        bytes[i] = f[i].payload_len;
+        pay[i] = NULL;
+        r->read_id = mem[i] + 2;
+        r->read_id_len = (uint16_t)f[i].read_id_len;
+        r->read_group = f[i].read_group;
+        r->digitisation = f[i].digitisation; r->offset = f[i].offset; r->range = f[i].range; r->sampling_rate = f[i].sampling_rate;
+        r->len_raw_signal = f[i].n_samples;
+        r->raw_signal = sig[i];
+        sig[i] = NULL;
+        r->aux = (const uint8_t *)mem[i] + f[i].aux_off;
+        r->aux_len = f[i].aux_len;
+    }
+    ret = 0;
+done:
+    if (pay) for (int64_t i = 0; i < n; i++) free(pay[i]);
+    if (sig) for (int64_t i = 0; i < n; i++) free(sig[i]);
+    free(pay); free(sig); free(f);
+    return ret;
+}
+
+int slow5_gpu_hook_rec_to_mem(int64_t n, const slow5_gpu_read_t *reads, int drop_aux, int to_record_method, int to_signal_method, void **out,
+                              size_t *out_len) {
+    if (n < 0 || !hook_method_ok(to_record_method, to_signal_method)) { slow5_errno = SLOW5_ERR_PRESS; return -1; }
+    if (n == 0) return 0;
+    struct slow5_rec *recs = (struct slow5_rec *)calloc((size_t)n, sizeof *recs);
+    struct slow5_rec **ptrs = (struct slow5_rec **)calloc((size_t)n, sizeof *ptrs);
+    int ret = -1;
+    if (!recs || !ptrs) { slow5_errno = SLOW5_ERR_MEM; goto done; }
+    for (int64_t i = 0; i < n; i++) {     /* views, nothing is copied: the batch call only reads them */
+        const slow5_gpu_read_t *r = &reads[i];
+        recs[i].read_id_len = r->read_id_len; recs[i].read_id = (char *)r->read_id; recs[i].read_group = r->read_group;
+        recs[i].digitisation = r->digitisation; recs[i].offset = r->offset; recs[i].range = r->range; recs[i].sampling_rate = r->sampling_rate;
+        recs[i].len_raw_signal = r->len_raw_signal; recs[i].raw_signal = r->raw_signal;
+        recs[i].aux_blob = (uint8_t *)r->aux; recs[i].aux_len = r->aux_len;
+        ptrs[i] = &recs[i];
+    }
+    {
+        slow5_press_method_t to = {(enum slow5_press_method)to_record_method, (enum slow5_press_method)to_signal_method};
+        ret = slow5_gpu_rec_to_mem_batch(n, ptrs, drop_aux, to, out, out_len);
+    }
+done:
+    free(recs); free(ptrs);
+    return ret;
 }

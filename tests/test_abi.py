@@ -72,3 +72,49 @@ def test_struct_layouts_match_header():
 
     assert C.sizeof(_lib.EncodeArgs) == 80
     assert C.sizeof(_lib.DecodeArgs) == 56
+
+
+SURVEY_8B_SYMBOLS = ["slow5_press_init", "slow5_press_free", "slow5_rec_to_mem", "slow5_rec_fwrite", "slow5_rec_depress_parse", "slow5_decode",
+                     "slow5_get_next_mem", "slow5_get_next_bytes", "slow5_get", "slow5_rec_free", "slow5_hdr_fwrite", "slow5_eof_fwrite",
+                     "slow5_set_log_level", "slow5_set_exit_condition", "slow5_set_skip_rid", "slow5_ptr_compress", "slow5_ptr_compress_solo",
+                     "slow5_ptr_depress", "slow5_ptr_depress_solo", "slow5_open", "slow5_open_with", "slow5_close", "slow5_idx_load", "slow5_idx_unload",
+                     "slow5_idx_create", "s5gpu_init", "s5gpu_init_mask", "s5gpu_encode_batch", "s5gpu_decode_batch", "s5gpu_shutdown"]
+
+
+def test_every_boundary_symbol_of_survey_8b_is_exported():
+    import subprocess
+
+    from slow5tools_amd import _lib
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    missing = [s for s in SURVEY_8B_SYMBOLS if s not in exported]
+    assert not missing, missing
+    assert "slow5_errno" in exported                      # the thread-local error code (TLS symbol)
+
+
+@pytest.mark.parametrize("compiler", [["gcc", "-std=c11"], ["g++", "-std=c++11", "-x", "c++"]])
+def test_integration_hunk_compiles_next_to_slow5lib_names(compiler, tmp_path):
+    """the patched src/view.c:292 hunk includes include/slow5gpu_hooks.h beside a header that defines
+    slow5lib's own names (tests/compile_check/slow5/slow5.h, a stand-in: the submodule is absent).  slow5_compat.h could not
+    be included there — both would define struct slow5_rec, enum slow5_press_method, ... — the hooks header declares none."""
+    import subprocess
+
+    cc = os.path.join(ROOT, "tests", "compile_check")
+    cmd = compiler + ["-Wall", "-Wextra", "-Werror", "-c", "-I", cc, "-I", os.path.join(ROOT, "include"), os.path.join(cc, "view_patch.c"),
+                      "-o", str(tmp_path / "view_patch.o")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # and the two headers really do clash, which is why the hooks header exists
+    clash = tmp_path / "clash.c"
+    clash.write_text("#include <slow5/slow5.h>\n#include <slow5_compat.h>\n")
+    r = subprocess.run(["gcc", "-std=c11", "-c", "-I", cc, "-I", os.path.join(ROOT, "include"), str(clash), "-o", str(tmp_path / "clash.o")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "redefinition" in r.stderr
+
+
+def test_hooks_header_declares_no_slow5lib_name():
+    txt = open(os.path.join(ROOT, "include", "slow5gpu_hooks.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    for name in ("struct slow5_rec", "enum slow5_press_method", "slow5_press_method_t", "struct slow5_file", "slow5_aux_meta", "slow5_fmt"):
+        assert name not in code, name
