@@ -409,6 +409,94 @@ __device__ __forceinline__ uint32_t fixed_code(int s) {
     return (__brev(c) >> (32 - l)) | (l << 16);
 }
 
+// ---- the code-length header of a dynamic block, one wave: HLIT, run-length coding of the hlit + hdist code lengths
+// (S.lens[0 .. hlit) then S.lens[DOFF .. DOFF + hdist)), choice of the code-length code, header cost in S.red[6] ----
+__device__ __forceinline__ void cl_header_wave(DeflShared &S, int hdist) {
+    const int lane = lane_id();
+    int hl = lane < 29 && S.lens[257 + lane] ? 258 + lane : 257;
+    const int hlit = __builtin_amdgcn_readlane(wave_incl_max(hl), 63), n = hlit + hdist;
+    if (lane == 0) S.hlit = (uint32_t)hlit;
+    wave_sync();
+    {
+        // Run-length code the hlit + hdist code lengths (RFC 1951 3.2.7, symbols 16/17/18): lane t owns
+        // positions 5t..5t+4; run bounds from a wave prefix-max and suffix-min; every position decides
+        // alone whether it emits an entry; a wave prefix sum compacts the entries.
+        constexpr int PP = 5;
+        const int p0 = PP * lane;
+        int v[PP];
+        int prevv = -1;
+        if (p0 - 1 >= 0 && p0 - 1 < n) prevv = p0 - 1 < hlit ? S.lens[p0 - 1] : S.lens[DOFF + p0 - 1 - hlit];
+        uint32_t bk = 0;
+#pragma unroll
+        for (int q = 0; q < PP; q++) {
+            const int p = p0 + q;
+            v[q] = p < n ? (p < hlit ? S.lens[p] : S.lens[DOFF + p - hlit]) : -2 - q;   // past the end: never equal
+            if (p < n && v[q] != (q == 0 ? prevv : v[q - 1])) bk |= 1u << q;
+        }
+        const int local_last = bk ? p0 + 31 - __clz(bk) : -1;
+        const int local_first = bk ? p0 + __ffs(bk) - 1 : n;
+        int lastb = wave_incl_max(local_last);
+        lastb = __shfl_up(lastb, 1);
+        if (lane == 0) lastb = -1;
+        int nextb = wave_suffix_incl_min(local_first);
+        nextb = __shfl_down(nextb, 1);
+        if (lane == 63) nextb = n;
+        uint32_t ent[PP], nent = 0;
+#pragma unroll
+        for (int q = 0; q < PP; q++) {
+            const int p = p0 + q;
+            ent[q] = 0xFFFFFFFFu;
+            if (p >= n) continue;
+            const uint32_t lo = bk & ((2u << q) - 1), hi = bk >> (q + 1);
+            const int s = lo ? p0 + 31 - __clz(lo) : lastb;
+            const int e = hi ? p + __ffs(hi) : nextb;
+            const int R = e - s, rel = p - s;
+            if (v[q] == 0) {
+                const int c = rel / 138, off = rel - c * 138, Lc = min(138, R - c * 138);
+                if (Lc >= 11) { if (off == 0) ent[q] = 18u | ((uint32_t)(Lc - 11) << 5); }
+                else if (Lc >= 3) { if (off == 0) ent[q] = 17u | ((uint32_t)(Lc - 3) << 5); }
+                else ent[q] = 0;
+            } else if (rel == 0) {
+                ent[q] = (uint32_t)v[q];
+            } else {
+                const int mm = rel - 1, c = mm / 6, off = mm - c * 6, Lc = min(6, R - 1 - c * 6);
+                if (Lc >= 3) { if (off == 0) ent[q] = 16u | ((uint32_t)(Lc - 3) << 5); }
+                else ent[q] = (uint32_t)v[q];
+            }
+            nent += ent[q] != 0xFFFFFFFFu;
+        }
+        const uint32_t incl = wave_incl_add(nent);
+        uint32_t at = incl - nent;
+#pragma unroll
+        for (int q = 0; q < PP; q++)
+            if (ent[q] != 0xFFFFFFFFu) {
+                S.clseq[at++] = (uint16_t)ent[q];
+                atomicAdd(&S.clfreq[ent[q] & 31], 1u);
+            }
+        if (lane == 63) S.ncl = incl;
+    }
+    wave_sync();
+    {
+        // The 19-symbol code-length code is not built per read: it is picked from two static prefix codes by cost.
+        // Its lengths travel in the block header (HCLEN x 3 bits), so any complete code is valid DEFLATE.  Code A is the
+        // 7-bit-limited optimum (package-merge) for the aggregate code-length statistics of svb-zd signal payloads
+        // (tools/clfreq_dump.py: 0.08 % larger records than a per-read optimum); code B covers every symbol for payloads
+        // that use code lengths 14 / 15.  Saves the serial Huffman construction on the critical wave.
+        static constexpr uint32_t CLA[19] = {0x30001, 0x7002f, 0x7006f, 0x7001f, 0x7005f, 0x50003, 0x50013, 0x5000b, 0x5001b, 0x50007,
+                                             0x30005, 0x20000, 0x20002, 0x7003f, 0x00000, 0x00000, 0x50017, 0x6000f, 0x7007f};
+        static constexpr uint32_t CLB[19] = {0x30002, 0x60017, 0x7002f, 0x7006f, 0x60037, 0x5000b, 0x40005, 0x5001b, 0x50007, 0x4000d,
+                                             0x30006, 0x30001, 0x20000, 0x7001f, 0x7005f, 0x7003f, 0x40003, 0x6000f, 0x7007f};
+        const uint32_t ca = lane < 19 ? CLA[lane] : 0u, cb = lane < 19 ? CLB[lane] : 0u;
+        const uint32_t f = lane < 19 ? S.clfreq[lane] : 0u;
+        const uint32_t eb = lane == 16 ? 2u : lane == 17 ? 3u : lane == 18 ? 7u : 0u;
+        const uint32_t costA = wave_sum(f * ((ca >> 16) + eb) + ((f && !(ca >> 16)) ? (1u << 24) : 0u));   // A lacks symbols 14, 15
+        const uint32_t costB = wave_sum(f * ((cb >> 16) + eb));
+        const bool useA = costA <= costB;
+        if (lane < 19) { const uint32_t c = useA ? ca : cb; S.clcode[lane] = c; S.cllens[lane] = (uint8_t)(c >> 16); }
+        if (lane == 0) { S.red[6] = useA ? costA : costB; S.hclen = useA ? 18u : 19u; }   // A: trailing zero length of symbol 15 is not sent
+    }
+}
+
 struct Tok { int sym; uint32_t eb, ev, mlen; };   // sym < 0: position covered by a match; mlen: bytes a match covers
 
 // Per-lane position masks: a lane owns K = ceil(len / 256) contiguous bytes; K <= 32 (blocks up to 8 KiB, the
@@ -741,94 +829,12 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     // code-length Huffman code and the header cost.  Wave 1: canonical lit/len codes.  Waves 2-3: dynamic /
     // fixed body costs.
     if (wave_id() == 0) {
-        const int lane = lane_id();
         // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
-        if (lane == 0) {
+        if (lane_id() == 0) {
             S.lens[DOFF] = 1; S.lens[DOFF + 1] = 1;
             S.code[DOFF] = 0u | (1u << 16); S.code[DOFF + 1] = 1u | (1u << 16);
         }
-        int hl = lane < 29 && S.lens[257 + lane] ? 258 + lane : 257;
-        const int hlit = __builtin_amdgcn_readlane(wave_incl_max(hl), 63), n = hlit + 2;
-        if (lane == 0) S.hlit = (uint32_t)hlit;
-        wave_sync();
-        {
-            // Run-length code the hlit + 2 code lengths (RFC 1951 3.2.7, symbols 16/17/18): lane t owns
-            // positions 5t..5t+4; run bounds from a wave prefix-max and suffix-min; every position decides
-            // alone whether it emits an entry; a wave prefix sum compacts the entries.
-            constexpr int PP = 5;
-            const int p0 = PP * lane;
-            int v[PP];
-            int prevv = -1;
-            if (p0 - 1 >= 0 && p0 - 1 < n) prevv = p0 - 1 < hlit ? S.lens[p0 - 1] : S.lens[DOFF + p0 - 1 - hlit];
-            uint32_t bk = 0;
-#pragma unroll
-            for (int q = 0; q < PP; q++) {
-                const int p = p0 + q;
-                v[q] = p < n ? (p < hlit ? S.lens[p] : S.lens[DOFF + p - hlit]) : -2 - q;   // past the end: never equal
-                if (p < n && v[q] != (q == 0 ? prevv : v[q - 1])) bk |= 1u << q;
-            }
-            const int local_last = bk ? p0 + 31 - __clz(bk) : -1;
-            const int local_first = bk ? p0 + __ffs(bk) - 1 : n;
-            int lastb = wave_incl_max(local_last);
-            lastb = __shfl_up(lastb, 1);
-            if (lane == 0) lastb = -1;
-            int nextb = wave_suffix_incl_min(local_first);
-            nextb = __shfl_down(nextb, 1);
-            if (lane == 63) nextb = n;
-            uint32_t ent[PP], nent = 0;
-#pragma unroll
-            for (int q = 0; q < PP; q++) {
-                const int p = p0 + q;
-                ent[q] = 0xFFFFFFFFu;
-                if (p >= n) continue;
-                const uint32_t lo = bk & ((2u << q) - 1), hi = bk >> (q + 1);
-                const int s = lo ? p0 + 31 - __clz(lo) : lastb;
-                const int e = hi ? p + __ffs(hi) : nextb;
-                const int R = e - s, rel = p - s;
-                if (v[q] == 0) {
-                    const int c = rel / 138, off = rel - c * 138, Lc = min(138, R - c * 138);
-                    if (Lc >= 11) { if (off == 0) ent[q] = 18u | ((uint32_t)(Lc - 11) << 5); }
-                    else if (Lc >= 3) { if (off == 0) ent[q] = 17u | ((uint32_t)(Lc - 3) << 5); }
-                    else ent[q] = 0;
-                } else if (rel == 0) {
-                    ent[q] = (uint32_t)v[q];
-                } else {
-                    const int mm = rel - 1, c = mm / 6, off = mm - c * 6, Lc = min(6, R - 1 - c * 6);
-                    if (Lc >= 3) { if (off == 0) ent[q] = 16u | ((uint32_t)(Lc - 3) << 5); }
-                    else ent[q] = (uint32_t)v[q];
-                }
-                nent += ent[q] != 0xFFFFFFFFu;
-            }
-            const uint32_t incl = wave_incl_add(nent);
-            uint32_t at = incl - nent;
-#pragma unroll
-            for (int q = 0; q < PP; q++)
-                if (ent[q] != 0xFFFFFFFFu) {
-                    S.clseq[at++] = (uint16_t)ent[q];
-                    atomicAdd(&S.clfreq[ent[q] & 31], 1u);
-                }
-            if (lane == 63) S.ncl = incl;
-        }
-        wave_sync();
-        {
-            // The 19-symbol code-length code is not built per read: it is picked from two static prefix codes by cost.
-            // Its lengths travel in the block header (HCLEN x 3 bits), so any complete code is valid DEFLATE.  Code A is the
-            // 7-bit-limited optimum (package-merge) for the aggregate code-length statistics of svb-zd signal payloads
-            // (tools/clfreq_dump.py: 0.08 % larger records than a per-read optimum); code B covers every symbol for payloads
-            // that use code lengths 14 / 15.  Saves the serial Huffman construction on the critical wave.
-            static constexpr uint32_t CLA[19] = {0x30001, 0x7002f, 0x7006f, 0x7001f, 0x7005f, 0x50003, 0x50013, 0x5000b, 0x5001b, 0x50007,
-                                                 0x30005, 0x20000, 0x20002, 0x7003f, 0x00000, 0x00000, 0x50017, 0x6000f, 0x7007f};
-            static constexpr uint32_t CLB[19] = {0x30002, 0x60017, 0x7002f, 0x7006f, 0x60037, 0x5000b, 0x40005, 0x5001b, 0x50007, 0x4000d,
-                                                 0x30006, 0x30001, 0x20000, 0x7001f, 0x7005f, 0x7003f, 0x40003, 0x6000f, 0x7007f};
-            const uint32_t ca = lane < 19 ? CLA[lane] : 0u, cb = lane < 19 ? CLB[lane] : 0u;
-            const uint32_t f = lane < 19 ? S.clfreq[lane] : 0u;
-            const uint32_t eb = lane == 16 ? 2u : lane == 17 ? 3u : lane == 18 ? 7u : 0u;
-            const uint32_t costA = wave_sum(f * ((ca >> 16) + eb) + ((f && !(ca >> 16)) ? (1u << 24) : 0u));   // A lacks symbols 14, 15
-            const uint32_t costB = wave_sum(f * ((cb >> 16) + eb));
-            const bool useA = costA <= costB;
-            if (lane < 19) { const uint32_t c = useA ? ca : cb; S.clcode[lane] = c; S.cllens[lane] = (uint8_t)(c >> 16); }
-            if (lane == 0) { S.red[6] = useA ? costA : costB; S.hclen = useA ? 18u : 19u; }   // A: trailing zero length of symbol 15 is not sent
-        }
+        cl_header_wave(S, 2);
     } else if (wave_id() == 1) {
         assign_codes_wave(S.blcount, S.lens, NLIT, S.code);   // canonical lit/len codes, concurrently with wave 0
     } else {

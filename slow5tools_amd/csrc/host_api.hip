@@ -237,7 +237,8 @@ int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_
     a.out_len = (uint32_t *)c->d_len.p;
     // First choice: ordered single-pass output — records land in the contiguous stream directly.  It needs every read
     // to fit the LDS budget of the fused kernel; if the device reports otherwise, the slot path below redoes the batch.
-    if (a.rec_method == S5GPU_REC_ZLIB && (uint64_t)a.max_payload * 100 / (a.sig_method == S5GPU_SIG_EX_ZD ? 950 : 325) <= 16384) {
+    // (signal press none goes through the LZ77 matcher of the slot path instead: see s5gpu_encode_dev)
+    if (a.rec_method == S5GPU_REC_ZLIB && a.sig_method != S5GPU_SIG_NONE && (uint64_t)a.max_payload * 100 / (a.sig_method == S5GPU_SIG_EX_ZD ? 950 : 325) <= 16384) {
         const size_t scan_bytes = 8ull * (n + 1) + 8ull * n + 16;
         if ((rc = c->d_stream.reserve(slots_bytes + 64)) || (rc = c->d_scan.reserve(scan_bytes)) ||
             (rc = c->h_out.reserve(up(8ull * (n + 1) + 16, 64) + 64)))

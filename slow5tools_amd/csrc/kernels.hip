@@ -13,6 +13,7 @@
 
 #include "../../include/slow5gpu.h"
 #include "deflate_dev.h"
+#include "lz_dev.h"
 #include "inflate_dev.h"
 #include "inflate_simt_dev.h"
 #include "zstd_dev.h"
@@ -302,6 +303,67 @@ __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list
                 flush_words(obuf, out32, z, false);
                 z.carry = obuf[0];      // uniform: every lane reads the same word (flush_words ends on a barrier)
                 __syncthreads();        // ... before the next block's scratch overwrites it
+            }
+        } while (done < plen);
+        z.bitpos = (z.bitpos + 7) & ~7u;
+        if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
+        z.bitpos += 32;
+        __syncthreads();
+        flush_words(obuf, out32, z, true);
+        const uint32_t total = z.bitpos >> 3;
+        __syncthreads();
+        if (tid == 0) {
+            *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
+            p.a.out_len[r] = total;
+        }
+    }
+}
+
+// Staged path with the LZ77 matcher (lz_dev.h): records whose signal press is "none" (raw int16 samples) and byte ranges of the
+// solo zlib press.  The parked payload goes through LDS 16 KiB at a time like k_deflate_staged; the previous block stays in
+// LDS as the matcher's history, and so does the table of recent positions.  One workgroup per CU (150 KiB of LDS).
+constexpr uint32_t LZ_BYTES = (sizeof(LzShared) + 15u) & ~15u;
+__global__ __launch_bounds__(NT) void k_deflate_lz(EncParams p, int use_list) {
+    DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
+    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
+    LzShared &X = *reinterpret_cast<LzShared *>(smem + S_BYTES + 4u * p.obuf_words);
+    const int tid = threadIdx.x;
+    const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const uint32_t r = use_list ? p.a.ovf[1 + it] : it;
+        const s5gpu_read_desc_t d = p.a.desc[r];
+        uint8_t *out = p.a.slots + d.out_off;
+        const uint8_t *src = out + park_offset(d, p.a.sig_method);
+        const uint32_t plen = p.a.out_len[r];
+        __syncthreads();
+        {   // a record starts with an empty table (the output must not depend on what this workgroup encoded before)
+            uint4 *t4 = reinterpret_cast<uint4 *>(X.table);
+            for (uint32_t i = tid; i < sizeof(X.table) / 16; i += NT) t4[i] = make_uint4(0, 0, 0, 0);
+        }
+        ZOut z;
+        z.bitpos = 80;        // u64 size prefix (words 0, 1: written last) + CMF/FLG 78 9c
+        z.flushed = 2;        // obuf[0] = stream word 2
+        z.carry = 0x9c78u;
+        uint32_t adA = 1, adB = 0, done = 0;
+        uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+        do {
+            const uint32_t blen = min(plen - done, (uint32_t)LZ_BLK);
+            const bool final = done + blen == plen;
+            {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
+                uint4 *d4 = reinterpret_cast<uint4 *>(X.win + LZ_BLK);
+                for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
+            }
+            __syncthreads();
+            deflate_block_lz(S, X, obuf, p.obuf_words, (int)blen, done ? (uint32_t)LZ_BLK : 0u, done, final, z, adA, adB);
+            done += blen;
+            if (!final) {
+                flush_words(obuf, out32, z, false);
+                z.carry = obuf[0];
+                const uint4 *c4 = reinterpret_cast<const uint4 *>(X.win + LZ_BLK);   // the block becomes the next one's history
+                uint4 *h4 = reinterpret_cast<uint4 *>(X.win);
+                for (uint32_t i = tid; i < LZ_BLK / 16; i += NT) h4[i] = c4[i];
+                __syncthreads();
             }
         } while (done < plen);
         z.bitpos = (z.bitpos + 7) & ~7u;
@@ -831,6 +893,7 @@ static int set_lds_attrs() {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_lz), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -878,6 +941,15 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
                                                               : a->max_payload > 4u * DEFL_BLK;
     const uint32_t st_obuf = (DEFL_BLK + 64) / 4;
     const size_t st_lds = S_BYTES + 4ull * st_obuf + DEFL_BLK;   // the build scratch overlays the bit buffer
+    if (a->rec_method == S5GPU_REC_ZLIB && a->sig_method == S5GPU_SIG_NONE) {
+        // raw int16 samples: the redundancy is repeated sample pairs at any distance, not runs — the LZ77 matcher (lz_dev.h)
+        p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
+        const uint32_t g = a->n_reads < 2048 ? a->n_reads : 2048;
+        hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
+        hipLaunchKernelGGL(k_deflate_lz, dim3(g), dim3(NT), S_BYTES + 4ull * st_obuf + LZ_BYTES, st, p, 0);
+        HIP_TRY(hipGetLastError());
+        return S5GPU_OK;
+    }
     if (!all_staged) {
         HIP_TRY(hipMemsetAsync(a->ovf, 0, 4, st));
         p.pay_cap = cap;
@@ -960,6 +1032,8 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
     p.pay_cap = DEFL_BLK;
     const size_t lds = S_BYTES + 4ull * p.obuf_words + DEFL_BLK;
     if (a->rec_method == S5GPU_REC_ZSTD) hipLaunchKernelGGL(k_zstd_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
+    else if (a->sig_method == S5GPU_SIG_NONE)   // byte ranges of unknown kind (the solo zlib press): the LZ77 matcher
+        hipLaunchKernelGGL(k_deflate_lz, dim3(a->n_reads < 2048 ? a->n_reads : 2048), dim3(NT), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, (hipStream_t)stream_, p, 0);
     else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;

@@ -1,0 +1,349 @@
+// lz_dev.h — DEFLATE block encoder with a real LZ77 matcher (distance codes of any size), for payloads whose redundancy is
+// NOT run-length: records written with signal press "none" (raw int16 samples: slow5tools view -s none -c zlib,
+// /root/reference/test/test_view.sh:89-91, every v0.1.0 file) and byte ranges handed to the solo zlib press.  svb-zd / ex-zd
+// payloads keep the run-length tokeniser of deflate_dev.h (an LZ77 window buys < 1 % there, SURVEY.md §0 finding 6).
+//
+// What the data asks for (tools/lz_probe2.py on the reference's exp_1_lossless_zlib.blow5, whose zlib-6 stream covers 82 % of
+// its bytes with matches of length 3-5 at distances spread evenly up to 32 K): a raw signal is noise around slowly moving
+// levels, so almost every 4-byte string (two samples) has occurred somewhere in the last 16 K samples.  Finding SOME
+// earlier occurrence of the next 4 bytes matters, the search depth hardly does, and 3-byte matches at long distances cost
+// more than the literals they replace.  Hence: minimum match 4; a 4-way table of most recent positions keyed by a 13-bit hash
+// of the 4 bytes (64 KiB of LDS), plus the four nearest distances 1..4; greedy parse (no lazy evaluation).  Measured on that
+// record: 1.02 x zlib level 6's size (zlib level 1: 1.036, level 2: 1.029), against 1.127 for run-length + Huffman alone.
+//
+// One workgroup per record, 16 KiB blocks, window = previous block + current block, both in LDS:
+//   match   rounds of 256 positions (one per lane): look up the table (positions of EARLIER rounds), verify by comparing
+//           bytes in the window — table entries are 16-bit positions and may be stale, the comparison is what makes a match —
+//           then enter the round's own positions, wave k into way k (same-address stores of one instruction resolve in a fixed
+//           lane order and different waves never share a way: the output is deterministic)
+//   parse   greedy and serial by nature; here: a lane parses its own 64 positions from an entry offset, hands the overhang of
+//           its last match to the next lane, and the workgroup iterates until no entry offset changes (parses started at
+//           different offsets fall into step after a few tokens, so two or three rounds settle everything; an all-equal
+//           payload, one match chain from end to end, takes as many rounds as there are lanes under a match)
+//   code    histograms of lit/len and distance symbols; both alphabets get their lengths from assign_lengths_wave on two
+//           waves at once; the header and the token bits as in deflate_dev.h, with real distance codes
+#pragma once
+#include "deflate_dev.h"
+
+namespace s5 {
+
+constexpr int LZ_BLK = DEFL_BLK;
+constexpr int LZ_HBITS = 13, LZ_WAYS = 4, LZ_MINLEN = 4;
+
+struct LzShared {
+    alignas(16) uint8_t win[2 * LZ_BLK + 16];              // [previous block | current block], slack for dword reads at the end
+    alignas(16) uint16_t table[(1 << LZ_HBITS) * LZ_WAYS];  // position & 0xFFFF of the most recent occurrences of a hash
+    alignas(16) uint16_t D[LZ_BLK + 8];                     // per position: match distance (0 none); after the parse D[p + 1] = length of the match starting at p
+    uint16_t entry[NT + 2];
+    uint32_t blcount_d[16];
+    uint32_t bins_d[64];
+};
+
+// four bytes at any LDS byte address (two aligned dwords + one alignbit)
+__device__ __forceinline__ uint32_t lds_load32u(const uint8_t *p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    return __builtin_amdgcn_alignbit(q[1], q[0], (uint32_t)(a & 3) * 8u);
+}
+// length of the match between window positions a (current) and b < a, at most maxl; the first LZ_MINLEN bytes are known equal
+__device__ __forceinline__ uint32_t lz_match_len(const uint8_t *win, uint32_t a, uint32_t b, uint32_t maxl) {
+    uint32_t l = LZ_MINLEN;
+    while (l + 4 <= maxl) {
+        const uint32_t x = lds_load32u(win + a + l) ^ lds_load32u(win + b + l);
+        if (x) return l + ((uint32_t)__ffs((int)x) - 1u) / 8u;
+        l += 4;
+    }
+    while (l < maxl && win[a + l] == win[b + l]) l++;
+    return l;
+}
+__device__ __forceinline__ void lz_len_sym(uint32_t len, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+    const uint32_t l = len - 3;
+    eb = 0; ev = 0;
+    if (len == 258) sym = 285;
+    else if (l < 8) sym = 257 + l;
+    else {
+        const uint32_t nb = 29u - (uint32_t)__clz((int)l);
+        sym = 261 + 4 * nb + ((l >> nb) & 3u);
+        eb = nb;
+        ev = l & ((1u << nb) - 1u);
+    }
+}
+__device__ __forceinline__ void lz_dist_sym(uint32_t dist, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+    const uint32_t d = dist - 1;
+    if (d < 4) { sym = d; eb = 0; ev = 0; return; }
+    const uint32_t nb = 30u - (uint32_t)__clz((int)d);
+    sym = 2 * nb + 2 + ((d >> nb) & 1u);
+    eb = nb;
+    ev = d & ((1u << nb) - 1u);
+}
+
+// Encode the `len` <= LZ_BLK bytes at X.win + LZ_BLK as one DEFLATE block into the bit buffer.  `hist` = bytes of history in
+// front of them in the window (0 for a record's first block, LZ_BLK afterwards), abs0 = position of the block in the record.
+// Same contract as deflate_block MODE 2: the bit buffer is cleared here and the stream's partial word travels in z.carry.
+__device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzShared &X, uint32_t *obuf, uint32_t obuf_words, int len, uint32_t hist,
+                                                 uint32_t abs0, bool final, ZOut &z, uint32_t &adA, uint32_t &adB) {
+    const int tid = threadIdx.x;
+    const uint8_t *cur = X.win + LZ_BLK;
+    constexpr int K = LZ_BLK / NT;   // 64 positions per lane
+    const int base = tid * K;
+    if (len == 0) {   // empty stream: a fixed block holding only end-of-block
+        for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
+        __syncthreads();
+        if (tid == 0) { obuf[0] = z.carry; put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 10); }
+        z.bitpos += 10;
+        __syncthreads();
+        return;
+    }
+    for (int i = tid; i < 320; i += NT) S.freq[i] = 0;
+    if (tid < 8) S.red[tid] = 0;
+    if (tid < 20) S.clfreq[tid] = 0;
+    // ---- match: rounds of NT positions ----
+    const int nround = (len + NT - 1) / NT;
+    for (int r = 0; r < nround; r++) {
+        const int i = r * NT + tid;
+        const bool act = i + LZ_MINLEN <= len;
+        uint32_t w = 0, h = 0, best_l = 0, best_d = 0;
+        const uint32_t p16 = (abs0 + (uint32_t)i) & 0xFFFFu;
+        if (act) {
+            const uint32_t widx = LZ_BLK + (uint32_t)i;
+            w = lds_load32u(X.win + widx);
+            h = (w * 2654435761u) >> (32 - LZ_HBITS);
+            const uint32_t maxl = min(258u, (uint32_t)(len - i)), avail = (uint32_t)i + hist;
+            const uint2 e = *reinterpret_cast<const uint2 *>(&X.table[h * LZ_WAYS]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t ent = k == 0 ? e.x & 0xFFFFu : k == 1 ? e.x >> 16 : k == 2 ? e.y & 0xFFFFu : e.y >> 16;
+                const uint32_t d = k < 4 ? (p16 - ent) & 0xFFFFu : (uint32_t)(k - 3);
+                if (d >= 1 && d <= avail && d <= 32768u && lds_load32u(X.win + widx - d) == w) {
+                    const uint32_t l = lz_match_len(X.win, widx, widx - d, maxl);
+                    if (l > best_l || (l == best_l && d < best_d)) { best_l = l; best_d = d; }
+                }
+            }
+        }
+        if (i < len) X.D[i] = best_l >= (uint32_t)LZ_MINLEN ? (uint16_t)best_d : (uint16_t)0;
+        __syncthreads();
+        if (act) X.table[h * LZ_WAYS + wave_id()] = (uint16_t)p16;   // wave k fills way k: see the header note on determinism
+        __syncthreads();
+    }
+    // ---- parse: lane-local greedy parses, entry offsets handed on until they settle ----
+    uint64_t tok = 0, mat = 0;
+    {
+        uint32_t my_entry = 0;
+        const int end = min(base + K, len);
+        for (int guard = 0; guard <= NT + 1; guard++) {
+            tok = 0; mat = 0;
+            int pos = base + (int)my_entry;
+            while (pos < end) {
+                const uint32_t d = X.D[pos];
+                const uint64_t bit = 1ull << (pos - base);
+                tok |= bit;
+                if (d) {
+                    mat |= bit;
+                    pos += (int)lz_match_len(X.win, LZ_BLK + (uint32_t)pos, LZ_BLK + (uint32_t)pos - d, min(258u, (uint32_t)(len - pos)));
+                } else pos++;
+            }
+            X.entry[tid + 1] = (uint16_t)(pos > base + K ? pos - (base + K) : 0);
+            __syncthreads();
+            const uint32_t ne = tid ? X.entry[tid] : 0u;
+            const int changed = ne != my_entry;
+            my_entry = ne;
+            if (!__syncthreads_or(changed)) break;
+        }
+        // the settled parse: park every match's length behind its distance (position p + 1 lies inside the match)
+        uint64_t m = mat;
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int pos = base + j;
+            X.D[pos + 1] = (uint16_t)lz_match_len(X.win, LZ_BLK + (uint32_t)pos, LZ_BLK + (uint32_t)pos - X.D[pos], min(258u, (uint32_t)(len - pos)));
+        }
+    }
+    __syncthreads();
+    // ---- histograms, Adler-32 partial sums ----
+    uint32_t nextra = 0, a_sum = 0, b_sum = 0;
+    {
+        uint64_t t = tok;
+        while (t) {
+            const int j = __ffsll((long long)t) - 1;
+            t &= t - 1;
+            const int pos = base + j;
+            if ((mat >> j) & 1ull) {
+                uint32_t ls, le, lv, ds, de, dv;
+                lz_len_sym(X.D[pos + 1], ls, le, lv);
+                lz_dist_sym(X.D[pos], ds, de, dv);
+                atomicAdd(&S.freq[ls], 1u);
+                atomicAdd(&S.freq[DOFF + ds], 1u);
+                nextra += le + de;
+            } else atomicAdd(&S.freq[cur[pos]], 1u);
+        }
+        const int kk = max(0, min(K, len - base));
+        int j = 0;
+        for (; j + 4 <= kk; j += 4) {
+            const uint32_t wd = *reinterpret_cast<const uint32_t *>(cur + base + j);
+            b_sum = __builtin_amdgcn_udot4(wd, 0x01020304u, b_sum + 4u * a_sum, false);
+            a_sum = __builtin_amdgcn_udot4(wd, 0x01010101u, a_sum, false);
+        }
+        for (; j < kk; j++) { a_sum += cur[base + j]; b_sum += a_sum; }
+        b_sum += a_sum * (uint32_t)max(0, len - (base + kk));
+    }
+    nextra = wave_sum(nextra);
+    a_sum = wave_sum(a_sum);
+    b_sum = wave_sum(b_sum % 65521u);
+    if (lane_id() == 0) {
+        atomicAdd(&S.red[1], nextra);
+        atomicAdd(&S.red[2], a_sum);
+        atomicAdd(&S.red[3], b_sum);
+    }
+    if (tid == 0) atomicAdd(&S.freq[256], 1u);
+    __syncthreads();
+    // ---- code lengths and codes: lit/len on wave 0, distances on wave 1; waves 2-3 clear the bit buffer ----
+    if (wave_id() == 0) {
+        const bool ok = assign_lengths_wave(S.freq, NLIT, S.lens, S.blcount, S.bins);
+        if (lane_id() == 0) S.dbg = ok ? 0u : 1u;
+        assign_codes_wave(S.blcount, S.lens, NLIT, S.code);
+    } else if (wave_id() == 1) {
+        const bool ok = assign_lengths_wave(S.freq + DOFF, 30, S.lens + DOFF, X.blcount_d, X.bins_d);
+        if (lane_id() == 0 && !ok) S.red[7] = 1;
+        assign_codes_wave(X.blcount_d, S.lens + DOFF, 30, S.code + DOFF);
+    } else {
+        for (uint32_t i = tid - 128; i < obuf_words; i += NT - 128) obuf[i] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) obuf[0] = z.carry;
+    // ---- header (wave 0), block costs (waves 1-3) ----
+    if (wave_id() == 0) {
+        int hd = lane_id() < 30 && S.lens[DOFF + lane_id()] ? lane_id() + 1 : 1;
+        const int hdist = __builtin_amdgcn_readlane(wave_incl_max(hd), 63);
+        if (lane_id() == 0) S.icount[0] = (uint32_t)hdist;
+        cl_header_wave(S, hdist);
+    } else {
+        uint32_t dynb = 0, fixb = 0;
+        for (int s = tid - 64; s < 320; s += NT - 64) {
+            const uint32_t f = S.freq[s];
+            if (s < NLIT) { dynb += f * S.lens[s]; fixb += f * fixed_len(s); }
+            else if (s >= DOFF && s < DOFF + 30) { dynb += f * S.lens[s]; fixb += f * 5u; }
+        }
+        dynb = wave_sum(dynb);
+        fixb = wave_sum(fixb);
+        if (lane_id() == 0) { atomicAdd(&S.red[4], dynb); atomicAdd(&S.red[5], fixb); }
+    }
+    __syncthreads();
+    const uint32_t extra = S.red[1], hdist = S.icount[0];
+    const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
+    const uint32_t dyn_total = hdr_dyn + S.red[4] + extra;
+    const uint32_t fix_total = 3 + S.red[5] + extra;
+    const uint32_t sto_total = 3 + ((0u - (z.bitpos + 3)) & 7) + 32 + 8u * (uint32_t)len;
+    {
+        const uint32_t nb = (uint32_t)(((uint64_t)adB + (uint64_t)len * adA + S.red[3]) % 65521u);
+        adA = (adA + S.red[2]) % 65521u;
+        adB = nb;
+    }
+    if (sto_total <= dyn_total && sto_total <= fix_total) {
+        const uint32_t bytepos = (z.bitpos + 3 + 7) >> 3;
+        uint8_t *ob8 = reinterpret_cast<uint8_t *>(obuf) + (bytepos - z.flushed * 4);
+        if (tid == 0) {
+            put_bits(obuf, z, z.bitpos, final ? 1u : 0u, 3);
+            put_bits(obuf, z, bytepos * 8, (uint32_t)len | ((~(uint32_t)len) << 16), 32);
+        }
+        __syncthreads();
+        for (int i = tid; i < len; i += NT) ob8[4 + i] = cur[i];
+        z.bitpos = (bytepos + 4 + (uint32_t)len) * 8;
+        __syncthreads();
+        return;
+    }
+    const bool use_fixed = fix_total < dyn_total || S.dbg != 0 || S.red[7] != 0;
+    uint32_t pos0;
+    uint32_t clv[2] = {0, 0}, clnb[2] = {0, 0};
+    if (use_fixed) {
+        __syncthreads();   // every lane has read the dynamic code's costs
+        for (int s = tid; s < 288; s += NT) S.code[s] = fixed_code(s);
+        if (tid < 30) S.code[DOFF + tid] = (__brev((uint32_t)tid) >> 27) | (5u << 16);
+        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
+        pos0 = z.bitpos + 3;
+        __syncthreads();
+    } else {
+        const uint32_t hclen = S.hclen;
+        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (2u << 1) | ((S.hlit - 257) << 3) | ((hdist - 1) << 8) | ((hclen - 4) << 13), 17);
+        if (tid < (int)hclen) {
+            const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            put_bits(obuf, z, z.bitpos + 17 + 3 * tid, S.cllens[order[tid]], 3);
+        }
+        const int ncl = S.ncl;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int e = 2 * tid + q;
+            if (e < ncl) {
+                const uint32_t ent = S.clseq[e];
+                const uint32_t sym = ent & 31, cc = S.clcode[sym], cl = cc >> 16;
+                const uint32_t eb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+                clv[q] = (cc & 0xFFFF) | ((ent >> 5) << cl);
+                clnb[q] = cl + eb;
+            }
+        }
+        pos0 = z.bitpos + hdr_dyn;
+    }
+    // ---- bit totals, one packed scan (13 bits of header entries, 19 of token bits), pack ----
+    uint32_t mybits = 0;
+    {
+        uint64_t t = tok;
+        while (t) {
+            const int j = __ffsll((long long)t) - 1;
+            t &= t - 1;
+            const int pos = base + j;
+            if ((mat >> j) & 1ull) {
+                uint32_t ls, le, lv, ds, de, dv;
+                lz_len_sym(X.D[pos + 1], ls, le, lv);
+                lz_dist_sym(X.D[pos], ds, de, dv);
+                mybits += (S.code[ls] >> 16) + le + (S.code[DOFF + ds] >> 16) + de;
+            } else mybits += S.code[cur[pos]] >> 16;
+        }
+    }
+    uint32_t packed_total;
+    const uint32_t packed = block_excl_add((clnb[0] + clnb[1]) | (mybits << 13), S.ws, packed_total);
+    const uint32_t total_bits = packed_total >> 13;
+    if (!use_fixed) {
+        const uint32_t p = z.bitpos + 17 + 3 * S.hclen + (packed & 0x1FFF);
+        if (clnb[0]) put_bits(obuf, z, p, clv[0], clnb[0]);
+        if (clnb[1]) put_bits(obuf, z, p + clnb[0], clv[1], clnb[1]);
+    }
+    {
+        uint32_t pos_b = pos0 + (packed >> 13);
+        auto or_bits = [&](uint64_t v, uint32_t nb) {          // nb <= 48
+            const uint32_t wd = (pos_b >> 5) - z.flushed, sh = pos_b & 31;
+            const uint64_t lo = v << sh;
+            atomicOr(&obuf[wd], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32)) atomicOr(&obuf[wd + 1], (uint32_t)(lo >> 32));
+            if (sh + nb > 64) atomicOr(&obuf[wd + 2], (uint32_t)(v >> (64 - sh)));
+            pos_b += nb;
+        };
+        uint64_t t = tok;
+        while (t) {
+            const int j = __ffsll((long long)t) - 1;
+            t &= t - 1;
+            const int pos = base + j;
+            if ((mat >> j) & 1ull) {
+                uint32_t ls, le, lv, ds, de, dv;
+                lz_len_sym(X.D[pos + 1], ls, le, lv);
+                lz_dist_sym(X.D[pos], ds, de, dv);
+                const uint32_t lc = S.code[ls], dc = S.code[DOFF + ds];
+                uint32_t nb = lc >> 16;
+                uint64_t v = (uint64_t)(lc & 0xFFFFu) | ((uint64_t)lv << nb);
+                nb += le;
+                v |= (uint64_t)(dc & 0xFFFFu) << nb;
+                nb += dc >> 16;
+                v |= (uint64_t)dv << nb;
+                nb += de;
+                or_bits(v, nb);
+            } else {
+                const uint32_t cc = S.code[cur[pos]];
+                or_bits((uint64_t)(cc & 0xFFFFu), cc >> 16);
+            }
+        }
+    }
+    const uint32_t eob = S.code[256];
+    if (tid == 0) put_bits(obuf, z, pos0 + total_bits, eob & 0xFFFF, eob >> 16);
+    z.bitpos = pos0 + total_bits + (eob >> 16);
+    __syncthreads();
+}
+
+}  // namespace s5
