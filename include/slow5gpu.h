@@ -194,6 +194,19 @@ int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec
                            int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
                            int32_t *status);
 
+/* The same worker on a CHUNK of a BLOW5 file (what bounds `view` end to end is the read and write phases around
+ * work_db, /root/reference/src/view.c:265-278,296-299, not the compute).  The n records sit framed — [u64 size][bytes] — in one
+ * host buffer `chunk` exactly as read from disk: rec_pos[i] = offset of record i's bytes (behind its size prefix), rec_len[i]
+ * their length.  The re-encoded records come back as ONE contiguous stream in out_buf, exactly the bytes the ordered write loop
+ * emits: out_off[i] = offset of record i (its u64 prefix), out_off[n] = total.  No per-record malloc or memcpy on either side.
+ * chunk / out_buf from s5gpu_host_alloc (pinned) move at PCIe speed; any host memory works.  If out_cap is too small the call
+ * fails with S5GPU_ERR_NOMEM and out_off[0] = the capacity needed. */
+void *s5gpu_host_alloc(size_t bytes);
+void s5gpu_host_free(void *p);
+int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int from_rec,
+                            int from_sig, int to_rec, int to_sig, const uint32_t *new_read_group, int drop_aux, void *out_buf, size_t out_cap,
+                            uint64_t *out_off, int32_t *status);
+
 /* ---- one-stage host-buffer calls behind slow5_ptr_compress_solo / slow5_ptr_depress_solo ----
  * stage: 0 zlib compress, 1 zlib inflate, 2 svb-zd encode (in = int16 samples, in_len in bytes),
  * 3 svb-zd decode, 4 zstd decompress (whole frames), 5 zstd compress, 6 ex-zd encode (in = int16 samples), 7 ex-zd decode.

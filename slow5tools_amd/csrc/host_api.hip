@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -227,12 +228,12 @@ extern "C" int s5gpu_event_destroy(void *ev) {
     return S5GPU_OK;
 }
 
-// Launch the encode for descriptors already on the device (a.desc/sig/hdr/aux set by the caller), gather the
-// worst-case slots into the contiguous record stream on the device (the bytes the ordered fwrite loop emits),
-// bring back only what was produced and hand out one malloc per record.
-int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
-                              void **out, size_t *out_len) {
+// Run the encode for descriptors already on the device and leave the contiguous BLOW5 record stream (the bytes the ordered
+// fwrite loop emits) in c->d_stream; off[i] / off[n] = record offsets / total, on the host.
+static int encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
+                                  std::vector<uint64_t> &off) {
     int rc;
+    off.resize((size_t)n + 1);
     if ((rc = c->d_len.reserve(4ull * n))) return rc;
     a.out_len = (uint32_t *)c->d_len.p;
     // First choice: ordered single-pass output — records land in the contiguous stream directly.  It needs every read
@@ -252,27 +253,9 @@ int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_
         HIP_TRY(hipStreamSynchronize(c->st));
         const uint32_t *ctl = (const uint32_t *)(h + 8ull * (n + 1));
         if (ctl[0] == 0 && ctl[2] == 0) {
-            std::vector<uint64_t> off(n + 1);
             memcpy(off.data(), h, 8ull * (n + 1));
-            const uint64_t produced = off[n];
             for (uint32_t i = 0; i < n; i++)
                 if (off[i + 1] < off[i] + 8 || off[i + 1] - off[i] > desc[i].slot_cap) { s5gpu_set_error("read %u: device produced an impossible record extent", i); return S5GPU_ERR_HIP; }
-            if ((rc = c->h_out.reserve(produced + 64))) return rc;
-            uint8_t *ho_stream = (uint8_t *)c->h_out.p;
-            HIP_TRY(hipMemcpyAsync(ho_stream, c->d_stream.p, produced, hipMemcpyDeviceToHost, c->st));
-            HIP_TRY(hipStreamSynchronize(c->st));
-            int oom = 0;
-            parallel_for(n, produced, [&](uint32_t lo, uint32_t hi) {
-                for (uint32_t i = lo; i < hi; i++) {
-                    const size_t len = (size_t)(off[i + 1] - off[i]);
-                    void *b = malloc(len);
-                    if (!b) { oom = 1; out[i] = NULL; continue; }
-                    memcpy(b, ho_stream + off[i], len);
-                    out[i] = b;
-                    out_len[i] = len;
-                }
-            });
-            if (oom) { for (uint32_t j = 0; j < n; j++) { free(out[j]); out[j] = NULL; } return S5GPU_ERR_NOMEM; }
             return S5GPU_OK;
         }
     }
@@ -298,20 +281,26 @@ int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_
     HIP_TRY(hipMemcpyAsync(ho_len, c->d_len.p, 4ull * n, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     const uint32_t *lens = (const uint32_t *)ho_len;
-    std::vector<uint64_t> off(n + 1);
     off[0] = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (lens[i] < 8 || lens[i] > desc[i].slot_cap) { s5gpu_set_error("read %u: device produced an impossible length %u", i, lens[i]); return S5GPU_ERR_HIP; }
         off[i + 1] = off[i] + lens[i];
     }
     const uint64_t produced = off[n];
-    if ((rc = c->d_stream.reserve(produced + 64)) || (rc = c->d_scan.reserve(8ull * (n + 1) + 8ull * (n / 1024 + 8))) ||
-        (rc = c->h_out.reserve(up(4ull * n, 64) + produced + 64)))   // may move h_out: lens were consumed into off[] already
-        return rc;
+    if ((rc = c->d_stream.reserve(produced + 64)) || (rc = c->d_scan.reserve(8ull * (n + 1) + 8ull * (n / 1024 + 8)))) return rc;
     uint64_t *d_off = (uint64_t *)c->d_scan.p, *d_tmp = d_off + (n + 1);
-    if ((rc = s5gpu_compact_dev(n, a.desc, (const uint8_t *)c->d_slots.p, (const uint32_t *)c->d_len.p, d_off, (uint8_t *)c->d_stream.p, d_tmp, c->st)))
-        return rc;
-    uint8_t *ho_stream = (uint8_t *)c->h_out.p + up(4ull * n, 64);
+    return s5gpu_compact_dev(n, a.desc, (const uint8_t *)c->d_slots.p, (const uint32_t *)c->d_len.p, d_off, (uint8_t *)c->d_stream.p, d_tmp, c->st);
+}
+
+// ... then bring back only what was produced and hand out one malloc per record.
+int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
+                              void **out, size_t *out_len) {
+    std::vector<uint64_t> off;
+    int rc = encode_stream_resident(c, n, desc, a, slots_bytes, off);
+    if (rc) return rc;
+    const uint64_t produced = off[n];
+    if ((rc = c->h_out.reserve(produced + 64))) return rc;
+    uint8_t *ho_stream = (uint8_t *)c->h_out.p;
     HIP_TRY(hipMemcpyAsync(ho_stream, c->d_stream.p, produced, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     int oom = 0;
@@ -730,8 +719,17 @@ extern "C" int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, co
 
 // Decode n host records on the device and leave payloads (c->d_pay) and signals (c->d_sig2) resident; rd[i] says where,
 // ff[i] what was found.  Records that overflow their guessed slots are redone once with exact sizes.
+// framed: the records sit in ONE host buffer (a chunk of a BLOW5 file as read from disk): it is uploaded as it is, no per-record
+// packing; rec[i] then point into it.
+struct FramedSrc { const uint8_t *base; size_t bytes; };
+static int decode_resident_impl(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
+                                std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status, const FramedSrc *framed);
 int s5host::decode_resident(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
                             std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status) {
+    return decode_resident_impl(c, n, rec, rec_len, from_rec, from_sig, rd, ff, status, nullptr);
+}
+static int decode_resident_impl(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
+                                std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status, const FramedSrc *framed) {
     int rc;
     std::vector<uint32_t> pcap(n), scap(n);
     for (uint32_t i = 0; i < n; i++) {
@@ -747,18 +745,22 @@ int s5host::decode_resident(Ctx *c, uint32_t n, const void *const *rec, const si
             s5gpu_rec_desc_t &d = rd[i];
             d.in_off = io; d.pay_off = po; d.sig_off = so;
             d.in_len = (uint32_t)rec_len[i]; d.pay_cap = pcap[i]; d.sig_cap = scap[i]; d.reserved = 0;
+            if (framed) d.in_off = (uint64_t)((const uint8_t *)rec[i] - framed->base);
             io += up(rec_len[i] + 16, 16); po += up((uint64_t)pcap[i] + 16, 16); so += up((uint64_t)scap[i] + 8, 8);
         }
-        if ((rc = c->h_in.reserve(up(io + 64, 64) + sizeof(s5gpu_rec_desc_t) * n)) || (rc = c->d_in.reserve(io + 64)) ||
+        if (framed) io = framed->bytes;
+        if ((rc = c->h_in.reserve((framed ? 0 : up(io + 64, 64)) + sizeof(s5gpu_rec_desc_t) * n)) || (rc = c->d_in.reserve(io + 64)) ||
             (rc = c->d_desc2.reserve(sizeof(s5gpu_rec_desc_t) * n)) || (rc = c->d_pay.reserve(po + 64)) ||
             (rc = c->d_sig2.reserve(so * 2 + 64)) || (rc = c->d_fields.reserve(sizeof(s5gpu_rec_fields_t) * n)))
             return rc;
-        uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + up(io + 64, 64);
-        parallel_for(n, io, [&](uint32_t lo, uint32_t hi_) {
-            for (uint32_t i = lo; i < hi_; i++) memcpy(hi + rd[i].in_off, rec[i], rec_len[i]);
-        });
+        uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + (framed ? 0 : up(io + 64, 64));
+        if (!framed)
+            parallel_for(n, io, [&](uint32_t lo, uint32_t hi_) {
+                for (uint32_t i = lo; i < hi_; i++) memcpy(hi + rd[i].in_off, rec[i], rec_len[i]);
+            });
         memcpy(hd, rd.data(), sizeof(s5gpu_rec_desc_t) * n);
-        HIP_TRY(hipMemcpyAsync(c->d_in.p, hi, io, hipMemcpyHostToDevice, c->st));
+        if (!framed || attempt == 0)   // a framed chunk is already on the device when overflowing records are redone
+            HIP_TRY(hipMemcpyAsync(c->d_in.p, framed ? framed->base : hi, io, hipMemcpyHostToDevice, c->st));
         HIP_TRY(hipMemcpyAsync(c->d_desc2.p, hd, sizeof(s5gpu_rec_desc_t) * n, hipMemcpyHostToDevice, c->st));
         HIP_TRY(hipMemsetAsync(c->d_fields.p, 0, sizeof(s5gpu_rec_fields_t) * n, c->st));
         s5gpu_decode_args_t da;
@@ -799,6 +801,9 @@ extern "C" int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const 
     return rc;
 }
 
+static int recompress_encode_half(Ctx *c, uint32_t n, const std::vector<s5gpu_rec_desc_t> &rd, const std::vector<s5gpu_rec_fields_t> &ff, int to_rec, int to_sig,
+                                  const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, std::vector<uint64_t> *stream_off);
+
 static int recompress_batch_dev(int slot, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
                                 int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, int32_t *status) {
     s5host::CtxHold hold;
@@ -808,6 +813,13 @@ static int recompress_batch_dev(int slot, uint32_t n, const void *const *rec, co
     std::vector<s5gpu_rec_desc_t> rd;
     std::vector<s5gpu_rec_fields_t> ff;
     if ((rc = s5host::decode_resident(c, n, rec, rec_len, from_rec, from_sig, rd, ff, status))) return rc;
+    return recompress_encode_half(c, n, rd, ff, to_rec, to_sig, new_read_group, drop_aux, out, out_len, nullptr);
+}
+
+// second half of the worker: encode descriptors straight from the decoded fields (payloads in c->d_pay, signals in c->d_sig2)
+static int recompress_encode_half(Ctx *c, uint32_t n, const std::vector<s5gpu_rec_desc_t> &rd, const std::vector<s5gpu_rec_fields_t> &ff, int to_rec, int to_sig,
+                                  const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, std::vector<uint64_t> *stream_off) {
+    int rc;
     // encode descriptors straight from the decoded fields: heads and aux tails are read out of the decoded payloads
     std::vector<s5gpu_read_desc_t> ed(n);
     uint64_t oo = 0;
@@ -848,5 +860,92 @@ static int recompress_batch_dev(int slot, uint32_t n, const void *const *rec, co
     a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
     a.sig = (const int16_t *)c->d_sig2.p; a.hdr = (const uint8_t *)c->d_pay.p; a.aux = (const uint8_t *)c->d_pay.p;
     a.max_payload = max_payload;
+    if (stream_off) return encode_stream_resident(c, n, ed, a, oo, *stream_off);   // the caller fetches c->d_stream itself
     return encode_and_collect(c, n, ed, a, oo, out, out_len);
+}
+
+// ---- pinned host memory for callers that stream a file through the library (examples/s5view.c) ----
+extern "C" void *s5gpu_host_alloc(size_t bytes) {
+    if (s5host::n_devices() == 0) return NULL;
+    void *p = NULL;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { s5gpu_set_error("pinned allocation of %zu bytes failed", bytes); return NULL; }
+    return p;
+}
+extern "C" void s5gpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// The view / merge worker on a CHUNK of a BLOW5 file: the records sit framed ([u64 size][bytes]) in one host buffer, exactly as
+// read from disk, and the re-encoded records come back as one contiguous stream, exactly as the ordered write loop would emit
+// them — no per-record malloc or memcpy on either side (the reader thread of the reference's loop, src/view.c:265-278, spends
+// its time in exactly those).  Device g of G takes the g-th contiguous share of the records.
+extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int from_rec,
+                                       int from_sig, int to_rec, int to_sig, const uint32_t *new_read_group, int drop_aux, void *out_buf,
+                                       size_t out_cap, uint64_t *out_off, int32_t *status) {
+    if (n == 0) { if (out_off) out_off[0] = 0; return S5GPU_OK; }
+    if (!chunk || !rec_pos || !rec_len || !out_buf || !out_off) { s5gpu_set_error("s5gpu_recompress_stream: NULL argument"); return S5GPU_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++) {
+        if (status) status[i] = 0;
+        if (rec_pos[i] > chunk_bytes || rec_len[i] > chunk_bytes - rec_pos[i]) { s5gpu_set_error("record %u lies outside the chunk", i); return S5GPU_ERR_ARG; }
+    }
+    const int G = s5host::n_devices();
+    if (G == 0) return S5GPU_ERR_NODEV;
+    // Every device thread encodes its share, publishes the size of its stream, waits for the shares in front of it (so it knows
+    // where its bytes go) and fetches them itself while it still owns its context.
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int64_t> totals(G, -1);
+    std::vector<uint32_t> firsts(G, 0xFFFFFFFFu);
+    bool failed = false;
+    uint64_t need = 0;
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
+        auto fail = [&](int r) -> int {
+            std::lock_guard<std::mutex> g(mu);
+            failed = true;
+            cv.notify_all();
+            return r;
+        };
+        s5host::CtxHold hold;
+        int r = hold.acquire(slot);
+        if (r) return fail(r);
+        Ctx *c = hold.c;
+        const uint32_t m = hi - lo;
+        // the extent of this share of the chunk (the records of a share are contiguous in a file chunk)
+        const uint64_t e0 = rec_pos[lo] & ~15ull;
+        uint64_t e1 = 0;
+        for (uint32_t i = lo; i < hi; i++) e1 = e1 > rec_pos[i] + rec_len[i] ? e1 : rec_pos[i] + rec_len[i];
+        uint64_t b0 = e0;
+        for (uint32_t i = lo; i < hi; i++) b0 = b0 < rec_pos[i] ? b0 : rec_pos[i] & ~15ull;
+        std::vector<const void *> rec(m);
+        std::vector<size_t> len(m);
+        for (uint32_t i = 0; i < m; i++) { rec[i] = (const uint8_t *)chunk + rec_pos[lo + i]; len[i] = rec_len[lo + i]; }
+        FramedSrc fs = {(const uint8_t *)chunk + b0, (size_t)(e1 - b0)};
+        std::vector<s5gpu_rec_desc_t> rd;
+        std::vector<s5gpu_rec_fields_t> ff;
+        std::vector<uint64_t> off;
+        if ((r = decode_resident_impl(c, m, rec.data(), len.data(), from_rec, from_sig, rd, ff, status ? status + lo : nullptr, &fs))) return fail(r);
+        if ((r = recompress_encode_half(c, m, rd, ff, to_rec, to_sig, new_read_group ? new_read_group + lo : nullptr, drop_aux, nullptr, nullptr, &off))) return fail(r);
+        uint64_t base = 0;
+        {
+            std::unique_lock<std::mutex> g(mu);
+            totals[slot] = (int64_t)off[m];
+            firsts[slot] = lo;
+            cv.notify_all();
+            // shares in front of this one: the slots that took lower record ranges (all of them when the batch was split)
+            for (;;) {
+                bool ready = true;
+                base = 0;
+                for (int q = 0; q < slot; q++) { if (totals[q] < 0) ready = false; else base += (uint64_t)totals[q]; }
+                if (ready || failed) break;
+                cv.wait(g);
+            }
+            if (failed) return S5GPU_ERR_HIP;
+            if (base + off[m] > out_cap) { need = need > base + off[m] ? need : base + off[m]; failed = true; cv.notify_all(); s5gpu_set_error("s5gpu_recompress_stream: output buffer too small"); return S5GPU_ERR_NOMEM; }
+        }
+        HIP_TRY(hipMemcpyAsync((uint8_t *)out_buf + base, c->d_stream.p, off[m], hipMemcpyDeviceToHost, c->st));
+        for (uint32_t i = 0; i < m; i++) out_off[lo + i] = base + off[i];
+        if (hi == n) out_off[n] = base + off[m];
+        HIP_TRY(hipStreamSynchronize(c->st));
+        return S5GPU_OK;
+    });
+    if (rc == S5GPU_ERR_NOMEM && need) out_off[0] = need;   // the size the caller has to bring
+    return rc;
 }

@@ -226,6 +226,39 @@ def test_pipelined_view_writes_the_same_bytes_as_the_serial_phases(tmp_path, K, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk_kb,readers", [(300, 1), (517, 3), (4096, 4)])
+def test_chunked_view_pipeline_equals_the_per_record_pipeline(tmp_path, chunk_kb, readers):
+    """BLOW5 -> BLOW5 through s5gpu_recompress_stream (file chunks into pinned memory, records framed in place, one contiguous
+    stream back, one write per chunk): byte-identical to the per-record pipeline, whatever the chunk size cuts in two"""
+    import struct
+
+    from slow5tools_amd import press
+
+    rng = np.random.default_rng(21)
+    n = 700
+    sigs = [(480 + 35 * rng.standard_normal(int(k))).astype(np.int16) for k in rng.integers(50, 9000, n)]
+    sigs[5] = (480 + 35 * rng.standard_normal(120000)).astype(np.int16)        # one record near the smallest chunk's size
+    hdrs = [press.pack_hdr(b"r%06d" % i, i % 3, 8192.0, 23.0, 1467.61, 4000.0) for i in range(n)]
+    recs = press.encode_records(sigs, hdrs, None, press.REC_NONE, press.SIG_NONE)
+    text = b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
+    head = bytearray(64)
+    head[:6] = b"BLOW5\x01"; head[6:9] = bytes([0, 2, 0]); head[9] = 0; head[10:14] = struct.pack("<I", 3); head[14] = 0
+    src = tmp_path / "in.blow5"
+    src.write_bytes(bytes(head) + struct.pack("<I", len(text)) + text + b"".join(recs) + b"5WOLB")
+    env = dict(os.environ, S5VIEW_CHUNK_KB=str(chunk_kb), S5VIEW_READERS=str(readers))
+    a, b = tmp_path / "chunked.blow5", tmp_path / "per_record.blow5"
+    r = subprocess.run([S5VIEW, str(src), str(a), "zlib", "svb-zd", "4096", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "chunked pipeline" in r.stderr, r.stderr
+    r = subprocess.run([S5VIEW, str(src), str(b), "zlib", "svb-zd", "64", "2"], capture_output=True, text=True, timeout=300, env=dict(os.environ, S5VIEW_PER_RECORD="1"))
+    assert r.returncode == 0 and "chunked pipeline" not in r.stderr, r.stderr
+    assert a.read_bytes() == b.read_bytes()
+    back = tmp_path / "back.blow5"                                   # and back: zlib + svb-zd -> none, through the chunks again
+    r = subprocess.run([S5VIEW, str(a), str(back), "none", "none", "4096", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == src.read_bytes()
+
+
+@pytest.mark.gpu
 def test_concurrent_host_batches_from_threads():
     """two host threads inside the batch API at once (each owns one context): results equal the single-threaded ones"""
     import threading

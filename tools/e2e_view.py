@@ -30,20 +30,27 @@ del b
 torch.cuda.empty_cache()
 exe = os.path.join(ROOT, "slow5tools_amd", "s5view")
 raw_gb = n_reads * n * 2 / 1e9
-runs = [("none", "none", "/tmp/e2e_raw.blow5", 4096, 2)]
-for K in (4096, 65536):
-    for W in (0, 1, 2, 3):
-        runs.append(("zlib", "svb-zd", "/tmp/e2e_z_%d_%d.blow5" % (K, W), K, W))
+# (record press, signal press, output, K, workers, env): the per-record pipeline of round 1 next to the chunked one
+runs = [("none", "none", "/tmp/e2e_raw.blow5", 4096, 2, {})]
+for K, W in ((4096, 0), (65536, 2)):
+    runs.append(("zlib", "svb-zd", "/tmp/e2e_z_%d_%d.blow5" % (K, W), K, W, {"S5VIEW_PER_RECORD": "1"}))
+for W, R, C in ((1, 1, 64), (2, 4, 64), (3, 4, 64), (3, 8, 64), (3, 4, 128), (4, 8, 32)):
+    runs.append(("zlib", "svb-zd", "/tmp/e2e_c_%d_%d_%d.blow5" % (W, R, C), 4096, W, {"S5VIEW_READERS": str(R), "S5VIEW_CHUNK_MB": str(C)}))
 ref_out = None
-for (rm, sm, dst, K, W) in runs:
+import re
+for (rm, sm, dst, K, W, env) in runs:
     inp = src if rm == "none" else "/tmp/e2e_raw.blow5"
     t0 = time.perf_counter()
-    r = subprocess.run([exe, inp, dst, rm, sm, str(K), str(W)], capture_output=True, text=True)
+    r = subprocess.run([exe, inp, dst, rm, sm, str(K), str(W)], capture_output=True, text=True, env=dict(os.environ, **env))
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr
-    print("s5view %s -> (%s,%s) K=%d workers=%d%s: %d reads in %.2f s = %.2f GB/s raw signal, %.0f k reads/s  [in %.0f MB, out %.0f MB]"
-          % (os.path.basename(inp), rm, sm, K, W, " (serial phases)" if W == 0 else "", n_reads, dt, raw_gb / dt, n_reads / dt / 1e3,
-             os.path.getsize(inp) / 1e6, os.path.getsize(dst) / 1e6))
+    m = re.search(r"chunked pipeline: ([0-9.]+) s", r.stderr)
+    inner = float(m.group(1)) if m else None
+    print("s5view %s -> (%s,%s) %s workers=%d: %d reads, whole process %.2f s = %.2f GB/s raw signal%s  [in %.0f MB, out %.0f MB]"
+          % (os.path.basename(inp), rm, sm, ("per-record pipeline K=%d%s" % (K, " (serial phases)" if W == 0 else "")) if "S5VIEW_PER_RECORD" in env or rm == "none" else
+             "chunked pipeline (%s MB chunks, %s pread threads)" % (env["S5VIEW_CHUNK_MB"], env["S5VIEW_READERS"]), W, n_reads, dt, raw_gb / dt,
+             "; first read to last write %.3f s = %.2f GB/s" % (inner, raw_gb / inner) if inner else "", os.path.getsize(inp) / 1e6, os.path.getsize(dst) / 1e6))
+    sys.stdout.flush()
     if rm == "zlib":   # the pipeline must not change a byte
         data = open(dst, "rb").read()
         if ref_out is None:
