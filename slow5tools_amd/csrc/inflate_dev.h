@@ -391,13 +391,28 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
                         const uint32_t w0 = T.win[abit >> 5], w1 = T.win[(abit >> 5) + 1];
                         const uint32_t ev = T.llut[(uint32_t)((((uint64_t)w1 << 32) | w0) >> (abit & 31)) & ((1 << INF_LBITS) - 1)];
                         // per lane: is the code at my offset a LUT-resolved literal, and where would the next code start
-                        const uint64_t lit_at = __ballot((ev >> 9) != 0 && (ev & 511u) < 256u);
-                        const uint32_t nxt = (uint32_t)lane + (ev >> 9);
+                        const bool is_lit = (ev >> 9) != 0 && (ev & 511u) < 256u;
+                        const uint64_t lit_at = __ballot(is_lit);
+                        // Where does a walk that starts at my offset stand after up to 4 literal codes, and which offsets did it
+                        // visit?  Two rounds of pointer doubling across the lanes (ds_bpermute): E = offset reached (a code that
+                        // is not a literal absorbs: E = its own offset; >= 64 = beyond this round), R = literal offsets visited.
+                        // The scalar unit then hops four codes at a time — it is the one unit the 16 waves of a CU share, and the
+                        // code-by-code hop (a v_readlane with a scalar index per code) was what bounded this kernel.
+                        uint32_t E = is_lit ? (uint32_t)lane + (ev >> 9) : (uint32_t)lane;
+                        uint32_t Rlo = is_lit && lane < 32 ? 1u << lane : 0u, Rhi = is_lit && lane >= 32 ? 1u << (lane - 32) : 0u;
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int src = (int)(E & 63u) << 2;
+                            const uint32_t e2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)E);
+                            const uint32_t r2lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)Rlo);
+                            const uint32_t r2hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)Rhi);
+                            if (E < 64u) { Rlo |= r2lo; Rhi |= r2hi; E = e2; }
+                        }
                         uint32_t off = 0;
                         uint64_t visited = 0;
                         while ((lit_at >> off) & 1) {
-                            visited |= 1ull << off;
-                            off = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)off);
+                            visited |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)Rlo, (int)off) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)Rhi, (int)off) << 32);
+                            off = (uint32_t)__builtin_amdgcn_readlane((int)E, (int)off);
                             if (off >= 64) break;
                         }
                         if (visited) {
