@@ -27,16 +27,17 @@ struct LaneTables {                    // per lane, in LDS
     uint8_t lsym[288];                 // lit/len symbols in canonical order, low 8 bits
     uint32_t lhi[9];                   // ... and their bit 8 (length codes and end-of-block), one bit per entry
     int16_t ladj[16];                  // canonical index - first code, per length
-    uint16_t dcount[16];               // distance code (and, before it, the code-length code): counts per length
-    uint8_t dsym[32];                  // ... symbols in canonical order
 };
-static_assert(sizeof(LaneTables) == 420 && (sizeof(LaneTables) / 4) % 2 == 1, "LaneTables layout: odd dword stride spreads the lanes over the banks");
+static_assert(sizeof(LaneTables) == 356 && (sizeof(LaneTables) / 4) % 2 == 1, "LaneTables layout: odd dword stride spreads the lanes over the banks");
 
 // What only the table construction needs lives in PRIVATE memory (scratch: per-lane, swizzled so that the 64 lanes' copies of one
 // element are contiguous), not in LDS: the LDS footprint per lane is what decides how many waves a CU holds.
 struct LaneBuild {
     uint8_t lens4[160];                // code lengths of the block header, 4 bits each (<= 316 of them)
     uint16_t tmp[16];                  // counts, then next free index per length
+    uint16_t dcount[16];               // distance code (and, before it, the code-length code): counts per length.  Used once per
+    uint8_t dsym[32];                  // match (and per header entry), not per symbol: private memory is good enough, and the 64 bytes
+                                       // they took per lane in LDS were the difference between six and seven waves per CU
 };
 
 typedef short lane_s2 __attribute__((ext_vector_type(2)));
@@ -227,7 +228,7 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
             for (int s = 0; s < 288; s++) nib_set(B.lens4, s, s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u);
             nl = 288;
             nd = 30;
-            if (lane_build_small([](int) { return 5u; }, nd, T.dcount, T.dsym)) return INF_ERR_DATA;
+            if (lane_build_small([](int) { return 5u; }, nd, B.dcount, B.dsym)) return INF_ERR_DATA;
         } else {
             lb_need32(b);
             const uint32_t hd = lb_get(b, 14);
@@ -243,13 +244,13 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
                 const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
                 for (int i = 0; i < ncl; i++) { lb_need32(b); cl[order[i]] = (uint8_t)lb_get(b, 3); }
             }
-            if (lane_build_small([&](int s) { return (uint32_t)cl[s]; }, 19, T.dcount, T.dsym)) return INF_ERR_DATA;
+            if (lane_build_small([&](int s) { return (uint32_t)cl[s]; }, 19, B.dcount, B.dsym)) return INF_ERR_DATA;
             uint32_t prev = 0;
             int idx = 0;
             const int tot = nl + nd;
             while (idx < tot) {
                 lb_need32(b);
-                const int sym = lane_slow(b, T.dcount, T.dsym);
+                const int sym = lane_slow(b, B.dcount, B.dsym);
                 if (sym < 0) return INF_ERR_DATA;
                 if (sym < 16) { prev = (uint32_t)sym; nib_set(B.lens4, idx++, prev); }
                 else {
@@ -266,7 +267,7 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
             if (lb_consumed(b) > total_bits) return INF_ERR_TRUNC;
             if (nib_get(B.lens4, 256) == 0) return INF_ERR_DATA;
             // distance tables (their lengths sit behind the lit/len ones)
-            if (lane_build_small([&](int s) { return nib_get(B.lens4, nl + s); }, nd, T.dcount, T.dsym)) return INF_ERR_DATA;
+            if (lane_build_small([&](int s) { return nib_get(B.lens4, nl + s); }, nd, B.dcount, B.dsym)) return INF_ERR_DATA;
         }
         if (lane_build_litlen(T, B, nl, lim)) return INF_ERR_DATA;
         for (;;) {
@@ -282,7 +283,7 @@ __device__ __forceinline__ int zlib_inflate_lane(LaneTables &T, const uint8_t *i
             const uint32_t le = sym < 8 || sym == 28 ? 0u : (uint32_t)(sym >> 2) - 1u;
             const uint32_t mlen = (sym == 28 ? 258u : sym < 8 ? 3u + (uint32_t)sym : 3u + ((4u + ((uint32_t)sym & 3u)) << le)) + lb_get(b, (int)le);
             lb_need32(b);
-            const int ds = lane_slow(b, T.dcount, T.dsym);
+            const int ds = lane_slow(b, B.dcount, B.dsym);
             if (ds < 0 || ds >= 30) return INF_ERR_DATA;
             const uint32_t de = ds < 4 ? 0u : (uint32_t)(ds >> 1) - 1u;
             const uint32_t mdist = (ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + lb_get(b, (int)de);

@@ -164,8 +164,11 @@ __device__ __forceinline__ uint32_t build_payload_hbm(const s5gpu_encode_args_t 
 // K1+K5+K3+K6 fused: svb-zd -> pack -> one DEFLATE block -> zlib frame.  One read per workgroup, every
 // intermediate in LDS.  A read whose payload does not fit the LDS budget (p.pay_cap: long read, or an
 // unusually incompressible signal) is appended to the overflow list and redone by the staged kernels.
+#ifndef S5_FUSED_WG_PER_CU
+#define S5_FUSED_WG_PER_CU 8
+#endif
 template <typename M, bool EXZD = false>
-__global__ __launch_bounds__(NT, 8) void k_encode_fused(EncParams p) {
+__global__ __launch_bounds__(NT, S5_FUSED_WG_PER_CU) void k_encode_fused(EncParams p) {
     const uint32_t r = blockIdx.x;
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
@@ -201,7 +204,7 @@ struct StreamParams {
     uint64_t *rec_off;           // n_reads + 1
 };
 template <typename M, bool EXZD = false>
-__global__ __launch_bounds__(NT, 8) void k_encode_stream(EncParams p, StreamParams sp) {
+__global__ __launch_bounds__(NT, S5_FUSED_WG_PER_CU) void k_encode_stream(EncParams p, StreamParams sp) {
     __shared__ uint32_t s_r;
     __shared__ uint64_t s_off;
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
