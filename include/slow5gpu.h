@@ -128,7 +128,9 @@ int s5gpu_devices_in_use(void);          /* devices the batch calls run on (0 be
 void s5gpu_shutdown(void);
 const char *s5gpu_last_error(void);
 int s5gpu_device_count(void);
-/* tuning knobs.  "inflate_simt_min": batches with at least this many zlib records use the lane-per-record
+/* tuning knobs.  "inflate_par" (0/1, default 1): zlib records are inflated by the decoder that is parallel inside a record (one record
+ * per wave, 64 self-synchronising segment decoders; whatever it declines is redone by the wave-per-record decoder).  With 0 the two
+ * older kernels are used, chosen by batch size:  "inflate_simt_min": batches with at least this many zlib records use the lane-per-record
  * inflate kernel (throughput), smaller ones the wave-per-record kernel (latency); default 24576.
  * "inflate_route" (0/1, default 1): such batches are first counting-sorted by compressed length on the device, and records
  * of >= 32 KiB go to the wave-per-record kernel beside the lane kernel (real runs have read lengths spread over two decades).

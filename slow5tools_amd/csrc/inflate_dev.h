@@ -182,6 +182,83 @@ __device__ __forceinline__ int infl_slow(BitIn &b, const uint16_t *count, const 
     return -1;
 }
 
+// Code lengths of a fixed (type 1) or dynamic (type 2) block and the decode tables of both alphabets, by the whole wave with the
+// wave-uniform bit reader (the dynamic header is read out of the LDS window T.win, INF_IW bytes).  T: any struct with the table
+// fields of InflShared.  Returns INF_OK or an error status; nl / nd = number of lit/len and distance codes.
+template <class TT>
+__device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint32_t total, uint64_t total_bits, BitIn &b, int type, int &nl, int &nd) {
+    const int lane = lane_id();
+    // ---- code lengths ----
+    if (type == 1) {
+        for (int s = lane; s < 288; s += 64) T.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+        if (lane < 32) T.lens[288 + lane] = 5;
+        nl = 288;
+        nd = 30;
+        wave_sync();
+    } else {
+        // the whole dynamic header is at most 14 + 57 + 316 * 14 bits = 562 bytes: make sure it is in the window
+        if (b.wpos > INF_IW / 4 - 160) {
+            infl_reload(T.win, src, total, b);
+        }
+        bi_need32_u(b, T.win);
+        const uint32_t hd = bi_get(b, 14);
+        nl = (int)(hd & 31) + 257;
+        nd = (int)((hd >> 5) & 31) + 1;
+        const int ncl = (int)(hd >> 10) + 4;
+        if (nl > 286 || nd > 30) return INF_ERR_DATA;
+        if (lane < 19) T.lens[lane] = 0;
+        wave_sync();
+        {
+            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            for (int i = 0; i < ncl; i++) {
+                bi_need32_u(b, T.win);
+                const uint8_t v = (uint8_t)bi_get(b, 3);
+                if (lane == 0) T.lens[order[i]] = v;
+            }
+        }
+        wave_sync();
+        // the code-length code reuses the distance tables' storage (built before the real ones)
+        if (infl_build(T.lens, 19, T.dcount, T.dsym, T.dlut, 7, 5)) return INF_ERR_DATA;
+        int bad = 0;
+        {
+            uint8_t prev = 0;
+            int idx = 0;
+            const int tot = nl + nd;
+            while (idx < tot) {
+                bi_need32_u(b, T.win);
+                const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.dlut[(uint32_t)b.buf & 127]);
+                if (!(e >> 5)) { bad = 1; break; }
+                const int sym = e & 31;
+                bi_get(b, e >> 5);
+                if (sym < 16) { prev = (uint8_t)sym; if (lane == 0) T.lens[32 + idx] = prev; idx++; }
+                else {
+                    int rep;
+                    uint8_t v = 0;
+                    if (sym == 16) { if (idx == 0) { bad = 1; break; } v = prev; rep = 3 + (int)bi_get(b, 2); }
+                    else if (sym == 17) rep = 3 + (int)bi_get(b, 3);
+                    else rep = 11 + (int)bi_get(b, 7);
+                    if (idx + rep > tot) { bad = 1; break; }
+                    if (lane < rep) T.lens[32 + idx + lane] = v;   // rep <= 138: two rounds at most
+                    if (lane + 64 < rep) T.lens[32 + idx + lane + 64] = v;
+                    if (lane + 128 < rep) T.lens[32 + idx + lane + 128] = v;
+                    idx += rep;
+                    if (sym != 16) prev = 0;
+                }
+            }
+            if (!bad && bi_consumed_bits(b) > total_bits) bad = 2;
+        }
+        if (bad) return bad == 2 ? INF_ERR_TRUNC : INF_ERR_DATA;
+        wave_sync();
+    }
+    // tables: dynamic lengths sit at T.lens[32 ..] (lit/len then dist); fixed at [0..288) + [288..)
+    const uint8_t *ll = type == 1 ? T.lens : T.lens + 32;
+    const uint8_t *dl = type == 1 ? T.lens + 288 : T.lens + 32 + nl;
+    if (type == 2 && ll[256] == 0) return INF_ERR_DATA;
+    if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, INF_LBITS, 9)) return INF_ERR_DATA;
+    if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, INF_DBITS, 5)) return INF_ERR_DATA;
+    return INF_OK;
+}
+
 // All lanes: write ring bytes [from, to) to HBM (nothing at or beyond cap) and fold them into the Adler-32.
 __device__ __forceinline__ void infl_flush(const uint8_t *ring, uint8_t *out, uint32_t from, uint32_t to, uint32_t cap,
                                            uint32_t &adA, uint32_t &adB) {
@@ -278,75 +355,9 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
             b.wbase = pos + len; b.wpos = 0; b.buf = 0; b.cnt = 0;
             continue;
         }
-        // ---- code lengths ----
+        // ---- code lengths and tables ----
         int nl, nd;
-        if (type == 1) {
-            for (int s = lane; s < 288; s += 64) T.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
-            if (lane < 32) T.lens[288 + lane] = 5;
-            nl = 288;
-            nd = 30;
-            wave_sync();
-        } else {
-            // the whole dynamic header is at most 14 + 57 + 316 * 14 bits = 562 bytes: make sure it is in the window
-            if (b.wpos > INF_IW / 4 - 160) {
-                infl_reload(T.win, src, total, b);
-            }
-            bi_need32_u(b, T.win);
-            const uint32_t hd = bi_get(b, 14);
-            nl = (int)(hd & 31) + 257;
-            nd = (int)((hd >> 5) & 31) + 1;
-            const int ncl = (int)(hd >> 10) + 4;
-            if (nl > 286 || nd > 30) { status = INF_ERR_DATA; break; }
-            if (lane < 19) T.lens[lane] = 0;
-            wave_sync();
-            {
-                const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                for (int i = 0; i < ncl; i++) {
-                    bi_need32_u(b, T.win);
-                    const uint8_t v = (uint8_t)bi_get(b, 3);
-                    if (lane == 0) T.lens[order[i]] = v;
-                }
-            }
-            wave_sync();
-            // the code-length code reuses the distance tables' storage (built before the real ones)
-            if (infl_build(T.lens, 19, T.dcount, T.dsym, T.dlut, 7, 5)) { status = INF_ERR_DATA; break; }
-            int bad = 0;
-            {
-                uint8_t prev = 0;
-                int idx = 0;
-                const int tot = nl + nd;
-                while (idx < tot) {
-                    bi_need32_u(b, T.win);
-                    const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.dlut[(uint32_t)b.buf & 127]);
-                    if (!(e >> 5)) { bad = 1; break; }
-                    const int sym = e & 31;
-                    bi_get(b, e >> 5);
-                    if (sym < 16) { prev = (uint8_t)sym; if (lane == 0) T.lens[32 + idx] = prev; idx++; }
-                    else {
-                        int rep;
-                        uint8_t v = 0;
-                        if (sym == 16) { if (idx == 0) { bad = 1; break; } v = prev; rep = 3 + (int)bi_get(b, 2); }
-                        else if (sym == 17) rep = 3 + (int)bi_get(b, 3);
-                        else rep = 11 + (int)bi_get(b, 7);
-                        if (idx + rep > tot) { bad = 1; break; }
-                        if (lane < rep) T.lens[32 + idx + lane] = v;   // rep <= 138: two rounds at most
-                        if (lane + 64 < rep) T.lens[32 + idx + lane + 64] = v;
-                        if (lane + 128 < rep) T.lens[32 + idx + lane + 128] = v;
-                        idx += rep;
-                        if (sym != 16) prev = 0;
-                    }
-                }
-                if (!bad && bi_consumed_bits(b) > total_bits) bad = 2;
-            }
-            if (bad) { status = bad == 2 ? INF_ERR_TRUNC : INF_ERR_DATA; break; }
-            wave_sync();
-        }
-        // tables: dynamic lengths sit at T.lens[32 ..] (lit/len then dist); fixed at [0..288) + [288..)
-        const uint8_t *ll = type == 1 ? T.lens : T.lens + 32;
-        const uint8_t *dl = type == 1 ? T.lens + 288 : T.lens + 32 + nl;
-        if (type == 2 && ll[256] == 0) { status = INF_ERR_DATA; break; }
-        if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, INF_LBITS, 9)) { status = INF_ERR_DATA; break; }
-        if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, INF_DBITS, 5)) { status = INF_ERR_DATA; break; }
+        { const int rc = infl_block_tables(T, src, total, total_bits, b, type, nl, nd); if (rc != INF_OK) { status = rc; break; } }
         // Codes longer than the LUT: every length tested at once.  Lane L (1..15) holds limit = first[L] + count[L] and
         // base = offs[L] - first[L] of the canonical lit/len code; the code of length L is the top L bits of the bit-reversed
         // peek, the true length is the smallest L with code < limit (one ballot), the symbol is lsym[code + base].

@@ -1,0 +1,345 @@
+// inflate_par_dev.h — zlib (RFC 1950/1951) decoder, one record per wave64, PARALLEL INSIDE THE RECORD.
+//
+// The two older decoders leave a record's symbol stream serial: inflate_dev.h walks it on the scalar unit (one record per
+// wave: ~26 dependent instructions per symbol, 0.83 ms for a `get` batch of 4096 records however few of them there are), and
+// inflate_simt_dev.h gives every lane a record of its own (64 private table sets: six waves per CU, latency bound at 20 M
+// records/s).  A Huffman stream does not have to be decoded from its first bit, though: a decoder dropped at an arbitrary bit
+// falls into step with the true code boundaries after a few codes (self-synchronisation), and that is all the parallelism
+// this decoder needs:
+//   window   up to 4 KiB of the compressed stream in LDS, cut into 64 segments of equal bit length (>= 64 bits: longer than
+//            any one token), one per lane; ONE set of tables for the whole wave (10-bit / 8-bit lookup tables, 4 KiB);
+//   sync     every lane decodes the tokens that start in its segment — literal, end of block, or length + distance with
+//            their extra bits — and reports where its last token ends; that is where the next lane's segment REALLY
+//            starts.  Lane 0 starts at a known boundary; the others start at their segment's first bit, which is almost
+//            always wrong, and almost always harmless: by the end of the segment the lane is in step, so its end position
+//            is right anyway.  The pass is repeated with the corrected starts until no start moves (two or three passes;
+//            pass k is certain to have lanes 0..k-1 right, so 64 passes is the bound and nothing can hang);
+//   count    the same pass counts the bytes each lane's tokens produce: a prefix sum gives every lane its output offset;
+//   output   one more pass writes literals (and matches whose source the lane wrote itself) into an 8 KiB LDS buffer; other
+//            matches — the source lies in another lane's output, or follows a match that had to wait — are put on a short
+//            per-lane list and replicated afterwards in stream order by the whole wave;
+//   flush    the buffer goes to HBM as coalesced bytes, Adler-32 folded in on the way.
+// A record larger than one window takes several rounds; block headers (stored / fixed / dynamic) are parsed by the wave
+// with the uniform reader of inflate_dev.h between rounds.  What this decoder declines — a lane with more waiting matches
+// than its list holds (zlib streams of raw, uncompressed signals: four out of five bytes are far matches), a segment that
+// expands past the output buffer, a payload slot that is too small — it reports as INF_NEED_FALLBACK and the wave-per-record
+// decoder redoes that record (k_inflate_fallback).  Same contract and status codes as inflate_dev.h otherwise.
+#pragma once
+#include "inflate_dev.h"
+
+namespace s5 {
+
+constexpr int IP_SPAN = 4096;          // compressed bytes per round
+constexpr int IP_DEF = 4;              // waiting matches per lane and round
+constexpr uint32_t IP_TAIL = 256;      // bits of its segment a lane walks in the first pass
+constexpr int INF_NEED_FALLBACK = 8;
+
+struct InflParShared {                 // per wave: 8.3 KiB, so a CU holds all the waves the hardware allows
+    uint32_t win[IP_SPAN / 4 + 8];     // window; the header parser uses its first INF_IW bytes
+    union {
+        uint16_t llut[1 << INF_LBITS]; // written by the shared header parser (unused here: lit/len codes are resolved by comparison, IpLimits) ...
+        struct {                       // ... and dead before the first waiting match is listed
+            uint32_t def_a[64 * IP_DEF];   // waiting match: position in the round's output | length << 20
+            uint32_t def_d[64 * IP_DEF];   // ... its distance
+        };
+    };
+    uint16_t dlut[1 << INF_DBITS];
+    uint16_t ladj[16];                 // lit/len: index of a length's first symbol in lsym - its first code
+    uint16_t lsym[288];
+    uint16_t dsym[32];
+    uint16_t lcount[16], dcount[16];
+    uint8_t lens[352];
+};
+static_assert(sizeof(uint32_t) * 64 * IP_DEF * 2 <= sizeof(uint16_t) << INF_LBITS, "the waiting lists fit the dead lookup table");
+static_assert(INF_IW <= IP_SPAN, "the header parser's window is the head of the round window");
+
+// 32 bits of the window starting at bit p (two aligned dwords + one alignbit)
+__device__ __forceinline__ uint32_t ip_peek(const uint32_t *win, uint32_t p) {
+    const uint32_t w = p >> 5;
+    return __builtin_amdgcn_alignbit(win[w + 1], win[w], p & 31u);
+}
+// window byte 0 = deflate byte `from` (a multiple of 4 keeps the copy aligned when src is); bytes at or past `total` read as zero
+__device__ __forceinline__ void ip_load_window(uint32_t *win, const uint8_t *src, uint32_t from, uint32_t total) {
+    const int lane = lane_id();
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(src) + from;
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(addr & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(addr & 3) * 8;
+    const uint32_t avail = from < total ? total - from : 0;
+    for (uint32_t i = lane; i < IP_SPAN / 4 + 8; i += 64) {
+        uint32_t w = 0;
+        if (4 * i < avail) {
+            const uint32_t lo = g[i];
+            w = lo;
+            if (sh) w = (lo >> sh) | (g[i + 1] << (32 - sh));   // 8 readable bytes follow the record (C ABI)
+            const uint32_t left = avail - 4 * i;
+            if (left < 4) w &= (1u << (8 * left)) - 1;
+        }
+        win[i] = w;
+    }
+    wave_sync();
+}
+
+struct IpSeg {            // what a lane learns about its segment
+    uint32_t cross;       // window bit where its last token ends (= the next segment's real start)
+    uint32_t nout;        // bytes its tokens produce (up to the end-of-block code, if the segment holds one)
+    uint32_t eob;         // 1: the segment holds the end-of-block code ...
+    uint32_t eobpos;      // ... and this is the bit behind it
+    uint32_t bad;         // 1: an invalid code (meaningless unless the segment was decoded from a real boundary)
+    uint32_t ndef;        // WRITE: waiting matches put on the list; > IP_DEF: the list overflowed
+};
+// The lit/len code is resolved WITHOUT a lookup table: with 64 lanes at 64 different places of the stream, some lane of the wave
+// meets a code longer than any affordable table in almost every step, and the wave then runs the slow path anyway.  So every
+// lane takes the same route for every code: the next 15 bits, first bit on top, are compared against the 15 left-justified
+// canonical limits — wave-uniform values, they live in scalar registers — and the code's length is the number of limits not
+// above it, plus one.  ~30 VALU instructions, no loop, no divergence; the symbol is one LDS read away.
+struct IpLimits { uint32_t lim[16]; };   // lim[l], l = 1..15: (first code of length l + codes of length l) << (15 - l)
+// (carrying the index adjustment of the code's length along in the same compare chain — a conditional move per limit instead of
+// the T.ladj read — was measured: 9 % slower; the wave is short of VALU issue slots, not of LDS latency)
+
+// Decode the tokens that start in [st, end) of the window.  WRITE: also produce the bytes, at dst + obase (dst = the record's
+// output at the round's first byte, o_abs0 bytes into the record; positions are relative to the round), and stop at the
+// end-of-block code.  The bytes go straight to HBM: a lane writes its own run of positions, and L2 collects the lines.  Without WRITE (the synchronisation passes) the walk goes on behind an end-of-block code: whatever follows
+// is another block's header, garbage to this decoder, but walking on keeps the lane's end position self-synchronised — a lane
+// that stopped there would cut the chain, and every lane behind it would have to be revived one pass at a time.
+template <bool WRITE>
+__device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLimits &L, uint32_t st, uint32_t end, uint32_t obase, uint32_t o_abs0,
+                                                   uint8_t *dst) {
+    IpSeg r;
+    r.cross = st; r.nout = 0; r.eob = 0; r.eobpos = 0; r.bad = 0; r.ndef = 0;
+    uint32_t p = st, o = obase;
+    const int lane = lane_id();
+    uint32_t wait_end = obase;     // output position behind this lane's last waiting match: nothing in front of it is certain yet
+    bool any_wait = false;
+    while (p < end) {
+        uint32_t bits = ip_peek(T.win, p);
+        const uint32_t v = __brev(bits) >> 17;
+        uint32_t len = 1;
+#pragma unroll
+        for (int l = 1; l <= 15; l++) len += v >= L.lim[l] ? 1u : 0u;
+        if (len > 15u) { r.bad = 1; break; }
+        uint32_t sym = T.lsym[(uint32_t)((int)(short)T.ladj[len] + (int)(v >> (15u - len)))];
+        p += len;
+        if (sym < 256u) {
+            if (WRITE) dst[o] = (uint8_t)sym;
+            o++;
+            continue;
+        }
+        if (sym == 256u) {
+            if (!r.eob) { r.eob = 1; r.eobpos = p; r.nout = o - obase; }
+            if (WRITE) break;
+            continue;
+        }
+        sym -= 257u;
+        if (sym >= 29u) { r.bad = 1; break; }
+        bits >>= len;
+        // length code: 3..10 one each, then 4 codes per extra-bit count, 258 on its own — arithmetic, no table in memory
+        const uint32_t le = sym < 8u || sym == 28u ? 0u : (sym >> 2) - 1u;
+        const uint32_t mlen = (sym == 28u ? 258u : sym < 8u ? 3u + sym : 3u + ((4u + (sym & 3u)) << le)) + (bits & ((1u << le) - 1u));
+        p += le;
+        bits = ip_peek(T.win, p);
+        const uint32_t de = T.dlut[bits & ((1u << INF_DBITS) - 1)];
+        uint32_t ds, dlen = de >> 5;
+        if (dlen) ds = de & 31u;
+        else {   // a distance code longer than the lookup table: canonical walk (rare)
+            uint32_t code = 0, first = 0, index = 0;
+            ds = 0xFFu;
+            for (dlen = 1; dlen <= 15; dlen++) {
+                code |= (bits >> (dlen - 1)) & 1u;
+                const uint32_t c = T.dcount[dlen];
+                if (code < first + c) { ds = T.dsym[index + (code - first)]; break; }
+                index += c;
+                first = (first + c) << 1;
+                code <<= 1;
+            }
+            if (ds == 0xFFu) { r.bad = 1; break; }
+        }
+        if (ds >= 30u) { r.bad = 1; break; }
+        p += dlen;
+        bits >>= dlen;
+        const uint32_t dx = ds < 4u ? 0u : (ds >> 1) - 1u;
+        const uint32_t mdist = (ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx)) + (bits & ((1u << dx) - 1u));
+        p += dx;
+        if (WRITE) {
+            if (mdist > o_abs0 + o) { r.bad = 1; break; }                       // reaches in front of the record
+            if (o >= mdist && o - mdist >= wait_end) {                         // the whole source is bytes this lane has written: copy now
+                if (mdist == 1) { const uint8_t x = dst[o - 1]; for (uint32_t k = 0; k < mlen; k++) dst[o + k] = x; }
+                else for (uint32_t k = 0; k < mlen; k++) dst[o + k] = dst[o + k - mdist];
+            } else {                                                           // another lane's bytes, or bytes that wait themselves
+                if (r.ndef < (uint32_t)IP_DEF) {
+                    T.def_a[lane * IP_DEF + r.ndef] = o | (mlen << 20);
+                    T.def_d[lane * IP_DEF + r.ndef] = mdist;
+                }
+                r.ndef++;
+                wait_end = o + mlen;
+                any_wait = true;
+            }
+        }
+        o += mlen;
+    }
+    (void)any_wait;
+    r.cross = p;
+    if (!r.eob) r.nout = o - obase;
+    return r;
+}
+
+// Inflate one zlib stream with one wave.  Returns a status of inflate_dev.h or INF_NEED_FALLBACK (nothing usable was written).
+__device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap,
+                                                uint32_t *out_len, uint32_t *dbg = nullptr) {
+    const int lane = lane_id();
+    *out_len = 0;
+    if (in_len < 6) return INF_ERR_TRUNC;
+    {
+        const uint32_t cmf = in[0], flg = in[1];
+        if ((cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) return INF_ERR_HEADER;
+    }
+    const uint8_t *src = in + 2;
+    const uint32_t total = in_len - 6;
+    const uint64_t total_bits = 8ull * total;
+    uint64_t pos = 0;            // bit position in the deflate data (uniform)
+    uint32_t o = 0;              // bytes produced and flushed (uniform)
+    uint32_t adA = 1, adB = 0;
+    int last = 0;
+    while (!last) {
+        // ---- block header, with the wave-uniform reader of inflate_dev.h on the head of the window ----
+        BitIn b;
+        b.buf = 0; b.cnt = 0; b.wpos = 0;
+        b.wbase = (uint32_t)(pos >> 3);
+        infl_load_window(T.win, src, b.wbase, total);
+        bi_need32_u(b, T.win);
+        bi_get(b, (int)(pos & 7));
+        const uint32_t hdr = bi_get(b, 3);
+        if (bi_consumed_bits(b) > total_bits) return INF_ERR_TRUNC;
+        last = hdr & 1;
+        const int type = hdr >> 1;
+        if (type == 3) return INF_ERR_DATA;
+        if (type == 0) {
+            bi_get(b, b.cnt & 7);
+            bi_need32_u(b, T.win);
+            const uint32_t len = bi_get(b, 16), nlen = bi_get(b, 16);
+            const uint32_t at = (uint32_t)(bi_consumed_bits(b) >> 3);
+            if ((len ^ 0xFFFFu) != nlen) return INF_ERR_DATA;
+            if ((uint64_t)at + len > total) return INF_ERR_TRUNC;
+            if (o + len > cap) return INF_NEED_FALLBACK;
+            for (uint32_t i = lane; i < len; i += 64) out[o + i] = src[at + i];
+            o += len;
+            pos = 8ull * ((uint64_t)at + len);
+            continue;
+        }
+        int nl, nd;
+        { const int rc = infl_block_tables(T, src, total, total_bits, b, type, nl, nd); if (rc != INF_OK) return rc; }
+        pos = bi_consumed_bits(b);
+        IpLimits L;
+        {   // canonical limits and index adjustments of the lit/len code (uniform)
+            uint32_t first = 0, offs = 0;
+            L.lim[0] = 0;
+#pragma unroll
+            for (int l = 1; l <= 15; l++) {
+                const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)T.lcount[l]);
+                L.lim[l] = (first + c) << (15 - l);
+                if (lane == l) T.ladj[l] = (uint16_t)(short)((int)offs - (int)first);
+                offs += c;
+                first = (first + c) << 1;
+            }
+            wave_sync();
+        }
+        // ---- the block's tokens, a window at a time ----
+        for (;;) {
+            if (pos >= total_bits) return INF_ERR_TRUNC;                      // no end-of-block code before the data ran out
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // bytes flushed by earlier rounds may be read back
+            const uint32_t wb = (uint32_t)(pos >> 3) & ~3u;                   // window byte 0
+            ip_load_window(T.win, src, wb, total);
+            const uint32_t rel0 = (uint32_t)(pos - 8ull * wb);               // 0..31
+            const uint64_t rem = total_bits - pos;
+            const uint32_t span = rem < (uint64_t)(8 * IP_SPAN - 64) ? (uint32_t)rem : (uint32_t)(8 * IP_SPAN - 64);
+            uint32_t B = (span + 63u) / 64u;
+            if (B < 64u) B = 64u;                                             // a token is at most 48 bits: it never skips a segment
+            const uint32_t wend = rel0 + span;
+            const uint32_t seg_lo = rel0 + (uint32_t)lane * B;
+            const uint32_t seg_end = min(seg_lo + B, wend);
+            // first pass: the other lanes only have to fall into step by the END of their segment, so they start late in it
+            // (a lane that is not in step by then is caught by the next pass, like any other wrong start)
+            uint32_t st = min(seg_lo, wend);
+            if (lane && seg_end - st > IP_TAIL) st = seg_end - IP_TAIL;
+            IpSeg sg;
+            if (dbg) dbg[1]++;
+            for (int pass = 0; pass < 66; pass++) {
+                if (dbg) dbg[0]++;
+                sg = ip_decode_segment<false>(T, L, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
+                uint32_t ns = wave_prev(sg.cross, 0u);
+                if (lane == 0) ns = st;
+                const bool moved = ns != st;
+                st = ns;
+                if (!__ballot(moved)) break;
+            }
+            // which lanes hold real tokens of this block, and where their bytes go
+            const uint64_t eobs = __ballot(sg.eob != 0u && st < seg_end);
+            const int eob_lane = eobs ? __ffsll((long long)eobs) - 1 : 64;
+            const int m = eob_lane < 64 ? eob_lane + 1 : 64;                   // lanes [0, m) go out
+            const uint32_t n_act = st < seg_end && lane < m ? sg.nout : 0u;
+            const uint32_t incl = wave_incl_add(n_act);
+            const uint32_t round_out = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (round_out >= (1u << 20)) { if (dbg) dbg[2] = 1; return INF_NEED_FALLBACK; }   // (positions on the waiting lists have 20 bits)
+            if (o + round_out > cap) { if (dbg) dbg[2] = 2; return INF_NEED_FALLBACK; }        // payload slot too small: the old decoder reports the size needed
+            const uint32_t obase = incl - n_act;
+            uint8_t *dst = out + o;
+            // ---- output pass ----
+            IpSeg wr;
+            wr.ndef = 0; wr.bad = 0; wr.eob = 0; wr.eobpos = 0; wr.cross = st; wr.nout = 0;
+            if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, L, st, seg_end, obase, o, dst);
+            if (__ballot(wr.bad != 0u)) return INF_ERR_DATA;
+            if (__ballot(wr.ndef > (uint32_t)IP_DEF)) { if (dbg) dbg[2] = 3; return INF_NEED_FALLBACK; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            wave_sync();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // ---- waiting matches, in stream order, by the whole wave ----
+            {
+                uint64_t has = __ballot(wr.ndef != 0u);
+                while (has) {
+                    const int l = __ffsll((long long)has) - 1;
+                    has &= has - 1;
+                    const int nd_l = __builtin_amdgcn_readlane((int)wr.ndef, l);
+                    for (int k = 0; k < nd_l; k++) {
+                        const uint32_t a = __builtin_amdgcn_readfirstlane(T.def_a[l * IP_DEF + k]);
+                        const uint32_t dist = __builtin_amdgcn_readfirstlane(T.def_d[l * IP_DEF + k]);
+                        const uint32_t op = a & 0xFFFFFu, mlen = a >> 20;
+                        for (uint32_t j = lane; j < mlen; j += 64) dst[op + j] = dst[(int)op - (int)dist + (int)(j % dist)];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        wave_sync();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                }
+            }
+            o += round_out;
+            // where the round ended: behind the end-of-block code, or at the last emitted lane's last token
+            const uint32_t endbit = (uint32_t)__builtin_amdgcn_readlane((int)wr.cross, m - 1);
+            pos = 8ull * wb + endbit;
+            if (m - 1 == eob_lane) break;                                    // the block is done
+            wave_sync();
+        }
+        if (pos > total_bits) return INF_ERR_TRUNC;
+    }
+    *out_len = o;
+    {   // Adler-32 over the finished record (coalesced reads of bytes that are still in L2), in pieces short enough for 64-bit sums
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t from = 0; from < o; from += 1u << 20) {
+            const uint32_t n = min(o - from, 1u << 20);
+            uint32_t sa = 0;
+            uint64_t sb = 0;
+            for (uint32_t i = lane; i < n; i += 64) {
+                const uint32_t x = out[from + i];
+                sa += x;
+                sb += (uint64_t)(n - i) * x;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+            adB = (uint32_t)(((uint64_t)adB + (uint64_t)n * adA + sb) % 65521u);
+            adA = (adA + sa) % 65521u;
+        }
+    }
+    const uint8_t *t = in + in_len - 4;
+    const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+    if (((adB << 16) | adA) != want) return INF_ERR_ADLER;
+    return INF_OK;
+}
+
+}  // namespace s5

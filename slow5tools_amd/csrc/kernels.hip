@@ -16,6 +16,7 @@
 #include "lz_dev.h"
 #include "inflate_dev.h"
 #include "inflate_simt_dev.h"
+#include "inflate_par_dev.h"
 #include "zstd_dev.h"
 #include "zstd_enc_dev.h"
 #include "svb_dev.h"
@@ -498,6 +499,42 @@ __global__ __launch_bounds__(64) void k_inflate(s5gpu_decode_args_t a) {
     if (lane == 0) {
         a.fields[r].status = status;
         a.fields[r].payload_len = olen;
+    }
+}
+
+// K4, parallel inside the record (inflate_par_dev.h): one record per wave64, 64 self-synchronising segment decoders.  Default for
+// every batch size; what it declines (status INF_NEED_FALLBACK) the wave-per-record decoder redoes right behind it.
+__global__ __launch_bounds__(64) void k_inflate_par(s5gpu_decode_args_t a) {
+    __shared__ InflParShared T;
+    const uint32_t r = blockIdx.x;
+    const s5gpu_rec_desc_t d = a.desc[r];
+    uint32_t olen = 0;
+    uint32_t dbg[3] = {0, 0, 0};
+    const int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, a.sig_method == 99 ? dbg : nullptr);
+    if (lane_id() == 0) {
+        a.fields[r].status = status;
+        a.fields[r].payload_len = olen;
+        if (a.sig_method == 99) { a.fields[r].n_samples = dbg[0]; a.fields[r].read_id_len = dbg[1]; a.fields[r].read_group = dbg[2]; }   // tools/par_probe.py
+    }
+}
+__global__ __launch_bounds__(64) void k_inflate_fallback(s5gpu_decode_args_t a) {   // persistent blocks scan the statuses
+    __shared__ InflShared T;
+    const int lane = lane_id();
+    for (uint32_t base = blockIdx.x * 64u; base < a.n_recs; base += gridDim.x * 64u) {
+        const uint32_t mine = base + (uint32_t)lane;
+        uint64_t need = __ballot(mine < a.n_recs && a.fields[mine].status == INF_NEED_FALLBACK);
+        while (need) {
+            const uint32_t r = base + (uint32_t)(__ffsll((long long)need) - 1);
+            need &= need - 1;
+            const s5gpu_rec_desc_t d = a.desc[r];
+            uint32_t olen = 0;
+            const int status = zlib_inflate_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+            if (lane == 0) {
+                a.fields[r].status = status;
+                a.fields[r].payload_len = olen;
+            }
+            wave_sync();
+        }
     }
 }
 
@@ -1044,11 +1081,13 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
 
 // Small batches (a single slow5_get) take the wave-per-record decoder (lowest latency); from
 // g_inflate_simt_min records on, the lane-per-record decoder (highest throughput).
+static uint32_t g_inflate_par = 1;             // zlib records: the decoder that is parallel inside a record (0: the two older kernels, chosen by batch size)
 static uint32_t g_inflate_route = 1;           // big zlib batches: sort by length, long records to the wave kernel (below)
 static uint32_t g_inflate_simt_min = 24576;   // measured crossover on 4000-sample reads: 16384 wave 3.0 ms vs lane 4.2 ms, 32768 wave 5.8 vs lane 4.5
 extern "C" int s5gpu_set_option(const char *key, long value) {
     if (key && strcmp(key, "inflate_simt_min") == 0 && value >= 0) { g_inflate_simt_min = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_route") == 0 && (value == 0 || value == 1)) { g_inflate_route = (uint32_t)value; return S5GPU_OK; }
+    if (key && strcmp(key, "inflate_par") == 0 && value >= 0 && value <= 2) { g_inflate_par = (uint32_t)value; return S5GPU_OK; }   // 2 (tools): no fallback pass, declined records keep status 8
     if (s5host_set_option(key, value) == S5GPU_OK) return S5GPU_OK;
     s5gpu_set_error("s5gpu_set_option: unknown option");
     return S5GPU_ERR_ARG;
@@ -1100,6 +1139,10 @@ void s5kern_release_aux() {   // s5gpu_shutdown
 static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st) {
     if (a->rec_method == S5GPU_REC_ZSTD) {
         hipLaunchKernelGGL(k_zstd_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
+    } else if (a->rec_method == S5GPU_REC_ZLIB && g_inflate_par) {
+        hipLaunchKernelGGL(k_inflate_par, dim3(a->n_recs), dim3(64), 0, st, *a);
+        const uint32_t g = (a->n_recs + 63) / 64 < 4096 ? (a->n_recs + 63) / 64 : 4096;
+        if (g_inflate_par == 1) hipLaunchKernelGGL(k_inflate_fallback, dim3(g), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
         { const int rc = set_lds_attrs(); if (rc) return rc; }
         const uint32_t nb64 = (a->n_recs + 63) / 64;

@@ -240,15 +240,18 @@ def test_reencode_fixture_records(press, name):
 
 
 # ---------------------------------------------------------------- decode
-@pytest.fixture(params=["wave-per-record", "lane-per-record"])
+@pytest.fixture(params=["wave-per-record", "lane-per-record", "parallel-in-record"])
 def inflate_kernel(request, press):
-    """both inflate kernels must pass every decode test: force one or the other through the tuning knob"""
+    """all three inflate kernels must pass every decode test: force each through the tuning knobs (the default is the decoder
+    that is parallel inside a record, with the wave-per-record one behind it for what it declines)"""
     from slow5tools_amd import _lib
 
     L = _lib.lib()
+    _lib.check(L.s5gpu_set_option(b"inflate_par", 1 if request.param == "parallel-in-record" else 0))
     _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 1 if request.param == "lane-per-record" else 1 << 30))
     yield request.param
     _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 24576))
+    _lib.check(L.s5gpu_set_option(b"inflate_par", 1))
 
 
 @pytest.mark.parametrize("name", ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES + NONE_NONE_FIXTURES)
@@ -408,6 +411,7 @@ def test_big_mixed_length_batch_is_routed_by_length(press):
     recs = [r[8:] for r in press.encode_records(sigs, hdrs)]
     assert sum(len(r) >= 32768 for r in recs) >= 2 and sum(len(r) < 32768 for r in recs) > 1024
     _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 1), "set_option")
+    _lib.check(L.s5gpu_set_option(b"inflate_par", 0), "set_option")
     try:
         outs = []
         for route in (1, 0):
@@ -416,8 +420,10 @@ def test_big_mixed_length_batch_is_routed_by_length(press):
     finally:
         _lib.check(L.s5gpu_set_option(b"inflate_route", 1), "set_option")
         _lib.check(L.s5gpu_set_option(b"inflate_simt_min", 24576), "set_option")
-    for g, h, s in zip(outs[0], outs[1], sigs):
-        assert g["status"] == 0 and h["status"] == 0 and np.array_equal(g["signal"], s) and g["payload"] == h["payload"]
+        _lib.check(L.s5gpu_set_option(b"inflate_par", 1), "set_option")
+    outs.append(press.decode_records(recs))            # and the default: parallel inside the record, many rounds for the long ones
+    for g, h, q, s in zip(outs[0], outs[1], outs[2], sigs):
+        assert g["status"] == 0 and h["status"] == 0 and q["status"] == 0 and np.array_equal(g["signal"], s) and g["payload"] == h["payload"] == q["payload"]
 
 
 def test_host_batch_with_one_very_long_read_keeps_the_short_reads_fused(press):
@@ -481,7 +487,8 @@ def test_lz77_matcher_streams_inflate_with_stock_zlib_and_find_the_redundancy(pr
     # the same streams come back through both GPU inflate kernels
     from slow5tools_amd import _lib
 
-    for thr in (1, 1 << 30):
+    for par, thr in ((1, 24576), (0, 1), (0, 1 << 30)):
+        _lib.check(_lib.lib().s5gpu_set_option(b"inflate_par", par))
         _lib.check(_lib.lib().s5gpu_set_option(b"inflate_simt_min", thr))
         import ctypes as C
         L = _lib.lib(); n = len(outs); vp = C.c_void_p
@@ -494,6 +501,7 @@ def test_lz77_matcher_streams_inflate_with_stock_zlib_and_find_the_redundancy(pr
             assert C.string_at(out[i], ol[i]) == bufs[i], i
             libc.free(out[i])
     _lib.check(_lib.lib().s5gpu_set_option(b"inflate_simt_min", 24576))
+    _lib.check(_lib.lib().s5gpu_set_option(b"inflate_par", 1))
 
 
 def test_lz77_matcher_output_is_deterministic_and_independent_of_the_batch(press):

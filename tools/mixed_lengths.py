@@ -41,9 +41,12 @@ def run(tag, order, thr):
     f = fields.cpu().numpy().view(_lib.REC_FIELDS)
     ms = min(ts[1:])
     print("%-34s %.2f ms  %.2f M reads/s  %.1f G samples/s ok=%s" % (tag, ms, n_reads / ms / 1e3, ns.sum() / ms / 1e6, bool((f["status"] == 0).all())))
+_lib.check(L.s5gpu_set_option(b"inflate_par", 0), "opt")
 ident = np.arange(n_reads)
 _lib.check(L.s5gpu_set_option(b"inflate_route", 0), "opt")
 run("lane kernel alone, file order", ident, 0)
 run("wave kernel alone, file order", ident, 1 << 30)
 _lib.check(L.s5gpu_set_option(b"inflate_route", 1), "opt")
 run("routed: sorted lanes + long on waves", ident, 0)
+_lib.check(L.s5gpu_set_option(b"inflate_par", 1), "opt")
+run("parallel inside the record (default)", ident, 0)
