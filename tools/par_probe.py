@@ -1,7 +1,7 @@
 """Which records does the parallel-inside-the-record inflate decline?  Status histogram of k_inflate_par alone (no fallback pass)
 on synthetic reads.  python tools/par_probe.py [reads] [samples]"""
 import ctypes as C, sys, collections
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from slow5tools_amd import _lib, press
 L = _lib.lib(); _lib.check(L.s5gpu_init(0), "init")
