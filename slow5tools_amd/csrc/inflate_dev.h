@@ -185,7 +185,133 @@ __device__ __forceinline__ int infl_slow(BitIn &b, const uint16_t *count, const 
 // Code lengths of a fixed (type 1) or dynamic (type 2) block and the decode tables of both alphabets, by the whole wave with the
 // wave-uniform bit reader (the dynamic header is read out of the LDS window T.win, INF_IW bytes).  T: any struct with the table
 // fields of InflShared.  Returns INF_OK or an error status; nl / nd = number of lit/len and distance codes.
+// Canonical tables WITHOUT a lookup table (the parallel decoder): count[l] and the symbols in canonical order.  Counts by LDS
+// atomics; a symbol's place = first place of its length + the symbols of that length in front of it, and the ballots that count
+// those run over the lengths that OCCUR in a slice of 64 symbols (six or seven), not over all fifteen.
+__device__ __forceinline__ int infl_build_syms(const uint8_t *lens, int n, uint16_t *count, uint16_t *syms, uint32_t *scratch16) {
+    const int lane = lane_id();
+    if (lane < 16) scratch16[lane] = 0;
+    wave_sync();
+    for (int base = 0; base < n; base += 64) {
+        const int s = base + lane;
+        const uint32_t l = s < n ? lens[s] : 0u;
+        if (l) atomicAdd(&scratch16[l], 1u);
+    }
+    wave_sync();
+    // first place of every length, over-subscription check (lane l holds length l)
+    const uint32_t c = lane >= 1 && lane < 16 ? scratch16[lane] : 0u;
+    const uint32_t incl = wave_incl_add(c);
+    uint32_t next = incl - c;                                  // my length's first place
+    {
+        // Kraft: sum c_l * 2^(15 - l) <= 2^15
+        const uint32_t k = wave_sum(lane >= 1 && lane < 16 ? c << (15 - lane) : 0u);
+        if (k > 32768u) return 1;
+    }
+    if (lane < 16) count[lane] = (uint16_t)c;
+    for (int base = 0; base < n; base += 64) {
+        const int s = base + lane;
+        const uint32_t l = s < n ? lens[s] : 0u;
+        uint64_t rem = __ballot(l != 0u);
+        uint32_t place = 0;
+        while (rem) {
+            const uint32_t L0 = (uint32_t)__builtin_amdgcn_readlane((int)l, __ffsll((long long)rem) - 1);
+            const uint64_t m = __ballot(l == L0);
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)next, (int)L0);
+            if (l == L0) place = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if ((uint32_t)lane == L0) next += (uint32_t)__popcll(m);
+            rem &= ~m;
+        }
+        if (l) syms[place] = (uint16_t)s;
+    }
+    wave_sync();
+    return 0;
+}
+
+// The code-length sequence of a dynamic header (hlit + hdist lengths, run-length coded in the code-length code) decoded by the
+// whole wave instead of token by token on the uniform reader: lane L looks up the token that WOULD start L bits ahead of the
+// reader (code-length codes are at most 7 bits: the 7-bit table always resolves them), three rounds of pointer doubling across
+// the lanes find which of the 64 offsets the token chain really visits (8 tokens per scalar hop), a prefix sum of the tokens'
+// run lengths places them, and a "repeat previous" token finds the length it repeats through a ballot.  ~9 rounds per header
+// instead of ~150 dependent steps.  lens32 = T.lens + 32 must be zero (zero runs are not written).  Returns 0, or 1 bad data.
 template <class TT>
+__device__ __forceinline__ int infl_cl_sequence_wave(TT &T, BitIn &b, int tot) {
+    const int lane = lane_id();
+    int idx = 0;
+    uint32_t prev = 0xFFu;                       // last length written (0xFF: none yet)
+    while (idx < tot) {
+        bi_need32_u(b, T.win);
+        const uint32_t abit = 32u * b.wpos - (uint32_t)b.cnt + (uint32_t)lane;      // window bit address of my offset
+        const uint32_t w0 = T.win[abit >> 5], w1 = T.win[(abit >> 5) + 1];
+        const uint32_t bits = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (abit & 31));
+        const uint32_t e = T.dlut[bits & 127u];
+        const uint32_t clen = e >> 5, sym = e & 31u;
+        const uint32_t ext = sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u;
+        const uint32_t x = (bits >> clen) & ((1u << ext) - 1u);
+        const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + x : 3u + x;
+        const bool ok = clen != 0u;
+        // E: offset reached after up to 8 tokens from mine (an invalid code absorbs), R: offsets visited on the way
+        uint32_t E = ok ? (uint32_t)lane + clen + ext : (uint32_t)lane;
+        uint32_t Rlo = ok && lane < 32 ? 1u << lane : 0u, Rhi = ok && lane >= 32 ? 1u << (lane - 32) : 0u;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int src = (int)(E & 63u) << 2;
+            const uint32_t e2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)E);
+            const uint32_t r2lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)Rlo);
+            const uint32_t r2hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)Rhi);
+            if (E < 64u) { Rlo |= r2lo; Rhi |= r2hi; E = e2; }
+        }
+        const uint64_t okm = __ballot(ok);
+        uint32_t off = 0;
+        uint64_t visited = 0;
+        while ((okm >> off) & 1) {
+            visited |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)Rlo, (int)off) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)Rhi, (int)off) << 32);
+            off = (uint32_t)__builtin_amdgcn_readlane((int)E, (int)off);
+            if (off >= 64) break;
+        }
+        if (!visited) return 1;                                   // the token at the reader is not a code of the code-length code
+        const bool mine = (visited >> lane) & 1;
+        const uint32_t incl = wave_incl_add(mine ? rep : 0u);
+        // the sequence ends exactly at `tot` lengths: the first visited token that reaches it is the last one
+        const uint64_t reach = __ballot(mine && (uint32_t)idx + incl >= (uint32_t)tot);
+        int last_lane = 64;
+        if (reach) {
+            last_lane = __ffsll((long long)reach) - 1;
+            if ((uint32_t)idx + (uint32_t)__builtin_amdgcn_readlane((int)incl, last_lane) > (uint32_t)tot) return 1;   // a run over the end
+            visited &= last_lane == 63 ? ~0ull : (2ull << last_lane) - 1;
+            off = (uint32_t)__builtin_amdgcn_readlane((int)(lane + clen + ext), last_lane);
+        }
+        const bool use = (visited >> lane) & 1;
+        // the length a "repeat previous" token repeats: the nearest earlier token of this round that is not one itself, else the
+        // length carried in from the round before
+        const uint64_t defm = __ballot(use && sym != 16u);
+        const uint64_t below = defm & ((1ull << lane) - 1);
+        const int from = below ? 63 - __clzll((long long)below) : 0;
+        const uint32_t dv = sym < 16u ? sym : 0u;                  // 17 / 18: zero runs
+        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)dv);
+        const uint32_t val = sym != 16u ? dv : (below ? got : prev);
+        if (__ballot(use && sym == 16u && val == 0xFFu)) return 1;   // "repeat previous" with nothing in front of it
+        if (use && sym <= 16u && val != 0u) {
+            const uint32_t at = 32u + (uint32_t)idx + incl - rep;
+            for (uint32_t k = 0; k < rep; k++) T.lens[at + k] = (uint8_t)val;
+        }
+        // carry: the value of the round's last token
+        const int lastv = 63 - __clzll((long long)visited);
+        prev = (uint32_t)__builtin_amdgcn_readlane((int)val, lastv);
+        idx += (int)(uint32_t)__builtin_amdgcn_readlane((int)incl, lastv);
+        while (off) {                                             // advance the uniform reader
+            bi_need32_u(b, T.win);
+            const uint32_t t = off < 32u ? off : 32u;
+            bi_get(b, (int)t);
+            off -= t;
+        }
+    }
+    wave_sync();
+    return 0;
+}
+
+// LITLUT = 0: no lit/len lookup table (the parallel decoder resolves those codes by comparison); PARCL: the code-length sequence by
+// the whole wave (infl_cl_sequence_wave)
+template <class TT, int LITLUT = INF_LBITS, bool PARCL = false>
 __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint32_t total, uint64_t total_bits, BitIn &b, int type, int &nl, int &nd) {
     const int lane = lane_id();
     // ---- code lengths ----
@@ -220,7 +346,12 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
         // the code-length code reuses the distance tables' storage (built before the real ones)
         if (infl_build(T.lens, 19, T.dcount, T.dsym, T.dlut, 7, 5)) return INF_ERR_DATA;
         int bad = 0;
-        {
+        if (PARCL) {
+            for (int i = lane; i < 320; i += 64) T.lens[32 + i] = 0;
+            wave_sync();
+            bad = infl_cl_sequence_wave(T, b, nl + nd);
+            if (!bad && bi_consumed_bits(b) > total_bits) bad = 2;
+        } else {
             uint8_t prev = 0;
             int idx = 0;
             const int tot = nl + nd;
@@ -254,7 +385,8 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
     const uint8_t *ll = type == 1 ? T.lens : T.lens + 32;
     const uint8_t *dl = type == 1 ? T.lens + 288 : T.lens + 32 + nl;
     if (type == 2 && ll[256] == 0) return INF_ERR_DATA;
-    if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, INF_LBITS, 9)) return INF_ERR_DATA;
+    if (LITLUT == 0) { if (infl_build_syms(ll, nl, T.lcount, T.lsym, reinterpret_cast<uint32_t *>(T.llut))) return INF_ERR_DATA; }
+    else if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, LITLUT, 9)) return INF_ERR_DATA;
     if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, INF_DBITS, 5)) return INF_ERR_DATA;
     return INF_OK;
 }

@@ -31,7 +31,9 @@ namespace s5 {
 
 constexpr int IP_SPAN = 4096;          // compressed bytes per round
 constexpr int IP_DEF = 4;              // waiting matches per lane and round
+constexpr int IP_FILL = 128;           // runs (distance-1 matches) per round that the whole wave fills afterwards
 constexpr uint32_t IP_TAIL = 256;      // bits of its segment a lane walks in the first pass
+constexpr uint32_t IP_MINSEG = 384;    // shortest segment, bits
 constexpr int INF_NEED_FALLBACK = 8;
 
 struct InflParShared {                 // per wave: 8.3 KiB, so a CU holds all the waves the hardware allows
@@ -49,6 +51,9 @@ struct InflParShared {                 // per wave: 8.3 KiB, so a CU holds all t
     uint16_t dsym[32];
     uint16_t lcount[16], dcount[16];
     uint8_t lens[352];
+    uint32_t fill_a[IP_FILL];          // run: position in the round's output | length << 20
+    uint8_t fill_x[IP_FILL];           // ... its byte
+    uint32_t nfill;
 };
 static_assert(sizeof(uint32_t) * 64 * IP_DEF * 2 <= sizeof(uint16_t) << INF_LBITS, "the waiting lists fit the dead lookup table");
 static_assert(INF_IW <= IP_SPAN, "the header parser's window is the head of the round window");
@@ -92,15 +97,24 @@ struct IpSeg {            // what a lane learns about its segment
 // lane takes the same route for every code: the next 15 bits, first bit on top, are compared against the 15 left-justified
 // canonical limits — wave-uniform values, they live in scalar registers — and the code's length is the number of limits not
 // above it, plus one.  ~30 VALU instructions, no loop, no divergence; the symbol is one LDS read away.
-struct IpLimits { uint32_t lim[16]; };   // lim[l], l = 1..15: (first code of length l + codes of length l) << (15 - l)
+typedef short ip_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short ip_u2 __attribute__((ext_vector_type(2)));
+// limit of length l = (first code of length l + codes of length l) << (15 - l), left-justified in 15 bits; kept minus one, two
+// per word (lengths 2k+1 | 2k+2): eight packed 16-bit subtractions compare all fifteen, and no compare ever goes through VCC
+// (on gfx950 a VALU write of VCC needs wait states before a VALU read of it: the cmp / addc form paid a nop per limit)
+struct IpLimits { ip_s2 m1[8]; };
 // (carrying the index adjustment of the code's length along in the same compare chain — a conditional move per limit instead of
-// the T.ladj read — was measured: 9 % slower; the wave is short of VALU issue slots, not of LDS latency)
+// the T.ladj read — was measured: 9 % slower; the wave is short of issue slots, not of LDS latency)
 
 // Decode the tokens that start in [st, end) of the window.  WRITE: also produce the bytes, at dst + obase (dst = the record's
 // output at the round's first byte, o_abs0 bytes into the record; positions are relative to the round), and stop at the
-// end-of-block code.  The bytes go straight to HBM: a lane writes its own run of positions, and L2 collects the lines.  Without WRITE (the synchronisation passes) the walk goes on behind an end-of-block code: whatever follows
-// is another block's header, garbage to this decoder, but walking on keeps the lane's end position self-synchronised — a lane
-// that stopped there would cut the chain, and every lane behind it would have to be revived one pass at a time.
+// end-of-block code.  The bytes go straight to HBM: a lane writes its own run of positions, and L2 collects the lines.
+// Without WRITE (the synchronisation passes) the walk goes on behind an end-of-block code: whatever follows is another
+// block's header, garbage to this decoder, but walking on keeps the lane's end position self-synchronised — a lane that
+// stopped there would cut the chain, and every lane behind it would have to be revived one pass at a time.
+// The loop is wave-uniform (it runs while any lane has tokens left) and the length / distance part is entered only in steps in
+// which some lane stands at a length code: a lane that is done, or at a literal, rides along predicated instead of parking
+// behind nested exec masks.
 template <bool WRITE>
 __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLimits &L, uint32_t st, uint32_t end, uint32_t obase, uint32_t o_abs0,
                                                    uint8_t *dst) {
@@ -108,75 +122,95 @@ __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLim
     r.cross = st; r.nout = 0; r.eob = 0; r.eobpos = 0; r.bad = 0; r.ndef = 0;
     uint32_t p = st, o = obase;
     const int lane = lane_id();
-    uint32_t wait_end = obase;     // output position behind this lane's last waiting match: nothing in front of it is certain yet
-    bool any_wait = false;
-    while (p < end) {
-        uint32_t bits = ip_peek(T.win, p);
+    uint32_t wait_end = obase;     // output position behind this lane's last waiting match / pending run: nothing in front of it is in memory yet
+    uint32_t lastb = 0x100u;       // WRITE: the byte this lane produced last (0x100: not known — nothing yet, or a waiting match)
+    bool act = p < end;
+    while (__ballot(act)) {
+        const uint32_t pp = act ? p : 0u;
+        uint32_t bits = ip_peek(T.win, pp);
         const uint32_t v = __brev(bits) >> 17;
-        uint32_t len = 1;
+        const ip_s2 vv = {(short)v, (short)v};
+        ip_u2 acc = {0, 0};
 #pragma unroll
-        for (int l = 1; l <= 15; l++) len += v >= L.lim[l] ? 1u : 0u;
-        if (len > 15u) { r.bad = 1; break; }
-        uint32_t sym = T.lsym[(uint32_t)((int)(short)T.ladj[len] + (int)(v >> (15u - len)))];
-        p += len;
-        if (sym < 256u) {
-            if (WRITE) dst[o] = (uint8_t)sym;
-            o++;
-            continue;
-        }
-        if (sym == 256u) {
-            if (!r.eob) { r.eob = 1; r.eobpos = p; r.nout = o - obase; }
-            if (WRITE) break;
-            continue;
-        }
-        sym -= 257u;
-        if (sym >= 29u) { r.bad = 1; break; }
-        bits >>= len;
-        // length code: 3..10 one each, then 4 codes per extra-bit count, 258 on its own — arithmetic, no table in memory
-        const uint32_t le = sym < 8u || sym == 28u ? 0u : (sym >> 2) - 1u;
-        const uint32_t mlen = (sym == 28u ? 258u : sym < 8u ? 3u + sym : 3u + ((4u + (sym & 3u)) << le)) + (bits & ((1u << le) - 1u));
-        p += le;
-        bits = ip_peek(T.win, p);
-        const uint32_t de = T.dlut[bits & ((1u << INF_DBITS) - 1)];
-        uint32_t ds, dlen = de >> 5;
-        if (dlen) ds = de & 31u;
-        else {   // a distance code longer than the lookup table: canonical walk (rare)
-            uint32_t code = 0, first = 0, index = 0;
-            ds = 0xFFu;
-            for (dlen = 1; dlen <= 15; dlen++) {
-                code |= (bits >> (dlen - 1)) & 1u;
-                const uint32_t c = T.dcount[dlen];
-                if (code < first + c) { ds = T.dsym[index + (code - first)]; break; }
-                index += c;
-                first = (first + c) << 1;
-                code <<= 1;
-            }
-            if (ds == 0xFFu) { r.bad = 1; break; }
-        }
-        if (ds >= 30u) { r.bad = 1; break; }
-        p += dlen;
-        bits >>= dlen;
-        const uint32_t dx = ds < 4u ? 0u : (ds >> 1) - 1u;
-        const uint32_t mdist = (ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx)) + (bits & ((1u << dx) - 1u));
-        p += dx;
-        if (WRITE) {
-            if (mdist > o_abs0 + o) { r.bad = 1; break; }                       // reaches in front of the record
-            if (o >= mdist && o - mdist >= wait_end) {                         // the whole source is bytes this lane has written: copy now
-                if (mdist == 1) { const uint8_t x = dst[o - 1]; for (uint32_t k = 0; k < mlen; k++) dst[o + k] = x; }
-                else for (uint32_t k = 0; k < mlen; k++) dst[o + k] = dst[o + k - mdist];
-            } else {                                                           // another lane's bytes, or bytes that wait themselves
-                if (r.ndef < (uint32_t)IP_DEF) {
-                    T.def_a[lane * IP_DEF + r.ndef] = o | (mlen << 20);
-                    T.def_d[lane * IP_DEF + r.ndef] = mdist;
+        for (int k = 0; k < 8; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;   // sign bit: v >= limit
+        const uint32_t len = 1u + acc.x + acc.y;
+        const bool badlen = len > 15u;
+        const uint32_t lc = badlen ? 15u : len;
+        uint32_t idx = (uint32_t)((int)(short)T.ladj[lc] + (int)(v >> (15u - lc)));
+        idx = min(idx, 287u);                                   // (a walk from a wrong start may compute anything)
+        const uint32_t sym = badlen ? 0x3FFu : (uint32_t)T.lsym[idx];
+        const bool lit = sym < 256u;
+        uint32_t adv = len, nby = 1;
+        bool stop = false;
+        if (__ballot(act && !lit)) {
+            if (act && !lit) {
+                nby = 0;
+                if (sym == 256u) {
+                    if (!r.eob) { r.eob = 1; r.eobpos = p + len; r.nout = o - obase; }
+                    if (WRITE) stop = true;
+                } else if (sym - 257u >= 29u) {
+                    r.bad = 1; stop = true; adv = 0;
+                } else {
+                    const uint32_t ls = sym - 257u;
+                    uint32_t b2 = bits >> len;
+                    // length code: 3..10 one each, then 4 codes per extra-bit count, 258 on its own — arithmetic, no table in memory
+                    const uint32_t le = ls < 8u || ls == 28u ? 0u : (ls >> 2) - 1u;
+                    const uint32_t mlen = (ls == 28u ? 258u : ls < 8u ? 3u + ls : 3u + ((4u + (ls & 3u)) << le)) + (b2 & ((1u << le) - 1u));
+                    adv += le;
+                    b2 = ip_peek(T.win, p + adv);
+                    const uint32_t de = T.dlut[b2 & ((1u << INF_DBITS) - 1)];
+                    uint32_t ds, dlen = de >> 5;
+                    if (dlen) ds = de & 31u;
+                    else {   // a distance code longer than the lookup table: canonical walk (rare)
+                        uint32_t code = 0, first = 0, index = 0;
+                        ds = 0xFFu;
+                        for (dlen = 1; dlen <= 15; dlen++) {
+                            code |= (b2 >> (dlen - 1)) & 1u;
+                            const uint32_t c = T.dcount[dlen];
+                            if (code < first + c) { ds = T.dsym[index + (code - first)]; break; }
+                            index += c;
+                            first = (first + c) << 1;
+                            code <<= 1;
+                        }
+                    }
+                    if (ds >= 30u) { r.bad = 1; stop = true; adv = 0; }
+                    else {
+                        adv += dlen;
+                        b2 >>= dlen;
+                        const uint32_t dx = ds < 4u ? 0u : (ds >> 1) - 1u;
+                        const uint32_t mdist = (ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx)) + (b2 & ((1u << dx) - 1u));
+                        adv += dx;
+                        nby = mlen;
+                        if (WRITE) {
+                            if (mdist > o_abs0 + o) { r.bad = 1; stop = true; }                 // reaches in front of the record
+                            else if (mdist == 1 && lastb < 0x100u) {
+                                // a run of the byte this lane produced last.  A lane that filled it itself would keep the other 63 waiting
+                                // (the key bytes of an svb-zd record are runs of zeros, and they all sit in the first two segments): the run
+                                // goes on a list and the wave fills all of them at once after the pass
+                                const uint32_t slot = atomicAdd(&T.nfill, 1u);
+                                if (slot < (uint32_t)IP_FILL) { T.fill_a[slot] = o | (mlen << 20); T.fill_x[slot] = (uint8_t)lastb; wait_end = o + mlen; }
+                                else for (uint32_t k = 0; k < mlen; k++) dst[o + k] = (uint8_t)lastb;
+                            } else if (o >= mdist && o - mdist >= wait_end) {                  // the whole source is bytes this lane has written: copy now
+                                for (uint32_t k = 0; k < mlen; k++) dst[o + k] = dst[o + k - mdist];
+                                lastb = dst[o + mlen - 1];
+                            } else {                                                           // another lane's bytes, or bytes that wait themselves
+                                if (r.ndef < (uint32_t)IP_DEF) {
+                                    T.def_a[lane * IP_DEF + r.ndef] = o | (mlen << 20);
+                                    T.def_d[lane * IP_DEF + r.ndef] = mdist;
+                                }
+                                r.ndef++;
+                                wait_end = o + mlen;
+                                lastb = 0x100u;
+                            }
+                        }
+                    }
                 }
-                r.ndef++;
-                wait_end = o + mlen;
-                any_wait = true;
             }
         }
-        o += mlen;
+        if (WRITE && act && lit) { dst[o] = (uint8_t)sym; lastb = sym; }
+        if (act) { p += adv; o += nby; }
+        act = act && !stop && p < end;
     }
-    (void)any_wait;
     r.cross = p;
     if (!r.eob) r.nout = o - obase;
     return r;
@@ -203,10 +237,13 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
         // ---- block header, with the wave-uniform reader of inflate_dev.h on the head of the window ----
         BitIn b;
         b.buf = 0; b.cnt = 0; b.wpos = 0;
-        b.wbase = (uint32_t)(pos >> 3);
-        infl_load_window(T.win, src, b.wbase, total);
+        b.wbase = (uint32_t)(pos >> 3) & ~3u;
+        ip_load_window(T.win, src, b.wbase, total);                           // the whole round window: the tokens behind the header are in it
+        const uint32_t hdr_wb = b.wbase;
+        bool win_fresh = true;
         bi_need32_u(b, T.win);
-        bi_get(b, (int)(pos & 7));
+        bi_get(b, (int)(pos - 8ull * b.wbase));
+        bi_need32_u(b, T.win);
         const uint32_t hdr = bi_get(b, 3);
         if (bi_consumed_bits(b) > total_bits) return INF_ERR_TRUNC;
         last = hdr & 1;
@@ -226,34 +263,47 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             continue;
         }
         int nl, nd;
-        { const int rc = infl_block_tables(T, src, total, total_bits, b, type, nl, nd); if (rc != INF_OK) return rc; }
+        { const int rc = infl_block_tables<InflParShared, 0, true>(T, src, total, total_bits, b, type, nl, nd); if (rc != INF_OK) return rc; }
         pos = bi_consumed_bits(b);
+        if (b.wbase != hdr_wb) win_fresh = false;                             // (the header parser slid its window: never, for a window that starts at the header)
+        if (dbg && dbg[3] == 1) return INF_OK;       // tools/par_probe.py cut-off: block header and tables only
         IpLimits L;
         {   // canonical limits and index adjustments of the lit/len code (uniform)
             uint32_t first = 0, offs = 0;
-            L.lim[0] = 0;
+            int lm1[17];
 #pragma unroll
             for (int l = 1; l <= 15; l++) {
                 const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)T.lcount[l]);
-                L.lim[l] = (first + c) << (15 - l);
+                lm1[l] = (int)((first + c) << (15 - l)) - 1;
                 if (lane == l) T.ladj[l] = (uint16_t)(short)((int)offs - (int)first);
                 offs += c;
                 first = (first + c) << 1;
             }
+            lm1[16] = 0x7FFF;                                                 // there is no sixteenth length: never counted
+#pragma unroll
+            for (int k = 0; k < 8; k++) { L.m1[k].x = (short)lm1[2 * k + 1]; L.m1[k].y = (short)lm1[2 * k + 2]; }
             wave_sync();
         }
         // ---- the block's tokens, a window at a time ----
         for (;;) {
             if (pos >= total_bits) return INF_ERR_TRUNC;                      // no end-of-block code before the data ran out
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // bytes flushed by earlier rounds may be read back
-            const uint32_t wb = (uint32_t)(pos >> 3) & ~3u;                   // window byte 0
-            ip_load_window(T.win, src, wb, total);
-            const uint32_t rel0 = (uint32_t)(pos - 8ull * wb);               // 0..31
+            // window byte 0: the header's window again if the tokens start in its first quarter (the usual case: one load per record)
+            uint32_t wb = (uint32_t)(pos >> 3) & ~3u;
+            if (win_fresh && pos - 8ull * hdr_wb < 8ull * (IP_SPAN / 4)) wb = hdr_wb;
+            else ip_load_window(T.win, src, wb, total);
+            win_fresh = false;
+            const uint32_t rel0 = (uint32_t)(pos - 8ull * wb);               // 0..31, or up to a quarter of the window when it is the header's
             const uint64_t rem = total_bits - pos;
-            const uint32_t span = rem < (uint64_t)(8 * IP_SPAN - 64) ? (uint32_t)rem : (uint32_t)(8 * IP_SPAN - 64);
+            const uint32_t room = (uint32_t)(8 * IP_SPAN - 64) - (rel0 & ~31u);
+            const uint32_t span = rem < (uint64_t)room ? (uint32_t)rem : room;
             uint32_t B = (span + 63u) / 64u;
-            if (B < 64u) B = 64u;                                             // a token is at most 48 bits: it never skips a segment
+            if (B < IP_MINSEG) B = IP_MINSEG;                                 // a lane needs a few dozen codes to fall into step: short streams get
+                                                                              // fewer, longer segments (with 64-bit segments a record of 64 samples
+                                                                              // took 56 passes, one lane corrected per pass); and a token, at most
+                                                                              // 48 bits, never skips a segment
             const uint32_t wend = rel0 + span;
+            const int nseg = (int)((span + B - 1u) / B);                      // lanes [0, nseg) have a segment (>= 1: span > 0)
             const uint32_t seg_lo = rel0 + (uint32_t)lane * B;
             const uint32_t seg_end = min(seg_lo + B, wend);
             // first pass: the other lanes only have to fall into step by the END of their segment, so they start late in it
@@ -266,15 +316,16 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
                 if (dbg) dbg[0]++;
                 sg = ip_decode_segment<false>(T, L, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
                 uint32_t ns = wave_prev(sg.cross, 0u);
-                if (lane == 0) ns = st;
-                const bool moved = ns != st;
+                if (lane == 0 || lane >= nseg) ns = st;                      // (a lane without a segment has nothing to correct: left alone, or
+                const bool moved = ns != st;                                 // a change at the last segment's end would ripple on one lane per pass)
                 st = ns;
                 if (!__ballot(moved)) break;
             }
+            if (dbg && dbg[3] == 2) return INF_OK;   // cut-off: + window load and synchronisation passes
             // which lanes hold real tokens of this block, and where their bytes go
             const uint64_t eobs = __ballot(sg.eob != 0u && st < seg_end);
             const int eob_lane = eobs ? __ffsll((long long)eobs) - 1 : 64;
-            const int m = eob_lane < 64 ? eob_lane + 1 : 64;                   // lanes [0, m) go out
+            const int m = eob_lane < nseg ? eob_lane + 1 : nseg;               // lanes [0, m) go out
             const uint32_t n_act = st < seg_end && lane < m ? sg.nout : 0u;
             const uint32_t incl = wave_incl_add(n_act);
             const uint32_t round_out = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -283,11 +334,28 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             const uint32_t obase = incl - n_act;
             uint8_t *dst = out + o;
             // ---- output pass ----
+            if (lane == 0) T.nfill = 0;
+            wave_sync();
             IpSeg wr;
             wr.ndef = 0; wr.bad = 0; wr.eob = 0; wr.eobpos = 0; wr.cross = st; wr.nout = 0;
             if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, L, st, seg_end, obase, o, dst);
             if (__ballot(wr.bad != 0u)) return INF_ERR_DATA;
             if (__ballot(wr.ndef > (uint32_t)IP_DEF)) { if (dbg) dbg[2] = 3; return INF_NEED_FALLBACK; }
+            wave_sync();
+            {   // ---- runs: one per lane, 64 at a time (they depend on nothing) ----
+                const uint32_t nf = min(__builtin_amdgcn_readfirstlane(T.nfill), (uint32_t)IP_FILL);
+                for (uint32_t f0 = 0; f0 < nf; f0 += 64) {
+                    if (f0 + (uint32_t)lane < nf) {
+                        const uint32_t a = T.fill_a[f0 + lane], op = a & 0xFFFFFu, mlen = a >> 20;
+                        const uint32_t x = T.fill_x[f0 + lane], x4 = x * 0x01010101u;
+                        uint8_t *q = dst + op;
+                        uint32_t k = 0;
+                        while (k < mlen && ((uintptr_t)(q + k) & 3)) q[k++] = (uint8_t)x;
+                        for (; k + 4 <= mlen; k += 4) *reinterpret_cast<uint32_t *>(q + k) = x4;
+                        for (; k < mlen; k++) q[k] = (uint8_t)x;
+                    }
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             wave_sync();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -319,17 +387,22 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
         if (pos > total_bits) return INF_ERR_TRUNC;
     }
     *out_len = o;
-    {   // Adler-32 over the finished record (coalesced reads of bytes that are still in L2), in pieces short enough for 64-bit sums
+    if (dbg && dbg[3] == 3) return INF_OK;           // cut-off: everything but the Adler-32 pass
+    {   // Adler-32 over the finished record (coalesced dwords of bytes that are still in L2; the payload slot is 16-byte aligned),
+        // in pieces short enough for 64-bit sums: A += sum x, B += n A_old + sum (n - i) x_i
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (uint32_t from = 0; from < o; from += 1u << 20) {
             const uint32_t n = min(o - from, 1u << 20);
+            const uint32_t *w32 = reinterpret_cast<const uint32_t *>(out + from);
             uint32_t sa = 0;
             uint64_t sb = 0;
-            for (uint32_t i = lane; i < n; i += 64) {
-                const uint32_t x = out[from + i];
-                sa += x;
-                sb += (uint64_t)(n - i) * x;
+            for (uint32_t i = lane; i < n / 4; i += 64) {
+                const uint32_t w = w32[i];
+                const uint32_t s4 = __builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
+                sa += s4;
+                sb += (uint64_t)((n - 4 * i) * s4 - __builtin_amdgcn_udot4(w, 0x03020100u, 0u, false));
             }
+            if ((uint32_t)lane < (n & 3u)) { const uint32_t i = (n & ~3u) + lane; const uint32_t x = out[from + i]; sa += x; sb += (uint64_t)(n - i) * x; }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
             adB = (uint32_t)(((uint64_t)adB + (uint64_t)n * adA + sb) % 65521u);

@@ -509,8 +509,8 @@ __global__ __launch_bounds__(64) void k_inflate_par(s5gpu_decode_args_t a) {
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
-    uint32_t dbg[3] = {0, 0, 0};
-    const int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, a.sig_method == 99 ? dbg : nullptr);
+    uint32_t dbg[4] = {0, 0, 0, a.sig_method >= 90 && a.sig_method < 99 ? (uint32_t)(a.sig_method - 90) : 0u};   // 91..93: tools/par_probe.py cut-offs
+    const int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, a.sig_method >= 90 ? dbg : nullptr);
     if (lane_id() == 0) {
         a.fields[r].status = status;
         a.fields[r].payload_len = olen;

@@ -33,4 +33,11 @@ for mode in (2, 1, 0):
         fields.zero_(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); torch.cuda.synchronize()
         f = fields.cpu().numpy().view(_lib.REC_FIELDS)
         print("   sync passes per record: mean %.1f max %d; rounds mean %.2f; decline reasons %s" % (f["n_samples"].mean(), f["n_samples"].max(), f["read_id_len"].mean(), dict(collections.Counter(f["read_group"].tolist()))))
+        for cut, what in ((91, "block header + tables"), (92, "+ window, sync passes"), (93, "+ output pass, waiting matches"), (1, "+ Adler-32 (whole kernel)")):
+            a.sig_method = cut
+            tt = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); e1.record(); torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
+            print("   cut-off %-34s %.3f ms" % (what, min(tt)))
         a.sig_method = 1
