@@ -370,6 +370,10 @@ int main(int argc, char **argv) {
     if (argc > 4) to.signal_method = strcmp(argv[4], "none") == 0 ? SLOW5_COMPRESS_NONE : strcmp(argv[4], "ex-zd") == 0 ? SLOW5_COMPRESS_EX_ZD : SLOW5_COMPRESS_SVB_ZD;
     const int64_t K = argc > 5 ? atoll(argv[5]) : 4096;
 
+    {   /* several GPUs: S5VIEW_DEV_MASK (bit d = HIP device d) — every batch call then splits its records over them */
+        const char *dm = getenv("S5VIEW_DEV_MASK");
+        if (dm && strtoull(dm, NULL, 0) && s5gpu_init_mask(strtoull(dm, NULL, 0)) != S5GPU_OK) return die("cannot initialise the devices of S5VIEW_DEV_MASK");
+    }
     slow5_file_t *in = slow5_open(argv[1], "r");
     if (!in) return die("cannot open input");
     FILE *out = fopen(argv[2], "wb");

@@ -38,6 +38,18 @@ int slow5_gpu_hook_recompress(int64_t n, char **mem, size_t *bytes, int from_rec
                               int to_record_method, int to_signal_method, const uint32_t *new_read_group, int drop_aux,
                               void **out, size_t *out_len);
 
+/* The same worker on a CHUNK of a BLOW5 file, for a loop that reads the file in large pieces instead of one record at a time
+ * (examples/s5view.c; 17 GB/s of raw signal end to end against 2.9 with one fread + malloc per record): the n records sit framed
+ * — [u64 size][bytes] — in `chunk` exactly as read from disk, rec_pos[i] / rec_len[i] = offset and length of record i's bytes
+ * behind its size prefix; the re-encoded records come back as ONE contiguous stream in out_buf, the bytes the ordered write loop
+ * emits (out_off[i] = offset of record i, out_off[n] = total).  Buffers from slow5_gpu_hook_alloc (pinned) move at PCIe speed.
+ * -1 with out_off[0] > out_cap: the output needs that much room. */
+void *slow5_gpu_hook_alloc(size_t bytes);
+void slow5_gpu_hook_free(void *p);
+int slow5_gpu_hook_recompress_chunk(int64_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len,
+                                    int from_record_method, int from_signal_method, int to_record_method, int to_signal_method,
+                                    const uint32_t *new_read_group, int drop_aux, void *out_buf, size_t out_cap, uint64_t *out_off);
+
 /* The same worker when either side is SLOW5 ASCII.  aux_types_line: the header's column-types line ("#char*\tuint32_t\t...",
  * with or without the newline; NULL or no aux columns: none).  ASCII output lines end in '\n'. */
 int slow5_gpu_hook_convert(int64_t n, char **mem, size_t *bytes, int from_fmt, int from_record_method, int from_signal_method,

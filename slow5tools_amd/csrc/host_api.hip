@@ -86,6 +86,7 @@ static int init_devices_locked(const int *phys, int count) {
     }
     for (int i = 0; i < count; i++) g_dev[i].phys = resolved[i];
     g_ndev = count;
+    { const char *mm = getenv("S5GPU_MULTI_MIN"); if (mm && atoi(mm) >= 1) g_multi_min = (uint32_t)atoi(mm); }   // = option "multi_min_per_device"
     HIP_TRY(hipSetDevice(resolved[0]));
     return S5GPU_OK;
 }

@@ -344,6 +344,22 @@ int slow5_gpu_hook_recompress(int64_t n, char **mem, size_t *bytes, int from_rec
     return slow5_gpu_recompress_batch(n, mem, bytes, from, to, new_read_group, drop_aux, out, out_len);
 }
 
+void *slow5_gpu_hook_alloc(size_t bytes) { return s5gpu_host_alloc(bytes); }
+void slow5_gpu_hook_free(void *p) { s5gpu_host_free(p); }
+int slow5_gpu_hook_recompress_chunk(int64_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len,
+                                    int from_record_method, int from_signal_method, int to_record_method, int to_signal_method,
+                                    const uint32_t *new_read_group, int drop_aux, void *out_buf, size_t out_cap, uint64_t *out_off) {
+    if (n < 0 || n > 0xFFFFFFFFll || !hook_method_ok(from_record_method, from_signal_method) || !hook_method_ok(to_record_method, to_signal_method)) {
+        slow5_errno = SLOW5_ERR_PRESS;
+        return -1;
+    }
+    const int rc = s5gpu_recompress_stream((uint32_t)n, chunk, chunk_bytes, rec_pos, rec_len, rec_code((enum slow5_press_method)from_record_method),
+                                           sig_code((enum slow5_press_method)from_signal_method), rec_code((enum slow5_press_method)to_record_method),
+                                           sig_code((enum slow5_press_method)to_signal_method), new_read_group, drop_aux, out_buf, out_cap, out_off, NULL);
+    if (rc != S5GPU_OK) { slow5_errno = rc == S5GPU_ERR_NOMEM ? SLOW5_ERR_MEM : SLOW5_ERR_RECPARSE; return -1; }
+    return 0;
+}
+
 int slow5_gpu_hook_convert(int64_t n, char **mem, size_t *bytes, int from_fmt, int from_record_method, int from_signal_method,
                            const char *aux_types_line, int to_fmt, int to_record_method, int to_signal_method,
                            const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len) {

@@ -252,6 +252,12 @@ def test_chunked_view_pipeline_equals_the_per_record_pipeline(tmp_path, chunk_kb
     r = subprocess.run([S5VIEW, str(src), str(b), "zlib", "svb-zd", "64", "2"], capture_output=True, text=True, timeout=300, env=dict(os.environ, S5VIEW_PER_RECORD="1"))
     assert r.returncode == 0 and "chunked pipeline" not in r.stderr, r.stderr
     assert a.read_bytes() == b.read_bytes()
+    if chunk_kb == 517:                                               # the chunks over three (aliased) devices: same bytes
+        c = tmp_path / "three.blow5"
+        env3 = dict(env, S5GPU_ALIAS_DEVICES="1", S5VIEW_DEV_MASK="7", S5GPU_MULTI_MIN="8")
+        r = subprocess.run([S5VIEW, str(src), str(c), "zlib", "svb-zd", "4096", "2"], capture_output=True, text=True, timeout=300, env=env3)
+        assert r.returncode == 0 and "chunked pipeline" in r.stderr, r.stderr
+        assert c.read_bytes() == a.read_bytes()
     back = tmp_path / "back.blow5"                                   # and back: zlib + svb-zd -> none, through the chunks again
     r = subprocess.run([S5VIEW, str(a), str(back), "none", "none", "4096", "1"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
