@@ -154,14 +154,25 @@ __device__ __forceinline__ int infl_build(const uint8_t *lens, int n, uint16_t *
             next[b] += __popcll(mask);
             offs[b] += __popcll(mask);
         }
-        if (l) {
-            syms[idx] = (uint16_t)s;
-            if (l <= lutbits) {
-                const uint32_t rev = __brev(code) >> (32 - l);
-                const uint16_t ent = (uint16_t)(s | (l << lenshift));
-                for (uint32_t k = rev; k < (1u << lutbits); k += (1u << l)) lut[k] = ent;
-            }
+        if (l) syms[idx] = (uint16_t)s;
+        // lookup-table entries: a code of l bits owns 2^(lutbits - l) of them.  A lane that fills its own symbol's entries keeps
+        // the other 63 waiting for as long as the shortest code takes (the two 1-bit distance codes of a run-length stream: 128
+        // stores each): codes with 16 entries or more are filled by the whole wave, one symbol at a time, the rest per lane
+        const bool inl = l != 0 && l <= lutbits;
+        const uint32_t rev = inl ? __brev(code) >> (32 - l) : 0u;
+        const uint32_t ent = (uint32_t)s | ((uint32_t)l << lenshift);
+        const bool wide = inl && l + 4 <= lutbits;
+        uint64_t wm = __ballot(wide);
+        while (wm) {
+            const int from = __ffsll((long long)wm) - 1;
+            wm &= wm - 1;
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)rev, from);
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ent, from);
+            const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane(l, from);
+            for (uint32_t k = r0 + ((uint32_t)lane << l0); k < (1u << lutbits); k += 64u << l0) lut[k] = (uint16_t)e0;
         }
+        if (inl && !wide)
+            for (uint32_t k = rev; k < (1u << lutbits); k += (1u << l)) lut[k] = (uint16_t)ent;
     }
     wave_sync();
     return 0;
@@ -334,12 +345,20 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
         if (nl > 286 || nd > 30) return INF_ERR_DATA;
         if (lane < 19) T.lens[lane] = 0;
         wave_sync();
-        {
-            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-            for (int i = 0; i < ncl; i++) {
+        {   // the 3-bit lengths of the code-length code, one per lane, straight out of the window; then the reader steps over them
+            const uint32_t abit = 32u * b.wpos - (uint32_t)b.cnt + 3u * (uint32_t)lane;
+            if (lane < ncl) {
+                const uint32_t w0 = T.win[abit >> 5], w1 = T.win[(abit >> 5) + 1];
+                // order[]: 16 17 18 0 | 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (even lanes count up from 8, odd ones down from 7)
+                const int at = lane < 3 ? 16 + lane : lane == 3 ? 0 : (lane & 1) ? 7 - ((lane - 5) >> 1) : 8 + ((lane - 4) >> 1);
+                T.lens[at] = (uint8_t)(__builtin_amdgcn_alignbit(w1, w0, abit & 31u) & 7u);
+            }
+            uint32_t off = 3u * (uint32_t)ncl;
+            while (off) {
                 bi_need32_u(b, T.win);
-                const uint8_t v = (uint8_t)bi_get(b, 3);
-                if (lane == 0) T.lens[order[i]] = v;
+                const uint32_t t = off < 32u ? off : 32u;
+                bi_get(b, (int)t);
+                off -= t;
             }
         }
         wave_sync();

@@ -306,17 +306,20 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             const int nseg = (int)((span + B - 1u) / B);                      // lanes [0, nseg) have a segment (>= 1: span > 0)
             const uint32_t seg_lo = rel0 + (uint32_t)lane * B;
             const uint32_t seg_end = min(seg_lo + B, wend);
-            // first pass: the other lanes only have to fall into step by the END of their segment, so they start late in it
-            // (a lane that is not in step by then is caught by the next pass, like any other wrong start)
+            // first pass: a lane only has to fall into step by the END of its segment, so it starts late in it (a lane that is not in
+            // step by then is caught by the next pass, like any other wrong start).  Lane 0 too, although it knows its real start: the
+            // pass takes as long as its longest walk, and all this pass is for is a first guess of every other lane's start — lane 0
+            // walks its whole segment in the second pass, with everybody else
             uint32_t st = min(seg_lo, wend);
-            if (lane && seg_end - st > IP_TAIL) st = seg_end - IP_TAIL;
+            if (seg_end - st > IP_TAIL) st = seg_end - IP_TAIL;
             IpSeg sg;
             if (dbg) dbg[1]++;
-            for (int pass = 0; pass < 66; pass++) {
+            for (int pass = 0; pass < 67; pass++) {
                 if (dbg) dbg[0]++;
                 sg = ip_decode_segment<false>(T, L, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
                 uint32_t ns = wave_prev(sg.cross, 0u);
-                if (lane == 0 || lane >= nseg) ns = st;                      // (a lane without a segment has nothing to correct: left alone, or
+                if (lane == 0) ns = rel0;
+                else if (lane >= nseg) ns = st;                              // (a lane without a segment has nothing to correct: left alone, or
                 const bool moved = ns != st;                                 // a change at the last segment's end would ripple on one lane per pass)
                 st = ns;
                 if (!__ballot(moved)) break;
