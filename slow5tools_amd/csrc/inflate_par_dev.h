@@ -32,7 +32,10 @@ namespace s5 {
 constexpr int IP_SPAN = 4096;          // compressed bytes per round
 constexpr int IP_DEF = 4;              // waiting matches per lane and round
 constexpr int IP_FILL = 128;           // runs (distance-1 matches) per round that the whole wave fills afterwards
-constexpr uint32_t IP_TAIL = 256;      // bits of its segment a lane walks in the first pass
+#ifndef S5_IP_TAIL
+#define S5_IP_TAIL 224
+#endif
+constexpr uint32_t IP_TAIL = S5_IP_TAIL;   // bits of its segment a lane walks in the first pass
 constexpr uint32_t IP_MINSEG = 384;    // shortest segment, bits
 constexpr int INF_NEED_FALLBACK = 8;
 
@@ -134,9 +137,11 @@ __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLim
 #pragma unroll
         for (int k = 0; k < 8; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;   // sign bit: v >= limit
         const uint32_t len = 1u + acc.x + acc.y;
-        const bool badlen = len > 15u;
+        // len = 16: v lies behind the last code of an incomplete code.  The output pass reports it; a synchronisation pass
+        // just walks on (16 bits: T.ladj[16] is T.lsym[0], any value will do) — three instructions less per step
+        const bool badlen = WRITE && len > 15u;
         const uint32_t lc = badlen ? 15u : len;
-        uint32_t idx = (uint32_t)((int)(short)T.ladj[lc] + (int)(v >> (15u - lc)));
+        uint32_t idx = (uint32_t)((int)(short)T.ladj[lc] + (int)(v >> ((15u - lc) & 31u)));
         idx = min(idx, 287u);                                   // (a walk from a wrong start may compute anything)
         const uint32_t sym = badlen ? 0x3FFu : (uint32_t)T.lsym[idx];
         const bool lit = sym < 256u;
