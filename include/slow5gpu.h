@@ -138,7 +138,9 @@ int s5gpu_device_count(void);
  * of >= 32 KiB go to the wave-per-record kernel beside the lane kernel (real runs have read lengths spread over two decades).
  * In inflate-only calls fields[i].reserved, fields[0..128].read_group and fields[128].aux_len are then left holding routing
  * scratch (s5gpu_decode_dev overwrites all of them with the parsed fields).
- * "multi_min_per_device" (default 1024): a host batch of fewer than this many records per device stays on the first device. */
+ * "multi_min_per_device" (default 1024): a host batch of fewer than this many records per device stays on the first device.
+ * "zstd_sequences" (0/1, default 1): the zstd encoder sends runs of >= 5 equal bytes as one literal + one match at the repeat
+ * offset (predefined FSE tables); 0 = literals-only frames cut at the record's seams (round 1; ~2 % larger records). */
 int s5gpu_set_option(const char *key, long value);
 
 /* ---- device-resident entry points (asynchronous on `hip_stream`, a hipStream_t; NULL = default) ---- */

@@ -48,7 +48,10 @@ struct EncParams {
     uint32_t obuf_words;   // LDS words of the bit buffer
     uint32_t pay_cap;      // LDS bytes of the payload buffer (fused) / staging buffer (staged)
     uint32_t dbg;          // tools/ only (env S5GPU_DEBUG_STAGE): 1 = stop after the payload is built
+    uint32_t zseq;         // zstd records: runs as sequences (option "zstd_sequences", default 1; 0 = the literals-only frames of round 1)
 };
+
+static uint32_t g_zstd_sequences = 1;   // zstd encoder: runs as sequences (zstd_enc_dev.h); 0 = literals-only frames (option "zstd_sequences")
 
 __device__ __forceinline__ uint32_t payload_bound_dev(const s5gpu_read_desc_t &d, int sig_method) {
     const uint32_t n = d.n_samples;
@@ -402,12 +405,12 @@ __global__ __launch_bounds__(NT, 6) void k_zstd_fused(EncParams p) {
     }
     __syncthreads();
     if (p.dbg == 9) { if (threadIdx.x == 0) p.a.out_len[r] = plen; return; }   // payload only
-    uint32_t split = 0;   // svb-zd: head + key bytes in a block of their own
-    if (!EXZD && p.a.sig_method == S5GPU_SIG_SVB_ZD) {
+    uint32_t split = 0;   // literals-only frames of an svb-zd record: head + key bytes in a block of their own (with sequences the key bytes' runs are matches)
+    if (!EXZD && !p.zseq && p.a.sig_method == S5GPU_SIG_SVB_ZD) {
         const uint32_t at = d.hdr_len + 12 + ((d.n_samples + 3) >> 2);
         if (at >= 256 && at + 256 <= plen && at <= (uint32_t)DEFL_BLK) split = at;
     }
-    const uint32_t total = zstd_record<false>(S, obuf, p.obuf_words, pay, nullptr, plen, p.a.slots + d.out_off, p.dbg, split, split ? d.hdr_len + 12 : 0u);
+    const uint32_t total = zstd_record<false>(S, obuf, p.obuf_words, pay, nullptr, plen, p.a.slots + d.out_off, p.dbg, split, split ? d.hdr_len + 12 : 0u, p.zseq != 0);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
 }
 // ... and staged: a parked payload, 16 KiB block at a time through LDS (k_deflate_staged's twin)
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(NT) void k_zstd_staged(EncParams p, int use_list) {
         uint8_t *out = p.a.slots + d.out_off;
         const uint32_t plen = p.a.out_len[r];
         __syncthreads();
-        const uint32_t total = zstd_record<true>(S, obuf, p.obuf_words, out + park_offset(d, p.a.sig_method), stage, plen, out);
+        const uint32_t total = zstd_record<true>(S, obuf, p.obuf_words, out + park_offset(d, p.a.sig_method), stage, plen, out, 0, 0, 0, p.zseq != 0);
         if (threadIdx.x == 0) p.a.out_len[r] = total;
     }
 }
@@ -953,6 +956,7 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     EncParams p;
     p.a = *a;
     p.dbg = getenv("S5GPU_DEBUG_STAGE") ? (uint32_t)atoi(getenv("S5GPU_DEBUG_STAGE")) : 0;
+    p.zseq = g_zstd_sequences;
     if (a->rec_method == S5GPU_REC_NONE) {
         p.obuf_words = 0; p.pay_cap = 0;
         hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 1);
@@ -1041,7 +1045,7 @@ extern "C" int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *a, uint8_t *st
     hipStream_t st = (hipStream_t)stream_;
     EncParams p;
     p.a = *a;
-    p.dbg = 0;
+    p.dbg = 0; p.zseq = g_zstd_sequences;
     const uint32_t cap = fused_cap(a);
     p.pay_cap = cap;
     p.obuf_words = (cap + 64 > B_BYTES ? cap + 64 : B_BYTES) / 4;
@@ -1067,7 +1071,7 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
     if ((rc = set_lds_attrs())) return rc;
     EncParams p;
     p.a = *a;
-    p.dbg = 0;
+    p.dbg = 0; p.zseq = g_zstd_sequences;
     p.obuf_words = (DEFL_BLK + 64) / 4;
     p.pay_cap = DEFL_BLK;
     const size_t lds = S_BYTES + 4ull * p.obuf_words + DEFL_BLK;
@@ -1087,6 +1091,7 @@ static uint32_t g_inflate_simt_min = 24576;   // measured crossover on 4000-samp
 extern "C" int s5gpu_set_option(const char *key, long value) {
     if (key && strcmp(key, "inflate_simt_min") == 0 && value >= 0) { g_inflate_simt_min = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_route") == 0 && (value == 0 || value == 1)) { g_inflate_route = (uint32_t)value; return S5GPU_OK; }
+    if (key && strcmp(key, "zstd_sequences") == 0 && (value == 0 || value == 1)) { g_zstd_sequences = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_par") == 0 && value >= 0 && value <= 2) { g_inflate_par = (uint32_t)value; return S5GPU_OK; }   // 2 (tools): no fallback pass, declined records keep status 8
     if (s5host_set_option(key, value) == S5GPU_OK) return S5GPU_OK;
     s5gpu_set_error("s5gpu_set_option: unknown option");
@@ -1195,7 +1200,7 @@ extern "C" int s5gpu_svbzd_encode_dev(const s5gpu_encode_args_t *a, void *stream
     if (a->n_reads == 0) return S5GPU_OK;
     EncParams p;
     p.a = *a;
-    p.dbg = 0;
+    p.dbg = 0; p.zseq = g_zstd_sequences;
     p.obuf_words = 0;
     // LDS for one blob at ~1.55 bytes/sample (max_payload is the 3.25 bytes/sample bound), at most 64 KiB
     uint64_t cap = a->lds_payload_cap ? a->lds_payload_cap : (uint64_t)a->max_payload * 155 / 325 + 128;

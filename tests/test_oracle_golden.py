@@ -4,6 +4,7 @@ Mirrors the byte-identical diffs of the reference's shell tests:
   test/test_view.sh:90-165 (all codec combos, both directions), test/test_merge.sh:131-140,
   test/test_index.sh cases 3-4 (record offsets/sizes).
 """
+import ctypes as C
 import struct
 import zlib
 
@@ -430,3 +431,42 @@ def test_zstd_literals_only_frames_are_valid():
     b5 = Blow5(golden("exp_1_lossless_zstd_svb_v0.2.0.blow5"))
     p = ob.zstd_decompress(b5.records[0])
     assert len(ob.zstd_literals_compress(p)) < 1.04 * len(b5.records[0])     # literals only: within 4 % of the reference's frame
+
+
+def test_zstd_sequence_tables_of_the_device_are_the_predefined_ones():
+    """csrc/zstd_seq_tables.h is generated (tools/gen_zstd_seq_tables.py); the generator, the oracle's run-time construction
+    (oracle/zstd_enc.c, whose frames libzstd reads) and the committed header must agree"""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_zstd_seq_tables as g
+    assert open(os.path.join(root, "slow5tools_amd", "csrc", "zstd_seq_tables.h")).read() == g.text()
+    L = ob.lib()
+    for which, norm in ((0, g.LL), (1, g.ML)):
+        nx, dnb, dfs = (C.c_uint16 * 64)(), (C.c_int32 * 53)(), (C.c_int32 * 53)()
+        n = L.s5o_zstd_seq_ctable(which, nx, dnb, dfs)
+        a, b, c = g.ctable(norm)
+        assert n == len(norm) and list(nx) == a and list(dnb)[:n] == b and list(dfs)[:n] == c
+
+
+@needs_zstd
+def test_zstd_twin_run_sequences():
+    """the run sequences of oracle/zstd_enc.c: runs of every length around the threshold, > 127 sequences, long literal and
+    match lengths; and the gain on a real record (the key bytes)"""
+    rng = np.random.default_rng(14)
+    for n in (64, 300, 5000, 16384, 50000):
+        for R in (4, 5, 6, 9, 40, 300):
+            pat = bytes([5]) * R + bytes(rng.integers(6, 256, 3, dtype=np.uint8))
+            d = (pat * (n // len(pat) + 1))[:n]
+            f = ob.zstd_literals_compress(d)
+            assert ob.zstd_decompress(f) == d and ob.zstd_restated_decompress(f, len(d)) == d
+        d = bytes(np.repeat(rng.integers(0, 256, n, dtype=np.uint8), rng.integers(1, 30, n))[:n])
+        f = ob.zstd_literals_compress(d)
+        assert ob.zstd_decompress(f) == d and ob.zstd_restated_decompress(f, len(d)) == d
+    tot = ref = 0
+    for i in range(10):
+        sig = ob.synth_read(0x5105, i, 4000)
+        rec, keep = ob.make_rec(ob.synth_read_id(i), 0, 8192.0, 3.0, 1400.0, 4000.0, sig)
+        p = ob.rec_pack(rec, ob.SIG_SVB_ZD)
+        tot += len(ob.zstd_literals_compress(p)); ref += len(ob.zstd_compress(p, 1))
+    assert tot < 1.003 * ref
