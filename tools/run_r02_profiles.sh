@@ -1,14 +1,23 @@
 #!/bin/bash
-# end-of-round profile set (run on the GPU box): kernel stats of every bench mode + PMC passes of k_encode_stream; results under gpurun_out/r02p/
+# end-of-round profile set (run on the GPU box): kernel stats of every bench mode, PMC passes of k_encode_stream and of the inflate
+# kernels, the side tools' own outputs; results under gpurun_out/r02p/.  Then, back in the container: python tools/install_profiles.py
 set -x
-mkdir -p gpurun_out/r02p
-python bench.py > gpurun_out/r02p/bench_default.json 2> gpurun_out/r02p/bench_default.err
+O=gpurun_out/r02p
+rm -rf $O; mkdir -p $O
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --decode > $O/bench_decode.json 2> $O/bench_decode.err
 tools/kstats.sh r02p/enc python bench.py --no-long --cpu-seconds 0
 tools/kstats.sh r02p/svb python bench.py --svb-only --cpu-seconds 0
 tools/kstats.sh r02p/long python bench.py --long --cpu-seconds 0
 tools/kstats.sh r02p/mixed python bench.py --mixed --cpu-seconds 0
-tools/kstats.sh r02p/decode python bench.py --decode
+tools/kstats.sh r02p/decode python bench.py --decode --cpu-seconds 0
 tools/kstats.sh r02p/zstd python tools/zstd_time.py 1000000 4000
 tools/kstats.sh r02p/lz python tools/lz_time.py 65536 4000
-KERNEL=k_encode_stream tools/pmc.sh 400000 > gpurun_out/r02p/pmc_k_encode_stream.txt 2>&1
-tail -30 gpurun_out/r02p/pmc_k_encode_stream.txt
+tools/kstats.sh r02p/mixed_decode python tools/mixed_lengths.py
+python tools/par_probe.py 262144 4000 > $O/par_probe_262144.txt 2>&1
+python tools/par_probe.py 4096 4000 > $O/par_probe_4096.txt 2>&1
+python tools/e2e_view.py > $O/e2e_view.txt 2>&1
+python tools/pcie_rate.py > $O/pcie_rate.txt 2>&1
+bash tools/pmc_inflate.sh 65536 4000 > $O/pmc_k_inflate_par.txt 2>&1
+( echo "# tools/pmc.sh 400000 (KERNEL=k_encode_stream): per-launch averages over 400000 reads of 4000 samples; FETCH_SIZE / WRITE_SIZE in KiB"; KERNEL=k_encode_stream tools/pmc.sh 400000 ) > $O/pmc_k_encode_stream.txt 2>&1
+tail -30 $O/pmc_k_encode_stream.txt
