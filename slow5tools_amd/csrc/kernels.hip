@@ -507,17 +507,65 @@ __global__ __launch_bounds__(64) void k_inflate(s5gpu_decode_args_t a) {
 
 // K4, parallel inside the record (inflate_par_dev.h): one record per wave64, 64 self-synchronising segment decoders.  Default for
 // every batch size; what it declines (status INF_NEED_FALLBACK) the wave-per-record decoder redoes right behind it.
+// UNPACK (s5gpu_decode_dev on svb-zd records): the wave that inflated a record also parses it and decodes its signal — the payload
+// it just wrote is in L2, the window is free as a stage for the data bytes, and the chain of dependent loads a separate kernel
+// starts with (fields -> descriptor -> three length fields of the payload) is gone.  fields.reserved = 1 marks such a record;
+// k_unpack_rest does what is left (records the fallback decoder inflated) and clears the marks.
+static_assert(sizeof(InflParShared::win) >= SVB_WSTAGE, "the inflate window doubles as the svb-zd stage");
+__device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, const s5gpu_rec_desc_t &d, s5gpu_rec_fields_t &f, uint32_t plen, uint8_t *stage) {
+    const uint8_t *pay = a.payload + d.pay_off;
+    if (plen < 2) return 7;
+    const uint32_t idl = (uint32_t)ld_le(pay, 2), hl = 2 + idl + 4 + 32;
+    if ((uint64_t)hl + 8 > plen) return 7;
+    const uint64_t L = ld_le(pay + hl, 8);
+    const uint8_t *sigp = pay + hl + 8;
+    const uint32_t avail = plen - hl - 8;
+    if (L > avail || L < 4) return 7;
+    const uint32_t n = (uint32_t)ld_le(sigp, 4), nk = (n + 3) >> 2;
+    if ((uint64_t)4 + nk > L) return 7;
+    if (n > d.sig_cap) { if (lane_id() == 0) f.n_samples = n; return 6; }
+    const uint8_t *keys = sigp + 4, *data = keys + nk, *dend = sigp + L;
+    int16_t *out = a.sig_out + d.sig_off;
+    uint32_t total = 0;
+    int carry = 0, err = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += SVB_WTILE)
+        total += svb_decode_tile_wave(keys + (t0 >> 2), data + total, dend, n, t0, out, carry, err, stage);
+    if (__ballot(err != 0) || 4 + nk + total != L) return 7;
+    if (lane_id() == 0) {
+        f.n_samples = n;
+        f.read_id_len = idl;
+        f.read_group = (uint32_t)ld_le(pay + 2 + idl, 4);
+        uint64_t v[4];
+        for (int q = 0; q < 4; q++) v[q] = ld_le(pay + 2 + idl + 4 + 8 * q, 8);
+        f.digitisation = __longlong_as_double((long long)v[0]);
+        f.offset = __longlong_as_double((long long)v[1]);
+        f.range = __longlong_as_double((long long)v[2]);
+        f.sampling_rate = __longlong_as_double((long long)v[3]);
+        f.aux_off = hl + 8 + (uint32_t)L;
+        f.aux_len = plen - (hl + 8 + (uint32_t)L);
+    }
+    return 0;
+}
+template <bool UNPACK>
 __global__ __launch_bounds__(64) void k_inflate_par(s5gpu_decode_args_t a) {
     __shared__ InflParShared T;
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
     uint32_t dbg[4] = {0, 0, 0, a.sig_method >= 90 && a.sig_method < 99 ? (uint32_t)(a.sig_method - 90) : 0u};   // 91..93: tools/par_probe.py cut-offs
-    const int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, a.sig_method >= 90 ? dbg : nullptr);
+    int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, !UNPACK && a.sig_method >= 90 ? dbg : nullptr);
+    uint32_t mark = 0;
+    if (UNPACK && status == 0) {
+        wave_sync();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        status = unpack_svbzd_wave(a, d, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
+        mark = 1;
+    }
     if (lane_id() == 0) {
         a.fields[r].status = status;
         a.fields[r].payload_len = olen;
-        if (a.sig_method == 99) { a.fields[r].n_samples = dbg[0]; a.fields[r].read_id_len = dbg[1]; a.fields[r].read_group = dbg[2]; }   // tools/par_probe.py
+        if (UNPACK) a.fields[r].reserved = mark;
+        if (!UNPACK && a.sig_method == 99) { a.fields[r].n_samples = dbg[0]; a.fields[r].read_id_len = dbg[1]; a.fields[r].read_group = dbg[2]; }   // tools/par_probe.py
     }
 }
 __global__ __launch_bounds__(64) void k_inflate_fallback(s5gpu_decode_args_t a) {   // persistent blocks scan the statuses
@@ -655,11 +703,7 @@ __global__ __launch_bounds__(NT) void k_route_scatter(s5gpu_decode_args_t a) {  
 }
 
 // K2 + field parse: payload -> primary fields + int16 raw_signal (slow5_rec_depress_parse, a7/a8)
-__global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
-    __shared__ uint32_t ws[16];
-    __shared__ __attribute__((aligned(16))) uint8_t svb_stage[SVB_STAGE];
-    __shared__ int s_err;
-    const uint32_t r = blockIdx.x;
+__device__ __forceinline__ void unpack_record_wg(const s5gpu_decode_args_t &a, uint32_t r, uint32_t *ws, uint8_t *svb_stage, int &s_err) {
     const int tid = threadIdx.x;
     s5gpu_rec_fields_t &f = a.fields[r];
     if (f.status != 0) return;
@@ -723,6 +767,38 @@ __global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
         f.aux_off = hl + 8 + sig_bytes;
         f.aux_len = plen - (hl + 8 + sig_bytes);
         f.reserved = 0;   // scratch of the routing kernels
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
+    __shared__ uint32_t ws[16];
+    __shared__ __attribute__((aligned(16))) uint8_t svb_stage[SVB_STAGE];
+    __shared__ int s_err;
+    unpack_record_wg(a, blockIdx.x, ws, svb_stage, s_err);
+}
+// ... behind k_inflate_par<true>: only the records that kernel did not unpack itself (fields.reserved == 0: the ones the fallback
+// decoder inflated); persistent workgroups look at 256 records at a time, and every mark is cleared on the way
+__global__ __launch_bounds__(NT) void k_unpack_rest(s5gpu_decode_args_t a) {
+    __shared__ uint32_t ws[16];
+    __shared__ __attribute__((aligned(16))) uint8_t svb_stage[SVB_STAGE];
+    __shared__ int s_err;
+    __shared__ uint32_t list[NT], cnt;
+    const int tid = threadIdx.x;
+    for (uint32_t base = blockIdx.x * NT; base < a.n_recs; base += gridDim.x * NT) {
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        const uint32_t mine = base + (uint32_t)tid;
+        if (mine < a.n_recs) {
+            if (a.fields[mine].reserved) a.fields[mine].reserved = 0;
+            else list[atomicAdd(&cnt, 1u)] = mine;
+        }
+        __syncthreads();
+        const uint32_t c = cnt;
+        for (uint32_t i = 0; i < c; i++) {
+            unpack_record_wg(a, list[i], ws, svb_stage, s_err);
+            __syncthreads();
+        }
+        __syncthreads();
     }
 }
 
@@ -1085,6 +1161,7 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
 
 // Small batches (a single slow5_get) take the wave-per-record decoder (lowest latency); from
 // g_inflate_simt_min records on, the lane-per-record decoder (highest throughput).
+static uint32_t g_unpack_fused = 1;            // s5gpu_decode_dev, zlib + svb-zd: k_inflate_par unpacks the records it inflates (0: always k_unpack)
 static uint32_t g_inflate_par = 1;             // zlib records: the decoder that is parallel inside a record (0: the two older kernels, chosen by batch size)
 static uint32_t g_inflate_route = 1;           // big zlib batches: sort by length, long records to the wave kernel (below)
 static uint32_t g_inflate_simt_min = 24576;   // measured crossover on 4000-sample reads: 16384 wave 3.0 ms vs lane 4.2 ms, 32768 wave 5.8 vs lane 4.5
@@ -1092,6 +1169,7 @@ extern "C" int s5gpu_set_option(const char *key, long value) {
     if (key && strcmp(key, "inflate_simt_min") == 0 && value >= 0) { g_inflate_simt_min = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_route") == 0 && (value == 0 || value == 1)) { g_inflate_route = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "zstd_sequences") == 0 && (value == 0 || value == 1)) { g_zstd_sequences = (uint32_t)value; return S5GPU_OK; }
+    if (key && strcmp(key, "unpack_fused") == 0 && (value == 0 || value == 1)) { g_unpack_fused = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_par") == 0 && value >= 0 && value <= 2) { g_inflate_par = (uint32_t)value; return S5GPU_OK; }   // 2 (tools): no fallback pass, declined records keep status 8
     if (s5host_set_option(key, value) == S5GPU_OK) return S5GPU_OK;
     s5gpu_set_error("s5gpu_set_option: unknown option");
@@ -1141,11 +1219,12 @@ void s5kern_release_aux() {   // s5gpu_shutdown
     g_aux_all.clear();    // (a few dozen bytes per thread and shutdown: not freed, a thread-local may still point at it)
 }
 
-static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st) {
+static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, bool unpack = false) {   // unpack: k_inflate_par also parses + decodes (svb-zd)
     if (a->rec_method == S5GPU_REC_ZSTD) {
         hipLaunchKernelGGL(k_zstd_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && g_inflate_par) {
-        hipLaunchKernelGGL(k_inflate_par, dim3(a->n_recs), dim3(64), 0, st, *a);
+        if (unpack) hipLaunchKernelGGL(k_inflate_par<true>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        else hipLaunchKernelGGL(k_inflate_par<false>, dim3(a->n_recs), dim3(64), 0, st, *a);
         const uint32_t g = (a->n_recs + 63) / 64 < 4096 ? (a->n_recs + 63) / 64 : 4096;
         if (g_inflate_par == 1) hipLaunchKernelGGL(k_inflate_fallback, dim3(g), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
@@ -1224,10 +1303,13 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
     }
     if (a->n_recs == 0) return S5GPU_OK;
     hipStream_t st = (hipStream_t)stream_;
-    int rc = launch_inflate(a, st);
+    // zlib + svb-zd with the default inflate kernel: the wave that inflates a record unpacks it too (k_inflate_par<true>)
+    const bool fused = a->rec_method == S5GPU_REC_ZLIB && a->sig_method == S5GPU_SIG_SVB_ZD && g_inflate_par == 1 && g_unpack_fused;
+    int rc = launch_inflate(a, st, fused);
     if (rc) return rc;
     // the ex-zd decoder keeps one chunk of exceptions and a flag map in (dynamic) LDS; the other signal formats need none
-    hipLaunchKernelGGL(k_unpack, dim3(a->n_recs), dim3(NT), a->sig_method == S5GPU_SIG_EX_ZD ? sizeof(ExzdScratch) : 0, st, *a);
+    if (fused) hipLaunchKernelGGL(k_unpack_rest, dim3((a->n_recs + NT - 1) / NT < 2048 ? (a->n_recs + NT - 1) / NT : 2048), dim3(NT), 0, st, *a);
+    else hipLaunchKernelGGL(k_unpack, dim3(a->n_recs), dim3(NT), a->sig_method == S5GPU_SIG_EX_ZD ? sizeof(ExzdScratch) : 0, st, *a);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }

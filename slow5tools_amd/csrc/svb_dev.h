@@ -176,4 +176,82 @@ __device__ __forceinline__ uint32_t svb_decode_tile(const uint8_t *keys, const u
     return total;
 }
 
+// The same tile by ONE wave (the fused inflate + unpack of k_inflate_par): 64 lanes x 16 values, wave scans instead of block scans,
+// stage: SVB_WSTAGE bytes of LDS (the inflate window, dead by then), 16-byte aligned.
+constexpr uint32_t SVB_WTILE = 64u * 16u;
+constexpr uint32_t SVB_WSTAGE = 4u * SVB_WTILE + 16u;
+__device__ __forceinline__ uint32_t svb_decode_tile_wave(const uint8_t *keys, const uint8_t *data, const uint8_t *data_end, uint32_t n, uint32_t t0,
+                                                         int16_t *__restrict__ out, int &carry, int &err, uint8_t *stage) {
+    const int lane = lane_id();
+    const uint32_t i0 = t0 + 16u * (uint32_t)lane;
+    const int valid = i0 >= n ? 0 : (int)min(16u, n - i0);
+    const int nk = (valid + 3) >> 2;
+    uint32_t key = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q < nk) key |= (uint32_t)keys[4 * lane + q] << (8 * q);
+    // bytes of my values: one each + the sum of the 2-bit codes (bits of values past `valid` are masked out)
+    uint32_t nbytes;
+    {
+        const uint32_t km = valid >= 16 ? key : key & ((1u << (2 * valid)) - 1u);
+        uint32_t c = (km & 0x33333333u) + ((km >> 2) & 0x33333333u);
+        c = (c + (c >> 4)) & 0x0F0F0F0Fu;
+        nbytes = (uint32_t)valid + ((c * 0x01010101u) >> 24);
+    }
+    const uint32_t incl = wave_incl_add(nbytes);
+    const uint32_t off = incl - nbytes;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    {   // data[0 .. min(total, bytes left)) -> stage
+        const uint32_t have = (uint32_t)min((uint64_t)total, (uint64_t)(data_end - data));
+        typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(1)));
+        typedef uint32_t v4a __attribute__((ext_vector_type(4)));
+        for (uint32_t k = 16u * (uint32_t)lane; k < have; k += 16u * 64u) {
+            if (k + 16 <= have) *reinterpret_cast<v4a *>(stage + k) = *reinterpret_cast<const v4u *>(data + k);
+            else for (uint32_t j = k; j < have; j++) stage[j] = data[j];
+        }
+        wave_sync();
+    }
+    const uint8_t *dp = stage + off;
+    const bool ok = !(valid > 0 && data + off + nbytes > data_end);
+    if (!ok) err = 1;
+    int dlt[16];
+    int sum = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        dlt[q] = 0;
+        if (q < valid && ok) {
+            const uint32_t code = (key >> (2 * q)) & 3;
+            uint32_t zz = dp[0];
+            if (code > 0) zz |= (uint32_t)dp[1] << 8;
+            if (code > 1) zz |= (uint32_t)dp[2] << 16;
+            if (code > 2) zz |= (uint32_t)dp[3] << 24;
+            dp += code + 1;
+            dlt[q] = (int)(zz >> 1) ^ -(int)(zz & 1);
+        }
+        sum += dlt[q];
+    }
+    const uint32_t incl2 = wave_incl_add((uint32_t)sum);
+    int acc = carry + (int)(incl2 - (uint32_t)sum);
+    if (valid == 16) {
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            acc += dlt[2 * q];
+            const uint32_t lo = (uint32_t)acc & 0xFFFFu;
+            acc += dlt[2 * q + 1];
+            w[q] = lo | ((uint32_t)acc << 16);
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(out + i0);
+        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (q < valid) { acc += dlt[q]; out[i0 + q] = (int16_t)acc; }
+    }
+    carry += (int)(uint32_t)__builtin_amdgcn_readlane((int)incl2, 63);
+    wave_sync();                                   // the next tile refills the stage
+    return total;
+}
+
 }  // namespace s5

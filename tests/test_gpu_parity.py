@@ -515,3 +515,52 @@ def test_lz77_matcher_output_is_deterministic_and_independent_of_the_batch(press
     for rec, s, h in zip(a, sigs, hdrs):
         pay = zlib.decompress(rec[8:])
         assert pay == h + struct.pack("<Q", s.size) + s.tobytes()
+
+
+def test_fused_unpack_and_the_records_it_leaves_to_the_second_kernel(press):
+    """s5gpu_decode_dev on zlib + svb-zd records: the wave that inflates a record also unpacks it (k_inflate_par<true>); records the
+    parallel decoder declines (periodic signals: their svb bytes are far matches for stock zlib) are inflated by the fallback
+    decoder and unpacked by k_unpack_rest.  One batch with both kinds + malformed payloads + a signal slot that is too small;
+    identical answers with the fusion switched off"""
+    from slow5tools_amd import _lib
+    rng = np.random.default_rng(91)
+    sigs, streams = [], []
+    for i in range(96):
+        n = int(rng.integers(1, 9000))
+        if i % 3 == 0:
+            sig = np.tile((400 + rng.integers(-300, 300, 53)).astype(np.int16), n // 53 + 1)[:n]     # periodic: far matches
+        elif i % 3 == 1:
+            sig = ob.synth_read(0x5105, i, n)
+        else:
+            sig = (rng.integers(-2000, 2000, n)).astype(np.int16)
+        payload, _ = _oracle_payload(_hdr(press, i), sig, bytes(rng.integers(0, 256, int(rng.integers(0, 50)), dtype=np.uint8)), 1)
+        sigs.append(sig)
+        streams.append(zlib.compress(payload, 9 if i % 2 else 6))
+    # a payload whose svb-zd length field lies, and one that is cut short: malformed records (status 7) on either path
+    good, _ = _oracle_payload(_hdr(press, 500), ob.synth_read(1, 1, 500), b"", 1)
+    hl = 2 + int.from_bytes(good[:2], "little") + 4 + 32
+    lying = good[:hl] + (int.from_bytes(good[hl:hl + 8], "little") + 9).to_bytes(8, "little") + good[hl + 8:]
+    streams += [zlib.compress(lying), zlib.compress(good[:hl + 4])]
+    res = {}
+    for fused in (1, 0):
+        _lib.check(_lib.lib().s5gpu_set_option(b"unpack_fused", fused))
+        try:
+            res[fused] = press.decode_records(streams, raise_on_error=False)
+        finally:
+            _lib.check(_lib.lib().s5gpu_set_option(b"unpack_fused", 1))
+    for a, b in zip(res[1], res[0]):
+        assert a["status"] == b["status"]
+        if a["status"] == 0:
+            assert np.array_equal(a["signal"], b["signal"]) and a["aux"] == b["aux"] and a["read_id"] == b["read_id"] and a["payload"] == b["payload"]
+    for g, s in zip(res[1], sigs):
+        assert g["status"] == 0 and np.array_equal(g["signal"], s)
+    assert res[1][-2]["status"] == 7 and res[1][-1]["status"] == 7
+    # some of the periodic records really took the second kernel: the parallel decoder alone declines them
+    import ctypes as C
+    L = _lib.lib()
+    _lib.check(L.s5gpu_set_option(b"inflate_par", 2))       # tools mode: no fallback pass, declined records keep status 8
+    try:
+        alone = press.decode_records(streams[:96], raise_on_error=False)
+    finally:
+        _lib.check(L.s5gpu_set_option(b"inflate_par", 1))
+    assert any(g["status"] == 8 for g in alone)
