@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--cpu-sweep-seconds", type=float, default=5.0, help="CPU baseline: seconds per point of the -t / -K sweep (0 = skip)")
     ap.add_argument("--svb-only", action="store_true", help="configs[1]: svb-zd stage alone")
     ap.add_argument("--two-pass", action="store_true", help="encode into worst-case slots + compaction pass instead of the ordered single-pass stream")
+    ap.add_argument("--fused-cap", type=int, default=8192, help="--mixed: LDS payload budget of the fused kernel, bytes (longer payloads take the staged path)")
     ap.add_argument("--mixed", action="store_true", help="read lengths of a real run: log-normal, median 6000 samples (--reads reads, default 262144)")
     ap.add_argument("--long", action="store_true", help="configs[3] alone (the long-read leg as the whole line)")
     ap.add_argument("--no-long", action="store_true", help="skip the configs[3] leg of the default run")
@@ -270,7 +271,7 @@ def main():
         rng = np.random.default_rng(5)
         ns = np.clip(np.exp(rng.normal(np.log(6000), 0.9, n_reads)), 200, 400000).astype(np.uint64)
         # the device entry point only knows the longest read; the host batch calls name this budget from the lengths themselves
-        b = press.DeviceBatch(ns, device=dev, lds_payload_cap=8192)
+        b = press.DeviceBatch(ns, device=dev, lds_payload_cap=args.fused_cap)
         tot = b.sig.numel()
         # one long synthetic trace cut into the reads (the event model is position-keyed)
         _lib.check(L.s5gpu_synth_dev(b.sig.data_ptr(), 1, tot - 64, tot, 0x5105 + rank, 0, b._stream()), "synth")

@@ -404,8 +404,8 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
     const uint8_t *ll = type == 1 ? T.lens : T.lens + 32;
     const uint8_t *dl = type == 1 ? T.lens + 288 : T.lens + 32 + nl;
     if (type == 2 && ll[256] == 0) return INF_ERR_DATA;
-    if (LITLUT == 0) { if (infl_build_syms(ll, nl, T.lcount, T.lsym, reinterpret_cast<uint32_t *>(T.llut))) return INF_ERR_DATA; }
-    else if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, LITLUT, 9)) return INF_ERR_DATA;
+    if constexpr (LITLUT == 0) { if (infl_build_syms(ll, nl, T.lcount, T.lsym, reinterpret_cast<uint32_t *>(T.llut))) return INF_ERR_DATA; }   // (T.llut: >= 64 bytes of scratch)
+    else { if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, LITLUT, 9)) return INF_ERR_DATA; }
     if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, INF_DBITS, 5)) return INF_ERR_DATA;
     return INF_OK;
 }

@@ -30,8 +30,8 @@
 namespace s5 {
 
 constexpr int IP_SPAN = 4096;          // compressed bytes per round
-constexpr int IP_DEF = 4;              // waiting matches per lane and round
-constexpr int IP_FILL = 128;           // runs (distance-1 matches) per round that the whole wave fills afterwards
+constexpr int IP_WAIT = 192;           // waiting matches per round (the whole wave's, in stream order)
+constexpr int IP_FILL = 96;            // runs (distance-1 matches) per round that the whole wave fills afterwards
 #ifndef S5_IP_TAIL
 #define S5_IP_TAIL 224
 #endif
@@ -39,26 +39,28 @@ constexpr uint32_t IP_TAIL = S5_IP_TAIL;   // bits of its segment a lane walks i
 constexpr uint32_t IP_MINSEG = 384;    // shortest segment, bits
 constexpr int INF_NEED_FALLBACK = 8;
 
-struct InflParShared {                 // per wave: 8.3 KiB, so a CU holds all the waves the hardware allows
+struct InflParShared {                 // per wave: 6.6 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
+                                       // LDS per wave = + 33 % time), so nothing here is larger than it has to be
     uint32_t win[IP_SPAN / 4 + 8];     // window; the header parser uses its first INF_IW bytes
     union {
-        uint16_t llut[1 << INF_LBITS]; // written by the shared header parser (unused here: lit/len codes are resolved by comparison, IpLimits) ...
-        struct {                       // ... and dead before the first waiting match is listed
-            uint32_t def_a[64 * IP_DEF];   // waiting match: position in the round's output | length << 20
-            uint32_t def_d[64 * IP_DEF];   // ... its distance
-        };
+        uint32_t wq_a[IP_WAIT];        // waiting match: position in the round's output | length << 20 ...
+        uint16_t llut[32];             // (64 bytes of scratch for the header parser's symbol sort; no lit/len lookup table here)
     };
+    uint16_t wq_d[IP_WAIT];            // ... its distance
     uint16_t dlut[1 << INF_DBITS];
     uint16_t ladj[16];                 // lit/len: index of a length's first symbol in lsym - its first code
     uint16_t lsym[288];
     uint16_t dsym[32];
     uint16_t lcount[16], dcount[16];
-    uint8_t lens[352];
-    uint32_t fill_a[IP_FILL];          // run: position in the round's output | length << 20
-    uint8_t fill_x[IP_FILL];           // ... its byte
+    union {
+        uint8_t lens[352];             // code lengths: dead once the tables stand ...
+        struct {
+            uint32_t fill_a[IP_FILL];  // ... run: position in the round's output | length << 20
+            uint8_t fill_x[IP_FILL];   //     its byte
+        };
+    };
     uint32_t nfill;
 };
-static_assert(sizeof(uint32_t) * 64 * IP_DEF * 2 <= sizeof(uint16_t) << INF_LBITS, "the waiting lists fit the dead lookup table");
 static_assert(INF_IW <= IP_SPAN, "the header parser's window is the head of the round window");
 
 // 32 bits of the window starting at bit p (two aligned dwords + one alignbit)
@@ -87,13 +89,25 @@ __device__ __forceinline__ void ip_load_window(uint32_t *win, const uint8_t *src
     wave_sync();
 }
 
+// n bytes from s to d, the two ranges disjoint, any alignment (one lane; global memory takes unaligned dwords)
+__device__ __forceinline__ void ip_copy_disjoint(uint8_t *d, const uint8_t *s, int n) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(1)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
+    typedef uint32_t u1 __attribute__((aligned(1)));
+    int k = 0;
+    for (; k + 16 <= n; k += 16) *reinterpret_cast<u4 *>(d + k) = *reinterpret_cast<const u4 *>(s + k);
+    if (k + 8 <= n) { *reinterpret_cast<u2 *>(d + k) = *reinterpret_cast<const u2 *>(s + k); k += 8; }
+    if (k + 4 <= n) { *reinterpret_cast<u1 *>(d + k) = *reinterpret_cast<const u1 *>(s + k); k += 4; }
+    for (; k < n; k++) d[k] = s[k];
+}
+
 struct IpSeg {            // what a lane learns about its segment
     uint32_t cross;       // window bit where its last token ends (= the next segment's real start)
     uint32_t nout;        // bytes its tokens produce (up to the end-of-block code, if the segment holds one)
     uint32_t eob;         // 1: the segment holds the end-of-block code ...
     uint32_t eobpos;      // ... and this is the bit behind it
     uint32_t bad;         // 1: an invalid code (meaningless unless the segment was decoded from a real boundary)
-    uint32_t ndef;        // WRITE: waiting matches put on the list; > IP_DEF: the list overflowed
+    uint32_t nwait;       // matches that have to wait (source in another lane's output, or behind a match that waits itself); up to the end-of-block code
 };
 // The lit/len code is resolved WITHOUT a lookup table: with 64 lanes at 64 different places of the stream, some lane of the wave
 // meets a code longer than any affordable table in almost every step, and the wave then runs the slow path anyway.  So every
@@ -120,13 +134,14 @@ struct IpLimits { ip_s2 m1[8]; };
 // behind nested exec masks.
 template <bool WRITE>
 __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLimits &L, uint32_t st, uint32_t end, uint32_t obase, uint32_t o_abs0,
-                                                   uint8_t *dst) {
+                                                   uint8_t *dst, uint32_t wbase = 0, uint32_t wmax = 0) {
     IpSeg r;
-    r.cross = st; r.nout = 0; r.eob = 0; r.eobpos = 0; r.bad = 0; r.ndef = 0;
+    r.cross = st; r.nout = 0; r.eob = 0; r.eobpos = 0; r.bad = 0; r.nwait = 0;
     uint32_t p = st, o = obase;
-    const int lane = lane_id();
     uint32_t wait_end = obase;     // output position behind this lane's last waiting match / pending run: nothing in front of it is in memory yet
-    uint32_t lastb = 0x100u;       // WRITE: the byte this lane produced last (0x100: not known — nothing yet, or a waiting match)
+    uint32_t lastb = 0x100u;       // the byte this lane produced last (0x100: not known — nothing yet, or a waiting match); a synchronisation
+                                   // pass only keeps track of whether it is known (0 / 0x100): which matches will have to wait is counted there,
+                                   // so that the output pass can put every lane's waiting matches at their place in ONE list in stream order
     bool act = p < end;
     while (__ballot(act)) {
         const uint32_t pp = act ? p : 0u;
@@ -186,33 +201,38 @@ __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLim
                         const uint32_t mdist = (ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx)) + (b2 & ((1u << dx) - 1u));
                         adv += dx;
                         nby = mlen;
-                        if (WRITE) {
-                            if (mdist > o_abs0 + o) { r.bad = 1; stop = true; }                 // reaches in front of the record
-                            else if (mdist == 1 && lastb < 0x100u) {
-                                // a run of the byte this lane produced last.  A lane that filled it itself would keep the other 63 waiting
-                                // (the key bytes of an svb-zd record are runs of zeros, and they all sit in the first two segments): the run
-                                // goes on a list and the wave fills all of them at once after the pass
+                        if (WRITE && mdist > o_abs0 + o) { r.bad = 1; stop = true; }                    // reaches in front of the record
+                        else if (mdist == 1 && lastb < 0x100u) {
+                            // a run of the byte this lane produced last.  A lane that filled it itself would keep the other 63 waiting
+                            // (the key bytes of an svb-zd record are runs of zeros, and they all sit in the first two segments): the run
+                            // goes on a list and the wave fills all of them at once after the pass
+                            if (WRITE) {
                                 const uint32_t slot = atomicAdd(&T.nfill, 1u);
-                                if (slot < (uint32_t)IP_FILL) { T.fill_a[slot] = o | (mlen << 20); T.fill_x[slot] = (uint8_t)lastb; wait_end = o + mlen; }
+                                if (slot < (uint32_t)IP_FILL) { T.fill_a[slot] = o | (mlen << 20); T.fill_x[slot] = (uint8_t)lastb; }
                                 else for (uint32_t k = 0; k < mlen; k++) dst[o + k] = (uint8_t)lastb;
-                            } else if (o >= mdist && o - mdist >= wait_end) {                  // the whole source is bytes this lane has written: copy now
+                            }
+                            wait_end = o + mlen;                                                      // (also when the list was full: both kinds of pass must agree)
+                        } else if (o >= mdist && o - mdist >= wait_end) {                             // the whole source is bytes this lane has written: copy now
+                            if (WRITE) {
                                 for (uint32_t k = 0; k < mlen; k++) dst[o + k] = dst[o + k - mdist];
                                 lastb = dst[o + mlen - 1];
-                            } else {                                                           // another lane's bytes, or bytes that wait themselves
-                                if (r.ndef < (uint32_t)IP_DEF) {
-                                    T.def_a[lane * IP_DEF + r.ndef] = o | (mlen << 20);
-                                    T.def_d[lane * IP_DEF + r.ndef] = mdist;
+                            } else lastb = 0u;
+                        } else {                                                                      // another lane's bytes, or bytes that wait themselves
+                            if (WRITE) {
+                                if (r.nwait < wmax) {
+                                    T.wq_a[wbase + r.nwait] = o | (mlen << 20);
+                                    T.wq_d[wbase + r.nwait] = (uint16_t)mdist;
                                 }
-                                r.ndef++;
-                                wait_end = o + mlen;
-                                lastb = 0x100u;
-                            }
+                                r.nwait++;
+                            } else if (!r.eob) r.nwait++;
+                            wait_end = o + mlen;
+                            lastb = 0x100u;
                         }
                     }
                 }
             }
         }
-        if (WRITE && act && lit) { dst[o] = (uint8_t)sym; lastb = sym; }
+        if (act && lit) { if (WRITE) dst[o] = (uint8_t)sym; lastb = sym; }
         if (act) { p += adv; o += nby; }
         act = act && !stop && p < end;
     }
@@ -333,11 +353,24 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             // which lanes hold real tokens of this block, and where their bytes go
             const uint64_t eobs = __ballot(sg.eob != 0u && st < seg_end);
             const int eob_lane = eobs ? __ffsll((long long)eobs) - 1 : 64;
-            const int m = eob_lane < nseg ? eob_lane + 1 : nseg;               // lanes [0, m) go out
+            int m = eob_lane < nseg ? eob_lane + 1 : nseg;                     // lanes [0, m) go out
+            // every lane's waiting matches (counted by the last synchronisation pass) get their place in ONE list, in stream order.  If
+            // they do not all fit, only the lanes in front go out in this round and the next round starts behind them (stock zlib
+            // leaves ~190 matches in 4 KiB of an svb-zd stream of real signal, and several hundred in the key bytes of a long read)
+            const uint32_t w_all = st < seg_end && lane < m ? sg.nwait : 0u;
+            const uint32_t wincl = wave_incl_add(w_all);
+            {
+                const uint64_t over = __ballot(wincl > (uint32_t)IP_WAIT);       // (the sums never decrease: the lanes that fit are a prefix)
+                const int mfit = over ? __ffsll((long long)over) - 1 : 64;
+                if (mfit < m) m = mfit;
+                if (m == 0) { if (dbg) dbg[2] = 3; return INF_NEED_FALLBACK; }   // one segment with more waiting matches than the list holds
+            }
+            const uint32_t w_act = lane < m ? w_all : 0u;
+            const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)wincl, m - 1);
             const uint32_t n_act = st < seg_end && lane < m ? sg.nout : 0u;
             const uint32_t incl = wave_incl_add(n_act);
             const uint32_t round_out = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (round_out >= (1u << 20)) { if (dbg) dbg[2] = 1; return INF_NEED_FALLBACK; }   // (positions on the waiting lists have 20 bits)
+            if (round_out >= (1u << 20)) { if (dbg) dbg[2] = 1; return INF_NEED_FALLBACK; }   // (positions on the waiting list have 20 bits)
             if (o + round_out > cap) { if (dbg) dbg[2] = 2; return INF_NEED_FALLBACK; }        // payload slot too small: the old decoder reports the size needed
             const uint32_t obase = incl - n_act;
             uint8_t *dst = out + o;
@@ -345,10 +378,10 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             if (lane == 0) T.nfill = 0;
             wave_sync();
             IpSeg wr;
-            wr.ndef = 0; wr.bad = 0; wr.eob = 0; wr.eobpos = 0; wr.cross = st; wr.nout = 0;
-            if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, L, st, seg_end, obase, o, dst);
+            wr.nwait = 0; wr.bad = 0; wr.eob = 0; wr.eobpos = 0; wr.cross = st; wr.nout = 0;
+            if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, L, st, seg_end, obase, o, dst, wincl - w_act, w_act);
             if (__ballot(wr.bad != 0u)) return INF_ERR_DATA;
-            if (__ballot(wr.ndef > (uint32_t)IP_DEF)) { if (dbg) dbg[2] = 3; return INF_NEED_FALLBACK; }
+            if (__ballot(wr.nwait != w_act)) { if (dbg) dbg[2] = 4; return INF_NEED_FALLBACK; }   // (the two kinds of pass disagree: never seen)
             wave_sync();
             {   // ---- runs: one per lane, 64 at a time (they depend on nothing) ----
                 const uint32_t nf = min(__builtin_amdgcn_readfirstlane(T.nfill), (uint32_t)IP_FILL);
@@ -367,22 +400,47 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             wave_sync();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // ---- waiting matches, in stream order, by the whole wave ----
-            {
-                uint64_t has = __ballot(wr.ndef != 0u);
-                while (has) {
-                    const int l = __ffsll((long long)has) - 1;
-                    has &= has - 1;
-                    const int nd_l = __builtin_amdgcn_readlane((int)wr.ndef, l);
-                    for (int k = 0; k < nd_l; k++) {
-                        const uint32_t a = __builtin_amdgcn_readfirstlane(T.def_a[l * IP_DEF + k]);
-                        const uint32_t dist = __builtin_amdgcn_readfirstlane(T.def_d[l * IP_DEF + k]);
-                        const uint32_t op = a & 0xFFFFFu, mlen = a >> 20;
-                        for (uint32_t j = lane; j < mlen; j += 64) dst[op + j] = dst[(int)op - (int)dist + (int)(j % dist)];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        wave_sync();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // ---- waiting matches: 64 at a time, each copied by ITS lane as soon as nothing it reads is still to come.  The list is
+            // in stream order, so the destinations are ascending and disjoint: the only entry whose destination can reach into my
+            // source is the last one that starts in front of my source's end (binary search over the lanes in front of me); if it
+            // does, I wait until every entry up to it is done.  Stock zlib leaves ~110 such matches in an svb-zd record of 4000
+            // samples (half of them in the key bytes); nearly all copy literals from far back and go in the first round.
+            for (uint32_t c0 = 0; c0 < wtot; c0 += 64) {
+                const uint32_t j = c0 + (uint32_t)lane;
+                const bool have = j < wtot;
+                const uint32_t a = have ? T.wq_a[j] : 0u, dist = have ? (uint32_t)T.wq_d[j] : 1u;
+                const int op = (int)(a & 0xFFFFFu), mlen = (int)(a >> 20);
+                const int ss = op - (int)dist, se = min(ss + mlen, op);          // source bytes [ss, se) exist before this match starts writing
+                int lo = 0, hi = lane;
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const int mid = (lo + hi) >> 1;
+                    const int v = __builtin_amdgcn_ds_bpermute(mid << 2, op);
+                    if (lo < hi) { if (v < se) lo = mid + 1; else hi = mid; }
+                }
+                const int cand = lo - 1;                                          // the last entry in front of me that starts before se
+                const int c_op = __builtin_amdgcn_ds_bpermute(max(cand, 0) << 2, op), c_len = __builtin_amdgcn_ds_bpermute(max(cand, 0) << 2, mlen);
+                const int dep = have && cand >= 0 && c_op + c_len > ss ? cand : -1;
+                uint64_t donem = ~__ballot(have);
+                while (~donem) {
+                    const int u = __ffsll((long long)~donem) - 1;                 // first entry not done: everything in front of it is
+                    const bool ready = !((donem >> lane) & 1ull) && dep < u;
+                    if (ready) {
+                        // the bytes in front of q are periodic with period dist; every step copies as much as is known without
+                        // reading what it writes, and then twice as much is known (a run at distance 1 takes 9 steps, not 258)
+                        uint8_t *q = dst + op;
+                        int k = 0, d = (int)dist;
+                        while (k < mlen) {
+                            const int nb = min(mlen - k, d);
+                            ip_copy_disjoint(q + k, q + k - d, nb);
+                            k += nb;
+                            d += d;
+                        }
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    wave_sync();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    donem |= __ballot(ready);
                 }
             }
             o += round_out;

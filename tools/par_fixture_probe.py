@@ -1,0 +1,45 @@
+"""The reference's own zlib records (tests/golden: real signals, written by slow5tools with stock zlib) through the inflate kernels:
+which does the parallel-inside-the-record decoder take without the fallback pass, and how fast is a batch of them (the file's
+records tiled to `batch` records)?  python tools/par_fixture_probe.py [batch]"""
+import ctypes as C, os, sys, zlib, collections
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np, torch
+from blow5_fixture import Blow5, golden, ZLIB_SVB_FIXTURES, ZLIB_NONE_FIXTURES
+from slow5tools_amd import _lib
+L = _lib.lib(); _lib.check(L.s5gpu_init(0), "init")
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+for name in ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES:
+    f = Blow5(golden(name))
+    streams = list(f.records)
+    plen = max(len(zlib.decompress(s)) for s in streams)
+    lens = np.array([len(s) for s in streams], dtype=np.int64)
+    off1 = np.concatenate([[0], np.cumsum((lens + 15) // 16 * 16)])
+    blob = np.zeros(off1[-1] + 64, dtype=np.uint8)
+    for s, o in zip(streams, off1[:-1]):
+        blob[o:o + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    idx = np.arange(batch) % len(streams)
+    pay_cap = 16 * ((plen + 31) // 16)
+    d = np.zeros(batch, dtype=_lib.REC_DESC)
+    d["in_off"] = off1[idx]; d["in_len"] = lens[idx]
+    d["pay_off"] = np.arange(batch, dtype=np.uint64) * pay_cap; d["pay_cap"] = pay_cap
+    desc = torch.from_numpy(d.view(np.uint8).copy()).cuda()
+    inp = torch.from_numpy(blob).cuda()
+    pay = torch.empty(batch * pay_cap + 64, dtype=torch.uint8, device="cuda")
+    fields = torch.zeros(batch * 64, dtype=torch.uint8, device="cuda")
+    a = _lib.DecodeArgs(); a.n_recs, a.rec_method, a.sig_method = batch, 1, f.sig_method
+    a.desc, a.in_, a.payload, a.fields = desc.data_ptr(), inp.data_ptr(), pay.data_ptr(), fields.data_ptr()
+    out = []
+    zbytes = float(lens[idx].sum())
+    for mode in (2, 1, 0):
+        _lib.check(L.s5gpu_set_option(b"inflate_par", mode), "opt")
+        ts = []
+        for _ in range(3):
+            fields.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+        st = fields.cpu().numpy().view(_lib.REC_FIELDS)["status"][:len(streams)]
+        out.append((mode, min(ts), dict(collections.Counter(st.tolist()))))
+    print("%-44s %2d records (%d..%d B) x %d:  " % (name, len(streams), lens.min(), lens.max(), batch) +
+          "   ".join("par=%d %.2f ms (%.1f GB/s of zlib stream) %s" % (m, t, zbytes / t / 1e6, s) for m, t, s in out))
+_lib.check(L.s5gpu_set_option(b"inflate_par", 1), "opt")
