@@ -30,8 +30,14 @@
 namespace s5 {
 
 constexpr int IP_SPAN = 4096;          // compressed bytes per round
-constexpr int IP_WAIT = 192;           // waiting matches per round (the whole wave's, in stream order)
-constexpr int IP_FILL = 96;            // runs (distance-1 matches) per round that the whole wave fills afterwards
+#ifndef S5_IP_WAIT
+#define S5_IP_WAIT 512
+#endif
+#ifndef S5_IP_FILL
+#define S5_IP_FILL 96
+#endif
+constexpr int IP_WAIT = S5_IP_WAIT;    // waiting matches per round (the whole wave's, in stream order)
+constexpr int IP_FILL = S5_IP_FILL;    // runs (distance-1 matches) per round that the whole wave fills afterwards
 #ifndef S5_IP_TAIL
 #define S5_IP_TAIL 224
 #endif
@@ -43,10 +49,10 @@ struct InflParShared {                 // per wave: 6.6 KiB — the kernel's spe
                                        // LDS per wave = + 33 % time), so nothing here is larger than it has to be
     uint32_t win[IP_SPAN / 4 + 8];     // window; the header parser uses its first INF_IW bytes
     union {
-        uint32_t wq_a[IP_WAIT];        // waiting match: position in the round's output | length << 20 ...
+        uint16_t wq[IP_WAIT];          // waiting match: position in the round's output (< 64 Ki); its length and distance wait in the
+                                       // first three of the bytes it will produce — a match is at least three bytes long
         uint16_t llut[32];             // (64 bytes of scratch for the header parser's symbol sort; no lit/len lookup table here)
     };
-    uint16_t wq_d[IP_WAIT];            // ... its distance
     uint16_t dlut[1 << INF_DBITS];
     uint16_t ladj[16];                 // lit/len: index of a length's first symbol in lsym - its first code
     uint16_t lsym[288];
@@ -220,8 +226,8 @@ __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLim
                         } else {                                                                      // another lane's bytes, or bytes that wait themselves
                             if (WRITE) {
                                 if (r.nwait < wmax) {
-                                    T.wq_a[wbase + r.nwait] = o | (mlen << 20);
-                                    T.wq_d[wbase + r.nwait] = (uint16_t)mdist;
+                                    T.wq[wbase + r.nwait] = (uint16_t)o;
+                                    dst[o] = (uint8_t)(mlen - 3u); dst[o + 1] = (uint8_t)(mdist - 1u); dst[o + 2] = (uint8_t)((mdist - 1u) >> 8);
                                 }
                                 r.nwait++;
                             } else if (!r.eob) r.nwait++;
@@ -359,18 +365,20 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             // leaves ~190 matches in 4 KiB of an svb-zd stream of real signal, and several hundred in the key bytes of a long read)
             const uint32_t w_all = st < seg_end && lane < m ? sg.nwait : 0u;
             const uint32_t wincl = wave_incl_add(w_all);
+            const uint32_t n_all = st < seg_end && lane < m ? sg.nout : 0u;
+            const uint32_t nincl = wave_incl_add(n_all);
             {
-                const uint64_t over = __ballot(wincl > (uint32_t)IP_WAIT);       // (the sums never decrease: the lanes that fit are a prefix)
+                // (the sums never decrease: the lanes that fit are a prefix; list positions have 16 bits)
+                const uint64_t over = __ballot(wincl > (uint32_t)IP_WAIT || nincl > 0xFFFFu);
                 const int mfit = over ? __ffsll((long long)over) - 1 : 64;
                 if (mfit < m) m = mfit;
-                if (m == 0) { if (dbg) dbg[2] = 3; return INF_NEED_FALLBACK; }   // one segment with more waiting matches than the list holds
+                if (m == 0) { if (dbg) dbg[2] = 3; return INF_NEED_FALLBACK; }   // one segment over the list's capacity or with >= 64 KiB of output
             }
             const uint32_t w_act = lane < m ? w_all : 0u;
             const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)wincl, m - 1);
-            const uint32_t n_act = st < seg_end && lane < m ? sg.nout : 0u;
-            const uint32_t incl = wave_incl_add(n_act);
-            const uint32_t round_out = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (round_out >= (1u << 20)) { if (dbg) dbg[2] = 1; return INF_NEED_FALLBACK; }   // (positions on the waiting list have 20 bits)
+            const uint32_t n_act = lane < m ? n_all : 0u;
+            const uint32_t incl = lane < m ? nincl : 0u;
+            const uint32_t round_out = (uint32_t)__builtin_amdgcn_readlane((int)nincl, m - 1);
             if (o + round_out > cap) { if (dbg) dbg[2] = 2; return INF_NEED_FALLBACK; }        // payload slot too small: the old decoder reports the size needed
             const uint32_t obase = incl - n_act;
             uint8_t *dst = out + o;
@@ -408,8 +416,10 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             for (uint32_t c0 = 0; c0 < wtot; c0 += 64) {
                 const uint32_t j = c0 + (uint32_t)lane;
                 const bool have = j < wtot;
-                const uint32_t a = have ? T.wq_a[j] : 0u, dist = have ? (uint32_t)T.wq_d[j] : 1u;
-                const int op = (int)(a & 0xFFFFFu), mlen = (int)(a >> 20);
+                const int op = have ? (int)T.wq[j] : 0;
+                uint32_t dist = 1u;
+                int mlen = 0;
+                if (have) { const uint8_t *h = dst + op; mlen = 3 + (int)h[0]; dist = 1u + (uint32_t)h[1] + ((uint32_t)h[2] << 8); }
                 const int ss = op - (int)dist, se = min(ss + mlen, op);          // source bytes [ss, se) exist before this match starts writing
                 int lo = 0, hi = lane;
 #pragma unroll

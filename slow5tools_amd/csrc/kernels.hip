@@ -546,8 +546,11 @@ __device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, c
     }
     return 0;
 }
+#ifndef S5_IP_WAVES
+#define S5_IP_WAVES 6
+#endif
 template <bool UNPACK>
-__global__ __launch_bounds__(64) void k_inflate_par(s5gpu_decode_args_t a) {
+__global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_args_t a) {
     __shared__ InflParShared T;
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];

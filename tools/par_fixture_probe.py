@@ -40,6 +40,22 @@ for name in ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES:
             e0.record(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
         st = fields.cpu().numpy().view(_lib.REC_FIELDS)["status"][:len(streams)]
         out.append((mode, min(ts), dict(collections.Counter(st.tolist()))))
+    if "merged" in name or "exp_1_lossless_zlib_svb" in name:     # where the time goes (cut-offs of the parallel decoder)
+        _lib.check(L.s5gpu_set_option(b"inflate_par", 2), "opt")
+        keep = a.sig_method
+        a.sig_method = 99
+        fields.zero_(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); torch.cuda.synchronize()
+        ff = fields.cpu().numpy().view(_lib.REC_FIELDS)[:len(streams)]
+        cuts = []
+        for cut in (91, 92, 93, 1):
+            a.sig_method = cut
+            tt = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); e1.record(); torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
+            cuts.append(min(tt))
+        a.sig_method = keep
+        print("    sync passes per record %s, rounds %s; cumulative ms: header %.2f, + sync %.2f, + output / runs / waiting %.2f, + Adler %.2f" % (ff["n_samples"].tolist(), ff["read_id_len"].tolist(), *cuts))
     print("%-44s %2d records (%d..%d B) x %d:  " % (name, len(streams), lens.min(), lens.max(), batch) +
           "   ".join("par=%d %.2f ms (%.1f GB/s of zlib stream) %s" % (m, t, zbytes / t / 1e6, s) for m, t, s in out))
 _lib.check(L.s5gpu_set_option(b"inflate_par", 1), "opt")
