@@ -6,24 +6,32 @@
 // records/s).  A Huffman stream does not have to be decoded from its first bit, though: a decoder dropped at an arbitrary bit
 // falls into step with the true code boundaries after a few codes (self-synchronisation), and that is all the parallelism
 // this decoder needs:
-//   window   up to 4 KiB of the compressed stream in LDS, cut into 64 segments of equal bit length (>= 64 bits: longer than
-//            any one token), one per lane; ONE set of tables for the whole wave (10-bit / 8-bit lookup tables, 4 KiB);
+//   window   up to 4 KiB of the compressed stream in LDS, cut into 64 segments of equal bit length (>= 384 bits: a lane needs a
+//            few dozen codes to fall into step), one per lane; ONE set of tables for the whole wave.  No lookup table for
+//            lit/len codes: 15 packed compares against the canonical limits (IpLimits) — every lane the same route;
 //   sync     every lane decodes the tokens that start in its segment — literal, end of block, or length + distance with
 //            their extra bits — and reports where its last token ends; that is where the next lane's segment REALLY
-//            starts.  Lane 0 starts at a known boundary; the others start at their segment's first bit, which is almost
-//            always wrong, and almost always harmless: by the end of the segment the lane is in step, so its end position
-//            is right anyway.  The pass is repeated with the corrected starts until no start moves (two or three passes;
-//            pass k is certain to have lanes 0..k-1 right, so 64 passes is the bound and nothing can hang);
-//   count    the same pass counts the bytes each lane's tokens produce: a prefix sum gives every lane its output offset;
-//   output   one more pass writes literals (and matches whose source the lane wrote itself) into an 8 KiB LDS buffer; other
-//            matches — the source lies in another lane's output, or follows a match that had to wait — are put on a short
-//            per-lane list and replicated afterwards in stream order by the whole wave;
-//   flush    the buffer goes to HBM as coalesced bytes, Adler-32 folded in on the way.
-// A record larger than one window takes several rounds; block headers (stored / fixed / dynamic) are parsed by the wave
-// with the uniform reader of inflate_dev.h between rounds.  What this decoder declines — a lane with more waiting matches
-// than its list holds (zlib streams of raw, uncompressed signals: four out of five bytes are far matches), a segment that
-// expands past the output buffer, a payload slot that is too small — it reports as INF_NEED_FALLBACK and the wave-per-record
-// decoder redoes that record (k_inflate_fallback).  Same contract and status codes as inflate_dev.h otherwise.
+//            starts.  The first pass walks only the tail of every segment (a first guess of every start), the second the whole
+//            segment from the corrected start; repeated until no start moves (2.1 passes on average; pass k is certain to have
+//            lanes 0..k-1 right, so nothing can hang).  The walk goes on behind an end-of-block code (stopping would cut the chain);
+//   count    the same pass counts the bytes each lane's tokens produce and the matches that will have to WAIT (source in another
+//            lane's output, or behind a match that waits itself): prefix sums give every lane its output offset and its place in
+//            the round's one list of waiting matches, in stream order;
+//   output   one more pass writes the bytes straight to HBM.  A run of a byte the lane knows goes on a list and the wave fills all
+//            runs at once afterwards; a match whose whole source the lane has written itself is copied on the spot; a waiting
+//            match leaves its position (16 bits) on the list and parks its length and distance in the first three bytes it will
+//            produce;
+//   waiting  64 at a time, each copied by ITS lane as soon as nothing it reads is still to come: destinations are ascending and
+//            disjoint, so only the last earlier entry that starts in front of my source's end can reach into it (a binary search
+//            over the lanes in front), and I wait until everything up to it is done; copies double the known period every step.
+//            Stock zlib leaves ~110 such matches in a 4000-sample svb-zd record, ~190 per window of real signal, several hundred
+//            in the key bytes of a long read or in raw-signal records: if a round's do not fit the list (768), only the lanes in
+//            front go out and the next round starts behind them;
+//   Adler    a last coalesced pass over the finished record.
+// A record larger than one window takes several rounds; block headers (stored / fixed / dynamic) are parsed by the wave (the
+// code-length sequence too: infl_cl_sequence_wave).  What this decoder declines — a payload slot that is too small, a single
+// segment that expands to 64 KiB or holds more waiting matches than the list — it reports as INF_NEED_FALLBACK and the
+// wave-per-record decoder redoes that record (k_inflate_fallback).  Same contract and status codes as inflate_dev.h otherwise.
 #pragma once
 #include "inflate_dev.h"
 
@@ -31,7 +39,7 @@ namespace s5 {
 
 constexpr int IP_SPAN = 4096;          // compressed bytes per round
 #ifndef S5_IP_WAIT
-#define S5_IP_WAIT 512
+#define S5_IP_WAIT 768
 #endif
 #ifndef S5_IP_FILL
 #define S5_IP_FILL 96
