@@ -562,6 +562,49 @@ def bench_decode(args):
                 "roofline": {"bound": "hbm", "kernel": "k_inflate_par+k_unpack", "achieved": round(alg / ms / 1e6, 2), "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": round(alg / ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": alg}}
         ok &= same
+        # ---- the same call on records WRITTEN BY STOCK ZLIB (what the reference's own files hold: level 6, arbitrary LZ77
+        # distances): 2048 distinct records compressed on the CPU, tiled to 262 144; every decoded signal compared ----
+        try:
+            import zlib
+            distinct, nb = 2048, min(262144, n_reads)
+            hostsig = b.sig[: distinct * sig_cap].view(distinct, sig_cap)[:, :n].cpu().numpy()
+            streams = []
+            for i in range(distinct):
+                rec, keep = ob.make_rec(ob.synth_read_id(i), 0, 8192.0, 3.0, 1400.0, 4000.0, np.ascontiguousarray(hostsig[i]))
+                streams.append(zlib.compress(ob.rec_pack(rec, ob.SIG_SVB_ZD), 6))
+            zl = np.array([len(x) for x in streams], dtype=np.int64)
+            zo = np.concatenate([[0], np.cumsum((zl + 15) // 16 * 16)])
+            blob = np.zeros(zo[-1] + 64, dtype=np.uint8)
+            for x, o_ in zip(streams, zo[:-1]):
+                blob[o_:o_ + len(x)] = np.frombuffer(x, dtype=np.uint8)
+            zin = torch.from_numpy(blob).to(dev)
+            idx = np.arange(nb) % distinct
+            d2 = d[:nb].copy()
+            d2["in_off"] = zo[idx]; d2["in_len"] = zl[idx]
+            zdesc = torch.from_numpy(d2.view(np.uint8)).to(dev)
+            a.n_recs, a.desc, a.in_ = nb, zdesc.data_ptr(), zin.data_ptr()
+            ts = []
+            for _ in range(3):
+                L.s5gpu_event_record(ev[0], st)
+                _lib.check(L.s5gpu_decode_dev(C.byref(a), st), "s5gpu_decode_dev")
+                L.s5gpu_event_record(ev[1], st)
+                torch.cuda.synchronize()
+                ms2 = C.c_float()
+                _lib.check(L.s5gpu_event_elapsed_ms(ev[0], ev[1], C.byref(ms2)))
+                ts.append(ms2.value)
+            ms2 = min(ts[1:])
+            stt = big_fields.view(torch.int32).view(n_reads, 16)[:nb, 0]
+            got = big_sig[: nb * sig_cap].view(nb, sig_cap)[:, :n]
+            want = b.sig[: distinct * sig_cap].view(distinct, sig_cap)[:, :n]
+            same2 = bool((stt == 0).all().item()) and all(bool(torch.equal(got[k0:k0 + distinct], want[: min(distinct, nb - k0)])) for k0 in range(0, nb, distinct))
+            bulk["stock_zlib_records"] = {"reads": nb, "distinct": distinct, "ms": round(ms2, 2), "reads_per_s": round(nb / ms2 * 1e3, 1),
+                                          "raw_signal_GB_per_s": round(nb * 2 * n / ms2 / 1e6, 2), "roundtrip_identical": same2,
+                                          "what": "svb-zd records compressed by zlib %s level 6 on the CPU (the reference's writer), decoded by the same call" % zlib.ZLIB_VERSION}
+            ok &= same2
+            a.in_ = b.stream_out.data_ptr()
+            del zin, zdesc
+        except Exception as e:      # (never fatal for the line)
+            bulk["stock_zlib_records"] = {"error": repr(e)}
         del big_desc, big_pay, big_sig, big_fields
     except torch.OutOfMemoryError:
         bulk = None

@@ -564,3 +564,34 @@ def test_fused_unpack_and_the_records_it_leaves_to_the_second_kernel(press):
     finally:
         _lib.check(L.s5gpu_set_option(b"inflate_par", 1))
     assert any(g["status"] == 8 for g in alone)
+
+
+def test_parallel_inflate_takes_stock_zlib_streams_without_the_fallback(press):
+    """Records written by stock zlib (the reference's encoder) hold ~110 matches per 4000-sample svb-zd record whose source is not
+    the decoding lane's own output, several hundred per window in raw-signal records: with inflate_par = 2 (no fallback pass: a
+    declined record keeps status 8) every golden zlib fixture and zlib-1/6/9 streams of synthetic records must still decode,
+    bit-exactly"""
+    from slow5tools_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(17)
+    streams, want, sms = [], [], []
+    for i in range(48):
+        n = int(rng.integers(50, 30000))
+        sig = ob.synth_read(0x5105, 1000 + i, n)
+        sm = 1 if i % 4 else 0
+        payload, _ = _oracle_payload(_hdr(press, i), sig, b"", sm)
+        streams.append(zlib.compress(payload, (1, 6, 9)[i % 3])); want.append(sig); sms.append(sm)
+    _lib.check(L.s5gpu_set_option(b"inflate_par", 2))
+    try:
+        for sm in (0, 1):
+            idx = [i for i in range(len(streams)) if sms[i] == sm]
+            got = press.decode_records([streams[i] for i in idx], 1, sm, raise_on_error=False)
+            for g, i in zip(got, idx):
+                assert g["status"] == 0 and np.array_equal(g["signal"], want[i])
+        for name in ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES:
+            f = Blow5(golden(name))
+            got = press.decode_records(f.records, f.rec_method, f.sig_method, raise_on_error=False)
+            for g, rec in zip(got, f.records):
+                assert g["status"] == 0 and g["payload"] == zlib.decompress(rec), name
+    finally:
+        _lib.check(L.s5gpu_set_option(b"inflate_par", 1))
