@@ -51,6 +51,10 @@ constexpr int IP_FILL = S5_IP_FILL;    // runs (distance-1 matches) per round th
 #endif
 constexpr uint32_t IP_TAIL = S5_IP_TAIL;   // bits of its segment a lane walks in the first pass
 constexpr uint32_t IP_MINSEG = 384;    // shortest segment, bits
+#ifndef S5_IP_LENSTEP
+#define S5_IP_LENSTEP 4
+#endif
+constexpr uint32_t IP_LENSTEP = S5_IP_LENSTEP;   // a power of two: the length / distance part of the token loop runs every IP_LENSTEP-th step
 constexpr int INF_NEED_FALLBACK = 8;
 
 struct InflParShared {                 // per wave: 6.6 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
@@ -133,7 +137,8 @@ typedef unsigned short ip_u2 __attribute__((ext_vector_type(2)));
 // limit of length l = (first code of length l + codes of length l) << (15 - l), left-justified in 15 bits; kept minus one, two
 // per word (lengths 2k+1 | 2k+2): eight packed 16-bit subtractions compare all fifteen, and no compare ever goes through VCC
 // (on gfx950 a VALU write of VCC needs wait states before a VALU read of it: the cmp / addc form paid a nop per limit)
-struct IpLimits { ip_s2 m1[8]; };
+struct IpLimits { ip_s2 m1[8]; uint32_t base; int np; uint32_t lenmask; };   // pairs from the shortest length in use on (lengths below it always count, the
+                                                           // longest one's limit is the end of the code space and never does): np pairs matter
 // (carrying the index adjustment of the code's length along in the same compare chain — a conditional move per limit instead of
 // the T.ladj read — was measured: 9 % slower; the wave is short of issue slots, not of LDS latency)
 
@@ -157,6 +162,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLim
                                    // pass only keeps track of whether it is known (0 / 0x100): which matches will have to wait is counted there,
                                    // so that the output pass can put every lane's waiting matches at their place in ONE list in stream order
     bool act = p < end;
+    uint32_t step = 0;
     while (__ballot(act)) {
         const uint32_t pp = act ? p : 0u;
         uint32_t bits = ip_peek(T.win, pp);
@@ -164,8 +170,16 @@ __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLim
         const ip_s2 vv = {(short)v, (short)v};
         ip_u2 acc = {0, 0};
 #pragma unroll
-        for (int k = 0; k < 8; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;   // sign bit: v >= limit
-        const uint32_t len = 1u + acc.x + acc.y;
+        for (int k = 0; k < 4; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;   // sign bit: v >= limit
+        if (L.np > 4) {   // (uniform: a lit/len code whose lengths span more than nine values; svb-zd records usually stay below)
+#pragma unroll
+            for (int k = 4; k < 6; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;
+            if (L.np > 6) {
+#pragma unroll
+                for (int k = 6; k < 8; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;
+            }
+        }
+        const uint32_t len = L.base + acc.x + acc.y;
         // len = 16: v lies behind the last code of an incomplete code.  The output pass reports it; a synchronisation pass
         // just walks on (16 bits: T.ladj[16] is T.lsym[0], any value will do) — three instructions less per step
         const bool badlen = WRITE && len > 15u;
@@ -176,7 +190,13 @@ __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLim
         const bool lit = sym < 256u;
         uint32_t adv = len, nby = 1;
         bool stop = false;
-        if (__ballot(act && !lit)) {
+        // The length / distance part below costs as much as the literal part above and runs with the few lanes that stand at such
+        // a code: it is entered only every IP_LENSTEP-th step (or when no lane has a literal to go on with); in between those
+        // lanes hold their position.  They lose a step or two per match, the wave saves the part in most steps.
+        const bool lenstep = (step & L.lenmask) == L.lenmask || !__ballot(act && lit);
+        step++;
+        if (act && !lit && !lenstep) { adv = 0; nby = 0; }
+        if (lenstep && __ballot(act && !lit)) {
             if (act && !lit) {
                 nby = 0;
                 if (sym == 256u) {
@@ -307,20 +327,38 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
         if (b.wbase != hdr_wb) win_fresh = false;                             // (the header parser slid its window: never, for a window that starts at the header)
         if (dbg && dbg[3] == 1) return INF_OK;       // tools/par_probe.py cut-off: block header and tables only
         IpLimits L;
-        {   // canonical limits and index adjustments of the lit/len code (uniform)
+        {   // canonical limits and index adjustments of the lit/len code (uniform).  The limits go through LDS (the code lengths'
+            // bytes are dead by now) so that the pairs can start at the shortest length in use
             uint32_t first = 0, offs = 0;
-            int lm1[17];
+            int minlen = 16, maxlen = 0;
+            // how often the token loop enters its length / distance part: the code lengths tell how common such tokens are (the
+            // share of the code space the length symbols own).  Few (svb-zd payloads: 2-5 %): every fourth step; a quarter or more
+            // (raw-signal records: four tokens out of five are matches): every step
+            {
+                const uint8_t *ll = type == 1 ? T.lens : T.lens + 32;
+                const uint32_t l = lane < 29 && 257 + lane < nl ? (uint32_t)ll[257 + lane] : 0u;
+                const uint32_t mass = wave_sum(l ? 1u << (15u - l) : 0u);     // of 32768
+                L.lenmask = mass >= 8192u ? 0u : mass >= 3072u ? 1u : IP_LENSTEP - 1u;
+            }
+            wave_sync();
+            int16_t *lim = reinterpret_cast<int16_t *>(T.lens);               // lim[l], l = 1 .. 32
 #pragma unroll
             for (int l = 1; l <= 15; l++) {
                 const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)T.lcount[l]);
-                lm1[l] = (int)((first + c) << (15 - l)) - 1;
-                if (lane == l) T.ladj[l] = (uint16_t)(short)((int)offs - (int)first);
+                if (c) { if (minlen == 16) minlen = l; maxlen = l; }
+                if (lane == l) { T.ladj[l] = (uint16_t)(short)((int)offs - (int)first); lim[l] = (int16_t)((int)((first + c) << (15 - l)) - 1); }
                 offs += c;
                 first = (first + c) << 1;
             }
-            lm1[16] = 0x7FFF;                                                 // there is no sixteenth length: never counted
+            if (lane >= 16 && lane < 33) lim[lane] = 0x7FFF;                  // there is no sixteenth length: never counted
+            wave_sync();
 #pragma unroll
-            for (int k = 0; k < 8; k++) { L.m1[k].x = (short)lm1[2 * k + 1]; L.m1[k].y = (short)lm1[2 * k + 2]; }
+            for (int k = 0; k < 8; k++) {
+                L.m1[k].x = (short)__builtin_amdgcn_readfirstlane((int)lim[minlen + 2 * k]);
+                L.m1[k].y = (short)__builtin_amdgcn_readfirstlane((int)lim[minlen + 2 * k + 1]);
+            }
+            L.base = (uint32_t)minlen;
+            L.np = (maxlen - minlen + 1) >> 1;                                // limits of minlen .. maxlen - 1
             wave_sync();
         }
         // ---- the block's tokens, a window at a time ----
