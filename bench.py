@@ -346,7 +346,7 @@ def main():
             idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
             main_recs = (idx, b.stream_records(idx) if single_pass else b.records(idx), b.stream_ok() if single_pass else True)
         sig_cpu_t = None
-        if rank == 0 and (args.cpu_seconds > 0):
+        if rank == 0 and world == 1 and (args.cpu_seconds > 0):   # the CPU baseline is an N = 1 figure
             stride = (n + 7) // 8 * 8
             m = min(n_reads, 262144)
             sig_cpu_t = b.sig[: m * stride].cpu().numpy().reshape(m, stride)[:, :n].copy()
@@ -360,7 +360,7 @@ def main():
         if rank == 0:
             idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
             main_recs = (idx, b.stream_records(idx) if single_pass else b.records(idx), b.stream_ok() if single_pass else True)
-            if args.cpu_seconds > 0 and not args.svb_only and not args.mixed:
+            if world == 1 and args.cpu_seconds > 0 and not args.svb_only and not args.mixed:
                 stride = (n + 7) // 8 * 8
                 m = min(n_reads, 262144)
                 sig_cpu_t = b.sig[: m * stride].cpu().numpy().reshape(m, stride)[:, :n].copy()
