@@ -284,6 +284,9 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
 // always divides the slack, so a pass always finds a taker.  Lane t owns symbols 5t .. 5t+4 in registers; a pass is one LDS
 // histogram over 64 bins (ratio 0.5 .. 2 in steps of 1/32) and two wave scans.  n <= 320, N <= 2^15 (a block holds <= 16 KiB).
 // Returns false (uniform) if the pass limit was hit — never seen; the caller then sends the block with the fixed code.
+// MAXL: longest code allowed (15 DEFLATE, 11 zstd literals).  A Shannon length above MAXL is clamped; if the clamped lengths
+// over-subscribe the code space the function returns false as well (the caller then uses the exact construction).
+template <int MAXL = 15>
 __device__ __forceinline__ bool assign_lengths_wave(const uint32_t *freq, int n, uint8_t *lens, uint32_t *blcount, uint32_t *bins) {
     const int lane = lane_id();
     constexpr uint32_t HUGE_C = 0x80000000u;   // "cannot be shortened": no symbol / already 1 bit
@@ -314,14 +317,17 @@ __device__ __forceinline__ bool assign_lengths_wave(const uint32_t *freq, int n,
     for (int q = 0; q < 5; q++) {
         if (f[q]) {
             const int l0 = a - (32 - __clz((int)f[q]));           // f << l0 has a bits
-            const int lq = l0 + (((f[q] << l0) < N) ? 1 : 0);      // smallest l with f << l >= N; >= 1 because f < N
+            const int ls = l0 + (((f[q] << l0) < N) ? 1 : 0);      // smallest l with f << l >= N; >= 1 because f < N
+            const int lq = min(ls, MAXL);
             l[q] = lq;
-            csum += 1u << (15 - lq);
-            c[q] = lq > 1 ? 1u << (15 - lq) : HUGE_C;
-            b[q] = min(63u, (uint32_t)((float)(f[q] << lq) * inv));   // floor(32 * ratio), ratio in [1, 2)
+            csum += 1u << (MAXL - lq);
+            c[q] = lq > 1 ? 1u << (MAXL - lq) : HUGE_C;
+            b[q] = min(63u, (uint32_t)((float)(f[q] << ls) * inv) >> (ls - lq));   // floor(32 * ratio), ratio in [1, 2); a clamped symbol ranks lower
         } else { l[q] = 0; c[q] = HUGE_C; b[q] = 0; }
     }
-    uint32_t R = 32768u - wave_sum(csum);
+    const uint32_t used_c = wave_sum(csum);
+    if (used_c > (1u << MAXL)) return false;                         // (only possible with MAXL < 15: too many clamped symbols)
+    uint32_t R = (1u << MAXL) - used_c;
     int guard = 0;
     while (R) {   // uniform
         if (++guard > 40) return false;
