@@ -595,3 +595,44 @@ def test_parallel_inflate_takes_stock_zlib_streams_without_the_fallback(press):
                 assert g["status"] == 0 and g["payload"] == zlib.decompress(rec), name
     finally:
         _lib.check(L.s5gpu_set_option(b"inflate_par", 1))
+
+
+def test_parallel_inflate_on_awkward_zlib_streams(press, inflate_kernel):
+    """stock-zlib streams that stress the block / round / waiting-match machinery: a flush every few hundred bytes (dozens of
+    blocks and empty stored blocks per window), text-like data (long matches at every distance, dense in matches), runs of every
+    length, matches that reach back 32 KiB, levels 1 / 9, Z_RLE / Z_HUFFMAN_ONLY / Z_FIXED; the payload is a raw-signal record so
+    that any byte pattern is a valid signal"""
+    rng = np.random.default_rng(404)
+    def words(n):
+        vocab = [bytes(rng.integers(97, 123, int(rng.integers(2, 12)), dtype=np.uint8)) for _ in range(200)]
+        out = bytearray()
+        while len(out) < n:
+            out += vocab[int(rng.integers(0, len(vocab)))] + b" "
+        return bytes(out[:n])
+    blobs = [words(60000), words(3000),
+             bytes(np.repeat(rng.integers(0, 256, 4000, dtype=np.uint8), rng.integers(1, 40, 4000))),              # runs of every length
+             bytes(rng.integers(0, 256, 40000, dtype=np.uint8)) * 2,                                              # 40 000-byte period: > 32 KiB, no matches; then ...
+             bytes(rng.integers(0, 256, 30000, dtype=np.uint8)) * 3,                                              # ... 30 000: matches at distance 30 000
+             bytes(200000), bytes([1, 2, 3]) * 30000, words(500) * 100]
+    streams, sigs = [], []
+    for i, blob in enumerate(blobs):
+        blob = blob[: len(blob) // 2 * 2]
+        sig = np.frombuffer(blob, dtype=np.int16).copy()
+        payload, _ = _oracle_payload(_hdr(press, i), sig, b"", 0)
+        variants = [zlib.compress(payload, 1), zlib.compress(payload, 9)]
+        for strat in (zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_FIXED, zlib.Z_FILTERED):
+            c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, strat)
+            variants.append(c.compress(payload) + c.flush())
+        c = zlib.compressobj(6)
+        parts, step = [], int(rng.integers(150, 900))
+        for k in range(0, len(payload), step):
+            parts.append(c.compress(payload[k:k + step]))
+            parts.append(c.flush(zlib.Z_SYNC_FLUSH if (k // step) % 3 else zlib.Z_FULL_FLUSH))
+        parts.append(c.flush())
+        variants.append(b"".join(parts))
+        for v in variants:
+            assert zlib.decompress(v) == payload
+            streams.append(v); sigs.append(sig)
+    got = press.decode_records(streams, 1, 0)
+    for g, s in zip(got, sigs):
+        assert g["status"] == 0 and np.array_equal(g["signal"], s)
