@@ -16,6 +16,9 @@ tools/kstats.sh r02p/lz python tools/lz_time.py 65536 4000
 tools/kstats.sh r02p/mixed_decode python tools/mixed_lengths.py
 python tools/par_probe.py 262144 4000 > $O/par_probe_262144.txt 2>&1
 python tools/par_probe.py 4096 4000 > $O/par_probe_4096.txt 2>&1
+python tools/par_probe.py 16384 100000 > $O/par_probe_long_reads.txt 2>&1
+python tools/exzd_time.py > $O/exzd_time.txt 2>&1
+python tools/lz_time.py 16384 100000 > $O/lz_time_long_reads.txt 2>&1
 python tools/e2e_view.py 400000 > $O/e2e_view.txt 2>&1
 python tools/par_decline_probe.py 2048 4000 262144 > $O/par_stock_zlib.txt 2>&1
 python tools/par_fixture_probe.py 8192 > $O/par_fixtures.txt 2>&1
