@@ -382,6 +382,79 @@ __device__ __forceinline__ bool z_huf_stream(const uint16_t *huf, uint32_t L, co
     return !b.overrun() && b.done();
 }
 
+// Huffman literals by the WHOLE wave (the serial form above keeps 4 of 64 lanes busy for a thousand dependent steps each): every
+// stream gets G = 64 / streams lanes, each lane a G-th of the stream's bits.  A Huffman stream falls into step with the true code
+// boundaries after a few codes wherever the decoder is dropped (the same observation as inflate_par_dev.h): every lane decodes
+// the symbols that start in its bit range and reports where its last one ends = where the next lane's range REALLY starts; the
+// pass is repeated with the corrected starts until none moves (lane k of a group is certainly right after pass k: G passes
+// bound it), the symbol counts give the output offsets, one more pass writes the bytes.  zstd reads its streams from the last bit
+// down: positions are "bits still in front of the reader" (hi), falling.  All 64 lanes call; p / sl / dst / ns are the lane's
+// stream's.  false: malformed (symbol count or end position wrong).
+__device__ __forceinline__ void z_bits_at(ZBits &b, const uint8_t *p, int hi) {          // reader with hi bits in front of it
+    b.base = p;
+    if (hi <= 0) { b.ptr = 0; b.used = 64; b.c = 0; return; }
+    const uint32_t top = (uint32_t)(hi - 1) >> 3;                                        // byte that holds the next bit
+    b.ptr = top >= 7 ? top - 7 : 0;
+    b.c = *(const z_u64u *)(p + b.ptr);                                                  // (may reach 7 bytes past the stream: readable, skipped by `used`)
+    b.used = 8 * b.ptr + 64 - (uint32_t)hi;
+}
+__device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t L, const uint8_t *p, uint32_t sl, uint8_t *dst, uint32_t ns, int G) {
+    const int lane = lane_id(), j = lane & (G - 1), g0 = lane & ~(G - 1);
+    const uint32_t last = sl ? p[sl - 1] : 0u;
+    if (__ballot(last == 0u)) return false;
+    const int Bs = 8 * (int)(sl - 1) + z_highbit(last);                                  // bits below the end mark
+    const int B = max((Bs + G - 1) / G, 1);
+    const int seg_hi = Bs - j * B, seg_lo = max(seg_hi - B, 0);                          // my symbols start at hi in (seg_lo, seg_hi]
+    int st = seg_hi, cross = seg_hi;
+    uint32_t cnt = 0;
+    for (int pass = 0; pass <= G; pass++) {
+        ZBits b;
+        z_bits_at(b, p, st);
+        int hi = st;
+        cnt = 0;
+        while (__ballot(hi > seg_lo)) {
+            if (hi > seg_lo) {
+                b.need(L);
+                const uint32_t e = huf[b.peek(L)];
+                const uint32_t nb = max(e >> 8, 1u);                                     // (a complete table has no empty cell; never stall on one)
+                b.used += nb;
+                hi -= (int)nb;
+                cnt++;
+            }
+        }
+        cross = hi;
+        int nst = __shfl(cross, max(lane - 1, 0));
+        if (j == 0) nst = Bs;
+        const bool moved = nst != st;
+        st = nst;
+        if (!__ballot(moved)) break;
+    }
+    // the group's symbols must be exactly ns and the last one must end at the stream's first bit
+    const uint32_t incl = wave_incl_add(cnt);
+    const uint32_t prevg = (uint32_t)__shfl((int)incl, max(g0 - 1, 0));                  // (every lane takes part: a shuffle reads nothing from a lane that sits it out)
+    const uint32_t before = g0 ? prevg : 0u;
+    const uint32_t total = (uint32_t)__shfl((int)incl, g0 + G - 1) - before;
+    const int fin = __shfl(cross, g0 + G - 1);
+    if (__ballot(total != ns || fin != 0)) return false;
+    {   // ---- output ----
+        uint8_t *q = dst + (incl - cnt - before);
+        ZBits b;
+        z_bits_at(b, p, st);
+        int hi = st;
+        while (__ballot(hi > seg_lo)) {
+            if (hi > seg_lo) {
+                b.need(L);
+                const uint32_t e = huf[b.peek(L)];
+                const uint32_t nb = max(e >> 8, 1u);
+                b.used += nb;
+                hi -= (int)nb;
+                *q++ = (uint8_t)e;
+            }
+        }
+    }
+    return true;
+}
+
 // One frame -> out (olen bytes).  INF_OK, or INF_ERR_HEADER / DATA / TRUNC / OVERFLOW (olen = bytes needed when the frame says).
 __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out) {
     const int lane = lane_id();
@@ -493,7 +566,12 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 c += 6;
                 const uint32_t per = (lsize + 3) / 4;
                 if (s1 + s2 + s3 > cend - c || 3 * per > lsize) { status = INF_ERR_DATA; break; }
-                if (lane < 4) {
+                if (lsize >= 512) {                                  // 16 lanes per stream (z_huf_streams_par)
+                    const int k = lane >> 4;
+                    const uint32_t from = k == 0 ? 0 : k == 1 ? s1 : k == 2 ? s1 + s2 : s1 + s2 + s3;
+                    const uint32_t sl = k == 0 ? s1 : k == 1 ? s2 : k == 2 ? s3 : cend - c - s1 - s2 - s3;
+                    ok = z_huf_streams_par(T.huf, (uint32_t)huf_log, b + c + from, sl, park + (uint32_t)k * per, k == 3 ? lsize - 3 * per : per, 16);
+                } else if (lane < 4) {
                     const uint32_t from = lane == 0 ? 0 : lane == 1 ? s1 : lane == 2 ? s1 + s2 : s1 + s2 + s3;
                     const uint32_t sl = lane == 0 ? s1 : lane == 1 ? s2 : lane == 2 ? s3 : cend - c - s1 - s2 - s3;
                     ok = z_huf_stream(T.huf, (uint32_t)huf_log, b + c + from, sl, park + (uint32_t)lane * per, lane == 3 ? lsize - 3 * per : per);
