@@ -557,10 +557,11 @@ def bench_decode(args):
         same = bool((stt == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n],
                                                                    b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]))
         alg = z_total + 2 * n * n_reads                         # Z + 2N per record (decode)
+        dtraffic, dtraffic_src = pmc_traffic("k_inflate_par+k_unpack", n, n_reads)
         bulk = {"reads": n_reads, "ms": round(ms, 2), "reads_per_s": round(n_reads / ms * 1e3, 1),
                 "raw_signal_GB_per_s": round(n_reads * 2 * n / ms / 1e6, 2), "roundtrip_identical": same,
                 "roofline": {"bound": "hbm", "kernel": "k_inflate_par+k_unpack", "achieved": round(alg / ms / 1e6, 2), "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": round(alg / ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": alg}}
+                             "unit": "GB/s", "frac": round(alg / ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": dtraffic, "traffic_source": dtraffic_src, "algorithmic_bytes_per_launch": alg}}
         ok &= same
         # ---- the same call on records WRITTEN BY STOCK ZLIB (what the reference's own files hold: level 6, arbitrary LZ77
         # distances): 2048 distinct records compressed on the CPU, tiled to 262 144; every decoded signal compared ----

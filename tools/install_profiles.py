@@ -29,5 +29,17 @@ write = float(re.search(r"WRITE_SIZE\s+per-launch avg\s+([\d.]+)", txt).group(1)
 entry = {"kernel": "k_encode_stream", "samples_per_read": 4000, "hbm_bytes_per_read": round((2 * fetch + write) * 1024 / reads, 1),
          "source": "profiles/%s_pmc_k_encode_stream.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB per launch of %d reads; FETCH x 2: gfx950 correction)" % (tag, reads),
          "csrc_sha256": bench.csrc_sha256()}
-json.dump([entry], open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
-print(entry)
+entries = [entry]
+dt = os.path.join(src, "pmc_decode_traffic.txt")
+if os.path.exists(dt):      # bulk decode: the inflating wave also unpacks, so one kernel's traffic is the whole decode's
+    t = open(dt).read()
+    f2 = re.search(r"FETCH_SIZE\s+per-launch\s+([\d.]+)\s+grid (\d+)", t)
+    w2 = re.search(r"WRITE_SIZE\s+per-launch\s+([\d.]+)", t)
+    if f2 and w2:
+        recs = int(f2.group(2)) // 64
+        entries.append({"kernel": "k_inflate_par+k_unpack", "samples_per_read": 4000,
+                        "hbm_bytes_per_read": round((2 * float(f2.group(1)) + float(w2.group(1))) * 1024 / recs, 1),
+                        "source": "profiles/%s_pmc_decode_traffic.txt (k_inflate_par<true> over %d records; FETCH x 2: gfx950 correction)" % (tag, recs),
+                        "csrc_sha256": bench.csrc_sha256()})
+json.dump(entries, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+for e in entries: print(e)

@@ -25,4 +25,5 @@ python tools/par_fixture_probe.py 8192 > $O/par_fixtures.txt 2>&1
 python tools/pcie_rate.py > $O/pcie_rate.txt 2>&1
 bash tools/pmc_inflate.sh 65536 4000 > $O/pmc_k_inflate_par.txt 2>&1
 ( echo "# tools/pmc.sh 400000 (KERNEL=k_encode_stream): per-launch averages over 400000 reads of 4000 samples; FETCH_SIZE / WRITE_SIZE in KiB"; KERNEL=k_encode_stream tools/pmc.sh 400000 ) > $O/pmc_k_encode_stream.txt 2>&1
+bash tools/pmc_decode_traffic.sh > $O/pmc_decode_traffic.txt 2>&1
 tail -30 $O/pmc_k_encode_stream.txt
