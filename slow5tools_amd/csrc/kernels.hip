@@ -592,16 +592,28 @@ __global__ __launch_bounds__(64) void k_inflate_fallback(s5gpu_decode_args_t a) 
     }
 }
 
-// K4 for the zstd record press: one frame per wave64 (zstd_dev.h)
+// K4 for the zstd record press: one frame per wave64 (zstd_dev.h).  UNPACK: as k_inflate_par<true> — the wave parses the record and
+// decodes its svb-zd signal right away (the Huffman table's storage is the stage), k_unpack_rest clears the marks
+static_assert(sizeof(ZstdShared::huf) + sizeof(ZstdShared::ll_e) >= SVB_WSTAGE && offsetof(ZstdShared, ll_e) == sizeof(ZstdShared::huf),
+              "the Huffman table and the table behind it double as the svb-zd stage");
+template <bool UNPACK>
 __global__ __launch_bounds__(64) void k_zstd_inflate(s5gpu_decode_args_t a) {
-    __shared__ ZstdShared T;
+    __shared__ __attribute__((aligned(16))) ZstdShared T;
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
-    const int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+    int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+    uint32_t mark = 0;
+    if (UNPACK && status == 0) {
+        wave_sync();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        status = unpack_svbzd_wave(a, d, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.huf));
+        mark = 1;
+    }
     if (lane_id() == 0) {
         a.fields[r].status = status;
         a.fields[r].payload_len = olen;
+        if (UNPACK) a.fields[r].reserved = mark;
     }
 }
 
@@ -1224,7 +1236,8 @@ void s5kern_release_aux() {   // s5gpu_shutdown
 
 static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, bool unpack = false) {   // unpack: k_inflate_par also parses + decodes (svb-zd)
     if (a->rec_method == S5GPU_REC_ZSTD) {
-        hipLaunchKernelGGL(k_zstd_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
+        if (unpack) hipLaunchKernelGGL(k_zstd_inflate<true>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        else hipLaunchKernelGGL(k_zstd_inflate<false>, dim3(a->n_recs), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && g_inflate_par) {
         if (unpack) hipLaunchKernelGGL(k_inflate_par<true>, dim3(a->n_recs), dim3(64), 0, st, *a);
         else hipLaunchKernelGGL(k_inflate_par<false>, dim3(a->n_recs), dim3(64), 0, st, *a);
@@ -1306,8 +1319,9 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
     }
     if (a->n_recs == 0) return S5GPU_OK;
     hipStream_t st = (hipStream_t)stream_;
-    // zlib + svb-zd with the default inflate kernel: the wave that inflates a record unpacks it too (k_inflate_par<true>)
-    const bool fused = a->rec_method == S5GPU_REC_ZLIB && a->sig_method == S5GPU_SIG_SVB_ZD && g_inflate_par == 1 && g_unpack_fused;
+    // svb-zd records under zlib (default inflate kernel) or zstd: the wave that decompresses a record unpacks it too
+    const bool fused = a->sig_method == S5GPU_SIG_SVB_ZD && g_unpack_fused &&
+                       ((a->rec_method == S5GPU_REC_ZLIB && g_inflate_par == 1) || a->rec_method == S5GPU_REC_ZSTD);
     int rc = launch_inflate(a, st, fused);
     if (rc) return rc;
     // the ex-zd decoder keeps one chunk of exceptions and a flag map in (dynamic) LDS; the other signal formats need none
