@@ -139,7 +139,7 @@ int s5gpu_device_count(void);
  * In inflate-only calls fields[i].reserved, fields[0..128].read_group and fields[128].aux_len are then left holding routing
  * scratch (s5gpu_decode_dev overwrites all of them with the parsed fields).
  * "multi_min_per_device" (default 1024): a host batch of fewer than this many records per device stays on the first device.
- * "unpack_fused" (0/1, default 1): s5gpu_decode_dev on zlib + svb-zd records lets the wave that inflated a record parse it and decode
+ * "unpack_fused" (0/1, default 1): s5gpu_decode_dev on zlib / zstd + svb-zd records lets the wave that decompressed a record parse it and decode
  * its signal as well (fields.reserved is scratch on the way and 0 at the end); 0 = always the separate unpack kernel.
  * "zstd_sequences" (0/1, default 1): the zstd encoder sends runs of >= 5 equal bytes as one literal + one match at the repeat
  * offset (predefined FSE tables); 0 = literals-only frames cut at the record's seams (round 1; ~2 % larger records). */
