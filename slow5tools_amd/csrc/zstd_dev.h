@@ -455,6 +455,23 @@ __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t 
     return true;
 }
 
+// n bytes from s to d by the whole wave, d <= s when the two ranges overlap (literals parked behind the output are moved down in
+// place): 16 bytes per lane and step — all loads of a step are issued before its stores, and later steps read further up
+__device__ __forceinline__ void z_wave_move_down(uint8_t *d, const uint8_t *s, uint32_t n) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(1)));
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t body = n & ~15u;
+    for (uint32_t k = 16u * lane; k < body; k += 1024u) {
+        const u4 v = *reinterpret_cast<const u4 *>(s + k);
+        *reinterpret_cast<u4 *>(d + k) = v;
+    }
+    wave_sync();
+    uint8_t b = 0;
+    if (lane < n - body) b = s[body + lane];
+    wave_sync();
+    if (lane < n - body) d[body + lane] = b;
+}
+
 // One frame -> out (olen bytes).  INF_OK, or INF_ERR_HEADER / DATA / TRUNC / OVERFLOW (olen = bytes needed when the frame says).
 __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out) {
     const int lane = lane_id();
@@ -655,7 +672,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 // room: the output may not run into the parked literals still unread, nor past the end of the slot
                 const uint32_t lim = lit_parked ? E - lsize + li + llen : E;
                 if ((uint64_t)o + llen + mlen > lim) { status = fcs_bytes ? INF_ERR_DATA : INF_ERR_OVERFLOW; break; }
-                if (lit) { for (uint32_t k = lane; k < llen; k += 64) out[o + k] = lit[li + k]; }
+                if (lit) { if (llen > 64) z_wave_move_down(out + o, lit + li, llen); else if ((uint32_t)lane < llen) out[o + lane] = lit[li + lane]; }
                 else { for (uint32_t k = lane; k < llen; k += 64) out[o + k] = (uint8_t)lit_fill; }
                 o += llen; li += llen;
                 wave_sync();
@@ -670,7 +687,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
         }
         const uint32_t restl = lsize - li;
         if ((uint64_t)o + restl > E) { status = fcs_bytes ? INF_ERR_DATA : INF_ERR_OVERFLOW; break; }
-        if (lit) { for (uint32_t k = lane; k < restl; k += 64) out[o + k] = lit[li + k]; }
+        if (lit) z_wave_move_down(out + o, lit + li, restl);
         else { for (uint32_t k = lane; k < restl; k += 64) out[o + k] = (uint8_t)lit_fill; }
         o += restl;
         wave_sync();
