@@ -413,13 +413,18 @@ __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t 
         int hi = st;
         cnt = 0;
         while (__ballot(hi > seg_lo)) {
-            if (hi > seg_lo) {
-                b.need(L);
-                const uint32_t e = huf[b.peek(L)];
-                const uint32_t nb = max(e >> 8, 1u);                                     // (a complete table has no empty cell; never stall on one)
-                b.used += nb;
-                hi -= (int)nb;
-                cnt++;
+            // four symbols (<= 44 bits) per refill, and every lane refills HERE: a lane that refilled when it ran dry would make
+            // the wave wait for a global load in nearly every step (64 lanes, each dry every fifth step)
+            b.need(44);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                if (hi > seg_lo) {
+                    const uint32_t e = huf[b.peek(L)];
+                    const uint32_t nb = max(e >> 8, 1u);                                 // (a complete table has no empty cell; never stall on one)
+                    b.used += nb;
+                    hi -= (int)nb;
+                    cnt++;
+                }
             }
         }
         cross = hi;
@@ -442,13 +447,16 @@ __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t 
         z_bits_at(b, p, st);
         int hi = st;
         while (__ballot(hi > seg_lo)) {
-            if (hi > seg_lo) {
-                b.need(L);
-                const uint32_t e = huf[b.peek(L)];
-                const uint32_t nb = max(e >> 8, 1u);
-                b.used += nb;
-                hi -= (int)nb;
-                *q++ = (uint8_t)e;
+            b.need(44);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                if (hi > seg_lo) {
+                    const uint32_t e = huf[b.peek(L)];
+                    const uint32_t nb = max(e >> 8, 1u);
+                    b.used += nb;
+                    hi -= (int)nb;
+                    *q++ = (uint8_t)e;
+                }
             }
         }
     }
