@@ -398,6 +398,31 @@ __device__ __forceinline__ void z_bits_at(ZBits &b, const uint8_t *p, int hi) { 
     b.c = *(const z_u64u *)(p + b.ptr);                                                  // (may reach 7 bytes past the stream: readable, skipped by `used`)
     b.used = 8 * b.ptr + 64 - (uint32_t)hi;
 }
+// the same reader with the NEXT eight bytes already on their way: a refill shifts them in and asks for the eight below — the
+// global load is off the lane's critical path (what is left on it is the table lookup per symbol)
+struct ZPre {
+    const uint8_t *base;
+    uint32_t ptr, used;
+    uint64_t c, below;
+    __device__ __forceinline__ void at(const uint8_t *p, int hi) {
+        base = p;
+        if (hi <= 0) { ptr = 0; used = 64; c = 0; below = 0; return; }
+        const uint32_t top = (uint32_t)(hi - 1) >> 3;
+        ptr = top >= 7 ? top - 7 : 0;
+        c = *(const z_u64u *)(p + ptr);
+        below = *(const z_u64u *)(p + ptr - 8);                      // (bytes in front of a stream are the block's own: readable, never used past ptr = 0)
+        used = 8 * ptr + 64 - (uint32_t)hi;
+    }
+    __device__ __forceinline__ void refill() {                        // afterwards used <= 7 (or the stream's first byte is in the container)
+        const uint32_t nb = min(used >> 3, ptr);
+        if (nb) {
+            c = nb == 8 ? below : (c << (8 * nb)) | (below >> (64 - 8 * nb));
+            ptr -= nb; used -= 8 * nb;
+            below = *(const z_u64u *)(base + ptr - 8);
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return used < 64 ? (uint32_t)(((c << used) >> 1) >> (63 - n)) : 0u; }
+};
 __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t L, const uint8_t *p, uint32_t sl, uint8_t *dst, uint32_t ns, int G) {
     const int lane = lane_id(), j = lane & (G - 1), g0 = lane & ~(G - 1);
     const uint32_t last = sl ? p[sl - 1] : 0u;
@@ -408,14 +433,14 @@ __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t 
     int st = seg_hi, cross = seg_hi;
     uint32_t cnt = 0;
     for (int pass = 0; pass <= G; pass++) {
-        ZBits b;
-        z_bits_at(b, p, st);
+        ZPre b;
+        b.at(p, st);
         int hi = st;
         cnt = 0;
         while (__ballot(hi > seg_lo)) {
             // four symbols (<= 44 bits) per refill, and every lane refills HERE: a lane that refilled when it ran dry would make
             // the wave wait for a global load in nearly every step (64 lanes, each dry every fifth step)
-            b.need(44);
+            b.refill();
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) {
                 if (hi > seg_lo) {
@@ -443,11 +468,11 @@ __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t 
     if (__ballot(total != ns || fin != 0)) return false;
     {   // ---- output ----
         uint8_t *q = dst + (incl - cnt - before);
-        ZBits b;
-        z_bits_at(b, p, st);
+        ZPre b;
+        b.at(p, st);
         int hi = st;
         while (__ballot(hi > seg_lo)) {
-            b.need(44);
+            b.refill();
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) {
                 if (hi > seg_lo) {
