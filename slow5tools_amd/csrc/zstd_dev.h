@@ -275,27 +275,43 @@ __device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *
     if (!h) return 0;
     const ZFse wt = {T.wt_e, T.wt_s};
     if (z_fse_build_wave(T, wt, (int)T.x[5], log)) return 0;
-    if (lane == 0) {
+    {
+        // The two interleaved states share one bit cursor: a serial chain of ~255 steps.  Walked with the state in scalar registers:
+        // the table (<= 64 cells) sits one cell per lane and the stream (<= 127 bytes) one dword per lane, so a step is a few
+        // v_readlane and scalar shifts — no LDS or global round trip on the chain
+        const uint8_t *sp = p + 1 + h;
+        const uint32_t slen = hb - h;                                   // 1 .. 126
+        const uint32_t cell = lane < (1 << log) ? zfse_get(wt, (uint32_t)lane) : 0u;   // symbol | bits << 8 | baseline << 16
+        uint32_t sw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t at = 4u * (uint32_t)lane + k; if (at < slen) sw |= (uint32_t)sp[at] << (8 * k); }
+        const uint32_t lastb = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp[slen - 1]);
         uint32_t nsym = 0;
-        ZBits b;
-        if (b.init(p + 1 + h, hb - h)) {
-            uint32_t s1 = b.get((uint32_t)log);
-            uint32_t s2 = b.get((uint32_t)log);
-            for (;;) {                                            // two interleaved states
-                if (nsym >= 254) { nsym = 0; break; }
-                const uint32_t e1 = zfse_get(wt, s1), e2 = zfse_get(wt, s2);
-                T.w[nsym++] = (uint8_t)e1;
-                b.need(8);
-                if (b.overrun() || b.left() < ((e1 >> 8) & 255)) { T.w[nsym++] = (uint8_t)e2; break; }
-                s1 = (e1 >> 16) + b.get((e1 >> 8) & 255);
-                T.w[nsym++] = (uint8_t)e2;
-                b.need(8);
-                if (b.left() < ((e2 >> 8) & 255)) { T.w[nsym++] = T.wt_s[s1]; break; }
-                s2 = (e2 >> 16) + b.get((e2 >> 8) & 255);
+        if (lastb) {
+            int hi = 8 * (int)(slen - 1) + z_highbit(lastb);            // bits in front of the cursor (uniform)
+            if (hi >= 2 * log) {
+#define ZW_GET(dst, n) { hi -= (int)(n); const uint32_t wi_ = (uint32_t)hi >> 5; \
+                         const uint64_t two_ = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sw, (int)wi_) | \
+                                               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sw, (int)min(wi_ + 1u, 63u)) << 32); \
+                         dst = (uint32_t)(two_ >> ((uint32_t)hi & 31u)) & ((1u << (n)) - 1u); }
+                uint32_t s1, s2, t;
+                ZW_GET(s1, (uint32_t)log); ZW_GET(s2, (uint32_t)log);
+                for (;;) {
+                    if (nsym >= 254) { nsym = 0; break; }
+                    const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)cell, (int)s1), e2 = (uint32_t)__builtin_amdgcn_readlane((int)cell, (int)s2);
+                    const uint32_t n1 = (e1 >> 8) & 255u, n2 = (e2 >> 8) & 255u;
+                    if (lane == 0) { T.w[nsym] = (uint8_t)e1; T.w[nsym + 1] = (uint8_t)e2; }
+                    nsym += 2;
+                    if (hi < (int)n1) break;
+                    ZW_GET(t, n1); s1 = (e1 >> 16) + t;
+                    if (hi < (int)n2) { if (lane == 0) T.w[nsym] = (uint8_t)__builtin_amdgcn_readlane((int)cell, (int)s1); nsym++; break; }
+                    ZW_GET(t, n2); s2 = (e2 >> 16) + t;
+                }
+#undef ZW_GET
+                if (nsym > 255) nsym = 0;
             }
-            if (nsym > 255) nsym = 0;
         }
-        T.x[4] = nsym;
+        if (lane == 0) T.x[4] = nsym;
     }
     wave_sync();
     if (!T.x[4]) return 0;
