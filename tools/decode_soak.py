@@ -48,5 +48,17 @@ for label, recs, opts in (("own encoder, default", own, {}), ("stock zlib, defau
     fail = sum(1 for g in got if g["status"] not in (0, 8))
     bad += wrong + fail
     print("%-34s statuses %s  wrong signals %d  (%.1f s)" % (label, dict(st), wrong, time.time() - t1))
+if ob.zstd_ref() is not None:      # zstd records: this library's frames and libzstd's own (levels 1, 3, 9)
+    sub = list(range(0, n_rec, max(1, n_rec // 4000)))
+    own_z = [r[8:] for r in press.encode_records([sigs[i] for i in sub], [hdrs[i] for i in sub], None, press.REC_ZSTD, press.SIG_SVB_ZD)]
+    lib_z = []
+    for k, i in enumerate(sub):
+        rec, keep = ob.make_rec(b"read_%07d" % i, i % 5, 8192.0, 3.0, 1400.0, 4000.0, sigs[i])
+        lib_z.append(ob.zstd_compress(ob.rec_pack(rec, ob.SIG_SVB_ZD), (1, 3, 9)[k % 3]))
+    for label, recs in (("zstd, own frames", own_z), ("zstd, libzstd frames", lib_z)):
+        got = press.decode_records(recs, press.REC_ZSTD, press.SIG_SVB_ZD, raise_on_error=False)
+        wrong = sum(1 for g, i in zip(got, sub) if g["status"] != 0 or not np.array_equal(g["signal"], sigs[i]))
+        bad += wrong
+        print("%-34s %d records  wrong %d" % (label, len(recs), wrong))
 print("SOAK", "OK" if bad == 0 else "FAILED")
 sys.exit(1 if bad else 0)
