@@ -60,5 +60,12 @@ if ob.zstd_ref() is not None:      # zstd records: this library's frames and lib
         wrong = sum(1 for g, i in zip(got, sub) if g["status"] != 0 or not np.array_equal(g["signal"], sigs[i]))
         bad += wrong
         print("%-34s %d records  wrong %d" % (label, len(recs), wrong))
+sub = list(range(1, n_rec, max(1, n_rec // 4000)))     # ex-zd signal press under zlib and zstd: device round trip (the oracle checks the blobs in the suite)
+for rm_name, rm in (("zlib", press.REC_ZLIB), ("zstd", press.REC_ZSTD)):
+    recs = [r[8:] for r in press.encode_records([sigs[i] for i in sub], [hdrs[i] for i in sub], None, rm, press.SIG_EX_ZD)]
+    got = press.decode_records(recs, rm, press.SIG_EX_ZD, raise_on_error=False)
+    wrong = sum(1 for g, i in zip(got, sub) if g["status"] != 0 or not np.array_equal(g["signal"], sigs[i]))
+    bad += wrong
+    print("%-34s %d records  wrong %d" % ("ex-zd under " + rm_name, len(recs), wrong))
 print("SOAK", "OK" if bad == 0 else "FAILED")
 sys.exit(1 if bad else 0)
