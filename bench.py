@@ -2,8 +2,14 @@
 """bench.py — BLOW5 record press throughput on N MI355X (BASELINE.json's metric: raw-signal GB/s and reads/s).
 
 Default run = BASELINE configs[2] as the headline value (1 M reads x 4000 samples per GPU, full encode svb-zd + DEFLATE,
-weak scaling) PLUS a configs[3] leg in the same JSON line under "configs3" (100 k-sample reads, a fixed read-index space
-sharded over the ranks with shard.shard_range: strong scaling).
+weak scaling) PLUS, in the same JSON line, one object per other GPU config of BASELINE.json:
+    "configs1"  svb-zd encode alone on the same reads                                     (k_svbzd_encode, HBM-bound)
+    "configs4"  decode for random `get` over the index of the records just written: K = 4096 batches (p50 / p99 latency) and
+                the whole index in one call, on our own records and on records written by stock zlib, every signal compared
+                with the generator; fields + signals only (S5GPU_DEC_NO_PAYLOAD), the full-record form beside it
+    "configs3"  100 k-sample reads, a fixed read-index space sharded over the ranks with shard.shard_range (strong scaling)
+Every GPU leg runs for about a second of device time or more (the headline's K steps are what `value` is computed on; a
+"sustained" repeat of the same step follows it), so that a coarse utilisation sampler sees the legs.
 
 A step = one pass of the hot path over one resident batch of synthetic reads, ending in the contiguous BLOW5 record
 stream the ordered fwrite loop emits:
@@ -11,10 +17,11 @@ stream the ordered fwrite loop emits:
                      decoupled look-back: one launch)                                   [default]
     or k_encode_fused / k_pack + k_deflate_staged into worst-case slots + s5gpu_compact (--two-pass, long reads, --svb-only)
 Inputs (int16 signals, 74-byte record heads) are already in HBM when the timed region starts.
-Reads shard across ranks with no collective.  Prints ONE JSON line on rank 0.
+Reads shard across ranks with no collective (RCCL carries the timing barrier and the MAX of the elapsed time only).
+Prints ONE JSON line on rank 0.
 
 Other modes (one line each, for profiles/):  --svb-only (configs[1]), --long (configs[3] alone), --mixed (read lengths of a
-real run), --decode (configs[4]), --samples / --reads (any uniform shape).
+real run), --decode (configs[4] alone), --samples / --reads (any uniform shape).
 """
 import argparse
 import ctypes as C
@@ -68,6 +75,26 @@ def make_events(L, _lib, count):
     return evs
 
 
+def elapsed_ms(L, _lib, a, b):
+    ms = C.c_float()
+    _lib.check(L.s5gpu_event_elapsed_ms(a, b, C.byref(ms)))
+    return ms.value
+
+
+TIMING_DEV = None   # device of the one-element tensors of the timing all-reduces (the rank's GPU; "cpu" under the gloo pre-flight)
+
+
+def timed(shard, torch, dev, body):
+    """the contract's timed region: barrier + synchronize on both sides, MAX over ranks"""
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    body()
+    torch.cuda.synchronize()
+    shard.barrier()
+    return shard.max_over_ranks(time.perf_counter() - t0, device=TIMING_DEV or dev)
+
+
 def cpu_encode_baseline(ob, sig2d, first, n, ref_seconds, sweep_seconds):
     """The oracle's reference-shaped pthread batch encode on this box's host cores.  `value` is the reference's own shape
     (view -t <all cores> -K 4096: threads created and joined per batch, 16 records per thread on a 256-core box, so it is
@@ -92,7 +119,10 @@ def cpu_encode_baseline(ob, sig2d, first, n, ref_seconds, sweep_seconds):
            "reads_per_s": round(reads / secs, 1), "bytes_per_sample": round(out_bytes / (reads * n), 4),
            "shape": "view -t %d -K 4096 (the reference's defaults on this box; thread create/join per batch, src/thread.c:100-110)" % cores,
            "sample": "first %d reads of the same batch (%d samples each), compute phase only (svb-zd + zlib-1.2.11 level 6, per-record "
-                     "deflateInit), repeated for %.1f s" % (m, n, secs)}
+                     "deflateInit), repeated for %.1f s" % (m, n, secs),
+           "per_core_note": "the reference allocates and clears a 256 KiB deflate state per record (slow5_press_init, src/view.c:43-54) and "
+                            "creates / joins its threads per batch (src/thread.c:100-110): per-core throughput at -t all is a fraction of the "
+                            "single-thread figure; best_of is the -t / -K the same code runs fastest at"}
     if sweep_seconds > 0:
         sweep = []
         for t in sorted({min(32, cores), min(64, cores), min(128, cores), cores}):
@@ -149,22 +179,14 @@ def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
     for _ in range(W):
         step()
     torch.cuda.synchronize()
+    # at least ~1 s of device time: the leg's own step count (the headline's K is kept when it is larger)
+    K = max(K, args.min_leg_steps_long)
     evs = make_events(L, _lib, 3 * K * len(chunks))
-    shard.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(K):
-        step(evs, k)
-    torch.cuda.synchronize()
-    shard.barrier()
-    dt = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
-    ms = C.c_float()
+    dt = timed(shard, torch, dev, lambda: [step(evs, k) for k in range(K)])
     enc_ms = cmp_ms = 0.0
     for i in range(K * len(chunks)):
-        _lib.check(L.s5gpu_event_elapsed_ms(evs[3 * i], evs[3 * i + 1], C.byref(ms)))
-        enc_ms += ms.value
-        _lib.check(L.s5gpu_event_elapsed_ms(evs[3 * i + 1], evs[3 * i + 2], C.byref(ms)))
-        cmp_ms += ms.value
+        enc_ms += elapsed_ms(L, _lib, evs[3 * i], evs[3 * i + 1])
+        cmp_ms += elapsed_ms(L, _lib, evs[3 * i + 1], evs[3 * i + 2])
     for e in evs:
         L.s5gpu_event_destroy(e)
     enc_ms /= K
@@ -185,6 +207,7 @@ def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
     alg = 2 * n * mine + 74 * mine + z_bytes          # 2N + H + Z per read, this rank's shard per step
     achieved = alg / (enc_ms / 1e3) / 1e9
     reads_per_s = total * K / dt
+    traffic, traffic_src = pmc_traffic("k_pack+k_deflate_staged", n, mine)
     return {
         "workload": "BASELINE configs[3] shape: record-sharded full BLOW5 encode, %d reads x %d int16 samples = %.1f GB raw signal per step "
                     "(a 1/%.1f fraction of the 10 M-read job), read-index space split over %d rank(s) with shard_range, chunks of <= %d reads "
@@ -195,35 +218,317 @@ def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
         "bytes_per_sample": round(z_bytes / (mine * n), 4), "parity_spot_check": bool(parity),
         "kernel_ms": {"pack+deflate_staged": round(enc_ms, 3), "compact": round(cmp_ms, 3)},
         "roofline": {"bound": "hbm", "kernel": "k_pack+k_deflate_staged", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": alg,
+                     "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
                      "note": "rank 0's shard per step; launch = the chunk loop of one step (k_pack + k_deflate_staged per chunk)"},
     }
+
+
+def svb_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, K, W):
+    """BASELINE configs[1]: the svb-zd stage alone on the same resident reads (k_svbzd_encode into slots + the compaction
+    into one blob stream), bit-exact against the oracle on a spot sample (the full comparison is tests/test_full_size.py)."""
+    import numpy as np
+    import torch
+
+    st = b._stream()
+
+    def step(evs=None, k=0):
+        if evs is not None:
+            L.s5gpu_event_record(evs[3 * k], st)
+        b.svbzd_encode()
+        if evs is not None:
+            L.s5gpu_event_record(evs[3 * k + 1], st)
+        b.compact()
+        if evs is not None:
+            L.s5gpu_event_record(evs[3 * k + 2], st)
+
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    K = max(K, args.min_leg_steps_svb)
+    evs = make_events(L, _lib, 3 * K)
+    dt = timed(shard, torch, dev, lambda: [step(evs, k) for k in range(K)])
+    enc = [elapsed_ms(L, _lib, evs[3 * k], evs[3 * k + 1]) for k in range(K)]
+    cmp_ = [elapsed_ms(L, _lib, evs[3 * k + 1], evs[3 * k + 2]) for k in range(K)]
+    for e in evs:
+        L.s5gpu_event_destroy(e)
+    if rank != 0:
+        return None
+    s_bytes = int(b.out_len[:n_reads].sum().item())
+    idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
+    parity = True
+    for i, blob in zip(idx, b.records(idx)):
+        parity &= blob == ob.svbzd_encode(ob.synth_read(0x5105, rank * n_reads + i, n))
+    alg = 2 * n * n_reads + s_bytes                   # 2N + S per read (SURVEY 8d, K1)
+    kern_s = float(np.mean(enc)) / 1e3
+    traffic, traffic_src = pmc_traffic("k_svbzd_encode", n, n_reads)
+    return {
+        "workload": "BASELINE configs[1]: svb-zd zig-zag-delta encode only, %d reads x %d int16 samples per GPU, bit-exact vs the CPU svb" % (n_reads, n),
+        "value": round(2 * n * n_reads * world * K / dt / 1e9, 3), "unit": "GB/s", "reads_per_s": round(n_reads * world * K / dt, 1),
+        "scaling": "weak", "n_gpus": world, "steps": K, "ms_per_step": round(dt / K * 1e3, 3),
+        "svb_bytes_per_sample": round(s_bytes / (n_reads * n), 4), "parity_spot_check": bool(parity),
+        "kernel_ms": {"svbzd_encode": round(float(np.mean(enc)), 3), "compact": round(float(np.mean(cmp_)), 3)},
+        "roofline": {"bound": "hbm", "kernel": "k_svbzd_encode", "achieved": round(alg / kern_s / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(alg / kern_s / 1e9 / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg},
+    }
+
+
+def decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, want_cpu):
+    """BASELINE configs[4]: decode for random `get` over the index of the --reads records in b.stream_out / b.rec_off, batches of
+    --get-batch ids.  Per batch (what src/get.c:321-386 does per -K batch, minus the preads: the file-backed harness is
+    examples/s5get.c, tools/get_bench.py): build the batch's record descriptors from the index, upload them, inflate + unpack on the
+    GPU, synchronise.  Then the whole index in one call.  Every decoded signal is compared with the generator's.
+    Primary form: fields + signals only (S5GPU_DEC_NO_PAYLOAD: the caller of a get holds the read ids, the synthetic records have no
+    aux fields); the form that also writes the uncompressed record out is timed beside it."""
+    import numpy as np
+    import torch
+
+    torch.cuda.synchronize()
+    rec_off = b.rec_off.cpu().numpy().astype(np.int64)          # the "index": offset/size per read (Appendix A.5)
+    z_total = int(rec_off[n_reads])
+    rng = np.random.default_rng(1)
+    ids = rng.integers(0, n_reads, args.get_reads)
+    K = args.get_batch
+    pay_cap = 16 * ((int(b.tot["max_payload"]) + 31) // 16)
+    sig_cap = (n + 7) // 8 * 8
+    st = b._stream()
+    ev = make_events(L, _lib, 2)
+    L.s5gpu_decode_scratch_bytes.restype = C.c_uint64
+    L.s5gpu_decode_scratch_bytes.argtypes = [C.c_uint32]
+    scratch_bytes = int(L.s5gpu_decode_scratch_bytes(pay_cap))
+    scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+    sig = torch.empty(K * sig_cap + 64, dtype=torch.int16, device=dev)
+    fields = torch.zeros(K * 64, dtype=torch.uint8, device=dev)
+    desc_dev = torch.empty(K * _lib.REC_DESC.itemsize, dtype=torch.uint8, device=dev)
+    src_sig = b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)
+
+    def args_for(nrec, desc_t, sig_t, fields_t, in_ptr, payload_t=None):
+        a = _lib.DecodeArgs()
+        a.n_recs, a.rec_method, a.sig_method = nrec, 1, 1
+        a.desc, a.in_, a.sig_out, a.fields = desc_t.data_ptr(), in_ptr, sig_t.data_ptr(), fields_t.data_ptr()
+        if payload_t is None:
+            a.flags, a.payload, a.payload_bytes, a.max_pay_cap = _lib.DEC_NO_PAYLOAD, scratch.data_ptr(), scratch_bytes, pay_cap
+        else:
+            a.payload = payload_t.data_ptr()
+        return a
+
+    def descs(sel, with_payload):
+        k = len(sel)
+        d = np.zeros(k, dtype=_lib.REC_DESC)
+        d["in_off"] = rec_off[sel] + 8
+        d["in_len"] = rec_off[sel + 1] - rec_off[sel] - 8
+        if with_payload:
+            d["pay_off"] = np.arange(k, dtype=np.uint64) * pay_cap
+            d["pay_cap"] = pay_cap
+        d["sig_off"] = np.arange(k, dtype=np.uint64) * sig_cap
+        d["sig_cap"] = sig_cap
+        return d
+
+    a_get = args_for(K, desc_dev, sig, fields, b.stream_out.data_ptr())
+    kern = []
+
+    def run_batch(sel, timed_=False):
+        d = descs(sel, False)
+        # plain synchronous H2D of the 160 KB descriptor block (torch's pinned + non_blocking path stalls ~90 ms every few
+        # batches on this stack — measured — which has nothing to do with the decode)
+        desc_dev[: d.nbytes].copy_(torch.from_numpy(d.view(np.uint8)))
+        a_get.n_recs = len(sel)
+        if timed_:
+            L.s5gpu_event_record(ev[0], st)
+        _lib.check(L.s5gpu_decode_dev(C.byref(a_get), st), "s5gpu_decode_dev")
+        if timed_:
+            L.s5gpu_event_record(ev[1], st)
+        torch.cuda.synchronize()
+        if timed_:
+            kern.append((elapsed_ms(L, _lib, ev[0], ev[1]), int(d["in_len"].sum()) + 8 * len(sel)))
+
+    batches = [ids[lo:lo + K] for lo in range(0, len(ids), K)]
+    for sel in batches[:2]:      # warm-up
+        run_batch(sel)
+    # pass 1: latency, nothing but the decode between the clock reads; the id list is walked again until about a second has gone by
+    lat, done, passes = [], 0, 0
+    t_lat0 = time.perf_counter()
+
+    def latency_passes():
+        nonlocal done, passes
+        while passes < 3 or (time.perf_counter() - t_lat0 < args.min_leg_seconds and passes < 200):
+            for sel in batches:
+                t0 = time.perf_counter()
+                run_batch(sel)
+                if len(sel) == K:
+                    lat.append(time.perf_counter() - t0)
+                done += len(sel)
+            passes += 1
+
+    dt_get = timed(shard, torch, dev, latency_passes)
+    done_all = shard.sum_over_ranks(done, device=TIMING_DEV or dev)   # ids decoded by all ranks in that time
+    # pass 2: the same batches again, kernel time by HIP events on the launch stream, every decoded signal compared with
+    # the generator (untimed: the comparison allocates)
+    ok = True
+    for sel in batches:
+        k = len(sel)
+        run_batch(sel, timed_=True)
+        stt = fields[: k * 64].view(torch.int32).view(k, 16)[:, 0]
+        got = sig[: k * sig_cap].view(k, sig_cap)[:, :n]
+        want = src_sig[torch.from_numpy(sel).to(dev)][:, :n]
+        ok &= bool((stt == 0).all().item()) and bool((got == want).all().item())
+    # pass 3: the whole index in one call (what `view` / `merge` decode per batch when the batch is large)
+    del sig, fields, desc_dev
+    bulk = None
+    d = descs(np.arange(n_reads), True)
+    big_desc = torch.from_numpy(d.view(np.uint8)).to(dev)
+    big_sig = torch.empty(n_reads * sig_cap + 64, dtype=torch.int16, device=dev)
+    big_fields = torch.zeros(n_reads * 64, dtype=torch.uint8, device=dev)
+    a_bulk = args_for(n_reads, big_desc, big_sig, big_fields, b.stream_out.data_ptr())
+
+    def bulk_call(a, reps_min, secs):
+        ts = []
+        t0 = time.perf_counter()
+        while len(ts) < reps_min or (time.perf_counter() - t0 < secs and len(ts) < 400):
+            L.s5gpu_event_record(ev[0], st)
+            _lib.check(L.s5gpu_decode_dev(C.byref(a), st), "s5gpu_decode_dev")
+            L.s5gpu_event_record(ev[1], st)
+            torch.cuda.synchronize()
+            ts.append(elapsed_ms(L, _lib, ev[0], ev[1]))
+        return ts
+
+    ts = bulk_call(a_bulk, 3, args.min_leg_seconds)
+    ms = float(np.mean(ts[1:]))
+    stt = big_fields.view(torch.int32).view(n_reads, 16)[:, 0]
+    same = bool((stt == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n], src_sig[:, :n]))
+    ok &= same
+    alg = z_total + 2 * n * n_reads                         # Z + 2N per record (SURVEY 8d, decode)
+    dtraffic, dtraffic_src = pmc_traffic("k_inflate_par_np", n, n_reads)
+    bulk = {"reads": n_reads, "calls": len(ts) - 1, "ms": round(ms, 3), "ms_min": round(min(ts[1:]), 3), "reads_per_s": round(n_reads / ms * 1e3, 1),
+            "raw_signal_GB_per_s": round(n_reads * 2 * n / ms / 1e6, 2), "roundtrip_identical": same,
+            "roofline": {"bound": "hbm", "kernel": "k_inflate_par_np (inflate + parse + svb-zd unpack, one launch)", "achieved": round(alg / ms / 1e6, 2), "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": round(alg / ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": dtraffic, "traffic_source": dtraffic_src, "algorithmic_bytes_per_launch": alg}}
+    # ... the same call in the form that also writes every uncompressed record out (what the view / merge worker needs)
+    try:
+        big_pay = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device=dev)
+        a_full = args_for(n_reads, big_desc, big_sig, big_fields, b.stream_out.data_ptr(), payload_t=big_pay)
+        big_sig.zero_()
+        ts = bulk_call(a_full, 4, 0.3)
+        msf = float(np.mean(ts[1:]))
+        stt = big_fields.view(torch.int32).view(n_reads, 16)[:, 0]
+        samef = bool((stt == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n], src_sig[:, :n]))
+        ok &= samef
+        ftraffic, ftraffic_src = pmc_traffic("k_inflate_par+k_unpack", n, n_reads)
+        bulk["with_payload_output"] = {"ms": round(msf, 3), "reads_per_s": round(n_reads / msf * 1e3, 1), "roundtrip_identical": samef,
+                                       "roofline_frac": round(alg / msf / 1e6 / PEAK_HBM_GBS, 5), "traffic": ftraffic, "traffic_source": ftraffic_src}
+        del big_pay
+    except torch.OutOfMemoryError:
+        bulk["with_payload_output"] = None
+    # ---- the same call on records WRITTEN BY STOCK ZLIB (what the reference's own files hold: level 6, arbitrary LZ77
+    # distances): 2048 distinct records compressed on the CPU, tiled to 262 144; every decoded signal compared ----
+    try:
+        import zlib
+        distinct, nb = 2048, min(262144, n_reads)
+        hostsig = src_sig[:distinct, :n].cpu().numpy()
+        streams = []
+        for i in range(distinct):
+            rec, keep = ob.make_rec(ob.synth_read_id(i), 0, 8192.0, 3.0, 1400.0, 4000.0, np.ascontiguousarray(hostsig[i]))
+            streams.append(zlib.compress(ob.rec_pack(rec, ob.SIG_SVB_ZD), 6))
+        zl = np.array([len(x) for x in streams], dtype=np.int64)
+        zo = np.concatenate([[0], np.cumsum((zl + 15) // 16 * 16)])
+        blob = np.zeros(zo[-1] + 64, dtype=np.uint8)
+        for x, o_ in zip(streams, zo[:-1]):
+            blob[o_:o_ + len(x)] = np.frombuffer(x, dtype=np.uint8)
+        zin = torch.from_numpy(blob).to(dev)
+        idx = np.arange(nb) % distinct
+        d2 = d[:nb].copy()
+        d2["in_off"] = zo[idx]; d2["in_len"] = zl[idx]
+        zdesc = torch.from_numpy(d2.view(np.uint8)).to(dev)
+        a_z = args_for(nb, zdesc, big_sig, big_fields, zin.data_ptr())
+        big_sig.zero_()
+        ts = bulk_call(a_z, 3, args.min_leg_seconds / 2)
+        ms2 = float(np.mean(ts[1:]))
+        stt = big_fields.view(torch.int32).view(n_reads, 16)[:nb, 0]
+        got = big_sig[: nb * sig_cap].view(nb, sig_cap)[:, :n]
+        want = src_sig[:distinct, :n]
+        same2 = bool((stt == 0).all().item()) and all(bool(torch.equal(got[k0:k0 + distinct], want[: min(distinct, nb - k0)])) for k0 in range(0, nb, distinct))
+        bulk["stock_zlib_records"] = {"reads": nb, "distinct": distinct, "calls": len(ts) - 1, "ms": round(ms2, 3), "reads_per_s": round(nb / ms2 * 1e3, 1),
+                                      "raw_signal_GB_per_s": round(nb * 2 * n / ms2 / 1e6, 2), "roundtrip_identical": same2,
+                                      "what": "svb-zd records compressed by zlib %s level 6 on the CPU (the reference's writer), decoded by the same call" % zlib.ZLIB_VERSION}
+        ok &= same2
+        del zin, zdesc
+    except Exception as e:      # (never fatal for the line)
+        bulk["stock_zlib_records"] = {"error": repr(e)}
+    del big_desc, big_sig, big_fields, scratch
+    for e in ev:
+        L.s5gpu_event_destroy(e)
+    if rank != 0:
+        return None
+    lat_ms = np.array(lat) * 1e3
+    full = [(m, z) for (m, z), sel in zip(kern, batches) if len(sel) == K]
+    k_ms = float(np.mean([m for m, _ in full])) if full else None
+    k_alg = float(np.mean([z for _, z in full])) + 2 * n * K if full else None
+
+    # ---- CPU baseline beside it: the oracle's pthread get --benchmark shape (inflate + svb-zd decode per id), thread sweep
+    # as /root/reference/test/bench/simple_bench.sh:75-104 ----
+    cpu = None
+    if want_cpu:
+        cores = os.cpu_count() or 1
+        stream_h = b.stream_out[:z_total].cpu().numpy()
+        off_h = rec_off[:-1].astype(np.uint64)
+        ids32 = ids.astype(np.uint32)
+        sweep = []
+        per_point = max(1.5, args.cpu_seconds / 4)
+        for t in sorted({1, min(8, cores), min(32, cores), min(64, cores), min(128, cores), cores}):
+            got_, secs = 0, 0.0
+            while secs < per_point:
+                tot, s, _ = ob.decode_batch_mt(stream_h, off_h, ids32, t, K)
+                assert tot == len(ids32) * n, "CPU decode failed"
+                got_ += len(ids32); secs += s
+            sweep.append({"t": t, "reads_per_s": round(got_ / secs, 1), "GB_per_s": round(got_ * 2 * n / secs / 1e9, 3), "seconds": round(secs, 1)})
+        ref = [x for x in sweep if x["t"] == cores][0]
+        best = max(sweep, key=lambda x: x["reads_per_s"])
+        cpu = {"value": ref["GB_per_s"], "unit": "GB/s", "cores": cores, "kind": "port", "reads_per_s": ref["reads_per_s"],
+               "shape": "get --benchmark -t %d -K %d: per id inflate (per-record inflateInit) + parse + svb-zd decode, threads created per batch; preads excluded" % (cores, K),
+               "best_of": {"value": best["GB_per_s"], "unit": "GB/s", "t": best["t"], "reads_per_s": best["reads_per_s"]},
+               "sweep": sweep,
+               "sample": "the same %d random ids (seed 1) over the same %d-read index, repeated until each point ran >= %.1f s" % (len(ids), n_reads, per_point)}
+
+    return {"workload": "BASELINE configs[4]: random get decode (inflate + svb-zd unpack), %d ids (seed 1) over a %d-read index, batches of %d, %d samples/read, "
+                        "fields + signals out (S5GPU_DEC_NO_PAYLOAD); %d passes over the id list" % (len(ids), n_reads, K, n, passes),
+            "metric": "blow5_get_decode_throughput", "value": round(done_all * 2 * n / dt_get / 1e9, 3), "unit": "GB/s", "n_gpus": world, "scaling": "weak",
+            "reads_per_s": round(done_all / dt_get, 1), "dtype": "u8->int16",
+            "batch_latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p99": round(float(np.percentile(lat_ms, 99)), 3), "batches": len(lat_ms)},
+            "per_read_latency_us_p50": round(float(np.percentile(lat_ms, 50)) * 1e3 / K, 3),
+            "kernel_ms_per_batch": round(k_ms, 4) if k_ms else None,
+            "roofline": {"bound": "hbm", "kernel": "k_inflate_par_np (K = %d)" % K, "achieved": round(k_alg / k_ms / 1e6, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(k_alg / k_ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(k_alg)} if k_ms else None,
+            "bulk_decode_one_call": bulk,
+            "cpu_baseline": cpu,
+            "roundtrip_identical": bool(ok)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
     ap.add_argument("--samples", type=int, default=4000, help="int16 samples per read")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline, reference-shaped point: seconds (0 = skip)")
     ap.add_argument("--cpu-sweep-seconds", type=float, default=5.0, help="CPU baseline: seconds per point of the -t / -K sweep (0 = skip)")
-    ap.add_argument("--svb-only", action="store_true", help="configs[1]: svb-zd stage alone")
+    ap.add_argument("--svb-only", action="store_true", help="configs[1] alone: svb-zd stage")
     ap.add_argument("--two-pass", action="store_true", help="encode into worst-case slots + compaction pass instead of the ordered single-pass stream")
     ap.add_argument("--fused-cap", type=int, default=8192, help="--mixed: LDS payload budget of the fused kernel, bytes (longer payloads take the staged path)")
     ap.add_argument("--mixed", action="store_true", help="read lengths of a real run: log-normal, median 6000 samples (--reads reads, default 262144)")
     ap.add_argument("--long", action="store_true", help="configs[3] alone (the long-read leg as the whole line)")
     ap.add_argument("--no-long", action="store_true", help="skip the configs[3] leg of the default run")
+    ap.add_argument("--no-legs", action="store_true", help="skip the configs[1] and configs[4] legs of the default run")
     ap.add_argument("--long-reads", type=int, default=65536, help="configs[3] leg: size of the read-index space (all ranks together)")
     ap.add_argument("--long-samples", type=int, default=100_000)
     ap.add_argument("--long-chunk", type=int, default=16384, help="configs[3] leg: reads per launch")
-    ap.add_argument("--decode", action="store_true", help="configs[4]: random get-style decode (inflate + svb-zd unpack)")
-    ap.add_argument("--get-reads", type=int, default=100_000, help="--decode: random read ids to fetch (seed 1)")
-    ap.add_argument("--get-batch", type=int, default=4096, help="--decode: ids per batch (-K)")
+    ap.add_argument("--decode", action="store_true", help="configs[4] alone: random get-style decode (inflate + svb-zd unpack)")
+    ap.add_argument("--get-reads", type=int, default=100_000, help="configs[4]: random read ids to fetch (seed 1)")
+    ap.add_argument("--get-batch", type=int, default=4096, help="configs[4]: ids per batch (-K)")
+    ap.add_argument("--min-leg-seconds", type=float, default=1.2, help="every GPU leg keeps the device busy for about this long at least")
+    ap.add_argument("--min-leg-steps-svb", type=int, default=300, help="configs[1] leg: steps (2.8 ms each on 1 M reads)")
+    ap.add_argument("--min-leg-steps-long", type=int, default=40, help="configs[3] leg: steps (28 ms each on 65536 reads)")
     args = ap.parse_args()
-    if args.decode:
-        return bench_decode(args)
 
     import numpy as np
     import torch
@@ -231,13 +536,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # S5BENCH_ALIAS_DEVICES=1 (pre-flight of the N > 1 path on a one-GPU box, tests/test_multi_device.py): ranks share device 0
+    alias = os.environ.get("S5BENCH_ALIAS_DEVICES", "") not in ("", "0")
+    if alias:
+        local_rank = 0
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if alias:
+            dist.init_process_group("gloo", rank=rank, world_size=world)      # (RCCL refuses two ranks on one device)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int32, device="cpu" if alias else dev)
+        dist.all_reduce(t)                     # the one collective of the run that is not a timing barrier: who is here
+        ranks_seen = int(t.item())
 
     import oracle_bind as ob
     from slow5tools_amd import _lib, press, shard
@@ -245,19 +562,20 @@ def main():
     L = _lib.lib()
     _lib.check(L.s5gpu_init(local_rank), "s5gpu_init")
     K = args.steps
+    global TIMING_DEV
+    TIMING_DEV = "cpu" if alias else dev
 
     def finish(line):
-        print(json.dumps(line))
+        if line is not None:
+            print(json.dumps(line))
         if world > 1:
             dist.destroy_process_group()
 
     if args.long:
         leg = long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, args.warmup)
         if rank != 0:
-            if world > 1:
-                dist.destroy_process_group()
-            return
-        line = {"metric": "blow5_encode_raw_signal_throughput", "value": leg["value"], "unit": "GB/s", "n_gpus": world, "steps": K,
+            return finish(None)
+        line = {"metric": "blow5_encode_raw_signal_throughput", "value": leg["value"], "unit": "GB/s", "n_gpus": world, "steps": leg["steps"],
                 "warmup": args.warmup, "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "int16->u8", "data": "synthetic", "config": {"workload": leg["workload"], "record_press": "zlib", "signal_press": "svb-zd",
                                                                       "parallelism": "read-index space sharded over %d GPU(s), no collective" % world}}
@@ -286,6 +604,18 @@ def main():
         raw_bytes = 2 * n * n_reads
     torch.cuda.synchronize()
 
+    if args.decode:     # configs[4] alone: the records of one encode pass, then the decode leg as the whole line
+        b.encode_stream()
+        torch.cuda.synchronize()
+        assert b.stream_ok(), "a read overflowed the LDS budget: --decode needs the single-pass stream"
+        leg = decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, world == 1 and args.cpu_seconds > 0)
+        if rank != 0:
+            return finish(None)
+        line = {"metric": leg["metric"], "value": leg["value"], "unit": "GB/s", "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": leg["dtype"], "data": "synthetic", "config": {"workload": leg["workload"]}}
+        line.update({k: v for k, v in leg.items() if k not in ("metric", "value", "unit", "n_gpus", "scaling", "dtype", "workload")})
+        return finish(line)
+
     # Full encode, default: ONE launch per step — k_encode_stream writes every record straight to its place in the
     # contiguous BLOW5 record stream (ordered single pass, decoupled look-back).  It needs every read to fit the LDS
     # budget (true for 4000-sample reads); long reads, --two-pass, --mixed and --svb-only use slots + the compaction pass.
@@ -312,63 +642,54 @@ def main():
         torch.cuda.synchronize()
 
     evs = make_events(L, _lib, 3 * K)
-    shard.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(K):
-        L.s5gpu_event_record(evs[3 * k], st)
-        run_step()
-        L.s5gpu_event_record(evs[3 * k + 1], st)
-        second_half()
-        L.s5gpu_event_record(evs[3 * k + 2], st)
-    torch.cuda.synchronize()
-    shard.barrier()
-    dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, device=dev)
 
-    enc_ms, cmp_ms = [], []
-    ms = C.c_float()
-    for k in range(K):
-        _lib.check(L.s5gpu_event_elapsed_ms(evs[3 * k], evs[3 * k + 1], C.byref(ms)))
-        enc_ms.append(ms.value)
-        _lib.check(L.s5gpu_event_elapsed_ms(evs[3 * k + 1], evs[3 * k + 2], C.byref(ms)))
-        cmp_ms.append(ms.value)
+    def k_steps():
+        for k in range(K):
+            L.s5gpu_event_record(evs[3 * k], st)
+            run_step()
+            L.s5gpu_event_record(evs[3 * k + 1], st)
+            second_half()
+            L.s5gpu_event_record(evs[3 * k + 2], st)
+
+    dt = timed(shard, torch, dev, k_steps)
+    enc_ms = [elapsed_ms(L, _lib, evs[3 * k], evs[3 * k + 1]) for k in range(K)]
+    cmp_ms = [elapsed_ms(L, _lib, evs[3 * k + 1], evs[3 * k + 2]) for k in range(K)]
     for e in evs:
         L.s5gpu_event_destroy(e)
 
-    # ---- the configs[3] leg of the default run (every rank takes part: its shard of the fixed index space) ----
-    leg = None
     default_shape = not (args.svb_only or args.mixed or args.two_pass) and n == 4000
-    if default_shape and not args.no_long:
-        main_out_len = b.out_len[:n_reads].cpu().numpy().astype(np.int64)
-        main_recs = None
-        if rank == 0:
-            idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
-            main_recs = (idx, b.stream_records(idx) if single_pass else b.records(idx), b.stream_ok() if single_pass else True)
-        sig_cpu_t = None
-        if rank == 0 and world == 1 and (args.cpu_seconds > 0):   # the CPU baseline is an N = 1 figure
+    # the same step again for about a second (not what `value` is computed on: that is the K steps above)
+    sustained = None
+    if default_shape and args.min_leg_seconds > 0:
+        reps = max(1, int(args.min_leg_seconds / max(dt / K, 1e-6)))
+        reps = min(reps, 2000)
+        dts = timed(shard, torch, dev, lambda: [(run_step(), second_half()) for _ in range(reps)])
+        sustained = {"steps": reps, "seconds": round(dts, 3), "value": round(raw_bytes * world * reps / dts / 1e9, 3), "unit": "GB/s"}
+
+    main_out_len = b.out_len[:n_reads].cpu().numpy().astype(np.int64)
+    main_recs = None
+    sig_cpu_t = None
+    if rank == 0:
+        idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
+        main_recs = (idx, b.stream_records(idx) if single_pass else b.records(idx), b.stream_ok() if single_pass else True)
+        if world == 1 and args.cpu_seconds > 0 and not args.svb_only and not args.mixed:   # the CPU baseline is an N = 1 figure
             stride = (n + 7) // 8 * 8
             m = min(n_reads, 262144)
             sig_cpu_t = b.sig[: m * stride].cpu().numpy().reshape(m, stride)[:, :n].copy()
+
+    # ---- the other configs of BASELINE.json as legs of the same line (every rank takes part) ----
+    leg1 = leg3 = leg4 = None
+    if default_shape and not args.no_legs:
+        if single_pass:     # configs[4] decodes the records the headline wrote; it runs before configs[1] reuses the stream buffer
+            leg4 = decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, world == 1 and args.cpu_seconds > 0)
+        leg1 = svb_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, K, args.warmup)
+    if default_shape and not args.no_long:
         del b                                   # free the 1 M-read batch before the long leg allocates
         torch.cuda.empty_cache()
-        leg = long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, args.warmup)
-    else:
-        main_out_len = b.out_len[:n_reads].cpu().numpy().astype(np.int64)
-        main_recs = None
-        sig_cpu_t = None
-        if rank == 0:
-            idx = [0, 1, n_reads // 2, n_reads - 1] if n_reads >= 4 else list(range(n_reads))
-            main_recs = (idx, b.stream_records(idx) if single_pass else b.records(idx), b.stream_ok() if single_pass else True)
-            if world == 1 and args.cpu_seconds > 0 and not args.svb_only and not args.mixed:
-                stride = (n + 7) // 8 * 8
-                m = min(n_reads, 262144)
-                sig_cpu_t = b.sig[: m * stride].cpu().numpy().reshape(m, stride)[:, :n].copy()
+        leg3 = long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, args.warmup)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+        return finish(None)
 
     # ---- results, rank 0 ----
     z_bytes = int(main_out_len.sum())
@@ -386,7 +707,7 @@ def main():
         kernel = "k_encode_stream"
     elif args.mixed:
         kernel = "k_encode_fused+k_pack+k_deflate_staged"
-    elif main_recs is not None and (n * 13 // 4) * 100 // 325 <= 4 * 16384:
+    elif (n * 13 // 4) * 100 // 325 <= 4 * 16384:
         kernel = "k_encode_fused"
     else:
         kernel = "k_pack+k_deflate_staged"
@@ -427,6 +748,7 @@ def main():
         "config": {"workload": workload, "reads_per_gpu": n_reads, "samples_per_read": n if not args.mixed else "mixed",
                    "record_press": "none" if args.svb_only else "zlib",
                    "signal_press": "svb-zd", "parallelism": "reads sharded over %d GPU(s), no collective" % world},
+        "ranks_seen": ranks_seen,
         "reads_per_s": round(reads_per_s, 1),
         "bytes_per_sample": round(z_bytes / (raw_bytes / 2), 4),
         "parity_spot_check": bool(parity),
@@ -436,223 +758,13 @@ def main():
                      "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes},
+        "sustained": sustained,
         "cpu_baseline": cpu,
-        "configs3": leg,
+        "configs1": leg1,
+        "configs3": leg3,
+        "configs4": leg4,
     }
     finish(line)
-
-
-def bench_decode(args):
-    """BASELINE config 5: decode for random `get` over an index of --reads records, batches of --get-batch ids.
-    Per batch (what src/get.c:321-386 does per -K batch, minus the preads): build the batch's record
-    descriptors from the index, upload them, inflate + unpack on the GPU, synchronise.  Every decoded signal
-    is compared with the generator.  Prints one JSON line (not the headline metric)."""
-    import numpy as np
-    import torch
-
-    import oracle_bind as ob
-    from slow5tools_amd import _lib, press
-
-    L = _lib.lib()
-    _lib.check(L.s5gpu_init(0), "s5gpu_init")
-    dev = "cuda:0"
-    n_reads, n = args.reads, args.samples
-    b = press.DeviceBatch(np.full(n_reads, n, dtype=np.uint64), device=dev)
-    b.synth(seed=0x5105, first=0)
-    b.encode()
-    b.compact()
-    torch.cuda.synchronize()
-    rec_off = b.rec_off.cpu().numpy().astype(np.int64)          # the "index": offset/size per read (Appendix A.5)
-    z_total = int(rec_off[n_reads])
-    rng = np.random.default_rng(1)
-    ids = rng.integers(0, n_reads, args.get_reads)
-    K = args.get_batch
-    pay_cap = 16 * ((int(b.tot["max_payload"]) + 31) // 16)
-    sig_cap = (n + 7) // 8 * 8
-    payload = torch.empty(K * pay_cap + 64, dtype=torch.uint8, device=dev)
-    sig = torch.empty(K * sig_cap + 64, dtype=torch.int16, device=dev)
-    fields = torch.zeros(K * 64, dtype=torch.uint8, device=dev)
-    desc_dev = torch.empty(K * _lib.REC_DESC.itemsize, dtype=torch.uint8, device=dev)
-    a = _lib.DecodeArgs()
-    a.rec_method, a.sig_method = 1, 1
-    a.desc, a.in_, a.payload, a.sig_out, a.fields = desc_dev.data_ptr(), b.stream_out.data_ptr(), payload.data_ptr(), sig.data_ptr(), fields.data_ptr()
-    lat, ok, done = [], True, 0
-    t_all = time.perf_counter()
-    st = b._stream()
-    ev = make_events(L, _lib, 2)
-    kern_ms = []
-
-    def run_batch(sel, timed=False):
-        k = len(sel)
-        d = np.zeros(k, dtype=_lib.REC_DESC)
-        d["in_off"] = rec_off[sel] + 8
-        d["in_len"] = rec_off[sel + 1] - rec_off[sel] - 8
-        d["pay_off"] = np.arange(k, dtype=np.uint64) * pay_cap
-        d["pay_cap"] = pay_cap
-        d["sig_off"] = np.arange(k, dtype=np.uint64) * sig_cap
-        d["sig_cap"] = sig_cap
-        # plain synchronous H2D of the 160 KB descriptor block (torch's pinned + non_blocking path stalls ~90 ms every few
-        # batches on this stack — measured, tools note in DESIGN.md — which has nothing to do with the decode)
-        desc_dev[: d.nbytes].copy_(torch.from_numpy(d.view(np.uint8)))
-        a.n_recs = k
-        if timed:
-            L.s5gpu_event_record(ev[0], st)
-        _lib.check(L.s5gpu_decode_dev(C.byref(a), st), "s5gpu_decode_dev")
-        if timed:
-            L.s5gpu_event_record(ev[1], st)
-        torch.cuda.synchronize()
-        if timed:
-            ms = C.c_float()
-            _lib.check(L.s5gpu_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
-            kern_ms.append((ms.value, int(d["in_len"].sum()) + 8 * k))
-
-    # pass 1: latency, nothing but the decode between the clock reads (the first two batches are warm-up)
-    for lo in range(0, len(ids), K):
-        sel = ids[lo:lo + K]
-        t0 = time.perf_counter()
-        run_batch(sel)
-        lat.append(time.perf_counter() - t0)
-        if lo >= 2 * K:
-            done += len(sel)
-    # pass 2: the same batches again, kernel time by HIP events on the launch stream, every decoded signal compared with
-    # the generator (untimed: the comparison allocates)
-    for lo in range(0, len(ids), K):
-        sel = ids[lo:lo + K]
-        k = len(sel)
-        run_batch(sel, timed=True)
-        stt = fields[: k * 64].view(torch.int32).view(k, 16)[:, 0]
-        got = sig[: k * sig_cap].view(k, sig_cap)[:, :n]
-        want = b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[torch.from_numpy(sel).to(dev)][:, :n]
-        ok &= bool((stt == 0).all().item()) and bool((got == want).all().item())
-    # pass 3: the whole index in one call (what `view` / `merge` decode per batch when the batch is large): device time of
-    # inflate + unpack by HIP events, every signal compared afterwards
-    del payload, sig, fields, desc_dev
-    torch.cuda.empty_cache()
-    bulk = None
-    try:
-        d = np.zeros(n_reads, dtype=_lib.REC_DESC)
-        d["in_off"] = rec_off[:-1] + 8
-        d["in_len"] = rec_off[1:] - rec_off[:-1] - 8
-        d["pay_off"] = np.arange(n_reads, dtype=np.uint64) * pay_cap
-        d["pay_cap"] = pay_cap
-        d["sig_off"] = np.arange(n_reads, dtype=np.uint64) * sig_cap
-        d["sig_cap"] = sig_cap
-        big_desc = torch.from_numpy(d.view(np.uint8)).to(dev)
-        big_pay = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device=dev)
-        big_sig = torch.empty(n_reads * sig_cap + 64, dtype=torch.int16, device=dev)
-        big_fields = torch.zeros(n_reads * 64, dtype=torch.uint8, device=dev)
-        a.n_recs = n_reads
-        a.desc, a.payload, a.sig_out, a.fields = big_desc.data_ptr(), big_pay.data_ptr(), big_sig.data_ptr(), big_fields.data_ptr()
-        ts = []
-        for _ in range(3):
-            L.s5gpu_event_record(ev[0], st)
-            _lib.check(L.s5gpu_decode_dev(C.byref(a), st), "s5gpu_decode_dev")
-            L.s5gpu_event_record(ev[1], st)
-            torch.cuda.synchronize()
-            ms = C.c_float()
-            _lib.check(L.s5gpu_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
-            ts.append(ms.value)
-        ms = min(ts[1:])
-        stt = big_fields.view(torch.int32).view(n_reads, 16)[:, 0]
-        same = bool((stt == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n],
-                                                                   b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]))
-        alg = z_total + 2 * n * n_reads                         # Z + 2N per record (SURVEY 8d, decode)
-        dtraffic, dtraffic_src = pmc_traffic("k_inflate_par+k_unpack", n, n_reads)
-        bulk = {"reads": n_reads, "ms": round(ms, 2), "reads_per_s": round(n_reads / ms * 1e3, 1),
-                "raw_signal_GB_per_s": round(n_reads * 2 * n / ms / 1e6, 2), "roundtrip_identical": same,
-                "roofline": {"bound": "hbm", "kernel": "k_inflate_par+k_unpack", "achieved": round(alg / ms / 1e6, 2), "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": round(alg / ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": dtraffic, "traffic_source": dtraffic_src, "algorithmic_bytes_per_launch": alg}}
-        ok &= same
-        # ---- the same call on records WRITTEN BY STOCK ZLIB (what the reference's own files hold: level 6, arbitrary LZ77
-        # distances): 2048 distinct records compressed on the CPU, tiled to 262 144; every decoded signal compared ----
-        try:
-            import zlib
-            distinct, nb = 2048, min(262144, n_reads)
-            hostsig = b.sig[: distinct * sig_cap].view(distinct, sig_cap)[:, :n].cpu().numpy()
-            streams = []
-            for i in range(distinct):
-                rec, keep = ob.make_rec(ob.synth_read_id(i), 0, 8192.0, 3.0, 1400.0, 4000.0, np.ascontiguousarray(hostsig[i]))
-                streams.append(zlib.compress(ob.rec_pack(rec, ob.SIG_SVB_ZD), 6))
-            zl = np.array([len(x) for x in streams], dtype=np.int64)
-            zo = np.concatenate([[0], np.cumsum((zl + 15) // 16 * 16)])
-            blob = np.zeros(zo[-1] + 64, dtype=np.uint8)
-            for x, o_ in zip(streams, zo[:-1]):
-                blob[o_:o_ + len(x)] = np.frombuffer(x, dtype=np.uint8)
-            zin = torch.from_numpy(blob).to(dev)
-            idx = np.arange(nb) % distinct
-            d2 = d[:nb].copy()
-            d2["in_off"] = zo[idx]; d2["in_len"] = zl[idx]
-            zdesc = torch.from_numpy(d2.view(np.uint8)).to(dev)
-            a.n_recs, a.desc, a.in_ = nb, zdesc.data_ptr(), zin.data_ptr()
-            ts = []
-            for _ in range(3):
-                L.s5gpu_event_record(ev[0], st)
-                _lib.check(L.s5gpu_decode_dev(C.byref(a), st), "s5gpu_decode_dev")
-                L.s5gpu_event_record(ev[1], st)
-                torch.cuda.synchronize()
-                ms2 = C.c_float()
-                _lib.check(L.s5gpu_event_elapsed_ms(ev[0], ev[1], C.byref(ms2)))
-                ts.append(ms2.value)
-            ms2 = min(ts[1:])
-            stt = big_fields.view(torch.int32).view(n_reads, 16)[:nb, 0]
-            got = big_sig[: nb * sig_cap].view(nb, sig_cap)[:, :n]
-            want = b.sig[: distinct * sig_cap].view(distinct, sig_cap)[:, :n]
-            same2 = bool((stt == 0).all().item()) and all(bool(torch.equal(got[k0:k0 + distinct], want[: min(distinct, nb - k0)])) for k0 in range(0, nb, distinct))
-            bulk["stock_zlib_records"] = {"reads": nb, "distinct": distinct, "ms": round(ms2, 2), "reads_per_s": round(nb / ms2 * 1e3, 1),
-                                          "raw_signal_GB_per_s": round(nb * 2 * n / ms2 / 1e6, 2), "roundtrip_identical": same2,
-                                          "what": "svb-zd records compressed by zlib %s level 6 on the CPU (the reference's writer), decoded by the same call" % zlib.ZLIB_VERSION}
-            ok &= same2
-            a.in_ = b.stream_out.data_ptr()
-            del zin, zdesc
-        except Exception as e:      # (never fatal for the line)
-            bulk["stock_zlib_records"] = {"error": repr(e)}
-        del big_desc, big_pay, big_sig, big_fields
-    except torch.OutOfMemoryError:
-        bulk = None
-    wall = time.perf_counter() - t_all
-    lat_ms = np.array(lat[2:]) * 1e3
-    busy = float(np.sum(lat[2:]))
-    # roofline of the K-record batches: (Z + 2N) of the batch / kernel time of k_inflate + k_unpack (HIP events on the launch stream)
-    full = [(m, z) for m, z in kern_ms[2:] if True]
-    k_ms = float(np.mean([m for m, _ in full])) if full else None
-    k_alg = float(np.mean([z for _, z in full])) + 2 * n * K if full else None
-
-    # ---- CPU baseline beside it: the oracle's pthread get --benchmark shape (inflate + svb-zd decode per id), thread sweep
-    # as /root/reference/test/bench/simple_bench.sh:75-104 ----
-    cpu = None
-    if args.cpu_seconds > 0:
-        cores = os.cpu_count() or 1
-        stream_h = b.stream_out[:z_total].cpu().numpy()
-        off_h = rec_off[:-1].astype(np.uint64)
-        ids32 = ids.astype(np.uint32)
-        sweep = []
-        for t in sorted({1, min(8, cores), min(32, cores), min(64, cores), min(128, cores), cores}):
-            got, secs, reps = 0, 0.0, 0
-            while secs < max(2.0, args.cpu_seconds / 3):
-                tot, s, _ = ob.decode_batch_mt(stream_h, off_h, ids32, t, K)
-                assert tot == len(ids32) * n, "CPU decode failed"
-                got += len(ids32); secs += s; reps += 1
-            sweep.append({"t": t, "reads_per_s": round(got / secs, 1), "GB_per_s": round(got * 2 * n / secs / 1e9, 3), "seconds": round(secs, 1)})
-        ref = [x for x in sweep if x["t"] == cores][0]
-        best = max(sweep, key=lambda x: x["reads_per_s"])
-        cpu = {"value": ref["GB_per_s"], "unit": "GB/s", "cores": cores, "kind": "port", "reads_per_s": ref["reads_per_s"],
-               "shape": "get --benchmark -t %d -K %d: per id inflate (per-record inflateInit) + parse + svb-zd decode, threads created per batch; preads excluded" % (cores, K),
-               "best_of": {"value": best["GB_per_s"], "unit": "GB/s", "t": best["t"], "reads_per_s": best["reads_per_s"]},
-               "sweep": sweep,
-               "sample": "the same %d random ids (seed 1) over the same %d-read index, repeated until each point ran >= %.1f s" % (len(ids), n_reads, max(2.0, args.cpu_seconds / 3))}
-
-    line = {"metric": "blow5_get_decode_throughput", "value": round(done * 2 * n / busy / 1e9, 3), "unit": "GB/s",
-            "n_gpus": 1, "higher_is_better": True, "dtype": "u8->int16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4]: random get decode (inflate + svb-zd unpack), %d ids (seed 1) over a %d-read index, batches of %d, %d samples/read" % (len(ids), n_reads, K, n)},
-            "reads_per_s": round(done / busy, 1), "batch_latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p99": round(float(np.percentile(lat_ms, 99)), 3)},
-            "per_read_latency_us_p50": round(float(np.percentile(lat_ms, 50)) * 1e3 / K, 3),
-            "kernel_ms_per_batch": round(k_ms, 4) if k_ms else None,
-            "roofline": {"bound": "hbm", "kernel": "k_inflate_par+k_unpack (K = %d)" % K, "achieved": round(k_alg / k_ms / 1e6, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(k_alg / k_ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(k_alg)} if k_ms else None,
-            "bulk_decode_one_call": bulk,
-            "cpu_baseline": cpu,
-            "roundtrip_identical": bool(ok), "wall_s_including_verification": round(wall, 2)}
-    print(json.dumps(line))
 
 
 if __name__ == "__main__":

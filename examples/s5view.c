@@ -145,7 +145,7 @@ typedef struct {
     size_t chunk;
     int64_t next_work, total_batches;
     slow5_press_method_t from, to;
-    int failed, readers;
+    int failed, readers, oversize;
     char why[256];
     uint64_t records;
 } fpipe_t;
@@ -207,7 +207,7 @@ static void *freader_main(void *arg) {
         while (p + 8 <= have && n < b->cap) {
             uint64_t sz;
             memcpy(&sz, b->in + p, 8);
-            if (sz > P->chunk - 8) { fpipe_fail(P, "a record larger than the chunk size (raise S5VIEW_CHUNK_MB)"); return NULL; }
+            if (sz > P->chunk - 8) { P->oversize = 1; fpipe_fail(P, "a record larger than the chunk size"); return NULL; }   /* main() redoes the file record by record */
             if (p + 8 + sz > have) break;
             b->rec_pos[n] = p + 8;
             b->rec_len[n] = (uint32_t)sz;
@@ -216,8 +216,11 @@ static void *freader_main(void *arg) {
         }
         carry = have - p;
         carry_from = b->in + p;
-        const int last = P->pos >= P->end;
-        if (last && carry) { fpipe_fail(P, "bad record framing"); return NULL; }
+        /* the file is read to its end: what is left over is either whole records the slot had no descriptors for (tiny records:
+         * more than `cap` of them in one chunk) — they are framed in the next round, which reads nothing — or a cut record */
+        const int file_done = P->pos >= P->end;
+        if (file_done && carry && n == 0) { fpipe_fail(P, "bad record framing"); return NULL; }
+        const int last = file_done && carry == 0;
         b->in_have = p;
         pthread_mutex_lock(&P->mu);
         if (n) { b->n = n; b->seq = s; b->state = ST_FILLED; }
@@ -268,7 +271,8 @@ static void *fworker_main(void *arg) {
     }
 }
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
-/* returns 0 and the record count, or -1 */
+/* returns 0 and the record count, -1, or -2: a record does not fit a chunk (an uncompressed ultra-long read) — the caller redoes the
+ * file with the per-record pipeline */
 static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slow5_press_method_t to, int workers, uint64_t *total) {
     fpipe_t P;
     memset(&P, 0, sizeof P);
@@ -295,7 +299,9 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     const double t_alloc = now_s();
     for (int i = 0; i < FSLOT; i++) {
         fslot_t *b = &P.slot[i];
-        b->cap = (uint32_t)(P.chunk / 64);                          /* a record takes at least its prefix and a head */
+        b->cap = (uint32_t)(P.chunk / 48) + 1;                      /* descriptors per chunk; a chunk of smaller records than that is framed in two rounds */
+        e = getenv("S5VIEW_SLOT_RECS");                             /* tests: fewer descriptors than a chunk holds records */
+        if (e && atoi(e) > 0) b->cap = (uint32_t)atoi(e);
         b->in = (uint8_t *)s5gpu_host_alloc(P.chunk + 64);
         b->out_cap = P.chunk * 3;
         b->out = (uint8_t *)s5gpu_host_alloc(b->out_cap);
@@ -334,6 +340,7 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     for (int i = 0; i < W; i++) pthread_join(wk[i], NULL);
     const double t1 = now_s();
     for (int i = 0; i < FSLOT; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); }
+    if (P.failed && P.oversize) return -2;
     if (P.failed) { fprintf(stderr, "s5view: %s\n", P.why); return -1; }
     fprintf(stderr, "s5view: chunked pipeline: %.3f s for %llu records (%.1f MB in, %.1f MB out; buffers %.3f s), %d pread threads, %d GPU worker(s), chunks of %zu MB\n",
             t1 - t0, (unsigned long long)*total, (double)(P.end - in->meta.start_rec_offset) / 1e6, (double)out_bytes / 1e6, t0 - t_alloc, P.readers, W, P.chunk >> 20);
@@ -386,8 +393,17 @@ int main(int argc, char **argv) {
     const int workers = argc > 6 ? atoi(argv[6]) : 1;
     uint64_t total = 0;
     const char *nofast = getenv("S5VIEW_PER_RECORD");
-    if (workers > 0 && in->format == SLOW5_FORMAT_BINARY && fmt_out == SLOW5_FORMAT_BINARY && !(nofast && atoi(nofast))) {
-        if (fast_view(in, out, from, to, workers, &total) != 0) return die("chunked pipeline failed");
+    int fast = workers > 0 && in->format == SLOW5_FORMAT_BINARY && fmt_out == SLOW5_FORMAT_BINARY && !(nofast && atoi(nofast));
+    if (fast) {
+        const int rc = fast_view(in, out, from, to, workers, &total);
+        if (rc == -2) {   /* start the output over, record by record (the chunked reader used pread: in->fp still stands at the first record) */
+            fprintf(stderr, "s5view: a record larger than a chunk (S5VIEW_CHUNK_MB): per-record pipeline\n");
+            total = 0;
+            if (fflush(out) != 0 || ftruncate(fileno(out), 0) != 0 || fseek(out, 0, SEEK_SET) != 0 || slow5_hdr_fwrite(out, in->header, fmt_out, to) < 0) return die("cannot restart the output");
+            fast = 0;
+        } else if (rc != 0) return die("chunked pipeline failed");
+    }
+    if (fast) {
     } else if (workers > 0) {
         /* read || GPU || write.  The reference runs the three phases one after the other per batch
          * (src/view.c:265-278, 292, 296-299) and its authors note the overlap as the missing 2x (README.md:197). */

@@ -106,16 +106,34 @@ typedef struct s5gpu_rec_fields {
     double digitisation, offset, range, sampling_rate;
 } s5gpu_rec_fields_t;
 
+/* s5gpu_decode_args.flags */
+enum {
+    /* s5gpu_decode_dev, zlib or zstd records with svb-zd signals: the caller wants fields + signals only (what `get` and the
+     * decode half of a signal consumer need; read_id / aux bytes live in the uncompressed record and are NOT kept).  `payload` is then
+     * SCRATCH of payload_bytes bytes (s5gpu_decode_scratch_bytes() says how much is useful): the kernel runs as persistent
+     * workgroups, each with one scratch slot of max_pay_cap bytes that it reuses record after record, so an uncompressed record
+     * never has to reach HBM (measured traffic: DESIGN.md 4.7).  desc[i].pay_off / pay_cap are ignored; a record whose payload
+     * exceeds max_pay_cap reports status 5 with the size needed.  fields[i].aux_off / aux_len are still reported. */
+    S5GPU_DEC_NO_PAYLOAD = 1
+};
+
 typedef struct s5gpu_decode_args {
     uint32_t n_recs;
     int32_t rec_method, sig_method;
+    uint32_t flags;                  /* 0, or S5GPU_DEC_* (this word was padding before: zeroed structs keep their meaning)  */
     const s5gpu_rec_desc_t *desc;    /* device                                                       */
     const uint8_t *in;               /* device, compressed records; 16 readable bytes must follow the */
                                      /*   last record (the inflate kernels fetch aligned dwords ahead) */
-    uint8_t *payload;                /* device, out: uncompressed record per slot                    */
+    uint8_t *payload;                /* device, out: uncompressed record per slot (scratch with S5GPU_DEC_NO_PAYLOAD) */
     int16_t *sig_out;                /* device, out: raw_signal per record                           */
     s5gpu_rec_fields_t *fields;      /* device, out                                                  */
+    uint64_t payload_bytes;          /* S5GPU_DEC_NO_PAYLOAD: bytes of scratch at `payload`          */
+    uint32_t max_pay_cap;            /* S5GPU_DEC_NO_PAYLOAD: largest uncompressed record to expect  */
+    uint32_t reserved;
 } s5gpu_decode_args_t;
+/* scratch worth bringing for S5GPU_DEC_NO_PAYLOAD (one slot per workgroup the device can hold + the fallback decoder's);
+ * anything from 64 + 2 * (max_pay_cap + 32) bytes up works, less only means fewer workgroups */
+uint64_t s5gpu_decode_scratch_bytes(uint32_t max_pay_cap);
 
 /* ---- lifetime ---- */
 int s5gpu_init(int device);              /* select device; S5GPU_ERR_NODEV if it is not a gfx950 GPU */

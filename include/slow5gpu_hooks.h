@@ -25,6 +25,22 @@
 extern "C" {
 #endif
 
+/* The integer values above are what this library maps to codecs.  They are restated from memory of slow5lib >= 1.3.0 (the submodule
+ * is absent from the reference snapshot this was built against), so a patched source file puts
+ *     SLOW5_GPU_HOOK_CHECK_ENUMS;
+ * once at file scope behind #include <slow5/slow5.h>: if upstream's enums ever differ, the build fails there instead of the
+ * patch silently mis-mapping codecs.  (A macro: this header itself names no slow5lib identifier.) */
+#ifdef __cplusplus
+#define SLOW5_GPU_HOOK_STATIC_ASSERT(cond, msg) static_assert(cond, msg)
+#else
+#define SLOW5_GPU_HOOK_STATIC_ASSERT(cond, msg) _Static_assert(cond, msg)
+#endif
+#define SLOW5_GPU_HOOK_CHECK_ENUMS                                                                                                   \
+    SLOW5_GPU_HOOK_STATIC_ASSERT((int)SLOW5_COMPRESS_NONE == 0 && (int)SLOW5_COMPRESS_ZLIB == 1 && (int)SLOW5_COMPRESS_SVB_ZD == 2 &&      \
+                                 (int)SLOW5_COMPRESS_ZSTD == 3 && (int)SLOW5_COMPRESS_EX_ZD == 4 && (int)SLOW5_FORMAT_ASCII == 1 &&      \
+                                 (int)SLOW5_FORMAT_BINARY == 2,                                                                       \
+                                 "slow5lib's enum values differ from the ones slow5gpu_hooks.h documents: the hooks would mis-map codecs")
+
 /* Optional: name the GPUs (bit d = HIP device d); without it the first hook call takes device 0.  A batch is cut into one
  * contiguous index range per device, as work_db cuts it per thread (/root/reference/src/thread.c:76-90). */
 int slow5_gpu_hook_init(uint64_t dev_mask);

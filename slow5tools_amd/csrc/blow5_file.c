@@ -18,6 +18,7 @@
 #include "../../include/slow5gpu.h"
 
 void slow5_compat_error(const char *fmt, ...);   /* slow5_compat.c: printed per log level, fatal under SLOW5_EXIT_ON_ERR */
+void slow5_compat_warn(const char *fmt, ...);    /* ... a warning: printed from SLOW5_LOG_WARN on, never fatal on its own */
 extern int slow5_compat_skip_rid;                /* slow5_set_skip_rid() */
 
 static const char BLOW5_MAGIC[6] = {'B', 'L', 'O', 'W', '5', '\1'};
@@ -430,25 +431,24 @@ int slow5_idx_load(slow5_file_t *s) {
     s->index = idx_read(p);
     if (s->index) {
         /* an index is only as good as the file it was made from: same version, every entry inside the file (size covers the
-         * u64 prefix), and not older than the BLOW5 (a rewritten file keeps a stale .idx next to it) */
+         * u64 prefix).  An index OLDER than the BLOW5 is only warned about and still used, as slow5lib does: mtimes have one-second
+         * granularity and get reordered by cp / rsync, the directory may be read-only, and the index is the user's file */
         struct stat fs, is;
         int stale = 0;
         const struct slow5_version fv = s->header->version, iv = s->index->version;
         if (iv.major != fv.major || iv.minor != fv.minor || iv.patch != fv.patch) stale = 1;
         if (!stale && fstat(fileno(s->fp), &fs) == 0) {
+            const uint64_t fsz = (uint64_t)fs.st_size;
             for (uint64_t i = 0; i < s->index->n && !stale; i++) {
                 const struct idx_ent *e = &s->index->ents[i];
-                if (e->size < 8 || e->offset < s->meta.start_rec_offset || e->offset + e->size > (uint64_t)fs.st_size) stale = 1;
+                if (e->size < 8 || e->offset < s->meta.start_rec_offset || e->offset > fsz || e->size > fsz - e->offset) stale = 1;   /* (no sum: it could wrap) */
             }
-            if (!stale && stat(p, &is) == 0 && is.st_mtime < fs.st_mtime) stale = 2;
+            if (!stale && stat(p, &is) == 0 && is.st_mtime < fs.st_mtime)
+                slow5_compat_warn("index '%s' is older than '%s'; using it all the same (re-create it with slow5_idx_create if the file was rewritten)", p, s->meta.pathname);
         }
         if (stale) {
             slow5_idx_unload(s);
-            if (stale == 2) {       /* older than the file: rebuild instead of trusting it */
-                if (slow5_idx_create(s) == 0) s->index = idx_read(p);
-            } else {
-                slow5_compat_error("index '%s' does not belong to this file (version or record extents differ); remove it", p);
-            }
+            slow5_compat_error("index '%s' does not belong to this file (version or record extents differ); remove it", p);
         }
     }
     free(p);

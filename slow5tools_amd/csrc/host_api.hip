@@ -895,8 +895,9 @@ extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chu
     std::condition_variable cv;
     std::vector<int64_t> totals(G, -1);
     std::vector<uint32_t> firsts(G, 0xFFFFFFFFu);
-    bool failed = false;
-    uint64_t need = 0;
+    bool failed = false;      // a share failed for good: the shares waiting behind it give up
+    bool overflow = false;    // the output does not fit out_cap: nobody copies, every share still publishes its size so that
+                              // the caller learns the room the WHOLE output needs (out_off[0]), whatever the number of devices
     const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
         auto fail = [&](int r) -> int {
             std::lock_guard<std::mutex> g(mu);
@@ -939,7 +940,8 @@ extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chu
                 cv.wait(g);
             }
             if (failed) return S5GPU_ERR_HIP;
-            if (base + off[m] > out_cap) { need = need > base + off[m] ? need : base + off[m]; failed = true; cv.notify_all(); s5gpu_set_error("s5gpu_recompress_stream: output buffer too small"); return S5GPU_ERR_NOMEM; }
+            if (base + off[m] > out_cap) overflow = true;
+            if (overflow) return S5GPU_OK;     // (a share in front may have overflowed already: its total is published all the same)
         }
         HIP_TRY(hipMemcpyAsync((uint8_t *)out_buf + base, c->d_stream.p, off[m], hipMemcpyDeviceToHost, c->st));
         for (uint32_t i = 0; i < m; i++) out_off[lo + i] = base + off[i];
@@ -947,6 +949,13 @@ extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chu
         HIP_TRY(hipStreamSynchronize(c->st));
         return S5GPU_OK;
     });
-    if (rc == S5GPU_ERR_NOMEM && need) out_off[0] = need;   // the size the caller has to bring
-    return rc;
+    if (rc) return rc;
+    if (overflow) {
+        uint64_t need = 0;
+        for (int q = 0; q < G; q++) if (totals[q] > 0) need += (uint64_t)totals[q];
+        out_off[0] = need;   // the size the caller has to bring (the sum over ALL shares)
+        s5gpu_set_error("s5gpu_recompress_stream: output buffer too small (%llu bytes needed)", (unsigned long long)need);
+        return S5GPU_ERR_NOMEM;
+    }
+    return S5GPU_OK;
 }

@@ -512,8 +512,8 @@ __global__ __launch_bounds__(64) void k_inflate(s5gpu_decode_args_t a) {
 // starts with (fields -> descriptor -> three length fields of the payload) is gone.  fields.reserved = 1 marks such a record;
 // k_unpack_rest does what is left (records the fallback decoder inflated) and clears the marks.
 static_assert(sizeof(InflParShared::win) >= SVB_WSTAGE, "the inflate window doubles as the svb-zd stage");
-__device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, const s5gpu_rec_desc_t &d, s5gpu_rec_fields_t &f, uint32_t plen, uint8_t *stage) {
-    const uint8_t *pay = a.payload + d.pay_off;
+// pay: the record's uncompressed bytes — its payload slot, or the workgroup's scratch slot (S5GPU_DEC_NO_PAYLOAD)
+__device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, const s5gpu_rec_desc_t &d, const uint8_t *pay, s5gpu_rec_fields_t &f, uint32_t plen, uint8_t *stage) {
     if (plen < 2) return 7;
     const uint32_t idl = (uint32_t)ld_le(pay, 2), hl = 2 + idl + 4 + 32;
     if ((uint64_t)hl + 8 > plen) return 7;
@@ -555,20 +555,26 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_ar
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
-    uint32_t dbg[4] = {0, 0, 0, a.sig_method >= 90 && a.sig_method < 99 ? (uint32_t)(a.sig_method - 90) : 0u};   // 91..93: tools/par_probe.py cut-offs
+#ifdef S5_PAR_PROBE   // tools/par_probe.py only (a variant build, tools/variant.sh probe -DS5_PAR_PROBE): cut-offs 91..93 and counters (99) keyed on sig_method
+    uint32_t dbg[4] = {0, 0, 0, a.sig_method >= 90 && a.sig_method < 99 ? (uint32_t)(a.sig_method - 90) : 0u};
     int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, !UNPACK && a.sig_method >= 90 ? dbg : nullptr);
+#else
+    int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+#endif
     uint32_t mark = 0;
     if (UNPACK && status == 0) {
         wave_sync();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        status = unpack_svbzd_wave(a, d, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
+        status = unpack_svbzd_wave(a, d, a.payload + d.pay_off, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
         mark = 1;
     }
     if (lane_id() == 0) {
         a.fields[r].status = status;
         a.fields[r].payload_len = olen;
         if (UNPACK) a.fields[r].reserved = mark;
-        if (!UNPACK && a.sig_method == 99) { a.fields[r].n_samples = dbg[0]; a.fields[r].read_id_len = dbg[1]; a.fields[r].read_group = dbg[2]; }   // tools/par_probe.py
+#ifdef S5_PAR_PROBE
+        if (!UNPACK && a.sig_method == 99) { a.fields[r].n_samples = dbg[0]; a.fields[r].read_id_len = dbg[1]; a.fields[r].read_group = dbg[2]; }
+#endif
     }
 }
 __global__ __launch_bounds__(64) void k_inflate_fallback(s5gpu_decode_args_t a) {   // persistent blocks scan the statuses
@@ -592,6 +598,93 @@ __global__ __launch_bounds__(64) void k_inflate_fallback(s5gpu_decode_args_t a) 
     }
 }
 
+// ---- S5GPU_DEC_NO_PAYLOAD: fields + signals only, the uncompressed record never has to reach HBM ----
+// The caller of a signal consumer (`get`, the decode side of a basecaller feed) has no use for the uncompressed record, and writing
+// it out costs as much HBM traffic as the whole rest of the decode (5.1 KB written + read back per 4000-sample record against
+// Z + 2N = 11.5 KB: PMC, profiles/r02_pmc_decode_traffic.txt).  Persistent workgroups, one scratch slot each, reused record after
+// record: the slot's lines stay in the XCD's L2 (a workgroup never leaves its CU), the record is inflated into it and unpacked
+// out of it by the same wave.  Records come off a ticket counter, so workgroups that drew long records simply draw fewer.
+struct NpParams {
+    uint8_t *scratch;      // slot i at scratch + i * slot
+    uint32_t slot;         // bytes per slot (a multiple of 16)
+    uint32_t cap;          // payload bytes a slot takes (slot - 16)
+    uint32_t *ticket;      // [0]: next record of the main kernel
+    uint32_t first_fb;     // first slot of the fallback kernel's workgroups
+};
+__device__ __forceinline__ void np_write_fields(const s5gpu_decode_args_t &a, uint32_t r, int status, uint32_t olen) {
+    if (lane_id() == 0) {
+        a.fields[r].status = status;
+        a.fields[r].payload_len = olen;
+        a.fields[r].reserved = 0;
+    }
+}
+__global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode_args_t a, NpParams np) {
+    __shared__ InflParShared T;
+    uint8_t *pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
+    for (;;) {
+        uint32_t r = 0;
+        if (lane_id() == 0) r = atomicAdd(&np.ticket[0], 1u);
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r >= a.n_recs) return;
+        const s5gpu_rec_desc_t d = a.desc[r];
+        uint32_t olen = 0;
+        int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
+        if (status == 0) {
+            wave_sync();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
+        }
+        np_write_fields(a, r, status, olen);
+        wave_sync();                                   // the next record's window load overwrites the stage
+    }
+}
+// ... what the parallel decoder declined: the wave-per-record decoder, into its own scratch slot, and the unpack right behind it
+static_assert(offsetof(InflShared, llut) == offsetof(InflShared, ring) + INF_OW && INF_OW + sizeof(InflShared::llut) >= SVB_WSTAGE,
+              "the output ring and the table behind it double as the svb-zd stage");
+__global__ __launch_bounds__(64) void k_inflate_fallback_np(s5gpu_decode_args_t a, NpParams np) {
+    __shared__ InflShared T;
+    const int lane = lane_id();
+    uint8_t *pay = np.scratch + (uint64_t)(np.first_fb + blockIdx.x) * np.slot;
+    for (uint32_t base = blockIdx.x * 64u; base < a.n_recs; base += gridDim.x * 64u) {
+        const uint32_t mine = base + (uint32_t)lane;
+        uint64_t need = __ballot(mine < a.n_recs && a.fields[mine].status == INF_NEED_FALLBACK);
+        while (need) {
+            const uint32_t r = base + (uint32_t)(__ffsll((long long)need) - 1);
+            need &= need - 1;
+            const s5gpu_rec_desc_t d = a.desc[r];
+            uint32_t olen = 0;
+            int status = zlib_inflate_wave(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
+            if (status == 0) {
+                wave_sync();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, T.ring);
+            }
+            np_write_fields(a, r, status, olen);
+            wave_sync();
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_zstd_inflate_np(s5gpu_decode_args_t a, NpParams np) {
+    __shared__ __attribute__((aligned(16))) ZstdShared T;
+    uint8_t *pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
+    for (;;) {
+        uint32_t r = 0;
+        if (lane_id() == 0) r = atomicAdd(&np.ticket[0], 1u);
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r >= a.n_recs) return;
+        const s5gpu_rec_desc_t d = a.desc[r];
+        uint32_t olen = 0;
+        int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
+        if (status == 0) {
+            wave_sync();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.huf));
+        }
+        np_write_fields(a, r, status, olen);
+        wave_sync();
+    }
+}
+
 // K4 for the zstd record press: one frame per wave64 (zstd_dev.h).  UNPACK: as k_inflate_par<true> — the wave parses the record and
 // decodes its svb-zd signal right away (the Huffman table's storage is the stage), k_unpack_rest clears the marks
 static_assert(sizeof(ZstdShared::huf) + sizeof(ZstdShared::ll_e) >= SVB_WSTAGE && offsetof(ZstdShared, ll_e) == sizeof(ZstdShared::huf),
@@ -607,7 +700,7 @@ __global__ __launch_bounds__(64) void k_zstd_inflate(s5gpu_decode_args_t a) {
     if (UNPACK && status == 0) {
         wave_sync();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        status = unpack_svbzd_wave(a, d, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.huf));
+        status = unpack_svbzd_wave(a, d, a.payload + d.pay_off, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.huf));
         mark = 1;
     }
     if (lane_id() == 0) {
@@ -1190,26 +1283,27 @@ extern "C" int s5gpu_set_option(const char *key, long value) {
     s5gpu_set_error("s5gpu_set_option: unknown option");
     return S5GPU_ERR_ARG;
 }
-// Helper stream + two events for the routed inflate (the long records run beside the lane kernel).  One per host thread and
-// device — the batch API runs calls from several threads — owned by a registry so that s5gpu_shutdown can release them; a
-// thread notices a shutdown (or a change of device) by the generation / device stamp and takes a fresh one.
+// Helper stream + two events for the routed inflate (the long records run beside the lane kernel).  Pooled PER DEVICE: the batch
+// API spawns fresh host threads for every multi-device call, so a per-thread helper would leak a stream and two events per call
+// and extra device.  A launch takes one from its device's pool (or makes one) and gives it back once its work is enqueued — the
+// stream orders whatever the next user puts on it behind that work.  s5gpu_shutdown releases all of them.
 struct AuxStream {
     hipStream_t st = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     int dev = -1;
-    uint32_t gen = 0;
 };
 static std::mutex g_aux_mu;
-static std::vector<AuxStream *> g_aux_all;
-static thread_local AuxStream *t_aux_p = nullptr;
-static int aux_stream(AuxStream **out) {
+static std::vector<AuxStream *> g_aux_all, g_aux_free;
+static int aux_acquire(AuxStream **out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_aux_mu);   // also orders the read of the generation against s5gpu_shutdown
-    if (t_aux_p && t_aux_p->dev == dev && t_aux_p->gen == s5host_generation) { *out = t_aux_p; return S5GPU_OK; }
+    {
+        std::lock_guard<std::mutex> lk(g_aux_mu);
+        for (size_t i = 0; i < g_aux_free.size(); i++)
+            if (g_aux_free[i]->dev == dev) { *out = g_aux_free[i]; g_aux_free.erase(g_aux_free.begin() + (long)i); return S5GPU_OK; }
+    }
     AuxStream *a = new AuxStream();
     a->dev = dev;
-    a->gen = s5host_generation;
     if (hipStreamCreateWithFlags(&a->st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&a->join, hipEventDisableTiming) != hipSuccess) {
         if (a->st) (void)hipStreamDestroy(a->st);
@@ -1218,20 +1312,25 @@ static int aux_stream(AuxStream **out) {
         s5gpu_set_error("helper stream for the routed inflate could not be created");
         return S5GPU_ERR_HIP;
     }
+    std::lock_guard<std::mutex> lk(g_aux_mu);
     g_aux_all.push_back(a);
-    t_aux_p = a;
     *out = a;
     return S5GPU_OK;
 }
-void s5kern_release_aux() {   // s5gpu_shutdown
+static void aux_release(AuxStream *a, uint32_t gen) {
+    std::lock_guard<std::mutex> lk(g_aux_mu);
+    if (gen == s5host_generation) g_aux_free.push_back(a);   // (a shutdown in between has destroyed and freed it)
+}
+void s5kern_release_aux() {   // s5gpu_shutdown (bumps the generation right after)
     std::lock_guard<std::mutex> lk(g_aux_mu);
     for (AuxStream *a : g_aux_all) {
         (void)hipStreamDestroy(a->st);
         (void)hipEventDestroy(a->fork);
         (void)hipEventDestroy(a->join);
-        a->gen = 0;       // a thread still pointing at it sees a stale stamp (generations start at 1); the struct itself stays
+        delete a;
     }
-    g_aux_all.clear();    // (a few dozen bytes per thread and shutdown: not freed, a thread-local may still point at it)
+    g_aux_all.clear();
+    g_aux_free.clear();
 }
 
 static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, bool unpack = false) {   // unpack: k_inflate_par also parses + decodes (svb-zd)
@@ -1250,7 +1349,8 @@ static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, bool unp
             hipLaunchKernelGGL(k_inflate_simt<false>, dim3(nb64), dim3(64), 64 * sizeof(LaneTables), st, *a);
         } else {
             AuxStream *ax;
-            { const int rc = aux_stream(&ax); if (rc) return rc; }
+            const uint32_t aux_gen = s5host_generation;
+            { const int rc = aux_acquire(&ax); if (rc) return rc; }
             AuxStream &t_aux = *ax;
             const uint32_t nbt = (a->n_recs + NT - 1) / NT;
             hipLaunchKernelGGL(k_route_zero, dim3(1), dim3(NT), 0, st, *a);
@@ -1264,6 +1364,7 @@ static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, bool unp
             HIP_TRY(hipEventRecord(t_aux.join, t_aux.st));
             hipLaunchKernelGGL(k_inflate_simt<true>, dim3(nb64), dim3(64), 64 * sizeof(LaneTables), st, *a);
             HIP_TRY(hipStreamWaitEvent(st, t_aux.join, 0));
+            aux_release(ax, aux_gen);
         }
     } else {
         hipLaunchKernelGGL(k_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
@@ -1307,6 +1408,11 @@ extern "C" int s5gpu_svbzd_encode_dev(const s5gpu_encode_args_t *a, void *stream
     return S5GPU_OK;
 }
 
+extern "C" uint64_t s5gpu_decode_scratch_bytes(uint32_t max_pay_cap) {
+    const uint64_t slot = ((uint64_t)max_pay_cap + 16 + 15) & ~15ull;
+    return 64 + slot * (256ull * S5_IP_WAVES * 4 + 256);
+}
+
 extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
     if (!a || (a->n_recs && (!a->desc || !a->in || !a->payload || !a->sig_out || !a->fields))) {
         s5gpu_set_error("s5gpu_decode_dev: bad arguments");
@@ -1319,6 +1425,52 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
     }
     if (a->n_recs == 0) return S5GPU_OK;
     hipStream_t st = (hipStream_t)stream_;
+    if (a->flags & S5GPU_DEC_NO_PAYLOAD) {
+        // fields + signals only: persistent workgroups, one reused scratch slot each (k_inflate_par_np)
+        if (a->sig_method != S5GPU_SIG_SVB_ZD || (a->rec_method != S5GPU_REC_ZLIB && a->rec_method != S5GPU_REC_ZSTD)) {
+            s5gpu_set_error("s5gpu_decode_dev: S5GPU_DEC_NO_PAYLOAD serves zlib / zstd records with svb-zd signals");
+            return S5GPU_ERR_ARG;
+        }
+        const uint64_t slot = ((uint64_t)a->max_pay_cap + 16 + 15) & ~15ull;
+        if (a->max_pay_cap == 0 || slot > 0xFFFFFFF0ull || a->payload_bytes < 64 + 2 * slot) {
+            s5gpu_set_error("s5gpu_decode_dev: S5GPU_DEC_NO_PAYLOAD needs max_pay_cap and at least 64 + 2 * (max_pay_cap + 32) bytes of scratch");
+            return S5GPU_ERR_ARG;
+        }
+        const uint64_t n_slots = (a->payload_bytes - 64) / slot;
+        const bool zl = a->rec_method == S5GPU_REC_ZLIB;
+        uint64_t n_fb = zl ? (n_slots / 16 < 1 ? 1 : n_slots / 16 > 256 ? 256 : n_slots / 16) : 0;
+        uint64_t n_main = n_slots - n_fb;
+        // more workgroups than the device holds at once buy nothing: they would only spread the scratch over more of L2
+        static std::atomic<uint32_t> s_res[2] = {{0}, {0}};
+        uint32_t res = s_res[zl].load(std::memory_order_relaxed);
+        if (!res) {
+            int per_cu = 0, cus = 0, dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            if (zl) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_par_np, 64, 0));
+            else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_zstd_inflate_np, 64, 0));
+            res = (uint32_t)(per_cu > 0 && cus > 0 ? per_cu * cus : 4096);
+            s_res[zl].store(res, std::memory_order_relaxed);
+        }
+        const uint64_t resident = res;
+        if (n_main > resident) n_main = resident;
+        if (n_main > a->n_recs) n_main = a->n_recs;
+        NpParams np;
+        np.ticket = reinterpret_cast<uint32_t *>(a->payload);
+        np.scratch = a->payload + 64;
+        np.slot = (uint32_t)slot;
+        np.cap = (uint32_t)slot - 16;
+        np.first_fb = (uint32_t)n_main;
+        HIP_TRY(hipMemsetAsync(a->payload, 0, 64, st));
+        if (zl) {
+            hipLaunchKernelGGL(k_inflate_par_np, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
+            hipLaunchKernelGGL(k_inflate_fallback_np, dim3((uint32_t)n_fb), dim3(64), 0, st, *a, np);
+        } else {
+            hipLaunchKernelGGL(k_zstd_inflate_np, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
+        }
+        HIP_TRY(hipGetLastError());
+        return S5GPU_OK;
+    }
     // svb-zd records under zlib (default inflate kernel) or zstd: the wave that decompresses a record unpacks it too
     const bool fused = a->sig_method == S5GPU_SIG_SVB_ZD && g_unpack_fused &&
                        ((a->rec_method == S5GPU_REC_ZLIB && g_inflate_par == 1) || a->rec_method == S5GPU_REC_ZSTD);

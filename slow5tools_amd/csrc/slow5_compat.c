@@ -40,6 +40,18 @@ void slow5_compat_error(const char *fmt, ...) {
     if (g_exit_cond >= SLOW5_EXIT_ON_ERR) exit(EXIT_FAILURE);
 }
 
+void slow5_compat_warn(const char *fmt, ...) {
+    if (g_log_level >= SLOW5_LOG_WARN) {
+        va_list ap;
+        va_start(ap, fmt);
+        fputs("[slow5gpu::WARNING] ", stderr);
+        vfprintf(stderr, fmt, ap);
+        fputc('\n', stderr);
+        va_end(ap);
+    }
+    if (g_exit_cond >= SLOW5_EXIT_ON_WARN) exit(EXIT_FAILURE);
+}
+
 static int rec_code(enum slow5_press_method m) {
     return m == SLOW5_COMPRESS_NONE ? S5GPU_REC_NONE : m == SLOW5_COMPRESS_ZLIB ? S5GPU_REC_ZLIB : m == SLOW5_COMPRESS_ZSTD ? S5GPU_REC_ZSTD : -1;
 }

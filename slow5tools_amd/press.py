@@ -96,6 +96,49 @@ def decode_records(records, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD, raise_on
     return out
 
 
+def decode_signals_dev(records, rec_method=REC_ZLIB, max_pay_cap=None, sig_caps=None, scratch_bytes=None, device="cuda:0"):
+    """s5gpu_decode_dev with S5GPU_DEC_NO_PAYLOAD: fields + signals only, the uncompressed records stay in reused scratch slots
+    (what `get` needs of /root/reference/src/get.c:37-66 when the caller holds the read ids).  records: bytes without the u64 prefix.
+    Returns (fields as a numpy REC_FIELDS array, list of int16 arrays — empty where status != 0)."""
+    import torch
+
+    L = _lib.lib()
+    n = len(records)
+    lens = np.array([len(r) for r in records], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum((lens + 15) // 16 * 16)]).astype(np.int64)
+    blob = np.zeros(int(offs[-1]) + 64, dtype=np.uint8)
+    for r, o in zip(records, offs[:-1]):
+        blob[o:o + len(r)] = np.frombuffer(bytes(r), dtype=np.uint8)
+    if max_pay_cap is None:
+        max_pay_cap = int(8 * lens.max() + 4096) if n else 64
+    if sig_caps is None:
+        sig_caps = np.full(n, max_pay_cap, dtype=np.int64)
+    sig_caps = np.asarray(sig_caps, dtype=np.int64)
+    so = np.concatenate([[0], np.cumsum((sig_caps + 15) // 8 * 8)]).astype(np.int64)
+    d = np.zeros(n, dtype=_lib.REC_DESC)
+    d["in_off"], d["in_len"], d["sig_off"], d["sig_cap"] = offs[:-1], lens, so[:-1], sig_caps
+    dev = torch.device(device)
+    t_in = torch.from_numpy(blob).to(dev)
+    t_desc = torch.from_numpy(d.view(np.uint8).copy()).to(dev)
+    t_sig = torch.zeros(int(so[-1]) + 64, dtype=torch.int16, device=dev)
+    t_fields = torch.zeros(max(n, 1) * 64, dtype=torch.uint8, device=dev)
+    if scratch_bytes is None:
+        L.s5gpu_decode_scratch_bytes.restype = C.c_uint64
+        L.s5gpu_decode_scratch_bytes.argtypes = [C.c_uint32]
+        scratch_bytes = int(L.s5gpu_decode_scratch_bytes(max_pay_cap))
+    t_scr = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+    a = _lib.DecodeArgs()
+    a.n_recs, a.rec_method, a.sig_method, a.flags = n, rec_method, SIG_SVB_ZD, _lib.DEC_NO_PAYLOAD
+    a.desc, a.in_, a.payload, a.sig_out, a.fields = t_desc.data_ptr(), t_in.data_ptr(), t_scr.data_ptr(), t_sig.data_ptr(), t_fields.data_ptr()
+    a.payload_bytes, a.max_pay_cap = scratch_bytes, max_pay_cap
+    check(L.s5gpu_decode_dev(C.byref(a), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "s5gpu_decode_dev")
+    torch.cuda.synchronize(dev)
+    f = t_fields.cpu().numpy().view(_lib.REC_FIELDS)[:n].copy()
+    sig = t_sig.cpu().numpy()
+    out = [sig[int(so[i]):int(so[i]) + int(f["n_samples"][i])].copy() if f["status"][i] == 0 else np.zeros(0, np.int16) for i in range(n)]
+    return f, out
+
+
 def _free_all(pay, sig, n):
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]

@@ -24,6 +24,18 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
+def sum_over_ranks(count, device=None):
+    """units processed by all ranks together (bench: `value` = the units all ranks processed / the max-over-ranks time)"""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(count)
+    t = torch.tensor([int(count)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def barrier():
     import torch.distributed as dist
 

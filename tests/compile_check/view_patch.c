@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <slow5/slow5.h>        /* the stand-in of tests/compile_check/slow5/ (slow5lib is an absent submodule) */
 #include <slow5gpu_hooks.h>     /* include/ of this repo */
+SLOW5_GPU_HOOK_CHECK_ENUMS;     /* the build fails here if slow5lib's enum values are not the ones the hooks map to codecs */
 
 typedef struct { int32_t num_thread; slow5_file_t *fp; slow5_fmt format_out; slow5_press_method_t press_method; int lossy; } core_t;
 typedef struct { int len; void *buffer; } raw_record_t;

@@ -113,6 +113,24 @@ def test_integration_hunk_compiles_next_to_slow5lib_names(compiler, tmp_path):
     assert r.returncode != 0 and "redefinition" in r.stderr
 
 
+@pytest.mark.parametrize("compiler", [["gcc", "-std=c11"], ["g++", "-std=c++11", "-x", "c++"]])
+def test_integration_hunk_refuses_a_slow5lib_with_other_enum_values(compiler, tmp_path):
+    """the hooks take slow5lib's enum values as plain ints, and the values are recalled, not read (the submodule is absent): the
+    hunk carries SLOW5_GPU_HOOK_CHECK_ENUMS, so a slow5lib whose enums are ordered differently stops the build"""
+    import subprocess
+
+    cc = os.path.join(ROOT, "tests", "compile_check")
+    alt = tmp_path / "slow5"
+    alt.mkdir()
+    txt = open(os.path.join(cc, "slow5", "slow5.h")).read()
+    swapped = txt.replace("SLOW5_COMPRESS_SVB_ZD, SLOW5_COMPRESS_ZSTD", "SLOW5_COMPRESS_ZSTD, SLOW5_COMPRESS_SVB_ZD")
+    assert swapped != txt
+    (alt / "slow5.h").write_text(swapped)
+    cmd = compiler + ["-c", "-I", str(tmp_path), "-I", os.path.join(ROOT, "include"), os.path.join(cc, "view_patch.c"), "-o", str(tmp_path / "v.o")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode != 0 and "mis-map codecs" in r.stderr, r.stderr
+
+
 def test_hooks_header_declares_no_slow5lib_name():
     txt = open(os.path.join(ROOT, "include", "slow5gpu_hooks.h")).read()
     code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)

@@ -162,6 +162,38 @@ def test_index_load_and_get_mem(L, tmp_path):
     L.slow5_close(f)
 
 
+def test_index_older_than_the_file_is_still_used_and_a_hostile_index_is_refused(L, tmp_path):
+    """an index whose mtime lies before the BLOW5's (cp / rsync reorder mtimes) is warned about and used, as slow5lib does — never
+    rebuilt in place; an entry whose offset + size wraps 64 bits must not pass the extent check"""
+    import struct, zlib
+
+    blow = tmp_path / "f.blow5"
+    shutil.copy(golden("example_multi_rg_v0.2.0.blow5"), blow)
+    shutil.copy(golden("example_multi_rg_v0.2.0.blow5.idx.exp"), str(blow) + ".idx")
+    os.utime(str(blow) + ".idx", (1_000_000_000, 1_000_000_000))      # years older than the file
+    before = open(str(blow) + ".idx", "rb").read()
+    L.slow5_set_log_level(0)
+    f = L.slow5_open(str(blow).encode(), b"r")
+    assert L.slow5_idx_load(f) == 0
+    ref = Blow5(str(blow))
+    n = C.c_size_t()
+    rid = zlib.decompress(ref.records[3])[2:38]
+    p_ = L.slow5_get_mem(rid, C.byref(n), f)
+    assert p_ and C.string_at(p_, n.value) == ref.records[3]
+    libc.free(p_)
+    L.slow5_close(f)
+    assert open(str(blow) + ".idx", "rb").read() == before               # the user's index was not touched
+    # hostile entry: offset near 2^64 so that offset + size wraps to a small number
+    raw = bytearray(before)
+    first = 64 + 2 + struct.unpack_from("<H", raw, 64)[0]
+    struct.pack_into("<QQ", raw, first, 0xFFFFFFFFFFFFFF00, 0x200)
+    open(str(blow) + ".idx", "wb").write(raw)
+    f = L.slow5_open(str(blow).encode(), b"r")
+    assert L.slow5_idx_load(f) != 0
+    L.slow5_close(f)
+    L.slow5_set_log_level(1)
+
+
 # ---------------------------------------------------------------- end to end on the GPU
 def _run(*args):
     r = subprocess.run([S5VIEW] + [str(a) for a in args], capture_output=True, text=True, timeout=120)
@@ -262,6 +294,43 @@ def test_chunked_view_pipeline_equals_the_per_record_pipeline(tmp_path, chunk_kb
     r = subprocess.run([S5VIEW, str(a), str(back), "none", "none", "4096", "1"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     assert back.read_bytes() == src.read_bytes()
+
+
+@pytest.mark.gpu
+def test_chunked_view_takes_tiny_records_and_falls_back_on_a_record_larger_than_a_chunk(tmp_path):
+    """(a) a chunk of records smaller than the slot's descriptor pitch (empty reads: ~54 bytes framed) used to end in
+    'bad record framing' on the last chunk; (b) a record larger than the chunk aborted the tool: it now redoes the file record by record"""
+    import struct
+    from slow5tools_amd import press
+
+    text = b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
+    head = bytearray(64)
+    head[:6] = b"BLOW5\x01"; head[6:9] = bytes([0, 2, 0]); head[9] = 0; head[10:14] = struct.pack("<I", 1); head[14] = 0
+
+    def blow5(path, sigs, ids):
+        hdrs = [press.pack_hdr(i, 0, 8192.0, 23.0, 1467.61, 4000.0) for i in ids]
+        recs = press.encode_records(sigs, hdrs, None, press.REC_NONE, press.SIG_NONE)
+        path.write_bytes(bytes(head) + struct.pack("<I", len(text)) + text + b"".join(recs) + b"5WOLB")
+
+    def both(src, chunk_kb, expect_fallback, slot_recs=0):
+        a, b = tmp_path / "chunked.blow5", tmp_path / "per_record.blow5"
+        env = dict(os.environ, S5VIEW_CHUNK_KB=str(chunk_kb), S5VIEW_SLOT_RECS=str(slot_recs))
+        r = subprocess.run([S5VIEW, str(src), str(a), "zlib", "svb-zd", "4096", "2"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        assert ("per-record pipeline" in r.stderr) == expect_fallback, r.stderr
+        r = subprocess.run([S5VIEW, str(src), str(b), "zlib", "svb-zd", "64", "2"], capture_output=True, text=True, timeout=300, env=dict(os.environ, S5VIEW_PER_RECORD="1"))
+        assert r.returncode == 0, r.stderr
+        assert a.read_bytes() == b.read_bytes()
+
+    tiny = tmp_path / "tiny.blow5"                                     # 30 000 empty reads with one-character ids: 55 bytes framed
+    blow5(tiny, [np.zeros(0, np.int16)] * 30000, [b"%c" % (65 + i % 26) for i in range(30000)])
+    both(tiny, 300, False)
+    both(tiny, 64, False, slot_recs=1000)                              # 64 KiB hold 1191 of them: every chunk is framed in two rounds, the last one too
+    rng = np.random.default_rng(3)
+    big = tmp_path / "big.blow5"
+    sigs = [(480 + 35 * rng.standard_normal(int(k))).astype(np.int16) for k in (300, 5000, 90000, 20, 7000)]
+    blow5(big, sigs, [b"big%d" % i for i in range(5)])
+    both(big, 64, True)                                                # the 180 KB record does not fit a 64 KiB chunk
 
 
 @pytest.mark.gpu

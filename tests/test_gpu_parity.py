@@ -566,6 +566,60 @@ def test_fused_unpack_and_the_records_it_leaves_to_the_second_kernel(press):
     assert any(g["status"] == 8 for g in alone)
 
 
+@pytest.mark.parametrize("scratch", ["default", "three-slots"])
+def test_decode_without_payload_output_equals_the_full_decode(press, scratch):
+    """S5GPU_DEC_NO_PAYLOAD (fields + signals only; persistent workgroups inflate into a reused scratch slot and unpack out of it):
+    the same mixed batch as above — records the parallel decoder declines (its fallback has its own slots), malformed payloads, stock
+    zlib levels — must give the fields and signals of the full decode; with three slots of scratch as with thousands.  A record larger
+    than max_pay_cap reports status 5 and the size it needs; a signal slot that is too small status 6."""
+    rng = np.random.default_rng(92)
+    sigs, streams = [], []
+    for i in range(200):
+        n = int(rng.integers(1, 9000))
+        if i % 3 == 0:
+            sig = np.tile((400 + rng.integers(-300, 300, 53)).astype(np.int16), n // 53 + 1)[:n]
+        elif i % 3 == 1:
+            sig = ob.synth_read(0x5105, i, n)
+        else:
+            sig = (rng.integers(-2000, 2000, n)).astype(np.int16)
+        payload, _ = _oracle_payload(_hdr(press, i), sig, bytes(rng.integers(0, 256, int(rng.integers(0, 50)), dtype=np.uint8)), 1)
+        sigs.append(sig)
+        streams.append(zlib.compress(payload, 9 if i % 2 else 6))
+    good, _ = _oracle_payload(_hdr(press, 500), ob.synth_read(1, 1, 500), b"", 1)
+    hl = 2 + int.from_bytes(good[:2], "little") + 4 + 32
+    lying = good[:hl] + (int.from_bytes(good[hl:hl + 8], "little") + 9).to_bytes(8, "little") + good[hl + 8:]
+    big, _ = _oracle_payload(_hdr(press, 501), ob.synth_read(1, 2, 30000), b"", 1)          # larger than max_pay_cap below
+    streams += [zlib.compress(lying), zlib.compress(good[:hl + 4]), zlib.compress(big), streams[4][:30] + b"\x55" + streams[4][31:]]
+    own = press.encode_records([ob.synth_read(0x5105, 900 + i, 4000) for i in range(64)], [_hdr(press, 900 + i) for i in range(64)])
+    streams += [r[8:] for r in own]
+    sigs_all = sigs + [None] * 4 + [ob.synth_read(0x5105, 900 + i, 4000) for i in range(64)]
+    cap = 9000 * 3 + 300
+    caps = np.full(len(streams), 9000)
+    caps[7] = 10                                                                             # signal slot too small
+    f, got = press.decode_signals_dev(streams, 1, max_pay_cap=cap, sig_caps=caps, scratch_bytes=None if scratch == "default" else 64 + 3 * (cap + 32))
+    ref = press.decode_records(streams, raise_on_error=False)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        if i == 7:
+            assert f["status"][i] == 6 and f["n_samples"][i] == len(sigs[7])
+        elif i == 202:
+            assert f["status"][i] == 5 and f["payload_len"][i] == len(big)
+        else:
+            assert f["status"][i] == r["status"], (i, f["status"][i], r["status"])
+            if r["status"] == 0:
+                assert np.array_equal(g, r["signal"]) and np.array_equal(g, sigs_all[i])
+                assert f["read_group"][i] == r["read_group"] and f["payload_len"][i] == len(r["payload"]) and f["aux_len"][i] == len(r["aux"]) and f["digitisation"][i] == r["digitisation"]
+    assert f["status"][200] == 7 and f["status"][201] == 7 and f["status"][203] != 0
+    # zstd records through the same mode; and the reference's own files (stock zlib)
+    zrec = press.encode_records(sigs[:40], [_hdr(press, i) for i in range(40)], None, 2, 1)
+    f, got = press.decode_signals_dev([r[8:] for r in zrec], 2, max_pay_cap=cap)
+    assert (f["status"] == 0).all() and all(np.array_equal(g, s) for g, s in zip(got, sigs[:40]))
+    for name in ZLIB_SVB_FIXTURES:
+        fx = Blow5(golden(name))
+        want = press.decode_records(fx.records, 1, 1)
+        f, got = press.decode_signals_dev(fx.records, 1, max_pay_cap=max(len(w["payload"]) for w in want) + 8)
+        assert (f["status"] == 0).all() and all(np.array_equal(g, w["signal"]) for g, w in zip(got, want)), name
+
+
 def test_parallel_inflate_takes_stock_zlib_streams_without_the_fallback(press):
     """Records written by stock zlib (the reference's encoder) hold ~110 matches per 4000-sample svb-zd record whose source is not
     the decoding lane's own output, several hundred per window in raw-signal records: with inflate_par = 2 (no fallback pass: a

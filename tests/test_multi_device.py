@@ -59,6 +59,23 @@ plain = recompress([r[8:] for r in recs], (1, 1), (0, 0), rg=[7] * n)
 for i, p in enumerate(plain):
     rec, keep = ob.make_rec(ob.synth_read_id(i), 7, 8192.0, 23.0, 1467.61, 4000.0, sigs[i])
     assert p[8:] == ob.rec_pack(rec, ob.SIG_NONE), i
+# the chunk form of the worker (s5gpu_recompress_stream): one framed host buffer in, one contiguous stream out.  With too little
+# room it must say how much the WHOLE output needs, however many devices shared the work (ADVICE round 2: the first overflowing
+# share used to report only the shares up to itself, so the caller's retry could overflow again)
+chunk = b"".join(recs) + bytes(64)
+pos = np.cumsum([0] + [len(r) for r in recs])[:-1].astype(np.uint64) + 8
+ln32 = np.array([len(r) - 8 for r in recs], dtype=np.uint32)
+L.s5gpu_recompress_stream.argtypes = [C.c_uint32, vp, C.c_size_t, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_size_t, vp, vp]
+def stream(cap):
+    ob_ = C.create_string_buffer(max(cap, 1)); off = (C.c_uint64 * (n + 1))(); st = (C.c_int32 * n)()
+    rc = L.s5gpu_recompress_stream(n, chunk, len(chunk) - 64, pos.ctypes.data, ln32.ctypes.data, 1, 1, 0, 0, None, 0, ob_, cap, off, st)
+    return rc, list(off), ob_.raw
+full = sum(len(p) for p in plain)
+rc, off, raw = stream(full + 64)
+assert rc == 0 and off[n] == full and raw[:full] == b"".join(plain[i][:8] + ob.rec_pack(ob.make_rec(ob.synth_read_id(i), i %% 3, 8192.0, 23.0, 1467.61, 4000.0, sigs[i])[0], ob.SIG_NONE) for i in range(n))
+for cap in (full // 5, full // 2, full - 1):          # overflow in the first, the second and the last share
+    rc, off, raw = stream(cap)
+    assert rc == -3 and off[0] == full, (cap, rc, off[0], full)
 L.s5gpu_shutdown()
 assert L.s5gpu_devices_in_use() == 0
 print("multi ok", len(b"".join(recs)))
@@ -147,3 +164,28 @@ def test_two_gloo_ranks_run_the_hip_path_on_their_shards(tmp_path):
         pos += 8 + size
         i += 1
     assert i == n_total and pos == len(stream)
+
+
+def test_bench_two_ranks_preflight_on_one_gpu(tmp_path):
+    """The driver's N > 1 run is `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: rehearse that very launch
+    with two ranks on this box's one GPU (S5BENCH_ALIAS_DEVICES=1 maps both ranks onto device 0 and swaps RCCL — which refuses two
+    ranks on one device — for gloo; everything else is the production path: rendezvous, per-rank shards, barriers, MAX / SUM over
+    ranks, the legs of every config).  One JSON line, n_gpus 2, both ranks seen by the all-reduce, parity true in every leg."""
+    import json
+
+    port = str(29900 + os.getpid() % 1000)
+    env = dict(os.environ, S5BENCH_ALIAS_DEVICES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "20000", "--long-reads", "512", "--cpu-seconds", "0",
+           "--get-reads", "20000", "--min-leg-seconds", "0.2", "--min-leg-steps-svb", "4", "--min-leg-steps-long", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["scaling"] == "weak" and j["steps"] == 3
+    assert j["parity_spot_check"] is True and j["config"]["reads_per_gpu"] == 20000
+    assert j["configs1"]["parity_spot_check"] is True and j["configs1"]["n_gpus"] == 2
+    assert j["configs3"]["parity_spot_check"] is True and j["configs3"]["reads_rank0"] == 256 and j["configs3"]["scaling"] == "strong"
+    assert j["configs4"]["roundtrip_identical"] is True and j["configs4"]["bulk_decode_one_call"]["stock_zlib_records"]["roundtrip_identical"] is True
+    assert j["cpu_baseline"] is None                       # an N = 1 figure

@@ -1,5 +1,7 @@
 """Which records does the parallel-inside-the-record inflate decline?  Status histogram of k_inflate_par alone (no fallback pass)
-on synthetic reads.  python tools/par_probe.py [reads] [samples]"""
+on synthetic reads.  python tools/par_probe.py [reads] [samples]
+The cut-offs and counters need the probe build:  tools/variant.sh probe -DS5_PAR_PROBE && S5GPU_LIB=slow5tools_amd/_variants/libs5_probe.so python tools/par_probe.py
+(the product kernel carries no probe hooks; without the variant only the status histogram and the whole-kernel times are printed)"""
 import ctypes as C, sys, collections
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -28,7 +30,7 @@ for mode in (2, 1, 0):
     f = fields.cpu().numpy().view(_lib.REC_FIELDS)
     st = f["status"]
     print("inflate_par=%d: %.3f ms  statuses %s" % (mode, min(ts), dict(collections.Counter(st.tolist()))))
-    if mode == 2:
+    if mode == 2 and "probe" in os.environ.get("S5GPU_LIB", ""):
         a.sig_method = 99
         fields.zero_(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); torch.cuda.synchronize()
         f = fields.cpu().numpy().view(_lib.REC_FIELDS)
