@@ -67,11 +67,21 @@ def test_no_cpu_fallback_without_gpu(lib):
         press.encode_records([[1, 2, 3]], [press.pack_hdr("r", 0, 1.0, 2.0, 3.0, 4.0)])
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """the ctypes mirrors against what gcc makes of include/slow5gpu.h: sizes, and the offsets of the fields added in round 3"""
+    import subprocess
+
     from slow5tools_amd import _lib
 
-    assert C.sizeof(_lib.EncodeArgs) == 80
-    assert C.sizeof(_lib.DecodeArgs) == 56
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "slow5gpu.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(s5gpu_encode_args_t), sizeof(s5gpu_decode_args_t), offsetof(s5gpu_decode_args_t, flags), offsetof(s5gpu_decode_args_t, desc), '
+                   'offsetof(s5gpu_decode_args_t, payload_bytes), offsetof(s5gpu_decode_args_t, max_pay_cap), sizeof(s5gpu_rec_desc_t));return 0;}\n')
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "sz")])
+    got = [int(x) for x in subprocess.check_output([str(tmp_path / "sz")], text=True).split()]
+    D = _lib.DecodeArgs
+    assert got == [C.sizeof(_lib.EncodeArgs), C.sizeof(D), D.flags.offset, D.desc.offset, D.payload_bytes.offset, D.max_pay_cap.offset, _lib.REC_DESC.itemsize]
+    assert C.sizeof(_lib.EncodeArgs) == 80 and C.sizeof(D) == 72 and D.flags.offset == 12 and D.desc.offset == 16
 
 
 SURVEY_8B_SYMBOLS = ["slow5_press_init", "slow5_press_free", "slow5_rec_to_mem", "slow5_rec_fwrite", "slow5_rec_depress_parse", "slow5_decode",
