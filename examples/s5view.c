@@ -9,8 +9,8 @@
  *        src/misc.c:54-58, src/cmd.h:8; the input format is sniffed, the output format follows the extension as in
  *        src/view.c:170-190; press methods are ignored for a .slow5 output).  A 6th argument sets the number of GPU worker
  *        threads of the read || GPU || write pipeline (default 1); 0 runs the reference's serial read / compute / write phases.
- *        BLOW5 -> BLOW5 takes the chunked pipeline (no malloc / memcpy per record; S5VIEW_CHUNK_MB, S5VIEW_READERS tune it,
- *        S5VIEW_PER_RECORD=1 forces the per-record pipeline the tests compare it with).
+ *        BLOW5 -> BLOW5 and SLOW5 -> BLOW5 take the chunked pipeline (no malloc / memcpy per record; S5VIEW_CHUNK_MB, S5VIEW_READERS
+ *        tune it, S5VIEW_PER_RECORD=1 forces the per-record pipeline the tests compare it with).
  *   s5view --index in.blow5          writes in.blow5.idx (slow5tools index)
  *   s5view --get in.blow5 read_id    prints len_raw_signal and the first samples of one read (slow5tools get)
  */
@@ -146,6 +146,9 @@ typedef struct {
     int64_t next_work, total_batches;
     slow5_press_method_t from, to;
     int failed, readers, oversize;
+    int ascii;                   /* the input is a .slow5 file: the chunk is framed into lines, not [u64 size][bytes] records */
+    uint32_t n_aux;
+    const uint8_t *aux_type;
     char why[256];
     uint64_t records;
 } fpipe_t;
@@ -204,7 +207,18 @@ static void *freader_main(void *arg) {
         const size_t have = carry + want;
         size_t p = 0;
         uint32_t n = 0;
-        while (p + 8 <= have && n < b->cap) {
+        const int file_done_ = P->pos >= P->end;
+        while (P->ascii && p < have && n < b->cap) {                 /* one record per line; a line the chunk's end cut is carried */
+            const uint8_t *nl = (const uint8_t *)memchr(b->in + p, '\n', have - p);
+            if (!nl && !file_done_) break;
+            const size_t e = nl ? (size_t)(nl - b->in) : have;         /* (a last line without its newline) */
+            size_t l = e - p;
+            if (l && b->in[p + l - 1] == '\r') l--;
+            if (l) { b->rec_pos[n] = p; b->rec_len[n] = (uint32_t)l; n++; }
+            p = nl ? e + 1 : e;
+        }
+        if (P->ascii && n == 0 && have >= P->chunk) { P->oversize = 1; fpipe_fail(P, "a line larger than the chunk size"); return NULL; }
+        while (!P->ascii && p + 8 <= have && n < b->cap) {
             uint64_t sz;
             memcpy(&sz, b->in + p, 8);
             if (sz > P->chunk - 8) { P->oversize = 1; fpipe_fail(P, "a record larger than the chunk size"); return NULL; }   /* main() redoes the file record by record */
@@ -250,8 +264,11 @@ static void *fworker_main(void *arg) {
         b->state = ST_BUSY;
         pthread_mutex_unlock(&P->mu);
         for (int attempt = 0;; attempt++) {
-            const int rc = s5gpu_recompress_stream(b->n, b->in, b->in_have, b->rec_pos, b->rec_len, rec_code_of(P->from.record_method), sig_code_of(P->from.signal_method),
-                                                   rec_code_of(P->to.record_method), sig_code_of(P->to.signal_method), NULL, 0, b->out, b->out_cap, b->out_off, NULL);
+            const int rc = P->ascii
+                ? s5gpu_ascii_to_blow5_stream(b->n, b->in, b->in_have, b->rec_pos, b->rec_len, P->n_aux, P->aux_type, rec_code_of(P->to.record_method),
+                                              sig_code_of(P->to.signal_method), NULL, 0, b->out, b->out_cap, b->out_off, NULL)
+                : s5gpu_recompress_stream(b->n, b->in, b->in_have, b->rec_pos, b->rec_len, rec_code_of(P->from.record_method), sig_code_of(P->from.signal_method),
+                                          rec_code_of(P->to.record_method), sig_code_of(P->to.signal_method), NULL, 0, b->out, b->out_cap, b->out_off, NULL);
             if (rc == S5GPU_OK) break;
             if (rc == S5GPU_ERR_NOMEM && attempt == 0 && b->out_off[0] > b->out_cap) {   /* the output outgrew its buffer: bring a bigger one */
                 const size_t need = (size_t)b->out_off[0] + (size_t)b->out_off[0] / 8;
@@ -280,15 +297,17 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     pthread_cond_init(&P.cv, NULL);
     struct stat st;
     P.fd_in = fileno(in->fp);
-    if (fstat(P.fd_in, &st) != 0 || (uint64_t)st.st_size < in->meta.start_rec_offset + 5) return -1;
-    {   /* the end marker must close the file (src/quickcheck.c:93-97) */
+    P.ascii = in->format == SLOW5_FORMAT_ASCII;
+    if (P.ascii && in->header->aux_meta) { P.n_aux = in->header->aux_meta->num; P.aux_type = in->header->aux_meta->types; }
+    if (fstat(P.fd_in, &st) != 0 || (uint64_t)st.st_size < in->meta.start_rec_offset + (P.ascii ? 0 : 5)) return -1;
+    if (!P.ascii) {   /* the end marker must close the file (src/quickcheck.c:93-97) */
         char tail[5];
         if (pread(P.fd_in, tail, 5, st.st_size - 5) != 5 || memcmp(tail, "5WOLB", 5) != 0) { fprintf(stderr, "s5view: no BLOW5 end marker\n"); return -1; }
     }
     fflush(out);
     P.fd_out = fileno(out);
     P.pos = in->meta.start_rec_offset;
-    P.end = (uint64_t)st.st_size - 5;
+    P.end = (uint64_t)st.st_size - (P.ascii ? 0 : 5);
     const char *e = getenv("S5VIEW_CHUNK_MB");
     P.chunk = (size_t)(e ? atoi(e) : 32) << 20;
     e = getenv("S5VIEW_CHUNK_KB");                                   /* tests: chunks smaller than a record batch */
@@ -303,7 +322,7 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
         e = getenv("S5VIEW_SLOT_RECS");                             /* tests: fewer descriptors than a chunk holds records */
         if (e && atoi(e) > 0) b->cap = (uint32_t)atoi(e);
         b->in = (uint8_t *)s5gpu_host_alloc(P.chunk + 64);
-        b->out_cap = P.chunk * 3;
+        b->out_cap = P.ascii ? P.chunk : P.chunk * 3;              /* (a chunk that outgrows it is redone with the room it asked for) */
         b->out = (uint8_t *)s5gpu_host_alloc(b->out_cap);
         b->rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * b->cap);
         b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * b->cap);
@@ -342,8 +361,8 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     for (int i = 0; i < FSLOT; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); }
     if (P.failed && P.oversize) return -2;
     if (P.failed) { fprintf(stderr, "s5view: %s\n", P.why); return -1; }
-    fprintf(stderr, "s5view: chunked pipeline: %.3f s for %llu records (%.1f MB in, %.1f MB out; buffers %.3f s), %d pread threads, %d GPU worker(s), chunks of %zu MB\n",
-            t1 - t0, (unsigned long long)*total, (double)(P.end - in->meta.start_rec_offset) / 1e6, (double)out_bytes / 1e6, t0 - t_alloc, P.readers, W, P.chunk >> 20);
+    fprintf(stderr, "s5view: chunked pipeline%s: %.3f s for %llu records (%.1f MB in, %.1f MB out; buffers %.3f s), %d pread threads, %d GPU worker(s), chunks of %zu MB\n",
+            P.ascii ? " (SLOW5 text in)" : "", t1 - t0, (unsigned long long)*total, (double)(P.end - in->meta.start_rec_offset) / 1e6, (double)out_bytes / 1e6, t0 - t_alloc, P.readers, W, P.chunk >> 20);
     return 0;
 }
 
@@ -393,11 +412,13 @@ int main(int argc, char **argv) {
     const int workers = argc > 6 ? atoi(argv[6]) : 1;
     uint64_t total = 0;
     const char *nofast = getenv("S5VIEW_PER_RECORD");
-    int fast = workers > 0 && in->format == SLOW5_FORMAT_BINARY && fmt_out == SLOW5_FORMAT_BINARY && !(nofast && atoi(nofast));
+    /* chunked pipeline: BLOW5 -> BLOW5 and SLOW5 -> BLOW5 (the conversion BASELINE configs[0] names); a .slow5 OUTPUT takes the per-record one */
+    int fast = workers > 0 && fmt_out == SLOW5_FORMAT_BINARY && !(nofast && atoi(nofast));
     if (fast) {
         const int rc = fast_view(in, out, from, to, workers, &total);
         if (rc == -2) {   /* start the output over, record by record (the chunked reader used pread: in->fp still stands at the first record) */
             fprintf(stderr, "s5view: a record larger than a chunk (S5VIEW_CHUNK_MB): per-record pipeline\n");
+            if (in->format == SLOW5_FORMAT_ASCII && fseeko(in->fp, (off_t)in->meta.start_rec_offset, SEEK_SET) != 0) return die("cannot rewind the input");
             total = 0;
             if (fflush(out) != 0 || ftruncate(fileno(out), 0) != 0 || fseek(out, 0, SEEK_SET) != 0 || slow5_hdr_fwrite(out, in->header, fmt_out, to) < 0) return die("cannot restart the output");
             fast = 0;

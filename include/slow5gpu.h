@@ -245,7 +245,7 @@ int s5gpu_solo_batch(int stage, uint32_t n, const void *const *in, const size_t 
  * The raw_signal column (comma-separated decimal int16) is ~95 % of an ASCII record: it is parsed / formatted on the
  * device, one read per workgroup.  The handful of scalar columns and the aux columns are converted on the host. */
 typedef struct {             /* 32 B: one read's raw_signal text on the device */
-    uint64_t txt_off;        /* byte offset of the text in `text` (16-byte aligned for the parser) */
+    uint64_t txt_off;        /* byte offset of the text in `text` (any alignment) */
     uint64_t sig_off;        /* int16 index of the first sample in `sig` */
     uint32_t txt_len;        /* parse: length of the text; format: capacity of the text slot (7 bytes/sample is enough) */
     uint32_t n_samples;      /* parse: the count the len_raw_signal column promised; format: samples to print */
@@ -272,6 +272,15 @@ int s5gpu_aux_types_parse(const char *types_line, size_t len, uint8_t *aux_type,
 int s5gpu_ascii_to_blow5_batch(uint32_t n, const char *const *line, const size_t *line_len, uint32_t n_aux, const uint8_t *aux_type,
                                int to_rec, int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
                                int32_t *status);
+/* The same on a CHUNK of a .slow5 file, for a loop that reads the file in large pieces (examples/s5view.c; what s5gpu_recompress_stream
+ * is for BLOW5 input): the n record lines sit in one host buffer `chunk` exactly as read from disk, line_pos[i] / line_len[i] = offset and
+ * length of line i (with or without its newline).  The chunk is uploaded as it is and the raw_signal columns are parsed where they lie;
+ * the BLOW5 records come back as ONE contiguous stream in out_buf (out_off[i] = offset of record i's u64 prefix, out_off[n] = total):
+ * no per-line malloc or memcpy on either side.  Too little room: S5GPU_ERR_NOMEM and out_off[0] = the capacity needed.  `chunk` needs
+ * 32 readable bytes behind the last line. */
+int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *line_pos, const uint32_t *line_len,
+                                uint32_t n_aux, const uint8_t *aux_type, int to_rec, int to_sig, const uint32_t *new_read_group, int drop_aux,
+                                void *out_buf, size_t out_cap, uint64_t *out_off, int32_t *status);
 /* BLOW5 records (bytes without the u64 prefix) -> ASCII lines ending in a newline; out[i] malloc'd. */
 int s5gpu_blow5_to_ascii_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, uint32_t n_aux,
                                const uint8_t *aux_type, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,

@@ -356,6 +356,123 @@ extern "C" int s5gpu_ascii_to_blow5_batch(uint32_t n, const char *const *line, c
     return s5host::encode_and_collect(c, n, desc, a, oo, out, out_len);
 }
 
+// The same for a CHUNK of a .slow5 file: lines framed in place, the chunk uploaded as it is, one contiguous record stream back
+// (the ASCII twin of s5gpu_recompress_stream; /root/reference/src/view.c:35-57 with a .slow5 input, configs[0] of BASELINE.json).
+extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *line_pos, const uint32_t *line_len,
+                                           uint32_t n_aux, const uint8_t *aux_type, int to_rec, int to_sig, const uint32_t *new_read_group, int drop_aux,
+                                           void *out_buf, size_t out_cap, uint64_t *out_off, int32_t *status) {
+    if (n == 0) { if (out_off) out_off[0] = 0; return S5GPU_OK; }
+    if (!chunk || !line_pos || !line_len || !out_buf || !out_off || (n_aux && !aux_type)) { s5gpu_set_error("s5gpu_ascii_to_blow5_stream: NULL argument"); return S5GPU_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++) {
+        if (status) status[i] = 0;
+        if (line_pos[i] > chunk_bytes || line_len[i] > chunk_bytes - line_pos[i]) { s5gpu_set_error("line %u lies outside the chunk", i); return S5GPU_ERR_ARG; }
+    }
+    const int G = s5host::n_devices();
+    if (G == 0) return S5GPU_ERR_NODEV;
+    s5host::ShareGather sg(G);
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
+        s5host::CtxHold hold;
+        int r = hold.acquire(slot);
+        if (r) return sg.fail(r);
+        Ctx *c = hold.c;
+        const uint32_t m = hi - lo;
+        const char *base_p = (const char *)chunk;
+        // scalar and aux columns on the host; the raw_signal column stays where it is
+        std::vector<Line> L(m);
+        uint64_t text_bytes = 0, b0 = UINT64_MAX, e1 = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            text_bytes += line_len[i];
+            b0 = b0 < line_pos[i] ? b0 : line_pos[i];
+            e1 = e1 > line_pos[i] + line_len[i] ? e1 : line_pos[i] + line_len[i];
+        }
+        b0 &= ~15ull;
+        parallel_for(m, text_bytes, [&](uint32_t a, uint32_t b) {
+            for (uint32_t i = a; i < b; i++)
+                parse_line(base_p + line_pos[lo + i], line_len[lo + i], n_aux, aux_type, new_read_group ? new_read_group + lo + i : nullptr, drop_aux, L[i]);
+        });
+        bool bad = false;
+        for (uint32_t i = 0; i < m; i++)
+            if (L[i].status) { bad = true; if (status) status[lo + i] = L[i].status; }
+        if (bad) { s5gpu_set_error("s5gpu_ascii_to_blow5_stream: at least one line is malformed (see status[i])"); return sg.fail(S5GPU_ERR_DATA); }
+        std::vector<s5gpu_read_desc_t> desc(m);
+        std::vector<s5gpu_txt_desc_t> td(m);
+        uint64_t so = 0, ho = 0, ao = 0, oo = 0;
+        uint32_t max_payload = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            s5gpu_read_desc_t &d = desc[i];
+            d.sig_off = so; d.hdr_off = ho; d.aux_off = ao; d.out_off = oo;
+            d.n_samples = L[i].n_samples;
+            d.hdr_len = (uint32_t)L[i].head.size();
+            d.aux_len = (uint32_t)L[i].aux.size();
+            const uint64_t pb = s5gpu_payload_bound(d.n_samples, d.hdr_len, d.aux_len, to_sig);
+            const uint64_t sb = s5gpu_slot_bound(d.n_samples, d.hdr_len, d.aux_len, to_rec, to_sig);
+            if (pb > 0xFFFFFF00ull) { s5gpu_set_error("read %u: record larger than 4 GiB", lo + i); return sg.fail(S5GPU_ERR_ARG); }
+            d.slot_cap = (uint32_t)sb;
+            if (pb > max_payload) max_payload = (uint32_t)pb;
+            s5gpu_txt_desc_t &t = td[i];
+            memset(&t, 0, sizeof t);
+            t.txt_off = (uint64_t)(L[i].sig - base_p) - b0; t.sig_off = so; t.txt_len = L[i].sig_len; t.n_samples = d.n_samples;
+            so += up(d.n_samples, 8); ho += d.hdr_len; ao += d.aux_len; oo += sb;
+        }
+        const size_t h_hdr = up(ho + 64, 64), h_aux = up(ao + 64, 64), h_desc = up(sizeof(s5gpu_read_desc_t) * m, 64), h_td = sizeof(s5gpu_txt_desc_t) * m;
+        const uint64_t tbytes = e1 - b0;
+        if ((r = c->h_in.reserve(h_hdr + h_aux + h_desc + h_td)) || (r = c->d_txt.reserve(tbytes + 64)) || (r = c->d_sig.reserve(so * 2 + 64)) ||
+            (r = c->d_hdr.reserve(ho + 64)) || (r = c->d_aux.reserve(ao + 64)) || (r = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * m)) ||
+            (r = c->d_tdesc.reserve(h_td + 4ull * m)) || (r = c->h_out.reserve(4ull * m + 64)))
+            return sg.fail(r);
+        uint8_t *hh = (uint8_t *)c->h_in.p, *ha = hh + h_hdr, *hd = ha + h_aux, *htd = hd + h_desc;
+        for (uint32_t i = 0; i < m; i++) {
+            memcpy(hh + desc[i].hdr_off, L[i].head.data(), desc[i].hdr_len);
+            if (desc[i].aux_len) memcpy(ha + desc[i].aux_off, L[i].aux.data(), desc[i].aux_len);
+        }
+        memcpy(hd, desc.data(), sizeof(s5gpu_read_desc_t) * m);
+        memcpy(htd, td.data(), h_td);
+        auto hip = [&](hipError_t e, const char *what) -> int {
+            if (e == hipSuccess) return 0;
+            s5gpu_set_error("%s failed: %s", what, hipGetErrorString(e));
+            return sg.fail(S5GPU_ERR_HIP);
+        };
+        if ((r = hip(hipMemcpyAsync(c->d_txt.p, (const uint8_t *)chunk + b0, tbytes, hipMemcpyHostToDevice, c->st), "upload of the chunk"))) return r;
+        if ((r = hip(hipMemcpyAsync(c->d_hdr.p, hh, ho, hipMemcpyHostToDevice, c->st), "upload"))) return r;
+        if (ao && (r = hip(hipMemcpyAsync(c->d_aux.p, ha, ao, hipMemcpyHostToDevice, c->st), "upload"))) return r;
+        if ((r = hip(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_read_desc_t) * m, hipMemcpyHostToDevice, c->st), "upload"))) return r;
+        if ((r = hip(hipMemcpyAsync(c->d_tdesc.p, htd, h_td, hipMemcpyHostToDevice, c->st), "upload"))) return r;
+        int32_t *d_status = (int32_t *)((uint8_t *)c->d_tdesc.p + h_td);
+        if ((r = s5gpu_ascii_parse_dev(m, (const s5gpu_txt_desc_t *)c->d_tdesc.p, (const uint8_t *)c->d_txt.p, (int16_t *)c->d_sig.p, d_status, c->st))) return sg.fail(r);
+        if ((r = hip(hipMemcpyAsync(c->h_out.p, d_status, 4ull * m, hipMemcpyDeviceToHost, c->st), "status download"))) return r;
+        if ((r = hip(hipStreamSynchronize(c->st), "synchronise"))) return r;
+        const int32_t *hs = (const int32_t *)c->h_out.p;
+        for (uint32_t i = 0; i < m; i++)
+            if (hs[i]) { bad = true; if (status) status[lo + i] = hs[i]; }
+        if (bad) { s5gpu_set_error("s5gpu_ascii_to_blow5_stream: raw_signal text of at least one line is malformed (see status[i])"); return sg.fail(S5GPU_ERR_DATA); }
+        s5gpu_encode_args_t a;
+        memset(&a, 0, sizeof a);
+        a.n_reads = m; a.rec_method = to_rec; a.sig_method = to_sig;
+        a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
+        a.sig = (const int16_t *)c->d_sig.p; a.hdr = (const uint8_t *)c->d_hdr.p; a.aux = (const uint8_t *)c->d_aux.p;
+        a.max_payload = max_payload;
+        std::vector<uint64_t> off;
+        if ((r = s5host::encode_stream_resident(c, m, desc, a, oo, off))) return sg.fail(r);
+        uint64_t base = 0;
+        bool copy = false;
+        if ((r = sg.place(slot, off[m], out_cap, &base, &copy))) return r;
+        if (!copy) return S5GPU_OK;
+        HIP_TRY(hipMemcpyAsync((uint8_t *)out_buf + base, c->d_stream.p, off[m], hipMemcpyDeviceToHost, c->st));
+        for (uint32_t i = 0; i < m; i++) out_off[lo + i] = base + off[i];
+        if (hi == n) out_off[n] = base + off[m];
+        HIP_TRY(hipStreamSynchronize(c->st));
+        return S5GPU_OK;
+    });
+    if (rc) return rc;
+    if (sg.overflow) {
+        const uint64_t need = sg.need();
+        out_off[0] = need;
+        s5gpu_set_error("s5gpu_ascii_to_blow5_stream: output buffer too small (%llu bytes needed)", (unsigned long long)need);
+        return S5GPU_ERR_NOMEM;
+    }
+    return S5GPU_OK;
+}
+
 extern "C" int s5gpu_blow5_to_ascii_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, uint32_t n_aux,
                                           const uint8_t *aux_type, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
                                           int32_t *status) {

@@ -46,8 +46,11 @@ __global__ __launch_bounds__(NT) void k_ascii_parse(const s5gpu_txt_desc_t *desc
         uint32_t w[6] = {0, 0, 0, 0, 0, 0};
         uint32_t prev = ',';
         if (p0 < len) {
-            const uint4 a = *(const uint4 *)(t + p0);
-            const uint2 b = *(const uint2 *)(t + p0 + 16);
+            // the text may start at any byte (the chunk calls point into a file chunk as it was read): unaligned vector loads
+            typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(1)));
+            typedef uint32_t u2u __attribute__((ext_vector_type(2), aligned(1)));
+            const u4u a = *reinterpret_cast<const u4u *>(t + p0);
+            const u2u b = *reinterpret_cast<const u2u *>(t + p0 + 16);
             w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y;
             if (p0) prev = t[p0 - 1];
         }

@@ -231,8 +231,8 @@ extern "C" int s5gpu_event_destroy(void *ev) {
 
 // Run the encode for descriptors already on the device and leave the contiguous BLOW5 record stream (the bytes the ordered
 // fwrite loop emits) in c->d_stream; off[i] / off[n] = record offsets / total, on the host.
-static int encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
-                                  std::vector<uint64_t> &off) {
+int s5host::encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
+                                   std::vector<uint64_t> &off) {
     int rc;
     off.resize((size_t)n + 1);
     if ((rc = c->d_len.reserve(4ull * n))) return rc;
@@ -297,7 +297,7 @@ static int encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_re
 int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
                               void **out, size_t *out_len) {
     std::vector<uint64_t> off;
-    int rc = encode_stream_resident(c, n, desc, a, slots_bytes, off);
+    int rc = s5host::encode_stream_resident(c, n, desc, a, slots_bytes, off);
     if (rc) return rc;
     const uint64_t produced = off[n];
     if ((rc = c->h_out.reserve(produced + 64))) return rc;
@@ -861,7 +861,7 @@ static int recompress_encode_half(Ctx *c, uint32_t n, const std::vector<s5gpu_re
     a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
     a.sig = (const int16_t *)c->d_sig2.p; a.hdr = (const uint8_t *)c->d_pay.p; a.aux = (const uint8_t *)c->d_pay.p;
     a.max_payload = max_payload;
-    if (stream_off) return encode_stream_resident(c, n, ed, a, oo, *stream_off);   // the caller fetches c->d_stream itself
+    if (stream_off) return s5host::encode_stream_resident(c, n, ed, a, oo, *stream_off);   // the caller fetches c->d_stream itself
     return encode_and_collect(c, n, ed, a, oo, out, out_len);
 }
 
@@ -889,25 +889,11 @@ extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chu
     }
     const int G = s5host::n_devices();
     if (G == 0) return S5GPU_ERR_NODEV;
-    // Every device thread encodes its share, publishes the size of its stream, waits for the shares in front of it (so it knows
-    // where its bytes go) and fetches them itself while it still owns its context.
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<int64_t> totals(G, -1);
-    std::vector<uint32_t> firsts(G, 0xFFFFFFFFu);
-    bool failed = false;      // a share failed for good: the shares waiting behind it give up
-    bool overflow = false;    // the output does not fit out_cap: nobody copies, every share still publishes its size so that
-                              // the caller learns the room the WHOLE output needs (out_off[0]), whatever the number of devices
+    s5host::ShareGather sg(G);
     const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
-        auto fail = [&](int r) -> int {
-            std::lock_guard<std::mutex> g(mu);
-            failed = true;
-            cv.notify_all();
-            return r;
-        };
         s5host::CtxHold hold;
         int r = hold.acquire(slot);
-        if (r) return fail(r);
+        if (r) return sg.fail(r);
         Ctx *c = hold.c;
         const uint32_t m = hi - lo;
         // the extent of this share of the chunk (the records of a share are contiguous in a file chunk)
@@ -923,26 +909,12 @@ extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chu
         std::vector<s5gpu_rec_desc_t> rd;
         std::vector<s5gpu_rec_fields_t> ff;
         std::vector<uint64_t> off;
-        if ((r = decode_resident_impl(c, m, rec.data(), len.data(), from_rec, from_sig, rd, ff, status ? status + lo : nullptr, &fs))) return fail(r);
-        if ((r = recompress_encode_half(c, m, rd, ff, to_rec, to_sig, new_read_group ? new_read_group + lo : nullptr, drop_aux, nullptr, nullptr, &off))) return fail(r);
+        if ((r = decode_resident_impl(c, m, rec.data(), len.data(), from_rec, from_sig, rd, ff, status ? status + lo : nullptr, &fs))) return sg.fail(r);
+        if ((r = recompress_encode_half(c, m, rd, ff, to_rec, to_sig, new_read_group ? new_read_group + lo : nullptr, drop_aux, nullptr, nullptr, &off))) return sg.fail(r);
         uint64_t base = 0;
-        {
-            std::unique_lock<std::mutex> g(mu);
-            totals[slot] = (int64_t)off[m];
-            firsts[slot] = lo;
-            cv.notify_all();
-            // shares in front of this one: the slots that took lower record ranges (all of them when the batch was split)
-            for (;;) {
-                bool ready = true;
-                base = 0;
-                for (int q = 0; q < slot; q++) { if (totals[q] < 0) ready = false; else base += (uint64_t)totals[q]; }
-                if (ready || failed) break;
-                cv.wait(g);
-            }
-            if (failed) return S5GPU_ERR_HIP;
-            if (base + off[m] > out_cap) overflow = true;
-            if (overflow) return S5GPU_OK;     // (a share in front may have overflowed already: its total is published all the same)
-        }
+        bool copy = false;
+        if ((r = sg.place(slot, off[m], out_cap, &base, &copy))) return r;
+        if (!copy) return S5GPU_OK;
         HIP_TRY(hipMemcpyAsync((uint8_t *)out_buf + base, c->d_stream.p, off[m], hipMemcpyDeviceToHost, c->st));
         for (uint32_t i = 0; i < m; i++) out_off[lo + i] = base + off[i];
         if (hi == n) out_off[n] = base + off[m];
@@ -950,9 +922,8 @@ extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chu
         return S5GPU_OK;
     });
     if (rc) return rc;
-    if (overflow) {
-        uint64_t need = 0;
-        for (int q = 0; q < G; q++) if (totals[q] > 0) need += (uint64_t)totals[q];
+    if (sg.overflow) {
+        const uint64_t need = sg.need();
         out_off[0] = need;   // the size the caller has to bring (the sum over ALL shares)
         s5gpu_set_error("s5gpu_recompress_stream: output buffer too small (%llu bytes needed)", (unsigned long long)need);
         return S5GPU_ERR_NOMEM;

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -74,6 +75,52 @@ int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> 
 // decode host records, results resident in c->d_pay / c->d_sig2 (host_api.hip)
 int decode_resident(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
                     std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status);
+// encode descriptors already on the device -> the contiguous BLOW5 record stream in c->d_stream (what the ordered fwrite loop
+// emits); off[i] / off[n] = record offsets / total, on the host (host_api.hip)
+int encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
+                           std::vector<uint64_t> &off);
+
+// One output stream made of the shares of several devices (the chunk calls: s5gpu_recompress_stream, s5gpu_ascii_to_blow5_stream).
+// Every device thread publishes the size of its share, waits for the shares in front of it (so it knows where its bytes go) and
+// fetches them itself while it still owns its context.  If the whole does not fit the caller's buffer nobody copies, but every
+// share still publishes its size: the caller learns the room the WHOLE output needs, whatever the number of devices.
+struct ShareGather {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int64_t> totals;
+    bool failed = false, overflow = false;
+    explicit ShareGather(int G) : totals((size_t)G, -1) {}
+    int fail(int rc) {
+        std::lock_guard<std::mutex> g(mu);
+        failed = true;
+        cv.notify_all();
+        return rc;
+    }
+    // 0 and *base (where this share starts) / *copy (false: the output does not fit, skip the copy); S5GPU_ERR_HIP if a share in front failed
+    int place(int slot, uint64_t total, size_t out_cap, uint64_t *base, bool *copy) {
+        std::unique_lock<std::mutex> g(mu);
+        totals[(size_t)slot] = (int64_t)total;
+        cv.notify_all();
+        uint64_t b = 0;
+        for (;;) {
+            bool ready = true;
+            b = 0;
+            for (int q = 0; q < slot; q++) { if (totals[(size_t)q] < 0) ready = false; else b += (uint64_t)totals[(size_t)q]; }
+            if (ready || failed) break;
+            cv.wait(g);
+        }
+        if (failed) return S5GPU_ERR_HIP;
+        if (b + total > out_cap) overflow = true;
+        *base = b;
+        *copy = !overflow;
+        return S5GPU_OK;
+    }
+    uint64_t need() const {
+        uint64_t s = 0;
+        for (int64_t t : totals) if (t > 0) s += (uint64_t)t;
+        return s;
+    }
+};
 }  // namespace s5host
 
 static inline uint64_t up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }

@@ -322,7 +322,7 @@ __device__ __forceinline__ int infl_cl_sequence_wave(TT &T, BitIn &b, int tot) {
 
 // LITLUT = 0: no lit/len lookup table (the parallel decoder resolves those codes by comparison); PARCL: the code-length sequence by
 // the whole wave (infl_cl_sequence_wave)
-template <class TT, int LITLUT = INF_LBITS, bool PARCL = false>
+template <class TT, int LITLUT = INF_LBITS, bool PARCL = false, int DBITS = INF_DBITS>
 __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint32_t total, uint64_t total_bits, BitIn &b, int type, int &nl, int &nd) {
     const int lane = lane_id();
     // ---- code lengths ----
@@ -406,7 +406,7 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
     if (type == 2 && ll[256] == 0) return INF_ERR_DATA;
     if constexpr (LITLUT == 0) { if (infl_build_syms(ll, nl, T.lcount, T.lsym, reinterpret_cast<uint32_t *>(T.llut))) return INF_ERR_DATA; }   // (T.llut: >= 64 bytes of scratch)
     else { if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, LITLUT, 9)) return INF_ERR_DATA; }
-    if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, INF_DBITS, 5)) return INF_ERR_DATA;
+    if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, DBITS, 5)) return INF_ERR_DATA;
     return INF_OK;
 }
 

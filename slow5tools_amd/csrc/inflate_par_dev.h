@@ -56,6 +56,11 @@ constexpr uint32_t IP_MINSEG = 384;    // shortest segment, bits
 #endif
 constexpr uint32_t IP_LENSTEP = S5_IP_LENSTEP;   // a power of two: the length / distance part of the token loop runs every IP_LENSTEP-th step
 constexpr int INF_NEED_FALLBACK = 8;
+#ifndef S5_IP_DBITS
+#define S5_IP_DBITS 8
+#endif
+constexpr int IP_DBITS = S5_IP_DBITS;  // primary distance lookup bits (>= 7: the code-length code's 7-bit table is built in the same storage)
+static_assert(IP_DBITS >= 7 && IP_DBITS <= INF_DBITS, "");
 
 struct InflParShared {                 // per wave: 6.6 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
                                        // LDS per wave = + 33 % time), so nothing here is larger than it has to be
@@ -65,7 +70,7 @@ struct InflParShared {                 // per wave: 6.6 KiB — the kernel's spe
                                        // first three of the bytes it will produce — a match is at least three bytes long
         uint16_t llut[32];             // (64 bytes of scratch for the header parser's symbol sort; no lit/len lookup table here)
     };
-    uint16_t dlut[1 << INF_DBITS];
+    uint16_t dlut[1 << IP_DBITS];
     uint16_t ladj[16];                 // lit/len: index of a length's first symbol in lsym - its first code
     uint16_t lsym[288];
     uint16_t dsym[32];
@@ -78,6 +83,9 @@ struct InflParShared {                 // per wave: 6.6 KiB — the kernel's spe
         };
     };
     uint32_t nfill;
+#ifdef S5_IP_PAD
+    uint8_t pad[S5_IP_PAD];            // tools only: how the kernel's time follows the number of resident waves
+#endif
 };
 static_assert(INF_IW <= IP_SPAN, "the header parser's window is the head of the round window");
 
@@ -212,7 +220,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLim
                     const uint32_t mlen = (ls == 28u ? 258u : ls < 8u ? 3u + ls : 3u + ((4u + (ls & 3u)) << le)) + (b2 & ((1u << le) - 1u));
                     adv += le;
                     b2 = ip_peek(T.win, p + adv);
-                    const uint32_t de = T.dlut[b2 & ((1u << INF_DBITS) - 1)];
+                    const uint32_t de = T.dlut[b2 & ((1u << IP_DBITS) - 1)];
                     uint32_t ds, dlen = de >> 5;
                     if (dlen) ds = de & 31u;
                     else {   // a distance code longer than the lookup table: canonical walk (rare)
@@ -322,7 +330,7 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             continue;
         }
         int nl, nd;
-        { const int rc = infl_block_tables<InflParShared, 0, true>(T, src, total, total_bits, b, type, nl, nd); if (rc != INF_OK) return rc; }
+        { const int rc = infl_block_tables<InflParShared, 0, true, IP_DBITS>(T, src, total, total_bits, b, type, nl, nd); if (rc != INF_OK) return rc; }
         pos = bi_consumed_bits(b);
         if (b.wbase != hdr_wb) win_fresh = false;                             // (the header parser slid its window: never, for a window that starts at the header)
         if (dbg && dbg[3] == 1) return INF_OK;       // tools/par_probe.py cut-off: block header and tables only

@@ -622,19 +622,25 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode
     __shared__ InflParShared T;
     uint8_t *pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
     for (;;) {
-        uint32_t r = 0;
-        if (lane_id() == 0) r = atomicAdd(&np.ticket[0], 1u);
-        r = __builtin_amdgcn_readfirstlane(r);
+        uint32_t r = blockIdx.x;
+        if (np.ticket) {                               // (a batch no larger than the grid: workgroup b takes record b, no ticket)
+            if (lane_id() == 0) r = atomicAdd(&np.ticket[0], 1u);
+            r = __builtin_amdgcn_readfirstlane(r);
+        }
         if (r >= a.n_recs) return;
         const s5gpu_rec_desc_t d = a.desc[r];
         uint32_t olen = 0;
         int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
+#ifdef S5_IP_PAD
+        if (d.in_len == 0xFFFFFFFFu) T.pad[lane_id()] = 1;   // (keeps the padding alive)
+#endif
         if (status == 0) {
             wave_sync();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
         }
         np_write_fields(a, r, status, olen);
+        if (!np.ticket) return;
         wave_sync();                                   // the next record's window load overwrites the stage
     }
 }
@@ -1461,7 +1467,8 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         np.slot = (uint32_t)slot;
         np.cap = (uint32_t)slot - 16;
         np.first_fb = (uint32_t)n_main;
-        HIP_TRY(hipMemsetAsync(a->payload, 0, 64, st));
+        if (zl && a->n_recs <= n_main) np.ticket = nullptr;   // one record per workgroup: no ticket counter, nothing to clear (get batches)
+        else HIP_TRY(hipMemsetAsync(a->payload, 0, 64, st));
         if (zl) {
             hipLaunchKernelGGL(k_inflate_par_np, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
             hipLaunchKernelGGL(k_inflate_fallback_np, dim3((uint32_t)n_fb), dim3(64), 0, st, *a, np);

@@ -270,3 +270,53 @@ def test_view_between_slow5_and_blow5_matches_the_reference_twins(tmp_path):
     t2 = tmp_path / "b.slow5"
     _run(golden("aux_array_exp_lossless.slow5"), t2)             # ASCII -> ASCII
     assert t2.read_bytes() == open(golden("aux_array_exp_lossless.slow5"), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk_kb,env_extra", [(64, {}), (300, {}), (4096, {}), (300, {"S5GPU_ALIAS_DEVICES": "1", "S5VIEW_DEV_MASK": "7", "S5GPU_MULTI_MIN": "8"})])
+def test_chunked_slow5_to_blow5_equals_the_per_record_pipeline(tmp_path, chunk_kb, env_extra):
+    """SURVEY 8f row 3 for the conversion BASELINE configs[0] names (SLOW5 -> BLOW5, /root/reference/src/view.c:35-57 with a .slow5
+    input): the file is read in chunks, lines are framed in place (a line the chunk's end cuts is carried), each chunk goes through
+    ONE s5gpu_ascii_to_blow5_stream call (the raw_signal columns parsed where they lie) and comes back as one contiguous record
+    stream.  Byte-identical to the per-record pipeline (slow5_get_next_mem + slow5_gpu_convert_batch) whatever the chunk size cuts in
+    two, with every aux kind, CR LF line ends, a last line without its newline; also over three (aliased) devices."""
+    from slow5tools_amd import ascii as s5a
+    types = s5a.aux_types(TYPE_LINES[2])
+    rng = np.random.default_rng(23)
+    lines, pays = _random_lines(rng, 900, types)
+    lines[17] = lines[17][:-1] + b"\r\n"
+    lines[-1] = lines[-1][:-1]                                    # no newline at the end of the file
+    hdr = b"#slow5_version\t0.2.0\n#num_read_groups\t5\n@asic_id\ta\tb\tc\td\te\n" + TYPE_LINES[2] + b"\n" + \
+          b"#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\t" + b"\t".join(b"a%d" % i for i in range(len(types))) + b"\n"
+    src = tmp_path / "in.slow5"
+    src.write_bytes(hdr + b"".join(lines))
+    env = dict(os.environ, S5VIEW_CHUNK_KB=str(chunk_kb), **env_extra)
+    a, b = tmp_path / "chunked.blow5", tmp_path / "per_record.blow5"
+    r = subprocess.run([S5VIEW, str(src), str(a), "zlib", "svb-zd", "4096", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "chunked pipeline (SLOW5 text in)" in r.stderr, r.stderr
+    r = subprocess.run([S5VIEW, str(src), str(b), "zlib", "svb-zd", "64", "2"], capture_output=True, text=True, timeout=300, env=dict(os.environ, S5VIEW_PER_RECORD="1"))
+    assert r.returncode == 0 and "chunked pipeline" not in r.stderr, r.stderr
+    assert a.read_bytes() == b.read_bytes()
+    got = Blow5(str(a))
+    assert len(got.records) == len(pays)
+    for rec, pay in zip(got.records, pays):                       # and the records are the oracle's payloads (svb-zd inside)
+        assert unsvb(zlib.decompress(rec)) == pay
+    if chunk_kb == 64 and not env_extra:                          # a line longer than the chunk: the file is redone record by record
+        big = tmp_path / "big.slow5"
+        sig = rng.integers(-3000, 3000, 40000).astype(np.int16)
+        pay = struct.pack("<H", 2) + b"r0" + struct.pack("<I4d", 0, 8192.0, 3.0, 1400.5, 4000.0) + struct.pack("<Q", sig.size) + sig.tobytes()
+        big.write_bytes(b"#slow5_version\t0.2.0\n#num_read_groups\t1\n" + TYPE_LINES[0] + b"\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
+                        + lines_plain(3) + ob.payload_to_line(pay) + lines_plain(2))
+        o1, o2 = tmp_path / "big1.blow5", tmp_path / "big2.blow5"
+        r = subprocess.run([S5VIEW, str(big), str(o1), "none", "none", "4096", "1"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "per-record pipeline" in r.stderr, r.stderr
+        r = subprocess.run([S5VIEW, str(big), str(o2), "none", "none", "4096", "1"], capture_output=True, text=True, timeout=300, env=dict(os.environ, S5VIEW_PER_RECORD="1"))
+        assert r.returncode == 0, r.stderr
+        assert o1.read_bytes() == o2.read_bytes() and len(Blow5(str(o1)).records) == 6
+
+
+def lines_plain(k):
+    out = b""
+    for i in range(k):
+        out += b"p%d\t0\t8192\t1\t1400\t4000\t4\t1,-2,3,%d\n" % (i, i)
+    return out

@@ -39,6 +39,12 @@ for _ in range(reps):
     e0.record(); _lib.check(L.s5gpu_decode_dev(C.byref(a), None), "decode"); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
 st = fields.view(torch.int32).view(n_reads, 16)[:, 0]
 ok = bool((st == 0).all().item()) and bool(torch.equal(sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n], b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]))
+if not ok:
+    import collections
+    print("   statuses", dict(collections.Counter(st.cpu().tolist())))
+    neq = (sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n] != b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]).any(dim=1)
+    bad = torch.nonzero(neq).flatten().cpu().numpy()
+    print("   reads with a wrong signal: %d, first %s" % (len(bad), bad[:20]))
 z = int(off[-1])
 print("decode_bulk %s: %d reads x %d samples: %s ms (min %.3f)  %.1f M reads/s  Z+2N = %.0f B/read  identical %s" % (
     mode, n_reads, n, " ".join("%.3f" % t for t in ts), min(ts[1:] or ts), n_reads / min(ts[1:] or ts) / 1e3, (z + 2 * n * n_reads) / n_reads, ok))

@@ -40,7 +40,7 @@ for name in ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES:
             e0.record(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
         st = fields.cpu().numpy().view(_lib.REC_FIELDS)["status"][:len(streams)]
         out.append((mode, min(ts), dict(collections.Counter(st.tolist()))))
-    if "merged" in name or "exp_1_lossless_zlib_svb" in name:     # where the time goes (cut-offs of the parallel decoder)
+    if ("merged" in name or "exp_1_lossless_zlib_svb" in name) and "probe" in os.environ.get("S5GPU_LIB", ""):     # where the time goes (tools/variant.sh probe -DS5_PAR_PROBE) (cut-offs of the parallel decoder)
         _lib.check(L.s5gpu_set_option(b"inflate_par", 2), "opt")
         keep = a.sig_method
         a.sig_method = 99
