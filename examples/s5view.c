@@ -135,6 +135,7 @@ typedef struct {
     uint32_t n, cap;
     uint64_t *rec_pos, *out_off;
     uint32_t *rec_len;
+    uint32_t *nl, nl_cap;       /* SLOW5 text: newline positions found by the pread threads (16 equal shares) */
 } fslot_t;
 typedef struct {
     pthread_mutex_t mu;
@@ -160,7 +161,9 @@ static void fpipe_fail(fpipe_t *P, const char *what) {
     pthread_cond_broadcast(&P->cv);
     pthread_mutex_unlock(&P->mu);
 }
-typedef struct { int fd; uint8_t *dst; size_t len; uint64_t off; int ok; } pread_job_t;
+/* one part of a chunk: read it, and for SLOW5 text note where its newlines are while the bytes are still in this core's cache
+ * (the reader thread would otherwise scan the whole chunk again on its own: a third of its time) */
+typedef struct { int fd; uint8_t *dst; size_t len; uint64_t off; int ok; const uint8_t *base; uint32_t *nl, nl_cap, nl_n; int nl_over; } pread_job_t;
 static void *pread_main(void *arg) {
     pread_job_t *j = (pread_job_t *)arg;
     size_t got = 0;
@@ -169,7 +172,41 @@ static void *pread_main(void *arg) {
         if (r <= 0) { j->ok = 0; return NULL; }
         got += (size_t)r;
     }
+    j->nl_n = 0; j->nl_over = 0;
+    if (j->nl) {
+        const uint8_t *q = j->dst, *e = j->dst + j->len;
+        while (q < e && (q = (const uint8_t *)memchr(q, '\n', (size_t)(e - q)))) {
+            if (j->nl_n == j->nl_cap) { j->nl_over = 1; break; }
+            j->nl[j->nl_n++] = (uint32_t)(q - j->base);
+            q++;
+        }
+    }
     j->ok = 1;
+    return NULL;
+}
+/* the first newline at or behind p: in the carried bytes (scanned here), then in the parts' lists, in file order */
+static const uint8_t *next_newline(const fslot_t *b, const pread_job_t *job, int used, size_t carry, size_t p, int *jt, uint32_t *jk) {
+    if (p < carry) {
+        const uint8_t *q = (const uint8_t *)memchr(b->in + p, '\n', carry - p);
+        if (q) return q;
+        p = carry;
+    }
+    while (*jt < used) {
+        const pread_job_t *j = &job[*jt];
+        const size_t lo = (size_t)(j->dst - b->in), hi = lo + j->len;
+        if (p < hi) {
+            if (j->nl_over || !j->nl) {                              /* (lines of a few bytes: the list overflowed) */
+                const size_t from = p > lo ? p : lo;
+                const uint8_t *q = (const uint8_t *)memchr(b->in + from, '\n', hi - from);
+                if (q) return q;
+            } else {
+                while (*jk < j->nl_n && j->nl[*jk] < p) (*jk)++;
+                if (*jk < j->nl_n) return b->in + j->nl[*jk];
+            }
+        }
+        (*jt)++;
+        *jk = 0;
+    }
     return NULL;
 }
 static void *freader_main(void *arg) {
@@ -186,16 +223,18 @@ static void *freader_main(void *arg) {
         if (carry) memmove(b->in, carry_from, carry);            /* the record the previous chunk's end cut in two */
         size_t want = P->chunk - carry;
         if (want > P->end - P->pos) want = (size_t)(P->end - P->pos);
+        pread_job_t job[16];
+        int used = 0;
         {   /* the chunk in several pread threads: one thread copies out of the page cache at ~5 GB/s */
-            pread_job_t job[8];
-            pthread_t th[8];
-            const int T = P->readers < 1 ? 1 : P->readers > 8 ? 8 : P->readers;
+            pthread_t th[16];
+            const int T = P->readers < 1 ? 1 : P->readers > 16 ? 16 : P->readers;
             const size_t part = (want / T + 4095) & ~(size_t)4095;
-            int used = 0;
+            const uint32_t nl_part = b->nl ? b->nl_cap / 16 : 0;
             for (int t = 0; t < T; t++) {
                 const size_t lo = (size_t)t * part;
                 if (lo >= want) break;
                 job[t].fd = P->fd_in; job[t].dst = b->in + carry + lo; job[t].len = want - lo < part ? want - lo : part; job[t].off = P->pos + lo; job[t].ok = 0;
+                job[t].base = b->in; job[t].nl = b->nl ? b->nl + (size_t)t * nl_part : NULL; job[t].nl_cap = nl_part;
                 used++;
             }
             for (int t = 1; t < used; t++) pthread_create(&th[t], NULL, pread_main, &job[t]);
@@ -208,8 +247,12 @@ static void *freader_main(void *arg) {
         size_t p = 0;
         uint32_t n = 0;
         const int file_done_ = P->pos >= P->end;
+        /* SLOW5 text: the next newline comes from the parts' lists (in file order); the carried bytes in front of them, and any part
+         * whose list overflowed (lines of a few bytes), are scanned here */
+        int jt = 0;
+        uint32_t jk = 0;
         while (P->ascii && p < have && n < b->cap) {                 /* one record per line; a line the chunk's end cut is carried */
-            const uint8_t *nl = (const uint8_t *)memchr(b->in + p, '\n', have - p);
+            const uint8_t *nl = next_newline(b, job, used, carry, p, &jt, &jk);
             if (!nl && !file_done_) break;
             const size_t e = nl ? (size_t)(nl - b->in) : have;         /* (a last line without its newline) */
             size_t l = e - p;
@@ -313,7 +356,7 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     e = getenv("S5VIEW_CHUNK_KB");                                   /* tests: chunks smaller than a record batch */
     if (e && atoi(e) > 0) P.chunk = (size_t)atoi(e) << 10;
     e = getenv("S5VIEW_READERS");
-    P.readers = e ? atoi(e) : 4;
+    P.readers = e ? atoi(e) : (in->format == SLOW5_FORMAT_ASCII ? 8 : 4);   /* (text is twice the bytes per sample: more copy threads) */
     P.from = from; P.to = to; P.total_batches = -1;
     const double t_alloc = now_s();
     for (int i = 0; i < FSLOT; i++) {
@@ -327,7 +370,8 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
         b->rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * b->cap);
         b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * b->cap);
         b->out_off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)b->cap + 1));
-        if (!b->in || !b->out || !b->rec_pos || !b->rec_len || !b->out_off) { fprintf(stderr, "s5view: cannot allocate the chunk buffers (%s)\n", s5gpu_last_error()); return -1; }
+        if (P.ascii) { b->nl_cap = 16 * (uint32_t)(P.chunk / 16 / 64 + 64); b->nl = (uint32_t *)malloc(sizeof(uint32_t) * b->nl_cap); }
+        if (!b->in || !b->out || !b->rec_pos || !b->rec_len || !b->out_off || (P.ascii && !b->nl)) { fprintf(stderr, "s5view: cannot allocate the chunk buffers (%s)\n", s5gpu_last_error()); return -1; }
     }
     const double t0 = now_s();
     pthread_t rd, wk[8];
@@ -358,7 +402,7 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     pthread_join(rd, NULL);
     for (int i = 0; i < W; i++) pthread_join(wk[i], NULL);
     const double t1 = now_s();
-    for (int i = 0; i < FSLOT; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); }
+    for (int i = 0; i < FSLOT; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); free(b->nl); }
     if (P.failed && P.oversize) return -2;
     if (P.failed) { fprintf(stderr, "s5view: %s\n", P.why); return -1; }
     fprintf(stderr, "s5view: chunked pipeline%s: %.3f s for %llu records (%.1f MB in, %.1f MB out; buffers %.3f s), %d pread threads, %d GPU worker(s), chunks of %zu MB\n",
