@@ -135,6 +135,29 @@ def cpu_encode_baseline(ob, sig2d, first, n, ref_seconds, sweep_seconds):
         best = max(sweep, key=lambda x: x["GB_per_s"])
         cpu["best_of"] = {"value": best["GB_per_s"], "unit": "GB/s", "t": best["t"], "K": best["K"]}
         cpu["sweep"] = sweep
+        # the same worker fed with SLOW5 TEXT (BASELINE configs[0]: view in.slow5 -o out.blow5 — the ASCII parse of
+        # slow5_rec_depress_parse is part of the reference's compute phase there): a smaller sample, printed by the oracle
+        try:
+            import numpy as np
+            ma = min(m, 32768)
+            lines = []
+            for i in range(ma):
+                r, keep = ob.make_rec(ob.synth_read_id(first + i), 0, 8192.0, 23.0, 1467.61, 4000.0, np.ascontiguousarray(sig2d[i]))
+                lines.append(ob.payload_to_line(ob.rec_pack(r, 0)))
+            text = np.frombuffer(b"".join(lines), dtype=np.uint8)
+            off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.uint64)
+            pts = []
+            for t in sorted({best["t"], cores}):
+                got, secs_ = 0, 0.0
+                while secs_ < max(2.0, sweep_seconds / 2):
+                    tot, s_, _ = ob.convert_ascii_batch_mt(text, off, t, 4096)
+                    assert tot > 0, "CPU ASCII conversion failed"
+                    got += ma; secs_ += s_
+                pts.append({"t": t, "K": 4096, "GB_per_s": round(got * 2 * n / secs_ / 1e9, 3), "text_GB_per_s": round(got / ma * text.size / secs_ / 1e9, 3), "seconds": round(secs_, 1)})
+            cpu["slow5_text_input"] = {"what": "the same worker on SLOW5 text: ASCII line parse (oracle/ascii.c) + svb-zd + zlib per record, %d reads (%.2f GB of text)" % (ma, text.size / 1e9),
+                                       "points": pts, "value": max(p["GB_per_s"] for p in pts), "unit": "GB/s of raw signal"}
+        except Exception as e:      # (never fatal for the line)
+            cpu["slow5_text_input"] = {"error": repr(e)}
     return cpu
 
 

@@ -30,6 +30,9 @@ typedef struct {
     const uint8_t *stream;
     const uint64_t *rec_off;
     const uint32_t *ids;
+    /* SLOW5 text batches (s5o_convert_ascii_batch_mt): record lines of a .slow5 file */
+    const char *text;
+    const uint64_t *line_off;      /* n + 1 offsets: line i = text[line_off[i], line_off[i + 1]) incl. its newline */
     int failed;
     void (*one)(void *db, int32_t i);
 } batch_t;
@@ -216,6 +219,63 @@ uint64_t s5o_decode_batch_mt(const uint8_t *stream, const uint64_t *rec_off, con
                 const int16_t *sg = (const int16_t *)db.out[i];
                 ck = ck * 1000003ull + (uint16_t)sg[0] + ((uint64_t)(uint16_t)sg[db.out_len[i] / 2] << 16) + ((uint64_t)(uint16_t)sg[db.out_len[i] - 1] << 32);
             }
+            free(db.out[i]);
+        }
+    }
+    free(db.out);
+    free(db.out_len);
+    if (secs) *secs = t;
+    if (checksum) *checksum = ck;
+    return db.failed ? 0 : total;
+}
+
+/* ---- SLOW5 text in: the whole worker of `slow5tools view in.slow5 -o out.blow5` (src/view.c:35-57, BASELINE configs[0]): per record
+ * slow5_rec_depress_parse of the ASCII line (strtol per sample: ascii.c) -> slow5_press_init -> slow5_rec_to_mem (svb-zd + zlib) ->
+ * free, under the same work_db shape.  text / line_off: record lines back to back.  Returns total output bytes. */
+static void convert_ascii_one(void *dbv, int32_t i) {
+    batch_t *db = (batch_t *)dbv;
+    const uint64_t k = db->base + (uint64_t)i;
+    const char *line = db->text + db->line_off[k];
+    const size_t len = (size_t)(db->line_off[k + 1] - db->line_off[k]);
+    db->out[i] = NULL;
+    db->out_len[i] = 0;
+    uint8_t *pay = (uint8_t *)malloc(len + 128);                  /* 2 B/sample binary never exceeds the text that printed it */
+    const size_t plen = pay ? s5o_ascii_line_to_payload(line, len, NULL, 0, pay) : 0;
+    s5o_rec_t r;
+    if (!plen || s5o_rec_parse(pay, plen, S5O_SIG_NONE, &r, NULL) != 0) { free(pay); db->failed = 1; return; }
+    int16_t *sig = (int16_t *)malloc(r.len_raw_signal ? 2 * (size_t)r.len_raw_signal : 2);
+    if (!sig || s5o_rec_parse(pay, plen, S5O_SIG_NONE, &r, sig) != 0) { free(pay); free(sig); db->failed = 1; return; }
+    uint8_t *scratch = (uint8_t *)malloc(s5o_payload_bound(&r, db->sig_method));
+    uint8_t *out = (uint8_t *)malloc(s5o_rec_to_mem_bound(&r, db->sig_method));
+    db->out_len[i] = s5o_rec_to_mem(&r, db->rec_method, db->sig_method, scratch, out);
+    db->out[i] = out;
+    free(scratch);
+    free(sig);
+    free(pay);
+}
+
+uint64_t s5o_convert_ascii_batch_mt(const char *text, const uint64_t *line_off, uint64_t n_lines, int rec_method, int sig_method,
+                                    int n_threads, int batch_size, double *secs, uint64_t *checksum) {
+    batch_t db;
+    memset(&db, 0, sizeof db);
+    db.text = text;
+    db.line_off = line_off;
+    db.rec_method = rec_method;
+    db.sig_method = sig_method;
+    db.one = convert_ascii_one;
+    db.out = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)batch_size);
+    db.out_len = (size_t *)malloc(sizeof(size_t) * (size_t)batch_size);
+    uint64_t total = 0, ck = 0;
+    double t = 0;
+    for (uint64_t base = 0; base < n_lines; base += (uint64_t)batch_size) {
+        db.base = base;
+        db.n_batch = (int64_t)(n_lines - base < (uint64_t)batch_size ? n_lines - base : (uint64_t)batch_size);
+        double t0 = now_s();
+        work_batch(&db, n_threads);
+        t += now_s() - t0;
+        for (int64_t i = 0; i < db.n_batch; i++) {
+            total += db.out_len[i];
+            if (db.out[i]) ck = ck * 1000003ull + s5o_adler32(db.out[i], db.out_len[i]);
             free(db.out[i]);
         }
     }

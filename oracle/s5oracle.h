@@ -88,6 +88,11 @@ uint64_t s5o_decode_batch_mt(const uint8_t *stream, const uint64_t *rec_off, con
                              int rec_method, int sig_method, int n_threads, int batch_size, double *secs,
                              uint64_t *checksum);
 
+/* the same worker fed with SLOW5 text (BASELINE configs[0]: view in.slow5 -o out.blow5): per record parse of the ASCII line (ascii.c) +
+ * svb-zd + zlib; line i = text[line_off[i], line_off[i + 1]).  Returns total output bytes (0 if a line failed). */
+uint64_t s5o_convert_ascii_batch_mt(const char *text, const uint64_t *line_off, uint64_t n_lines, int rec_method, int sig_method,
+                                    int n_threads, int batch_size, double *secs, uint64_t *checksum);
+
 /* ---- §8f row 2: SLOW5 ASCII record lines <-> uncompressed payloads (ascii.c) ---- */
 /* aux type codes: low 4 bits 0..11 = int8,int16,int32,int64,uint8,uint16,uint32,uint64,float,double,char,enum; 0x80 = array */
 int s5o_aux_types(const char *types_line, size_t len, uint8_t *types, unsigned cap);

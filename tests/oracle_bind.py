@@ -74,6 +74,8 @@ def lib():
     L.s5o_decode_batch_mt.restype = C.c_uint64
     L.s5o_decode_batch_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.s5o_convert_ascii_batch_mt.restype = C.c_uint64
+    L.s5o_convert_ascii_batch_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.s5o_exzd_bound.restype = C.c_size_t
     L.s5o_exzd_bound.argtypes = [C.c_uint64]
     L.s5o_exzd_encode.restype = C.c_size_t
@@ -236,6 +238,17 @@ def decode_batch_mt(stream, rec_off, ids, n_threads, batch_size=4096, rec_method
     ck = C.c_uint64()
     total = lib().s5o_decode_batch_mt(_ptr(stream), _ptr(rec_off), _ptr(ids), ids.size, rec_method, sig_method, n_threads,
                                       batch_size, C.byref(secs), C.byref(ck))
+    return total, secs.value, ck.value
+
+
+def convert_ascii_batch_mt(text, line_off, n_threads, batch_size=4096, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD):
+    """the whole view worker on SLOW5 text (line parse + svb-zd + zlib) on the CPU: returns (output bytes, seconds, checksum)"""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    line_off = np.ascontiguousarray(line_off, dtype=np.uint64)
+    secs = C.c_double()
+    ck = C.c_uint64()
+    total = lib().s5o_convert_ascii_batch_mt(_ptr(text), _ptr(line_off), line_off.size - 1, rec_method, sig_method, n_threads, batch_size,
+                                             C.byref(secs), C.byref(ck))
     return total, secs.value, ck.value
 
 
