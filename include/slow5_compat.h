@@ -161,6 +161,12 @@ long slow5_eof_fwrite(FILE *fp);                                                
 int slow5_idx_create(slow5_file_t *s5p);   /* writes <pathname>.idx (slow5tools index, src/index.c) */
 int slow5_idx_load(slow5_file_t *s5p);     /* loads <pathname>.idx, building it first if absent (src/get.c:286) */
 void slow5_idx_unload(slow5_file_t *s5p);
+/* where read_id's record sits in the file: offset of its u64 size prefix, size = 8 + record bytes (slow5lib's slow5_idx_get [RECALLED]); 0, or
+ * -1 when the id is not in the index.  For loops that pread many records into one buffer (examples/s5get.c). */
+struct slow5_rec_idx { uint64_t offset, size; };
+int slow5_idx_get(struct slow5_idx *index, const char *read_id, struct slow5_rec_idx *read_index);
+/* the ids of the index in file order (slow5_get_rids, /root/reference/src/skim.c): *n of them; the array and the strings stay the index's */
+char **slow5_get_rids(const slow5_file_t *s5p, uint64_t *n);
 /* raw record bytes of read_id (pread by index), malloc'd; the decode half of slow5_get goes through the batch hooks */
 void *slow5_get_mem(const char *read_id, size_t *n, const slow5_file_t *s5p);
 int slow5_get(const char *read_id, struct slow5_rec **read, slow5_file_t *s5p);   /* src/get.c:45 */

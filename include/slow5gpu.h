@@ -184,6 +184,10 @@ int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *args, uint8_t *stream_out
 int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *args, void *hip_stream);   /* rec_method zstd: the zstd twin */
 int s5gpu_inflate_dev(const s5gpu_decode_args_t *args, void *hip_stream);
 int s5gpu_svbzd_decode_dev(const s5gpu_decode_args_t *args, void *hip_stream);
+/* inflate_head: only the first desc[i].pay_cap bytes of every zlib record (a record's head: u16 read_id_len | read_id | ...; what
+ * slow5_idx_create needs of a record), decoding stops there: fields[i].payload_len = bytes written, no Adler-32; desc[i].in_len may
+ * cover just the front of the record (status 3 if it ends before pay_cap bytes are out). */
+int s5gpu_inflate_head_dev(const s5gpu_decode_args_t *args, void *hip_stream);
 /* Gather the slots into one contiguous BLOW5 record stream (what the ordered fwrite loop emits):
  * rec_off[i] = byte offset of record i in `stream`, rec_off[n] = total bytes.  tmp: >= 8*(n/1024+2) bytes. */
 int s5gpu_compact_dev(uint32_t n_reads, const s5gpu_read_desc_t *desc, const uint8_t *slots, const uint32_t *out_len,
@@ -232,6 +236,20 @@ void s5gpu_host_free(void *p);
 int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int from_rec,
                             int from_sig, int to_rec, int to_sig, const uint32_t *new_read_group, int drop_aux, void *out_buf, size_t out_cap,
                             uint64_t *out_off, int32_t *status);
+
+/* The decode half alone on a chunk of framed records (`get --benchmark`, /root/reference/src/get.c:52, and any consumer of signals): the
+ * decoded signals come back as ONE contiguous int16 block — sig_off[i] = first sample of record i, sig_off[n] = total — and the parsed
+ * fields in fields[i]; no malloc per record.  sig_cap in samples; too little: S5GPU_ERR_NOMEM and sig_off[0] = samples needed.  A corrupt
+ * record fails the call with S5GPU_ERR_DATA (fields[i].status says which). */
+int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int rec_method,
+                        int sig_method, int16_t *sig_out, size_t sig_cap, uint64_t *sig_off, s5gpu_rec_fields_t *fields);
+
+/* The read ids of the n records of a file chunk (framed as for s5gpu_recompress_stream), for the index builder (slow5_idx_create): only the
+ * front of every zlib record crosses PCIe and only its first 2 + id_pitch bytes are inflated; uncompressed records are read on the host.
+ * ids: n * id_pitch bytes (id i at ids + i * id_pitch, id_len[i] bytes, not terminated).  status[i] != 0: this record needs the general
+ * decode (id longer than id_pitch: 5; corrupt: 1-4, 7).  rec_method zstd is refused (S5GPU_ERR_ARG). */
+int s5gpu_record_ids_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int rec_method,
+                            uint32_t id_pitch, char *ids, uint16_t *id_len, int32_t *status);
 
 /* ---- one-stage host-buffer calls behind slow5_ptr_compress_solo / slow5_ptr_depress_solo ----
  * stage: 0 zlib compress, 1 zlib inflate, 2 svb-zd encode (in = int16 samples, in_len in bytes),

@@ -60,14 +60,16 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-    # the view-loop example / end-to-end harness (plain C against the two public headers)
-    ex = os.path.join(ROOT, "examples", "s5view.c")
-    if os.path.exists(ex) and (force or _newer(S5VIEW, [ex, LIB] + deps)):
-        cmd = ["gcc", "-O2", "-g", "-Wall", "-std=c11", "-I", os.path.join(ROOT, "include"), ex, "-o", S5VIEW, "-pthread",
-               "-L", HERE, "-lslow5gpu", "-Wl,-rpath," + HERE]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+    # the view / get / merge loop examples = the end-to-end harnesses (plain C against the public headers)
+    for name in ("s5view", "s5get", "s5merge"):
+        ex = os.path.join(ROOT, "examples", name + ".c")
+        exe = os.path.join(HERE, name)
+        if os.path.exists(ex) and (force or _newer(exe, [ex, LIB] + deps)):
+            cmd = ["gcc", "-O2", "-g", "-Wall", "-std=c11", "-I", os.path.join(ROOT, "include"), ex, "-o", exe, "-pthread",
+                   "-L", HERE, "-lslow5gpu", "-Wl,-rpath," + HERE]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
     return LIB
 
 

@@ -33,6 +33,7 @@ struct slow5_idx {
     uint32_t *table;        /* open addressing: index into ents + 1, 0 = empty */
     uint64_t tsize;
     struct slow5_version version;
+    char **rids;            /* slow5_get_rids: the ids in file order (pointers into ents), made on first use */
 };
 
 static enum slow5_press_method rec_from_code(uint8_t c) { return c == 0 ? SLOW5_COMPRESS_NONE : c == 1 ? SLOW5_COMPRESS_ZLIB : c == 2 ? SLOW5_COMPRESS_ZSTD : (enum slow5_press_method)-1; }
@@ -315,6 +316,7 @@ static void idx_free(struct slow5_idx *ix) {
     for (uint64_t i = 0; i < ix->n; i++) free(ix->ents[i].id);
     free(ix->ents);
     free(ix->table);
+    free(ix->rids);
     free(ix);
 }
 void slow5_idx_unload(slow5_file_t *s) {
@@ -327,39 +329,123 @@ static char *idx_path(const slow5_file_t *s) {
     return p;
 }
 
-/* scan the records; read ids come out of the GPU batch decode, K records at a time (src/cmd.h:8) */
+/* Scan the records.  The file is read in chunks of tens of MB, the records are framed in place (their size prefixes chain through the
+ * chunk; a record the chunk's end cuts is carried into the next one) and the read ids of a chunk come from ONE s5gpu_record_ids_stream
+ * call, which inflates only the head of each record (k_inflate_head) — round 2 decoded every whole record, signal included, with three
+ * mallocs each, to read a 36-byte id.  Records that call declines (zstd frames, ids longer than 256 bytes) take the general decode. */
+static int idx_ids_general(slow5_file_t *s, struct slow5_idx *ix, const uint8_t *chunk, const uint64_t *pos, const uint32_t *len, const uint64_t *foff,
+                           const uint32_t *which, uint32_t m) {
+    slow5_press_method_t from = {s->compress->record_press->method, s->compress->signal_press->method};
+    char **mem = (char **)calloc(m, sizeof(char *));
+    size_t *bytes = (size_t *)calloc(m, sizeof(size_t));
+    struct slow5_rec **reads = (struct slow5_rec **)calloc(m, sizeof(void *));
+    int err = (!mem || !bytes || !reads) ? SLOW5_ERR_MEM : 0;
+    for (uint32_t k = 0; k < m && !err; k++) {
+        bytes[k] = len[which[k]];
+        mem[k] = (char *)malloc(bytes[k] ? bytes[k] : 1);
+        if (!mem[k]) err = SLOW5_ERR_MEM; else memcpy(mem[k], chunk + pos[which[k]], bytes[k]);
+    }
+    if (!err && slow5_gpu_depress_parse_batch(m, mem, bytes, from, reads) != 0) err = slow5_errno ? slow5_errno : SLOW5_ERR_RECPARSE;
+    for (uint32_t k = 0; k < m && !err; k++) {
+        struct idx_ent *e = &ix->ents[foff[which[k]]];          /* foff: index of the entry reserved for this record */
+        e->id = (char *)malloc((size_t)reads[k]->read_id_len + 1);
+        if (!e->id) { err = SLOW5_ERR_MEM; break; }
+        memcpy(e->id, reads[k]->read_id, reads[k]->read_id_len);
+        e->id[reads[k]->read_id_len] = '\0';
+        e->id_len = reads[k]->read_id_len;
+    }
+    for (uint32_t k = 0; k < m; k++) { if (mem) free(mem[k]); if (reads) slow5_rec_free(reads[k]); }
+    free(mem); free(bytes); free(reads);
+    return err;
+}
+
 static struct slow5_idx *idx_scan(slow5_file_t *s) {
-    enum { K = 4096 };
+    enum { ID_PITCH = 256 };
     struct slow5_idx *ix = (struct slow5_idx *)calloc(1, sizeof *ix);
     if (!ix) { slow5_errno = SLOW5_ERR_MEM; return NULL; }
     ix->version = s->header->version;
-    const long keep = ftell(s->fp);
-    if (fseek(s->fp, (long)s->meta.start_rec_offset, SEEK_SET) != 0) { idx_free(ix); slow5_errno = SLOW5_ERR_IO; return NULL; }
-    char **mem = (char **)calloc(K, sizeof(char *));
-    size_t *bytes = (size_t *)calloc(K, sizeof(size_t));
-    uint64_t *offs = (uint64_t *)calloc(K, sizeof(uint64_t)), *sizes = (uint64_t *)calloc(K, sizeof(uint64_t));
-    struct slow5_rec **reads = (struct slow5_rec **)calloc(K, sizeof(void *));
-    slow5_press_method_t from = {s->compress->record_press->method, s->compress->signal_press->method};
-    int err = (!mem || !bytes || !offs || !sizes || !reads) ? SLOW5_ERR_MEM : 0;
-    int done = 0;
-    while (!err && !done) {
-        int64_t k = 0;
-        while (k < K) {
-            offs[k] = (uint64_t)ftell(s->fp);
-            mem[k] = (char *)slow5_get_next_mem(&bytes[k], s);
-            if (!mem[k]) { if (slow5_errno == SLOW5_ERR_EOF) done = 1; else err = slow5_errno; break; }
-            sizes[k] = 8 + bytes[k];
-            k++;
-        }
-        if (!err && k > 0) {
-            if (slow5_gpu_depress_parse_batch(k, mem, bytes, from, reads) != 0) err = slow5_errno ? slow5_errno : SLOW5_ERR_RECPARSE;
-            for (int64_t i = 0; i < k && !err; i++)
-                if (idx_push(ix, reads[i]->read_id, reads[i]->read_id_len, offs[i], sizes[i]) != 0) err = SLOW5_ERR_MEM;
-        }
-        for (int64_t i = 0; i < K; i++) { free(mem[i]); mem[i] = NULL; slow5_rec_free(reads[i]); reads[i] = NULL; }
+    struct stat fst;
+    const int fd = fileno(s->fp);
+    if (fstat(fd, &fst) != 0 || (uint64_t)fst.st_size < s->meta.start_rec_offset + 5) { idx_free(ix); slow5_errno = SLOW5_ERR_TRUNC; return NULL; }
+    {   /* the end marker must close the file (src/quickcheck.c:93-97) */
+        char tail[5];
+        if (pread(fd, tail, 5, fst.st_size - 5) != 5 || memcmp(tail, BLOW5_EOF, 5) != 0) { idx_free(ix); slow5_errno = SLOW5_ERR_TRUNC; return NULL; }
     }
-    free(mem); free(bytes); free(offs); free(sizes); free(reads);
-    fseek(s->fp, keep, SEEK_SET);
+    const char *ce = getenv("SLOW5_IDX_CHUNK_KB");                       /* tests: chunks smaller than a record */
+    size_t chunk = ce && atoi(ce) > 0 ? (size_t)atoi(ce) << 10 : (size_t)64 << 20;
+    const int rec_code = rec_to_code(s->compress->record_press->method);
+    uint64_t pos = s->meta.start_rec_offset;
+    const uint64_t end = (uint64_t)fst.st_size - 5;
+    uint8_t *buf = (uint8_t *)malloc(chunk + 64);
+    uint32_t cap = (uint32_t)(chunk / 48) + 16;
+    uint64_t *rpos = (uint64_t *)malloc(sizeof(uint64_t) * cap), *ent = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+    uint32_t *rlen = (uint32_t *)malloc(sizeof(uint32_t) * cap), *redo = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    char *ids = (char *)malloc((size_t)cap * ID_PITCH);
+    uint16_t *idl = (uint16_t *)malloc(sizeof(uint16_t) * cap);
+    int32_t *st = (int32_t *)malloc(sizeof(int32_t) * cap);
+    int err = (!buf || !rpos || !ent || !rlen || !redo || !ids || !idl || !st) ? SLOW5_ERR_MEM : 0;
+    size_t carry = 0;
+    while (!err && (pos < end || carry)) {
+        size_t want = chunk - carry;
+        if (want > end - pos) want = (size_t)(end - pos);
+        size_t got = 0;
+        while (got < want) {
+            ssize_t r = pread(fd, buf + carry + got, want - got, (off_t)(pos + got));
+            if (r <= 0) { err = SLOW5_ERR_IO; break; }
+            got += (size_t)r;
+        }
+        if (err) break;
+        const uint64_t file_base = pos - carry;                          /* file offset of buf[0] */
+        pos += want;
+        const size_t have = carry + want;
+        size_t p = 0;
+        uint32_t n = 0;
+        while (p + 8 <= have && n < cap) {
+            uint64_t sz;
+            memcpy(&sz, buf + p, 8);
+            if (sz > 0xFFFFFF00ull) { err = SLOW5_ERR_TRUNC; break; }
+            if (sz > chunk - 8) {                                         /* a record larger than the chunk: grow the chunk and start this round over */
+                const size_t nc = (size_t)sz + 8 + (chunk >> 1);
+                uint8_t *nb = (uint8_t *)realloc(buf, nc + 64);
+                if (!nb) { err = SLOW5_ERR_MEM; break; }
+                buf = nb; chunk = nc;
+                break;
+            }
+            if (p + 8 + sz > have) break;
+            rpos[n] = p + 8; rlen[n] = (uint32_t)sz;
+            /* reserve the entry now (file order); its id is filled in below */
+            if (idx_push(ix, "", 0, file_base + p, 8 + sz) != 0) { err = SLOW5_ERR_MEM; break; }
+            free(ix->ents[ix->n - 1].id); ix->ents[ix->n - 1].id = NULL;
+            ent[n] = ix->n - 1;
+            n++;
+            p += 8 + (size_t)sz;
+        }
+        if (err) break;
+        if (n == 0 && pos >= end && have - p > 0 && have < chunk) { err = SLOW5_ERR_TRUNC; break; }   /* a cut record at the end of the file */
+        if (n) {
+            uint32_t m = 0;
+            if (rec_code == 2 || s5gpu_record_ids_stream(n, buf, have, rpos, rlen, rec_code == 1 ? S5GPU_REC_ZLIB : S5GPU_REC_NONE, ID_PITCH, ids, idl, st) != S5GPU_OK) {
+                if (rec_code != 2) { err = SLOW5_ERR_RECPARSE; break; }
+                for (uint32_t i = 0; i < n; i++) redo[m++] = i;           /* zstd frames: the general decode */
+            } else {
+                for (uint32_t i = 0; i < n; i++) {
+                    if (st[i] != 0) { redo[m++] = i; continue; }
+                    struct idx_ent *e = &ix->ents[ent[i]];
+                    e->id = (char *)malloc((size_t)idl[i] + 1);
+                    if (!e->id) { err = SLOW5_ERR_MEM; break; }
+                    memcpy(e->id, ids + (size_t)i * ID_PITCH, idl[i]);
+                    e->id[idl[i]] = '\0';
+                    e->id_len = idl[i];
+                }
+            }
+            if (!err && m) err = idx_ids_general(s, ix, buf, rpos, rlen, ent, redo, m);
+        }
+        carry = have - p;
+        if (carry && p) memmove(buf, buf + p, carry);
+        if (n == 0 && carry && pos >= end && carry < 8) { err = SLOW5_ERR_TRUNC; break; }
+    }
+    free(buf); free(rpos); free(ent); free(rlen); free(redo); free(ids); free(idl); free(st);
+    if (!err) for (uint64_t i = 0; i < ix->n; i++) if (!ix->ents[i].id) { err = SLOW5_ERR_RECPARSE; break; }
     if (!err && idx_build_table(ix) != 0) err = SLOW5_ERR_MEM;
     if (err) { idx_free(ix); slow5_errno = err; return NULL; }
     return ix;
@@ -454,6 +540,27 @@ int slow5_idx_load(slow5_file_t *s) {
     free(p);
     if (!s->index) { slow5_errno = SLOW5_ERR_NOIDX; return -1; }
     return 0;
+}
+
+int slow5_idx_get(struct slow5_idx *index, const char *read_id, struct slow5_rec_idx *read_index) {
+    if (!index || !read_id || !read_index) { slow5_errno = SLOW5_ERR_ARG; return -1; }
+    const struct idx_ent *e = idx_find(index, read_id);
+    if (!e) { slow5_errno = SLOW5_ERR_NOTFOUND; return -1; }
+    read_index->offset = e->offset;
+    read_index->size = e->size;
+    return 0;
+}
+
+char **slow5_get_rids(const slow5_file_t *s, uint64_t *n) {
+    if (!s || !s->index || !n) { slow5_errno = SLOW5_ERR_NOIDX; return NULL; }
+    struct slow5_idx *ix = s->index;
+    if (!ix->rids) {
+        ix->rids = (char **)malloc(sizeof(char *) * (size_t)(ix->n ? ix->n : 1));
+        if (!ix->rids) { slow5_errno = SLOW5_ERR_MEM; return NULL; }
+        for (uint64_t i = 0; i < ix->n; i++) ix->rids[i] = ix->ents[i].id;
+    }
+    *n = ix->n;
+    return ix->rids;
 }
 
 void *slow5_get_mem(const char *read_id, size_t *n, const slow5_file_t *s) {

@@ -865,6 +865,162 @@ static int recompress_encode_half(Ctx *c, uint32_t n, const std::vector<s5gpu_re
     return encode_and_collect(c, n, ed, a, oo, out, out_len);
 }
 
+// ---- the decode half alone on a chunk of framed records: `get --benchmark` (/root/reference/src/get.c:52: slow5_get per id, nothing
+// written) and any consumer of signals.  Records framed in one host buffer (as s5gpu_recompress_stream takes them: a file chunk, or the
+// records a get batch pread next to each other); the decoded signals come back as ONE contiguous int16 block, sig_off[i] = first sample
+// of record i, sig_off[n] = total — one D2H, no malloc per record.  fields[i] as s5gpu_decode_batch.  Too little room: S5GPU_ERR_NOMEM
+// and sig_off[0] = samples needed.  Device g of G takes the g-th contiguous share of the records. ----
+extern "C" int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int rec_method,
+                                   int sig_method, int16_t *sig_out, size_t sig_cap, uint64_t *sig_off, s5gpu_rec_fields_t *fields) {
+    if (n == 0) { if (sig_off) sig_off[0] = 0; return S5GPU_OK; }
+    if (!chunk || !rec_pos || !rec_len || !sig_out || !sig_off || !fields) { s5gpu_set_error("s5gpu_decode_stream: NULL argument"); return S5GPU_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++)
+        if (rec_pos[i] > chunk_bytes || rec_len[i] > chunk_bytes - rec_pos[i]) { s5gpu_set_error("record %u lies outside the chunk", i); return S5GPU_ERR_ARG; }
+    const int G = s5host::n_devices();
+    if (G == 0) return S5GPU_ERR_NODEV;
+    s5host::ShareGather sg(G);
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
+        s5host::CtxHold hold;
+        int r = hold.acquire(slot);
+        if (r) return sg.fail(r);
+        Ctx *c = hold.c;
+        const uint32_t m = hi - lo;
+        uint64_t b0 = UINT64_MAX, e1 = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            b0 = b0 < rec_pos[i] ? b0 : rec_pos[i];
+            e1 = e1 > rec_pos[i] + rec_len[i] ? e1 : rec_pos[i] + rec_len[i];
+        }
+        b0 &= ~15ull;
+        std::vector<const void *> rec(m);
+        std::vector<size_t> len(m);
+        for (uint32_t i = 0; i < m; i++) { rec[i] = (const uint8_t *)chunk + rec_pos[lo + i]; len[i] = rec_len[lo + i]; }
+        FramedSrc fs = {(const uint8_t *)chunk + b0, (size_t)(e1 - b0)};
+        std::vector<s5gpu_rec_desc_t> rd;
+        std::vector<s5gpu_rec_fields_t> ff;
+        std::vector<int32_t> st(m, 0);
+        r = decode_resident_impl(c, m, rec.data(), len.data(), rec_method, sig_method, rd, ff, st.data(), &fs);
+        if (r == S5GPU_ERR_DATA) {                     // corrupt records are the caller's to look at: fields[i].status says which
+            for (uint32_t i = 0; i < m; i++) { fields[lo + i] = ff[i]; if (st[i]) { fields[lo + i].status = st[i]; fields[lo + i].n_samples = 0; } }
+        }
+        if (r) return sg.fail(r);
+        // compact the signals (each sits in its own guessed slot) into one block on the device, then one D2H
+        std::vector<uint64_t> src(m), dst(m), off(m + 1);
+        std::vector<uint32_t> gl(m);
+        off[0] = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            src[i] = 2 * rd[i].sig_off; dst[i] = 2 * off[i]; gl[i] = 2 * ff[i].n_samples;
+            off[i + 1] = off[i] + ff[i].n_samples;
+            fields[lo + i] = ff[i];
+        }
+        uint64_t base = 0;
+        bool copy = false;
+        if ((r = sg.place(slot, off[m], sig_cap, &base, &copy))) return r;
+        if (!copy) return S5GPU_OK;
+        const size_t b8 = up(8ull * m, 64);
+        if ((r = c->d_gather.reserve(2 * off[m] + 64)) || (r = c->d_patch.reserve(2 * b8 + 4ull * m + 64)) || (r = c->h_in.reserve(2 * b8 + 4ull * m + 64))) return r;
+        uint8_t *h = (uint8_t *)c->h_in.p, *dv = (uint8_t *)c->d_patch.p;
+        memcpy(h, src.data(), 8ull * m); memcpy(h + b8, dst.data(), 8ull * m); memcpy(h + 2 * b8, gl.data(), 4ull * m);
+        HIP_TRY(hipMemcpyAsync(dv, h, 2 * b8 + 4ull * m, hipMemcpyHostToDevice, c->st));
+        if ((r = s5gpu_gather_dev(m, (const uint64_t *)dv, (const uint32_t *)(dv + 2 * b8), (const uint64_t *)(dv + b8), (const uint8_t *)c->d_sig2.p,
+                                  (uint8_t *)c->d_gather.p, c->st)))
+            return r;
+        if (off[m]) HIP_TRY(hipMemcpyAsync(sig_out + base, c->d_gather.p, 2 * off[m], hipMemcpyDeviceToHost, c->st));
+        for (uint32_t i = 0; i < m; i++) sig_off[lo + i] = base + off[i];
+        if (hi == n) sig_off[n] = base + off[m];
+        HIP_TRY(hipStreamSynchronize(c->st));
+        return S5GPU_OK;
+    });
+    if (rc) return rc;
+    if (sg.overflow) {
+        sig_off[0] = sg.need();
+        s5gpu_set_error("s5gpu_decode_stream: signal buffer too small (%llu samples needed)", (unsigned long long)sig_off[0]);
+        return S5GPU_ERR_NOMEM;
+    }
+    return S5GPU_OK;
+}
+
+// ---- read ids of the records of a file chunk: what slow5_idx_create needs of a record (csrc/blow5_file.c) ----
+// The reference's index builder (slow5_idx_create -> slow5_idx_build, reached from /root/reference/src/index.c and get.c:286) reads every
+// record to learn its read_id; decoding the whole record for that — 8 KB of signal for a 36-byte id — is what round 2 did.  Here only the
+// FRONT of every zlib record crosses PCIe (the dynamic-Huffman header + a few dozen symbols: 1 KiB covers it), the wave-per-record
+// decoder stops after the first 2 + id_pitch bytes (k_inflate_head), and uncompressed records are read on the host.  A record whose front
+// was too short, or whose id is longer than id_pitch, reports status != 0: the caller takes the general path for it.
+extern "C" int s5gpu_record_ids_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int rec_method,
+                                       uint32_t id_pitch, char *ids, uint16_t *id_len, int32_t *status) {
+    if (n == 0) return S5GPU_OK;
+    if (!chunk || !rec_pos || !rec_len || !ids || !id_len || !status || id_pitch == 0 || id_pitch > 65535) { s5gpu_set_error("s5gpu_record_ids_stream: bad argument"); return S5GPU_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++)
+        if (rec_pos[i] > chunk_bytes || rec_len[i] > chunk_bytes - rec_pos[i]) { s5gpu_set_error("record %u lies outside the chunk", i); return S5GPU_ERR_ARG; }
+    const uint8_t *base = (const uint8_t *)chunk;
+    auto take = [&](uint32_t i, const uint8_t *head, uint32_t have) {        // head = the record's first uncompressed bytes
+        status[i] = 7; id_len[i] = 0;
+        if (have < 2) return;
+        const uint32_t l = head[0] | ((uint32_t)head[1] << 8);
+        id_len[i] = (uint16_t)l;
+        if (l > id_pitch) { status[i] = 5; return; }
+        if (2 + l > have) return;
+        memcpy(ids + (size_t)i * id_pitch, head + 2, l);
+        status[i] = 0;
+    };
+    if (rec_method == S5GPU_REC_NONE) {
+        for (uint32_t i = 0; i < n; i++) take(i, base + rec_pos[i], rec_len[i]);
+        return S5GPU_OK;
+    }
+    if (rec_method != S5GPU_REC_ZLIB) { s5gpu_set_error("s5gpu_record_ids_stream: zlib or uncompressed records (zstd frames take the general decode)"); return S5GPU_ERR_ARG; }
+    s5host::CtxHold hold;
+    int rc = hold.acquire();
+    if (rc) return rc;
+    Ctx *c = hold.c;
+    const uint32_t FRONT = 1024, hp = (uint32_t)up(2ull + id_pitch, 16);
+    std::vector<uint32_t> todo(n);
+    for (uint32_t i = 0; i < n; i++) todo[i] = i;
+    for (int attempt = 0; attempt < 2 && !todo.empty(); attempt++) {
+        const uint32_t m = (uint32_t)todo.size();
+        std::vector<s5gpu_rec_desc_t> desc(m);
+        uint64_t io = 0;
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t i = todo[k], f = attempt == 0 && rec_len[i] > FRONT ? FRONT : rec_len[i];
+            s5gpu_rec_desc_t &d = desc[k];
+            memset(&d, 0, sizeof d);
+            d.in_off = io; d.in_len = f; d.pay_off = (uint64_t)k * hp; d.pay_cap = 2 + id_pitch;
+            io += up((uint64_t)f + 16, 16);
+        }
+        const size_t hin = up(io + 64, 64) + sizeof(s5gpu_rec_desc_t) * m, hout = (size_t)m * hp + sizeof(s5gpu_rec_fields_t) * m + 64;
+        if ((rc = c->h_in.reserve(hin)) || (rc = c->d_in.reserve(io + 64)) || (rc = c->d_desc.reserve(sizeof(s5gpu_rec_desc_t) * m)) ||
+            (rc = c->d_pay.reserve((uint64_t)m * hp + 64)) || (rc = c->d_fields.reserve(sizeof(s5gpu_rec_fields_t) * m)) || (rc = c->h_out.reserve(hout)))
+            return rc;
+        uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + up(io + 64, 64);
+        parallel_for(m, io, [&](uint32_t lo, uint32_t hi_) {
+            for (uint32_t k = lo; k < hi_; k++) memcpy(hi + desc[k].in_off, base + rec_pos[todo[k]], desc[k].in_len);
+        });
+        memcpy(hd, desc.data(), sizeof(s5gpu_rec_desc_t) * m);
+        HIP_TRY(hipMemcpyAsync(c->d_in.p, hi, io, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_rec_desc_t) * m, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemsetAsync(c->d_fields.p, 0, sizeof(s5gpu_rec_fields_t) * m, c->st));
+        s5gpu_decode_args_t a;
+        memset(&a, 0, sizeof a);
+        a.n_recs = m; a.rec_method = S5GPU_REC_ZLIB; a.sig_method = S5GPU_SIG_NONE;
+        a.desc = (const s5gpu_rec_desc_t *)c->d_desc.p; a.in = (const uint8_t *)c->d_in.p;
+        a.payload = (uint8_t *)c->d_pay.p; a.fields = (s5gpu_rec_fields_t *)c->d_fields.p;
+        if ((rc = s5gpu_inflate_head_dev(&a, c->st))) return rc;
+        uint8_t *hp_ = (uint8_t *)c->h_out.p, *hf = hp_ + (size_t)m * hp;
+        HIP_TRY(hipMemcpyAsync(hp_, c->d_pay.p, (size_t)m * hp, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipMemcpyAsync(hf, c->d_fields.p, sizeof(s5gpu_rec_fields_t) * m, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        const s5gpu_rec_fields_t *ff = (const s5gpu_rec_fields_t *)hf;
+        std::vector<uint32_t> again;
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t i = todo[k];
+            if (ff[k].status == 0) take(i, hp_ + (size_t)k * hp, ff[k].payload_len);
+            else { status[i] = ff[k].status; id_len[i] = 0; }
+            // the front ended before the id was out (a record with a very long code-length header, or stored blocks): the whole record next
+            if (status[i] != 0 && status[i] != 5 && attempt == 0 && rec_len[i] > FRONT) again.push_back(i);
+        }
+        todo.swap(again);
+    }
+    return S5GPU_OK;
+}
+
 // ---- pinned host memory for callers that stream a file through the library (examples/s5view.c) ----
 extern "C" void *s5gpu_host_alloc(size_t bytes) {
     if (s5host::n_devices() == 0) return NULL;

@@ -435,6 +435,10 @@ __device__ __forceinline__ void infl_flush(const uint8_t *ring, uint8_t *out, ui
 // Inflate one zlib stream.  out: HBM, cap bytes.  Returns status; *out_len = decoded length (also when
 // INF_ERR_OVERFLOW: the size needed; nothing at or beyond cap is written).  Adler-32 verified.
 // `in` must have 8 readable bytes after in + in_len.
+// HEAD: only the first `cap` bytes are wanted (a record's head: read_id_len | read_id | ..., for the index builder): decoding stops as soon
+// as they are there — no Adler-32 (the stream is not read to its end), *out_len = bytes written (<= cap); `in` may be just the front
+// of the stream: running out of input before cap bytes are there is INF_ERR_TRUNC.
+template <bool HEAD = false>
 __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *in, uint32_t in_len, uint8_t *out,
                                                  uint32_t cap, uint32_t *out_len) {
     const int lane = lane_id();
@@ -502,6 +506,7 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
             o += len;
             flushed = o;
             ring_lo = o;   // the ring holds none of these bytes: later matches read them back from HBM
+            if (HEAD && o >= cap) { last = 1; continue; }
             infl_load_window(T.win, src, pos + len, total);
             b.wbase = pos + len; b.wpos = 0; b.buf = 0; b.cnt = 0;
             continue;
@@ -539,6 +544,7 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
             uint32_t mlen = 0, mdist = 0, st = 0;
             {   // wave-uniform: all lanes walk the same bits (scalar unit); only lane 0 stores the literal
                 for (;;) {
+                    if (HEAD && o >= cap) { st = 6; break; }
                     if (b.wpos > INF_IW / 4 - 3) { st = 4; break; }
                     if (o - flushed >= INF_FLUSH) { st = 5; break; }
                     bi_need32_u(b, T.win);
@@ -614,6 +620,7 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
             }
             if (st == 2 || st == 3) { status = st == 2 ? INF_ERR_DATA : INF_ERR_TRUNC; break; }
             if (st == 1) break;
+            if (st == 6) { last = 1; break; }              // HEAD: enough bytes
             if (st == 4) {
                 infl_reload(T.win, src, total, b);
                 continue;
@@ -637,6 +644,11 @@ __device__ __forceinline__ int zlib_inflate_wave(InflShared &T, const uint8_t *i
         }
     }
     wave_sync();
+    if (HEAD) {
+        if (status == INF_OK) infl_flush(T.ring, out, flushed, o, cap, adA, adB);
+        *out_len = o < cap ? o : cap;
+        return status;
+    }
     if (status == INF_OK) {
         infl_flush(T.ring, out, flushed, o, cap, adA, adB);
         const uint8_t *t = in + in_len - 4;

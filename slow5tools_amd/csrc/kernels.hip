@@ -505,6 +505,20 @@ __global__ __launch_bounds__(64) void k_inflate(s5gpu_decode_args_t a) {
     }
 }
 
+// The first pay_cap bytes of every zlib record and no more (record heads for the index builder: read_id_len | read_id | ...): one
+// record per wave, the wave-per-record decoder stopped early.  d.in_len may cover just the front of the record.
+__global__ __launch_bounds__(64) void k_inflate_head(s5gpu_decode_args_t a) {
+    __shared__ InflShared T;
+    const uint32_t r = blockIdx.x;
+    const s5gpu_rec_desc_t d = a.desc[r];
+    uint32_t olen = 0;
+    const int status = zlib_inflate_wave<true>(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+    if (lane_id() == 0) {
+        a.fields[r].status = status;
+        a.fields[r].payload_len = olen;
+    }
+}
+
 // K4, parallel inside the record (inflate_par_dev.h): one record per wave64, 64 self-synchronising segment decoders.  Default for
 // every batch size; what it declines (status INF_NEED_FALLBACK) the wave-per-record decoder redoes right behind it.
 // UNPACK (s5gpu_decode_dev on svb-zd records): the wave that inflated a record also parses it and decodes its signal — the payload
@@ -1387,6 +1401,13 @@ extern "C" int s5gpu_inflate_dev(const s5gpu_decode_args_t *a, void *stream_) {
     if (dec_check(a, true, false)) { s5gpu_set_error("s5gpu_inflate_dev: bad arguments"); return S5GPU_ERR_ARG; }
     if (a->n_recs == 0) return S5GPU_OK;
     return launch_inflate(a, (hipStream_t)stream_);
+}
+extern "C" int s5gpu_inflate_head_dev(const s5gpu_decode_args_t *a, void *stream_) {
+    if (dec_check(a, true, false) || (a && a->rec_method != S5GPU_REC_ZLIB)) { s5gpu_set_error("s5gpu_inflate_head_dev: bad arguments (zlib records)"); return S5GPU_ERR_ARG; }
+    if (a->n_recs == 0) return S5GPU_OK;
+    hipLaunchKernelGGL(k_inflate_head, dim3(a->n_recs), dim3(64), 0, (hipStream_t)stream_, *a);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
 }
 extern "C" int s5gpu_svbzd_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
     if (dec_check(a, false, true)) { s5gpu_set_error("s5gpu_svbzd_decode_dev: bad arguments"); return S5GPU_ERR_ARG; }

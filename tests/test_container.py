@@ -221,6 +221,72 @@ def test_index_cases_3_and_4_of_the_reference(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk_kb", [0, 16, 200])
+def test_index_builder_reads_record_heads_only_and_agrees_with_the_files(tmp_path, chunk_kb):
+    """slow5_idx_create: the file in chunks, records framed in place, ids from the head of each record (k_inflate_head); the reference's
+    .idx files must come out byte for byte whatever the chunk size cuts (a 16 KiB chunk is smaller than most records: the chunk grows),
+    also for zstd files and 300-character ids (both take the general decode), and an index of 3000 own records finds every read"""
+    import struct, zlib
+    from slow5tools_amd import press
+
+    env = dict(os.environ)
+    if chunk_kb:
+        env["SLOW5_IDX_CHUNK_KB"] = str(chunk_kb)
+
+    def index(path):
+        r = subprocess.run([S5VIEW, "--index", str(path)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        return open(str(path) + ".idx", "rb").read()
+
+    for name in ("example_multi_rg_v0.2.0.blow5", "example_multi_rg_v0.2.0_none_none.blow5"):
+        if not os.path.exists(golden(name)):
+            continue
+        src = tmp_path / name
+        shutil.copy(golden(name), src)
+        assert index(src) == open(golden(name + ".idx.exp"), "rb").read(), name
+    z = tmp_path / "example_multi_rg_v0.2.0_zstd_svb-zd.blow5"
+    shutil.copy(golden("example_multi_rg_v0.2.0_zstd_svb-zd.blow5"), z)
+    zi, ref = index(z), open(golden("example_multi_rg_v0.2.0.blow5.idx.exp"), "rb").read()
+    ids = lambda raw: [raw[o + 2:o + 2 + struct.unpack_from("<H", raw, o)[0]] for o in _idx_entries(raw)]
+    assert ids(zi) == ids(ref)
+    # own records: short and 300-character ids, empty reads, a long read
+    rng = np.random.default_rng(4)
+    n = 3000
+    rid = [(b"r%05d" % i) if i % 7 else (b"long%05d_" % i) + b"x" * 290 for i in range(n)]
+    sigs = [ob.synth_read(0x5105, i, int(k)) for i, k in enumerate(rng.integers(0, 6000, n))]
+    sigs[11] = ob.synth_read(0x5105, 11, 150000)
+    recs = press.encode_records(sigs, [press.pack_hdr(r, 0, 8192.0, 23.0, 1467.61, 4000.0) for r in rid])
+    text = b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
+    head = bytearray(64)
+    head[:6] = b"BLOW5\x01"; head[6:9] = bytes([0, 2, 0]); head[9] = 1; head[10:14] = struct.pack("<I", 1); head[14] = 1
+    own = tmp_path / "own.blow5"
+    own.write_bytes(bytes(head) + struct.pack("<I", len(text)) + text + b"".join(recs) + b"5WOLB")
+    raw = index(own)
+    offs = _idx_entries(raw)
+    assert len(offs) == n
+    at = 68 + len(text)
+    for i, o in enumerate(offs):
+        l = struct.unpack_from("<H", raw, o)[0]
+        off, size = struct.unpack_from("<QQ", raw, o + 2 + l)
+        assert raw[o + 2:o + 2 + l] == rid[i] and off == at and size == len(recs[i]), i
+        at += len(recs[i])
+    r = subprocess.run([S5VIEW, "--get", str(own), rid[7].decode()], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.split("\t")[0] == rid[7].decode() and int(r.stdout.split("\t")[2]) == len(sigs[7]), r.stderr
+
+
+def _idx_entries(raw):
+    """offsets of the entries of a .idx file"""
+    import struct
+    assert raw[:9] == b"SLOW5IDX\x01" and raw[-8:] == b"XDI5WOLS"
+    o, out = 64, []
+    while o < len(raw) - 8:
+        out.append(o)
+        o += 2 + struct.unpack_from("<H", raw, o)[0] + 16
+    assert o == len(raw) - 8
+    return out
+
+
+@pytest.mark.gpu
 def test_view_roundtrip_and_get(tmp_path):
     a, b, c = tmp_path / "a.blow5", tmp_path / "b.blow5", tmp_path / "c.blow5"
     _run(golden("merged_expected_zlib_svb.blow5"), a, "none", "none", 4)     # batches of 4: crosses a batch boundary
@@ -331,6 +397,111 @@ def test_chunked_view_takes_tiny_records_and_falls_back_on_a_record_larger_than_
     sigs = [(480 + 35 * rng.standard_normal(int(k))).astype(np.int16) for k in (300, 5000, 90000, 20, 7000)]
     blow5(big, sigs, [b"big%d" % i for i in range(5)])
     both(big, 64, True)                                                # the 180 KB record does not fit a 64 KiB chunk
+
+
+S5GET = os.path.join(ROOT, "slow5tools_amd", "s5get")
+S5MERGE = os.path.join(ROOT, "slow5tools_amd", "s5merge")
+
+
+@pytest.mark.gpu
+def test_merge_harness_reproduces_the_reference_merged_file(tmp_path):
+    """test/test_merge.sh case 1.6: merge rg0..rg3.slow5 -c zlib -s svb-zd against merged_expected_zlib_svb.blow5 (tests/golden/merge_rg*.slow5 are
+    the reference's raw/merge inputs).  The four files have different aux fields (rg2 carries an enum the others lack, in another column
+    order): the output header — read groups appended per run_id, attributes as a sorted union with '.', aux fields enums first then sorted
+    (src/merge.c:217-350) — must equal the reference's byte for byte, and every record must inflate to the reference's payload (0xFF for the
+    missing enum).  Then the same merge from BLOW5 inputs, and lossy."""
+    import zlib
+
+    ins = [golden("merge_rg%d.slow5" % i) for i in range(4)]
+    ref = Blow5(golden("merged_expected_zlib_svb.blow5"))
+    out = tmp_path / "m.blow5"
+    r = subprocess.run([S5MERGE, str(out), "-c", "zlib", "-s", "svb-zd"] + ins, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = Blow5(str(out))
+    assert (got.version, got.rec_method, got.sig_method, got.num_read_groups) == (ref.version, 1, 1, 4)
+    assert got.header_text == ref.header_text
+    assert [zlib.decompress(x) for x in got.records] == [zlib.decompress(x) for x in ref.records]
+    assert sum(map(len, got.records)) <= 1.02 * sum(map(len, ref.records))
+    # BLOW5 inputs (each file converted first): one-read-group files with the output's columns would go straight through the device;
+    # these need the detour (other columns), a second merge of the merged file does not
+    bl = []
+    for i, f in enumerate(ins):
+        b = tmp_path / ("rg%d.blow5" % i)
+        _run(f, b, "zlib", "svb-zd")
+        bl.append(str(b))
+    out2 = tmp_path / "m2.blow5"
+    r = subprocess.run([S5MERGE, str(out2), "-K", "2"] + bl, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got2 = Blow5(str(out2))
+    assert got2.header_text == ref.header_text and [zlib.decompress(x) for x in got2.records] == [zlib.decompress(x) for x in ref.records]
+    out3 = tmp_path / "m3.blow5"                                        # the merged file merged again with one of its parts: same run_ids map back
+    r = subprocess.run([S5MERGE, str(out3), str(out), bl[2]], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got3 = Blow5(str(out3))
+    pay = [zlib.decompress(x) for x in ref.records]
+    assert got3.header_text == ref.header_text and [zlib.decompress(x) for x in got3.records] == pay + [pay[3], pay[4]]
+    # lossy (-l): no aux columns in the header, no aux bytes in the records
+    out4 = tmp_path / "m4.blow5"
+    r = subprocess.run([S5MERGE, str(out4), "-l"] + ins, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got4 = Blow5(str(out4))
+    assert got4.header_text.endswith(b"len_raw_signal\traw_signal\n")
+    for x, y in zip(got4.records, ref.records):
+        d, e = ob.rec_parse(zlib.decompress(x), 1), ob.rec_parse(zlib.decompress(y), 1)
+        assert d["aux"] == b"" and d["read_id"] == e["read_id"] and d["read_group"] == e["read_group"] and np.array_equal(d["signal"], e["signal"])
+
+
+@pytest.mark.gpu
+def test_get_harness_fetches_decodes_and_rewrites_the_reads_of_an_id_list(tmp_path):
+    """the loop of src/get.c:321-386 (test/test_get.sh): index, id list, batches of K — preads, ONE call per batch, ordered output.  500 ids drawn
+    with replacement from a 3000-read file: the output holds their records in list order, byte-identical payloads; --benchmark (get.c:52)
+    decodes the same reads and reports the sample count and checksum Python computes; an unknown id fails, or is skipped with S5GET_SKIP=1"""
+    import struct, zlib
+    from slow5tools_amd import press
+
+    rng = np.random.default_rng(8)
+    n = 3000
+    rid = [b"read-%06d" % i for i in range(n)]
+    sigs = [ob.synth_read(0x5105, i, int(k)) for i, k in enumerate(rng.integers(0, 9000, n))]
+    sigs[5] = ob.synth_read(0x5105, 5, 200000)
+    recs = press.encode_records(sigs, [press.pack_hdr(r, 0, 8192.0, 23.0, 1467.61, 4000.0) for r in rid])
+    text = b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
+    head = bytearray(64)
+    head[:6] = b"BLOW5\x01"; head[6:9] = bytes([0, 2, 0]); head[9] = 1; head[10:14] = struct.pack("<I", 1); head[14] = 1
+    src = tmp_path / "in.blow5"
+    src.write_bytes(bytes(head) + struct.pack("<I", len(text)) + text + b"".join(recs) + b"5WOLB")
+    ids = tmp_path / "ids.txt"
+    r = subprocess.run([S5GET, "--random", str(src), "500", "1", str(ids)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = [int(l.split("-")[1]) for l in ids.read_text().split()]
+    assert len(want) == 500 and len(set(want)) > 400
+    want[3] = 5                                                        # the 200 000-sample read: its record outgrows the first batch buffers
+    ids.write_text("".join("read-%06d\n" % i for i in want))
+    for K, readers in ((64, 3), (4096, 8)):
+        out = tmp_path / ("o%d.blow5" % K)
+        r = subprocess.run([S5GET, str(src), str(ids), str(out), "zlib", "svb-zd", str(K), str(readers)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        got = Blow5(str(out))
+        assert got.header_text == text and len(got.records) == 500
+        assert [zlib.decompress(x) for x in got.records] == [zlib.decompress(recs[i][8:]) for i in want]
+    out = tmp_path / "raw.blow5"
+    r = subprocess.run([S5GET, str(src), str(ids), str(out), "none", "none", "100"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert [x for x in Blow5(str(out)).records] == [ob.rec_pack(ob.make_rec(rid[i], 0, 8192.0, 23.0, 1467.61, 4000.0, sigs[i])[0], ob.SIG_NONE) for i in want]
+    r = subprocess.run([S5GET, "--benchmark", str(src), str(ids), "128", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "p50" in r.stderr, r.stderr
+    tot, samples, ck = r.stdout.split()
+    exp = 0
+    for i in want:
+        s_ = sigs[i]
+        if len(s_):
+            exp = (exp * 1000003 + (int(s_[0]) & 0xFFFF) + ((int(s_[len(s_) // 2]) & 0xFFFF) << 16) + ((int(s_[-1]) & 0xFFFF) << 32)) & 0xFFFFFFFFFFFFFFFF
+    assert int(tot) == 500 and int(samples) == sum(len(sigs[i]) for i in want) and int(ck, 16) == exp
+    ids.write_text("read-000001\nno-such-read\nread-000002\n")
+    r = subprocess.run([S5GET, str(src), str(ids), str(tmp_path / "x.blow5")], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "not in the index" in r.stderr
+    r = subprocess.run([S5GET, str(src), str(ids), str(tmp_path / "y.blow5")], capture_output=True, text=True, timeout=300, env=dict(os.environ, S5GET_SKIP="1"))
+    assert r.returncode == 0 and len(Blow5(str(tmp_path / "y.blow5")).records) == 2
 
 
 @pytest.mark.gpu
