@@ -327,21 +327,29 @@ __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list
 }
 
 // Staged path with the LZ77 matcher (lz_dev.h): records whose signal press is "none" (raw int16 samples) and byte ranges of the
-// solo zlib press.  The parked payload goes through LDS 16 KiB at a time like k_deflate_staged; the previous block stays in
-// LDS as the matcher's history, and so does the table of recent positions.  One workgroup per CU (150 KiB of LDS).
-constexpr uint32_t LZ_BYTES = (sizeof(LzShared) + 15u) & ~15u;
-__global__ __launch_bounds__(NT) void k_deflate_lz(EncParams p, int use_list) {
+// solo zlib press.  LzLong: the parked payload goes through LDS 16 KiB at a time like k_deflate_staged; the previous block stays in
+// LDS as the matcher's history, and so does the table of recent positions: one workgroup per CU (150 KiB of LDS).  LzShort: payloads of
+// at most 8 KiB (one block, no history, the bit buffer in the table's storage): 38 KiB, four workgroups per CU.  which: 0 = every
+// record (LzLong only), 1 = this kernel's share of a batch that runs both (LzShort: payloads <= 8 KiB, LzLong: the others).
+constexpr uint32_t LZ_BYTES = (sizeof(LzSharedT<LzLong>) + 15u) & ~15u;
+constexpr uint32_t LZS_BYTES = (sizeof(LzSharedT<LzShort>) + 15u) & ~15u;
+template <class C>
+__global__ __launch_bounds__(NT) void k_deflate_lz(EncParams p, int use_list, int which) {
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
-    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
-    LzShared &X = *reinterpret_cast<LzShared *>(smem + S_BYTES + 4u * p.obuf_words);
+    LzSharedT<C> &X = *reinterpret_cast<LzSharedT<C> *>(smem + S_BYTES + (C::HIST ? 4u * p.obuf_words : 0u));
+    uint32_t *obuf = C::HIST ? reinterpret_cast<uint32_t *>(smem + S_BYTES) : X.obuf_alias;
+    const uint32_t obuf_words = C::HIST ? p.obuf_words : (uint32_t)(C::BLK + 64) / 4u;
     const int tid = threadIdx.x;
     const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         const uint32_t r = use_list ? p.a.ovf[1 + it] : it;
         const s5gpu_read_desc_t d = p.a.desc[r];
+        // whose record: by the payload size the descriptor implies (signal press none: head + u64 + 2 bytes per sample + aux) — out_len[r]
+        // turns from the payload's length into the record's when a kernel is done with it, so it cannot say
+        if (which && (d.hdr_len + 8u + 2u * d.n_samples + d.aux_len <= (uint32_t)LzShort::BLK) != !C::HIST) continue;
+        const uint32_t plen = p.a.out_len[r];
         uint8_t *out = p.a.slots + d.out_off;
         const uint8_t *src = out + park_offset(d, p.a.sig_method);
-        const uint32_t plen = p.a.out_len[r];
         __syncthreads();
         {   // a record starts with an empty table (the output must not depend on what this workgroup encoded before)
             uint4 *t4 = reinterpret_cast<uint4 *>(X.table);
@@ -354,23 +362,25 @@ __global__ __launch_bounds__(NT) void k_deflate_lz(EncParams p, int use_list) {
         uint32_t adA = 1, adB = 0, done = 0;
         uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
         do {
-            const uint32_t blen = min(plen - done, (uint32_t)LZ_BLK);
+            const uint32_t blen = min(plen - done, (uint32_t)C::BLK);
             const bool final = done + blen == plen;
             {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
                 const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
-                uint4 *d4 = reinterpret_cast<uint4 *>(X.win + LZ_BLK);
+                uint4 *d4 = reinterpret_cast<uint4 *>(X.win + C::WOFF);
                 for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
             }
             __syncthreads();
-            deflate_block_lz(S, X, obuf, p.obuf_words, (int)blen, done ? (uint32_t)LZ_BLK : 0u, done, final, z, adA, adB);
+            deflate_block_lz<C>(S, X, obuf, obuf_words, (int)blen, done ? (uint32_t)C::WOFF : 0u, done, final, z, adA, adB);
             done += blen;
             if (!final) {
-                flush_words(obuf, out32, z, false);
-                z.carry = obuf[0];
-                const uint4 *c4 = reinterpret_cast<const uint4 *>(X.win + LZ_BLK);   // the block becomes the next one's history
-                uint4 *h4 = reinterpret_cast<uint4 *>(X.win);
-                for (uint32_t i = tid; i < LZ_BLK / 16; i += NT) h4[i] = c4[i];
-                __syncthreads();
+                if constexpr (C::HIST) {
+                    flush_words(obuf, out32, z, false);
+                    z.carry = obuf[0];
+                    const uint4 *c4 = reinterpret_cast<const uint4 *>(X.win + C::WOFF);   // the block becomes the next one's history
+                    uint4 *h4 = reinterpret_cast<uint4 *>(X.win);
+                    for (uint32_t i = tid; i < C::BLK / 16; i += NT) h4[i] = c4[i];
+                    __syncthreads();
+                }
             }
         } while (done < plen);
         z.bitpos = (z.bitpos + 7) & ~7u;
@@ -1113,6 +1123,7 @@ extern "C" uint64_t s5gpu_slot_bound(uint32_t n, uint32_t hdr_len, uint32_t aux_
     return (z + 16 + 15) & ~15ull;
 }
 
+static void launch_lz(EncParams p, uint32_t n, uint32_t max_payload, hipStream_t st);
 static int enc_check(const s5gpu_encode_args_t *a) {
     if (!a || (a->n_reads && (!a->desc || !a->sig || !a->hdr || !a->slots || !a->out_len))) return S5GPU_ERR_ARG;
     if (a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB && a->rec_method != S5GPU_REC_ZSTD) return S5GPU_ERR_ARG;
@@ -1140,7 +1151,8 @@ static int set_lds_attrs() {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_lz), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_lz<LzLong>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deflate_lz<LzShort>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zstd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -1192,9 +1204,8 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     if (a->rec_method == S5GPU_REC_ZLIB && a->sig_method == S5GPU_SIG_NONE) {
         // raw int16 samples: the redundancy is repeated sample pairs at any distance, not runs — the LZ77 matcher (lz_dev.h)
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
-        const uint32_t g = a->n_reads < 2048 ? a->n_reads : 2048;
         hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
-        hipLaunchKernelGGL(k_deflate_lz, dim3(g), dim3(NT), S_BYTES + 4ull * st_obuf + LZ_BYTES, st, p, 0);
+        launch_lz(p, a->n_reads, a->max_payload, st);
         HIP_TRY(hipGetLastError());
         return S5GPU_OK;
     }
@@ -1222,6 +1233,19 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     }
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
+}
+
+// The LZ77 kernels over parked payloads (out_len[r] = payload length): payloads of at most 8 KiB on LzShort (4 workgroups per CU), the rest on
+// LzLong (1 per CU).  max_payload == 0: unknown (the solo press does not say): both run, each takes its share.
+static void launch_lz(EncParams p, uint32_t n, uint32_t max_payload, hipStream_t st) {
+    p.obuf_words = (DEFL_BLK + 64) / 4;
+    const bool any_long = max_payload == 0 || max_payload > (uint32_t)LzShort::BLK;
+    const uint32_t gs = n < 8192 ? n : 8192;
+    hipLaunchKernelGGL(k_deflate_lz<LzShort>, dim3(gs), dim3(NT), S_BYTES + LZS_BYTES, st, p, 0, any_long ? 1 : 0 /* which = 0: every record is short */);
+    if (any_long) {
+        const uint32_t gl = n < 2048 ? n : 2048;
+        hipLaunchKernelGGL(k_deflate_lz<LzLong>, dim3(gl), dim3(NT), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, st, p, 0, 1);
+    }
 }
 
 static uint32_t fused_cap(const s5gpu_encode_args_t *a) {
@@ -1281,7 +1305,7 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
     const size_t lds = S_BYTES + 4ull * p.obuf_words + DEFL_BLK;
     if (a->rec_method == S5GPU_REC_ZSTD) hipLaunchKernelGGL(k_zstd_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
     else if (a->sig_method == S5GPU_SIG_NONE)   // byte ranges of unknown kind (the solo zlib press): the LZ77 matcher
-        hipLaunchKernelGGL(k_deflate_lz, dim3(a->n_reads < 2048 ? a->n_reads : 2048), dim3(NT), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, (hipStream_t)stream_, p, 0);
+        launch_lz(p, a->n_reads, a->max_payload, (hipStream_t)stream_);
     else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;

@@ -28,16 +28,31 @@
 namespace s5 {
 
 constexpr int LZ_BLK = DEFL_BLK;
-constexpr int LZ_HBITS = 13, LZ_WAYS = 4, LZ_MINLEN = 4;
+constexpr int LZ_MINLEN = 4, LZ_WAYS = 4;          // (four ways = four waves: wave k fills way k)
 
-struct LzShared {
-    alignas(16) uint8_t win[2 * LZ_BLK + 16];              // [previous block | current block], slack for dword reads at the end
-    alignas(16) uint16_t table[(1 << LZ_HBITS) * LZ_WAYS];  // position & 0xFFFF of the most recent occurrences of a hash
-    alignas(16) uint16_t D[LZ_BLK + 8];                     // per position: match distance (0 none); after the parse D[p + 1] = length of the match starting at p
+// Two shapes of the same encoder.  LzLong: records of any length — 16 KiB blocks, the previous block kept as history, a 13-bit table
+// (64 KiB): ~150 KiB of LDS, one workgroup per CU.  LzShort (round 3): records whose payload fits ONE block of 8 KiB (a 4000-sample
+// raw-signal record is 8086 bytes) need no history, a quarter of the positions and a table an eighth the size, and the table is dead
+// when the bit buffer comes to life, so the two share storage: 38 KiB, four workgroups per CU — the matcher is a chain of dependent
+// LDS round trips, so what it gains is resident waves (tools/lz_time.py).
+template <int BLK_, int HBITS_, bool HIST_>
+struct LzCfg { static constexpr int BLK = BLK_, HBITS = HBITS_; static constexpr bool HIST = HIST_; static constexpr int WOFF = HIST_ ? BLK_ : 0; };
+using LzLong = LzCfg<LZ_BLK, 13, true>;
+using LzShort = LzCfg<8192, 10, false>;
+
+template <class C>
+struct LzSharedT {
+    alignas(16) uint8_t win[C::WOFF + C::BLK + 16];        // [previous block |] current block, slack for dword reads at the end
+    union {
+        alignas(16) uint16_t table[(1 << C::HBITS) * LZ_WAYS];  // position & 0xFFFF of the most recent occurrences of a hash
+        alignas(16) uint32_t obuf_alias[C::HIST ? 4 : (C::BLK + 64) / 4];   // LzShort: the bit buffer lives where the table was
+    };
+    alignas(16) uint16_t D[C::BLK + 8];                     // per position: match distance (0 none); after the parse D[p + 1] = length of the match starting at p
     uint16_t entry[NT + 2];
     uint32_t blcount_d[16];
     uint32_t bins_d[64];
 };
+using LzShared = LzSharedT<LzLong>;
 
 // four bytes at any LDS byte address (two aligned dwords + one alignbit)
 __device__ __forceinline__ uint32_t lds_load32u(const uint8_t *p) {
@@ -80,11 +95,13 @@ __device__ __forceinline__ void lz_dist_sym(uint32_t dist, uint32_t &sym, uint32
 // Encode the `len` <= LZ_BLK bytes at X.win + LZ_BLK as one DEFLATE block into the bit buffer.  `hist` = bytes of history in
 // front of them in the window (0 for a record's first block, LZ_BLK afterwards), abs0 = position of the block in the record.
 // Same contract as deflate_block MODE 2: the bit buffer is cleared here and the stream's partial word travels in z.carry.
-__device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzShared &X, uint32_t *obuf, uint32_t obuf_words, int len, uint32_t hist,
+template <class C>
+__device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X, uint32_t *obuf, uint32_t obuf_words, int len, uint32_t hist,
                                                  uint32_t abs0, bool final, ZOut &z, uint32_t &adA, uint32_t &adB) {
     const int tid = threadIdx.x;
-    const uint8_t *cur = X.win + LZ_BLK;
-    constexpr int K = LZ_BLK / NT;   // 64 positions per lane
+    constexpr uint32_t WOFF = (uint32_t)C::WOFF;
+    const uint8_t *cur = X.win + WOFF;
+    constexpr int K = C::BLK / NT;   // positions per lane (64 / 32)
     const int base = tid * K;
     if (len == 0) {   // empty stream: a fixed block holding only end-of-block
         for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
@@ -105,9 +122,9 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzShared &X, uin
         uint32_t w = 0, h = 0, best_l = 0, best_d = 0;
         const uint32_t p16 = (abs0 + (uint32_t)i) & 0xFFFFu;
         if (act) {
-            const uint32_t widx = LZ_BLK + (uint32_t)i;
+            const uint32_t widx = WOFF + (uint32_t)i;
             w = lds_load32u(X.win + widx);
-            h = (w * 2654435761u) >> (32 - LZ_HBITS);
+            h = (w * 2654435761u) >> (32 - C::HBITS);
             const uint32_t maxl = min(258u, (uint32_t)(len - i)), avail = (uint32_t)i + hist;
             const uint2 e = *reinterpret_cast<const uint2 *>(&X.table[h * LZ_WAYS]);
 #pragma unroll
@@ -139,7 +156,7 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzShared &X, uin
                 tok |= bit;
                 if (d) {
                     mat |= bit;
-                    pos += (int)lz_match_len(X.win, LZ_BLK + (uint32_t)pos, LZ_BLK + (uint32_t)pos - d, min(258u, (uint32_t)(len - pos)));
+                    pos += (int)lz_match_len(X.win, WOFF + (uint32_t)pos, WOFF + (uint32_t)pos - d, min(258u, (uint32_t)(len - pos)));
                 } else pos++;
             }
             X.entry[tid + 1] = (uint16_t)(pos > base + K ? pos - (base + K) : 0);
@@ -155,7 +172,7 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzShared &X, uin
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
             const int pos = base + j;
-            X.D[pos + 1] = (uint16_t)lz_match_len(X.win, LZ_BLK + (uint32_t)pos, LZ_BLK + (uint32_t)pos - X.D[pos], min(258u, (uint32_t)(len - pos)));
+            X.D[pos + 1] = (uint16_t)lz_match_len(X.win, WOFF + (uint32_t)pos, WOFF + (uint32_t)pos - X.D[pos], min(258u, (uint32_t)(len - pos)));
         }
     }
     __syncthreads();
