@@ -17,5 +17,5 @@ for (name,_),v in acc.items():
     w=v.get("SQ_WAVES",1)
     if (name,w) in seen or w < 64: continue
     seen.add((name,w))
-    print("%-42s waves %7d  per wave: cycles %.0f  VALU %.0f  SALU %.0f  LDS %.0f  branch %.0f  lanes/VALU %.1f" % (name, w, 4*v["SQ_WAVE_CYCLES"]/w, v["SQ_INSTS_VALU"]/w, v["SQ_INSTS_SALU"]/w, v["SQ_INSTS_LDS"]/w, v["SQ_INSTS_BRANCH"]/w, v["SQ_THREAD_CYCLES_VALU"]/max(v["SQ_INSTS_VALU"],1)/4))
+    print("%-42s waves %7d  per wave: cycles %.0f  VALU %.0f  SALU %.0f  LDS %.0f  branch %.0f  lanes/VALU %.1f" % (name, w, 4*v["SQ_WAVE_CYCLES"]/w, v["SQ_INSTS_VALU"]/w, v["SQ_INSTS_SALU"]/w, v["SQ_INSTS_LDS"]/w, v["SQ_INSTS_BRANCH"]/w, v["SQ_THREAD_CYCLES_VALU"]/max(v["SQ_INSTS_VALU"],1)))   # = active lanes per VALU instruction (tools/pmc_lanes.sh: a full wave reads 64.0)
 PY
