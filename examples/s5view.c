@@ -148,6 +148,7 @@ typedef struct {
     slow5_press_method_t from, to;
     int failed, readers, oversize;
     int ascii;                   /* the input is a .slow5 file: the chunk is framed into lines, not [u64 size][bytes] records */
+    int ascii_out;               /* the output is a .slow5 file (BLOW5 input): every chunk comes back as one block of text lines */
     uint32_t n_aux;
     const uint8_t *aux_type;
     char why[256];
@@ -307,7 +308,10 @@ static void *fworker_main(void *arg) {
         b->state = ST_BUSY;
         pthread_mutex_unlock(&P->mu);
         for (int attempt = 0;; attempt++) {
-            const int rc = P->ascii
+            const int rc = P->ascii_out
+                ? s5gpu_blow5_to_ascii_stream(b->n, b->in, b->in_have, b->rec_pos, b->rec_len, rec_code_of(P->from.record_method), sig_code_of(P->from.signal_method),
+                                              P->n_aux, P->aux_type, NULL, 0, b->out, b->out_cap, b->out_off, NULL)
+                : P->ascii
                 ? s5gpu_ascii_to_blow5_stream(b->n, b->in, b->in_have, b->rec_pos, b->rec_len, P->n_aux, P->aux_type, rec_code_of(P->to.record_method),
                                               sig_code_of(P->to.signal_method), NULL, 0, b->out, b->out_cap, b->out_off, NULL)
                 : s5gpu_recompress_stream(b->n, b->in, b->in_have, b->rec_pos, b->rec_len, rec_code_of(P->from.record_method), sig_code_of(P->from.signal_method),
@@ -333,7 +337,7 @@ static void *fworker_main(void *arg) {
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 /* returns 0 and the record count, -1, or -2: a record does not fit a chunk (an uncompressed ultra-long read) — the caller redoes the
  * file with the per-record pipeline */
-static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slow5_press_method_t to, int workers, uint64_t *total) {
+static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slow5_press_method_t to, int ascii_out, int workers, uint64_t *total) {
     fpipe_t P;
     memset(&P, 0, sizeof P);
     pthread_mutex_init(&P.mu, NULL);
@@ -341,7 +345,8 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     struct stat st;
     P.fd_in = fileno(in->fp);
     P.ascii = in->format == SLOW5_FORMAT_ASCII;
-    if (P.ascii && in->header->aux_meta) { P.n_aux = in->header->aux_meta->num; P.aux_type = in->header->aux_meta->types; }
+    P.ascii_out = ascii_out;
+    if ((P.ascii || P.ascii_out) && in->header->aux_meta) { P.n_aux = in->header->aux_meta->num; P.aux_type = in->header->aux_meta->types; }
     if (fstat(P.fd_in, &st) != 0 || (uint64_t)st.st_size < in->meta.start_rec_offset + (P.ascii ? 0 : 5)) return -1;
     if (!P.ascii) {   /* the end marker must close the file (src/quickcheck.c:93-97) */
         char tail[5];
@@ -365,7 +370,7 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
         e = getenv("S5VIEW_SLOT_RECS");                             /* tests: fewer descriptors than a chunk holds records */
         if (e && atoi(e) > 0) b->cap = (uint32_t)atoi(e);
         b->in = (uint8_t *)s5gpu_host_alloc(P.chunk + 64);
-        b->out_cap = P.ascii ? P.chunk : P.chunk * 3;              /* (a chunk that outgrows it is redone with the room it asked for) */
+        b->out_cap = P.ascii ? P.chunk : P.ascii_out ? P.chunk * 6 : P.chunk * 3;   /* (a chunk that outgrows it is redone with the room it asked for) */
         b->out = (uint8_t *)s5gpu_host_alloc(b->out_cap);
         b->rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * b->cap);
         b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * b->cap);
@@ -405,8 +410,8 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     for (int i = 0; i < FSLOT; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); free(b->nl); }
     if (P.failed && P.oversize) return -2;
     if (P.failed) { fprintf(stderr, "s5view: %s\n", P.why); return -1; }
-    fprintf(stderr, "s5view: chunked pipeline%s: %.3f s for %llu records (%.1f MB in, %.1f MB out; buffers %.3f s), %d pread threads, %d GPU worker(s), chunks of %zu MB\n",
-            P.ascii ? " (SLOW5 text in)" : "", t1 - t0, (unsigned long long)*total, (double)(P.end - in->meta.start_rec_offset) / 1e6, (double)out_bytes / 1e6, t0 - t_alloc, P.readers, W, P.chunk >> 20);
+    fprintf(stderr, "s5view: chunked pipeline%s%s: %.3f s for %llu records (%.1f MB in, %.1f MB out; buffers %.3f s), %d pread threads, %d GPU worker(s), chunks of %zu MB\n",
+            P.ascii ? " (SLOW5 text in)" : "", P.ascii_out ? " (SLOW5 text out)" : "", t1 - t0, (unsigned long long)*total, (double)(P.end - in->meta.start_rec_offset) / 1e6, (double)out_bytes / 1e6, t0 - t_alloc, P.readers, W, P.chunk >> 20);
     return 0;
 }
 
@@ -456,10 +461,10 @@ int main(int argc, char **argv) {
     const int workers = argc > 6 ? atoi(argv[6]) : 1;
     uint64_t total = 0;
     const char *nofast = getenv("S5VIEW_PER_RECORD");
-    /* chunked pipeline: BLOW5 -> BLOW5 and SLOW5 -> BLOW5 (the conversion BASELINE configs[0] names); a .slow5 OUTPUT takes the per-record one */
-    int fast = workers > 0 && fmt_out == SLOW5_FORMAT_BINARY && !(nofast && atoi(nofast));
+    /* chunked pipeline: BLOW5 -> BLOW5, SLOW5 -> BLOW5 (the conversion BASELINE configs[0] names) and BLOW5 -> SLOW5; text to text takes the per-record one */
+    int fast = workers > 0 && (fmt_out == SLOW5_FORMAT_BINARY || in->format == SLOW5_FORMAT_BINARY) && !(nofast && atoi(nofast));
     if (fast) {
-        const int rc = fast_view(in, out, from, to, workers, &total);
+        const int rc = fast_view(in, out, from, to, fmt_out == SLOW5_FORMAT_ASCII, workers, &total);
         if (rc == -2) {   /* start the output over, record by record (the chunked reader used pread: in->fp still stands at the first record) */
             fprintf(stderr, "s5view: a record larger than a chunk (S5VIEW_CHUNK_MB): per-record pipeline\n");
             if (in->format == SLOW5_FORMAT_ASCII && fseeko(in->fp, (off_t)in->meta.start_rec_offset, SEEK_SET) != 0) return die("cannot rewind the input");

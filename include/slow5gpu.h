@@ -299,6 +299,16 @@ int s5gpu_ascii_to_blow5_batch(uint32_t n, const char *const *line, const size_t
 int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *line_pos, const uint32_t *line_len,
                                 uint32_t n_aux, const uint8_t *aux_type, int to_rec, int to_sig, const uint32_t *new_read_group, int drop_aux,
                                 void *out_buf, size_t out_cap, uint64_t *out_off, int32_t *status);
+/* slot r (desc[r].out_off in `slots`, len[r] bytes) -> dst + off[r], on the device (the copy of s5gpu_compact_dev with the destinations given) */
+int s5gpu_scatter_slots_dev(uint32_t n, const s5gpu_read_desc_t *desc, const uint8_t *slots, const uint32_t *len, const uint64_t *off, uint8_t *dst,
+                            void *hip_stream);
+/* ... and the other way round on a CHUNK of a BLOW5 file (records framed as for s5gpu_recompress_stream): the SLOW5 text lines of the n records
+ * come back as ONE contiguous block in out_buf (out_off[i] = start of line i, out_off[n] = total; every line ends in a newline) — the signal
+ * columns printed on the device, prefix | signal | suffix of every line put in place there, one D2H.  Too little room: S5GPU_ERR_NOMEM and
+ * out_off[0] = the capacity needed. */
+int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int from_rec,
+                                int from_sig, uint32_t n_aux, const uint8_t *aux_type, const uint32_t *new_read_group, int drop_aux,
+                                void *out_buf, size_t out_cap, uint64_t *out_off, int32_t *status);
 /* BLOW5 records (bytes without the u64 prefix) -> ASCII lines ending in a newline; out[i] malloc'd. */
 int s5gpu_blow5_to_ascii_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, uint32_t n_aux,
                                const uint8_t *aux_type, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,

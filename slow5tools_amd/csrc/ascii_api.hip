@@ -583,3 +583,165 @@ extern "C" int s5gpu_blow5_to_ascii_batch(uint32_t n, const void *const *rec, co
     }
     return S5GPU_OK;
 }
+
+// The same for a CHUNK of a BLOW5 file -> SLOW5 text lines as ONE contiguous block (the chunk twin of the call above, and the reverse of
+// s5gpu_ascii_to_blow5_stream; /root/reference/src/view.c:35-57 with a .slow5 output): records framed in one host buffer exactly as read
+// from disk; decode device-resident, raw_signal printed on the device into worst-case slots; the few scalar columns and the aux columns
+// are printed on the host from the decoded fields (ids and aux bytes gathered on the device, one small D2H) into a prefix
+// ("id \t rg \t ... \t n \t") and a suffix ("\t aux ... \n") per line; the device then puts prefix | signal text | suffix of every
+// line at its place in the output block (offsets = prefix sums of the three lengths), and ONE D2H brings the block back.
+extern "C" int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int from_rec,
+                                           int from_sig, uint32_t n_aux, const uint8_t *aux_type, const uint32_t *new_read_group, int drop_aux,
+                                           void *out_buf, size_t out_cap, uint64_t *out_off, int32_t *status) {
+    if (n == 0) { if (out_off) out_off[0] = 0; return S5GPU_OK; }
+    if (!chunk || !rec_pos || !rec_len || !out_buf || !out_off || (n_aux && !aux_type)) { s5gpu_set_error("s5gpu_blow5_to_ascii_stream: NULL argument"); return S5GPU_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++) {
+        if (status) status[i] = 0;
+        if (rec_pos[i] > chunk_bytes || rec_len[i] > chunk_bytes - rec_pos[i]) { s5gpu_set_error("record %u lies outside the chunk", i); return S5GPU_ERR_ARG; }
+    }
+    const int G = s5host::n_devices();
+    if (G == 0) return S5GPU_ERR_NODEV;
+    s5host::ShareGather sg(G);
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
+        s5host::CtxHold hold;
+        int r = hold.acquire(slot);
+        if (r) return sg.fail(r);
+        Ctx *c = hold.c;
+        const uint32_t m = hi - lo;
+        uint64_t b0 = UINT64_MAX, e1 = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            b0 = b0 < rec_pos[i] ? b0 : rec_pos[i];
+            e1 = e1 > rec_pos[i] + rec_len[i] ? e1 : rec_pos[i] + rec_len[i];
+        }
+        b0 &= ~15ull;
+        std::vector<const void *> rec(m);
+        std::vector<size_t> len(m);
+        for (uint32_t i = 0; i < m; i++) { rec[i] = (const uint8_t *)chunk + rec_pos[lo + i]; len[i] = rec_len[lo + i]; }
+        std::vector<s5gpu_rec_desc_t> rd;
+        std::vector<s5gpu_rec_fields_t> ff;
+        if ((r = s5host::decode_resident_framed(c, m, rec.data(), len.data(), from_rec, from_sig, rd, ff, status ? status + lo : nullptr,
+                                                (const uint8_t *)chunk + b0, (size_t)(e1 - b0))))
+            return sg.fail(r);
+        auto hip = [&](hipError_t e, const char *what) -> int {
+            if (e == hipSuccess) return 0;
+            s5gpu_set_error("%s failed: %s", what, hipGetErrorString(e));
+            return sg.fail(S5GPU_ERR_HIP);
+        };
+        // 1. signal text into worst-case slots; ids and aux bytes gathered for the host
+        std::vector<s5gpu_read_desc_t> slots(m);
+        std::vector<s5gpu_txt_desc_t> td(m);
+        std::vector<uint64_t> g_src(2ull * m), g_dst(2ull * m);
+        std::vector<uint32_t> g_len(2ull * m);
+        uint64_t to = 0, go = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            const uint64_t cap = up(7ull * ff[i].n_samples + 16, 16);
+            if (cap > 0xFFFFFF00ull) { s5gpu_set_error("read %u: signal text larger than 4 GiB", lo + i); return sg.fail(S5GPU_ERR_ARG); }
+            memset(&td[i], 0, sizeof td[i]);
+            td[i].txt_off = to; td[i].sig_off = rd[i].sig_off; td[i].txt_len = (uint32_t)cap; td[i].n_samples = ff[i].n_samples;
+            memset(&slots[i], 0, sizeof slots[i]);
+            slots[i].out_off = to; slots[i].slot_cap = (uint32_t)cap;
+            to += cap;
+            g_src[2 * i] = rd[i].pay_off + 2; g_len[2 * i] = ff[i].read_id_len; g_dst[2 * i] = go; go += ff[i].read_id_len;
+            const uint32_t al = drop_aux ? 0 : ff[i].aux_len;
+            g_src[2 * i + 1] = rd[i].pay_off + ff[i].aux_off; g_len[2 * i + 1] = al; g_dst[2 * i + 1] = go; go += al;
+        }
+        const size_t b_td = up(sizeof(s5gpu_txt_desc_t) * m, 64), b_rd = up(sizeof(s5gpu_read_desc_t) * m, 64), b_g8 = up(16ull * m, 64), b_g4 = up(8ull * m, 64), b_4 = up(4ull * m, 64);
+        // d_tdesc: txt desc | slot desc | gather src | gather dst | gather len | txt_len | status | (stage 2) piece src | piece dst | piece len | sig dst
+        const size_t o_rd = b_td, o_src = o_rd + b_rd, o_dst = o_src + b_g8, o_len = o_dst + b_g8, o_tl = o_len + b_g4, o_st = o_tl + b_4, o_p = o_st + b_4;
+        const size_t b_all = o_p + 2 * b_g8 + b_g4 + up(8ull * m, 64);
+        if ((r = c->d_tdesc.reserve(b_all)) || (r = c->d_txt.reserve(to + 64)) || (r = c->d_gather.reserve(go + 64)) || (r = c->h_in.reserve(b_all)) ||
+            (r = c->h_out.reserve(go + 64)))
+            return sg.fail(r);
+        uint8_t *h = (uint8_t *)c->h_in.p, *dv = (uint8_t *)c->d_tdesc.p;
+        memcpy(h, td.data(), sizeof(s5gpu_txt_desc_t) * m);
+        memcpy(h + o_rd, slots.data(), sizeof(s5gpu_read_desc_t) * m);
+        memcpy(h + o_src, g_src.data(), 16ull * m);
+        memcpy(h + o_dst, g_dst.data(), 16ull * m);
+        memcpy(h + o_len, g_len.data(), 8ull * m);
+        if ((r = hip(hipMemcpyAsync(dv, h, o_tl, hipMemcpyHostToDevice, c->st), "upload"))) return r;
+        uint32_t *d_tl = (uint32_t *)(dv + o_tl);
+        int32_t *d_st = (int32_t *)(dv + o_st);
+        if ((r = s5gpu_ascii_format_dev(m, (const s5gpu_txt_desc_t *)dv, (const int16_t *)c->d_sig2.p, (uint8_t *)c->d_txt.p, d_tl, d_st, c->st))) return sg.fail(r);
+        if ((r = s5gpu_gather_dev(2 * m, (const uint64_t *)(dv + o_src), (const uint32_t *)(dv + o_len), (const uint64_t *)(dv + o_dst),
+                                  (const uint8_t *)c->d_pay.p, (uint8_t *)c->d_gather.p, c->st)))
+            return sg.fail(r);
+        std::vector<uint32_t> tl(m);
+        std::vector<int32_t> fs(m);
+        uint8_t *h_g = (uint8_t *)c->h_out.p;
+        if ((r = hip(hipMemcpyAsync(tl.data(), d_tl, 4ull * m, hipMemcpyDeviceToHost, c->st), "download"))) return r;
+        if ((r = hip(hipMemcpyAsync(fs.data(), d_st, 4ull * m, hipMemcpyDeviceToHost, c->st), "download"))) return r;
+        if (go && (r = hip(hipMemcpyAsync(h_g, c->d_gather.p, go, hipMemcpyDeviceToHost, c->st), "download"))) return r;
+        if ((r = hip(hipStreamSynchronize(c->st), "synchronise"))) return r;
+        // 2. the other columns on the host: prefix and suffix of every line, back to back in one blob
+        std::vector<std::string> pre(m), suf(m);
+        int fail = 0;
+        parallel_for(m, to / 4, [&](uint32_t a, uint32_t b) {
+            for (uint32_t i = a; i < b; i++) {
+                const s5gpu_rec_fields_t &f = ff[i];
+                if (fs[i] || tl[i] > td[i].txt_len) { fail = 1; continue; }
+                std::string &s = pre[i];
+                s.reserve(f.read_id_len + 96);
+                s.append((const char *)h_g + g_dst[2 * i], f.read_id_len);
+                s.push_back('\t'); fmt_u64(s, new_read_group ? new_read_group[lo + i] : f.read_group);
+                s.push_back('\t'); fmt_f64(s, f.digitisation);
+                s.push_back('\t'); fmt_f64(s, f.offset);
+                s.push_back('\t'); fmt_f64(s, f.range);
+                s.push_back('\t'); fmt_f64(s, f.sampling_rate);
+                s.push_back('\t'); fmt_u64(s, f.n_samples);
+                s.push_back('\t');
+                if (!drop_aux && n_aux && !aux_to_text(h_g + g_dst[2 * i + 1], g_len[2 * i + 1], n_aux, aux_type, suf[i])) { if (status) status[lo + i] = 16; fail = 2; continue; }
+                suf[i].push_back('\n');
+            }
+        });
+        if (fail == 1) { s5gpu_set_error("s5gpu_blow5_to_ascii_stream: signal formatting failed"); return sg.fail(S5GPU_ERR_HIP); }
+        if (fail == 2) { s5gpu_set_error("s5gpu_blow5_to_ascii_stream: aux bytes of at least one record do not match the header's aux types"); return sg.fail(S5GPU_ERR_DATA); }
+        std::vector<uint64_t> off(m + 1), p_src(2ull * m), p_dst(2ull * m), s_dst(m);
+        std::vector<uint32_t> p_len(2ull * m);
+        uint64_t bo = 0;
+        off[0] = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            p_src[2 * i] = bo; p_len[2 * i] = (uint32_t)pre[i].size(); p_dst[2 * i] = off[i]; bo += pre[i].size();
+            s_dst[i] = off[i] + pre[i].size();
+            p_src[2 * i + 1] = bo; p_len[2 * i + 1] = (uint32_t)suf[i].size(); p_dst[2 * i + 1] = s_dst[i] + tl[i]; bo += suf[i].size();
+            off[i + 1] = p_dst[2 * i + 1] + suf[i].size();
+        }
+        uint64_t base = 0;
+        bool copy = false;
+        if ((r = sg.place(slot, off[m], out_cap, &base, &copy))) return r;
+        if (!copy) return S5GPU_OK;
+        // 3. prefix | signal text | suffix of every line to its place on the device, one D2H
+        if ((r = c->d_stream.reserve(off[m] + 64)) || (r = c->d_aux.reserve(bo + 64)) || (r = c->h_in.reserve(b_all + bo + 64))) return r;
+        h = (uint8_t *)c->h_in.p;
+        uint8_t *hb = h + b_all;
+        for (uint32_t i = 0; i < m; i++) {
+            memcpy(hb + p_src[2 * i], pre[i].data(), pre[i].size());
+            memcpy(hb + p_src[2 * i + 1], suf[i].data(), suf[i].size());
+        }
+        memcpy(h + o_p, p_src.data(), 16ull * m);
+        memcpy(h + o_p + b_g8, p_dst.data(), 16ull * m);
+        memcpy(h + o_p + 2 * b_g8, p_len.data(), 8ull * m);
+        memcpy(h + o_p + 2 * b_g8 + b_g4, s_dst.data(), 8ull * m);
+        HIP_TRY(hipMemcpyAsync(dv + o_p, h + o_p, b_all - o_p, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->d_aux.p, hb, bo, hipMemcpyHostToDevice, c->st));
+        if ((r = s5gpu_gather_dev(2 * m, (const uint64_t *)(dv + o_p), (const uint32_t *)(dv + o_p + 2 * b_g8), (const uint64_t *)(dv + o_p + b_g8),
+                                  (const uint8_t *)c->d_aux.p, (uint8_t *)c->d_stream.p, c->st)))
+            return r;
+        // the signal text: slot i -> stream + s_dst[i] (the compaction kernel's copy: dword-wise with a byte shift)
+        if ((r = s5gpu_scatter_slots_dev(m, (const s5gpu_read_desc_t *)(dv + o_rd), (const uint8_t *)c->d_txt.p, d_tl, (const uint64_t *)(dv + o_p + 2 * b_g8 + b_g4),
+                                         (uint8_t *)c->d_stream.p, c->st)))
+            return r;
+        HIP_TRY(hipMemcpyAsync((uint8_t *)out_buf + base, c->d_stream.p, off[m], hipMemcpyDeviceToHost, c->st));
+        for (uint32_t i = 0; i < m; i++) out_off[lo + i] = base + off[i];
+        if (hi == n) out_off[n] = base + off[m];
+        HIP_TRY(hipStreamSynchronize(c->st));
+        return S5GPU_OK;
+    });
+    if (rc) return rc;
+    if (sg.overflow) {
+        const uint64_t need = sg.need();
+        out_off[0] = need;
+        s5gpu_set_error("s5gpu_blow5_to_ascii_stream: output buffer too small (%llu bytes needed)", (unsigned long long)need);
+        return S5GPU_ERR_NOMEM;
+    }
+    return S5GPU_OK;
+}

@@ -729,6 +729,11 @@ int s5host::decode_resident(Ctx *c, uint32_t n, const void *const *rec, const si
                             std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status) {
     return decode_resident_impl(c, n, rec, rec_len, from_rec, from_sig, rd, ff, status, nullptr);
 }
+int s5host::decode_resident_framed(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
+                                   std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status, const uint8_t *base, size_t bytes) {
+    FramedSrc fs = {base, bytes};
+    return decode_resident_impl(c, n, rec, rec_len, from_rec, from_sig, rd, ff, status, &fs);
+}
 static int decode_resident_impl(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
                                 std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status, const FramedSrc *framed) {
     int rc;

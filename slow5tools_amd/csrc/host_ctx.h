@@ -75,6 +75,9 @@ int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> 
 // decode host records, results resident in c->d_pay / c->d_sig2 (host_api.hip)
 int decode_resident(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
                     std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status);
+// ... the records sitting framed in one host buffer (a file chunk): [base, base + bytes) is uploaded as it is, rec[i] point into it
+int decode_resident_framed(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
+                           std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status, const uint8_t *base, size_t bytes);
 // encode descriptors already on the device -> the contiguous BLOW5 record stream in c->d_stream (what the ordered fwrite loop
 // emits); off[i] / off[n] = record offsets / total, on the host (host_api.hip)
 int encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,

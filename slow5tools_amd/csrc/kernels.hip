@@ -1549,6 +1549,16 @@ extern "C" int s5gpu_compact_dev(uint32_t n, const s5gpu_read_desc_t *desc, cons
     return S5GPU_OK;
 }
 
+// slot r (desc[r].out_off in `slots`, len[r] bytes) -> dst + off[r]: k_compact with the destinations given (the text assembly of ascii_api.hip)
+extern "C" int s5gpu_scatter_slots_dev(uint32_t n, const s5gpu_read_desc_t *desc, const uint8_t *slots, const uint32_t *len, const uint64_t *off, uint8_t *dst,
+                                       void *stream_) {
+    if (n == 0) return S5GPU_OK;
+    if (!desc || !slots || !len || !off || !dst) return S5GPU_ERR_ARG;
+    hipLaunchKernelGGL(k_compact, dim3(n), dim3(NT), 0, (hipStream_t)stream_, desc, slots, len, off, dst);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
 extern "C" int s5gpu_patch_u32_dev(uint8_t *base, const uint64_t *off, const uint32_t *val, uint32_t n, void *stream_) {
     if (n == 0) return S5GPU_OK;
     if (!base || !off || !val) return S5GPU_ERR_ARG;

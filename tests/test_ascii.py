@@ -315,6 +315,31 @@ def test_chunked_slow5_to_blow5_equals_the_per_record_pipeline(tmp_path, chunk_k
         assert o1.read_bytes() == o2.read_bytes() and len(Blow5(str(o1)).records) == 6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk_kb", [150, 1024])
+def test_chunked_blow5_to_slow5_equals_the_per_record_pipeline_and_the_source_text(tmp_path, chunk_kb):
+    """the other direction through chunks (s5gpu_blow5_to_ascii_stream): a BLOW5 file made from 700 random lines with every aux kind is
+    printed back chunk by chunk — the signal columns on the device, prefix | signal | suffix of every line put in place there — and must
+    give the per-record pipeline's bytes and the source lines"""
+    from slow5tools_amd import ascii as s5a
+    types = s5a.aux_types(TYPE_LINES[2])
+    rng = np.random.default_rng(29)
+    lines, pays = _random_lines(rng, 700, types, max_len=9000)
+    hdr = b"#slow5_version\t0.2.0\n#num_read_groups\t5\n@asic_id\ta\tb\tc\td\te\n" + TYPE_LINES[2] + b"\n" + \
+          b"#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\t" + b"\t".join(b"a%d" % i for i in range(len(types))) + b"\n"
+    src = tmp_path / "in.slow5"
+    src.write_bytes(hdr + b"".join(lines))
+    z = tmp_path / "z.blow5"
+    _run(src, z, "zlib", "svb-zd")
+    env = dict(os.environ, S5VIEW_CHUNK_KB=str(chunk_kb))
+    a, b = tmp_path / "chunked.slow5", tmp_path / "per_record.slow5"
+    r = subprocess.run([S5VIEW, str(z), str(a), "none", "none", "4096", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "(SLOW5 text out)" in r.stderr, r.stderr
+    r = subprocess.run([S5VIEW, str(z), str(b), "none", "none", "64", "2"], capture_output=True, text=True, timeout=300, env=dict(os.environ, S5VIEW_PER_RECORD="1"))
+    assert r.returncode == 0 and "chunked pipeline" not in r.stderr, r.stderr
+    assert a.read_bytes() == b.read_bytes() == hdr + b"".join(lines)
+
+
 def lines_plain(k):
     out = b""
     for i in range(k):

@@ -38,7 +38,9 @@ for W, R, C in ((1, 1, 64), (2, 4, 64), (3, 4, 64), (3, 8, 64), (3, 4, 128), (4,
     runs.append(("zlib", "svb-zd", "/tmp/e2e_c_%d_%d_%d.blow5" % (W, R, C), 4096, W, {"S5VIEW_READERS": str(R), "S5VIEW_CHUNK_MB": str(C)}))
 # SLOW5 text in (the conversion BASELINE configs[0] names): the .slow5 twin of the same reads is printed first (BLOW5 -> SLOW5, per-record
 # pipeline), then converted by the per-record pipeline and by the chunked one
-runs.append(("txt", "txt", "/tmp/e2e_txt.slow5", 4096, 2, {}))
+runs.append(("txt", "txt", "/tmp/e2e_txt_pr.slow5", 4096, 2, {"S5VIEW_PER_RECORD": "1"}))
+runs.append(("txt", "txt", "/tmp/e2e_txt.slow5", 4096, 2, {"S5VIEW_READERS": "4", "S5VIEW_CHUNK_MB": "32"}))
+runs.append(("txt", "txt", "/tmp/e2e_txt3.slow5", 4096, 3, {"S5VIEW_READERS": "4", "S5VIEW_CHUNK_MB": "16"}))
 runs.append(("zlib", "svb-zd", "/tmp/e2e_t_pr.blow5", 4096, 2, {"S5VIEW_PER_RECORD": "1", "IN": "/tmp/e2e_txt.slow5"}))
 for W, R, C in ((1, 4, 32), (2, 4, 32), (2, 8, 32), (3, 8, 64), (3, 8, 128)):
     runs.append(("zlib", "svb-zd", "/tmp/e2e_t_%d_%d_%d.blow5" % (W, R, C), 4096, W, {"S5VIEW_READERS": str(R), "S5VIEW_CHUNK_MB": str(C), "IN": "/tmp/e2e_txt.slow5"}))
@@ -52,13 +54,20 @@ for (rm, sm, dst, K, W, env) in runs:
     r = subprocess.run([exe, inp, dst, rm, sm, str(K), str(W)], capture_output=True, text=True, env=dict(os.environ, **env))
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr
-    m = re.search(r"chunked pipeline(?: \(SLOW5 text in\))?: ([0-9.]+) s", r.stderr)
+    m = re.search(r"chunked pipeline(?: \(SLOW5 text (?:in|out)\))?: ([0-9.]+) s", r.stderr)
     inner = float(m.group(1)) if m else None
     print("s5view %s -> (%s,%s) %s workers=%d: %d reads, whole process %.2f s = %.2f GB/s raw signal%s  [in %.0f MB, out %.0f MB]"
-          % (os.path.basename(inp), rm, sm, ("per-record pipeline K=%d%s" % (K, " (serial phases)" if W == 0 else "")) if "S5VIEW_PER_RECORD" in env or rm == "none" or dst.endswith(".slow5") else
+          % (os.path.basename(inp), rm, sm, ("per-record pipeline K=%d%s" % (K, " (serial phases)" if W == 0 else "")) if "S5VIEW_PER_RECORD" in env or "S5VIEW_CHUNK_MB" not in env else
              "chunked pipeline (%s MB chunks, %s pread threads)" % (env["S5VIEW_CHUNK_MB"], env["S5VIEW_READERS"]), W, n_reads, dt, raw_gb / dt,
              "; first read to last write %.3f s = %.2f GB/s" % (inner, raw_gb / inner) if inner else "", os.path.getsize(inp) / 1e6, os.path.getsize(dst) / 1e6))
     sys.stdout.flush()
+    if dst.endswith(".slow5"):   # text out: the same bytes whichever pipeline printed them
+        import hashlib
+        hsh = hashlib.sha256(open(dst, "rb").read()).hexdigest()
+        ref_txt = globals().setdefault("ref_txt", hsh)
+        assert hsh == ref_txt, "text output differs between pipeline settings"
+        if dst != "/tmp/e2e_txt.slow5":
+            os.remove(dst)
     if rm == "zlib":   # the pipeline must not change a byte
         data = open(dst, "rb").read()
         if ref_out is None:
