@@ -1,0 +1,55 @@
+#!/bin/bash
+# HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes: each fills the TCC counter budget) of the dominant kernel of every
+# bench leg, written to profiles/pmc_traffic.json with the hash of the kernel sources it was collected on (bench.py only quotes a figure
+# whose hash matches the build it runs).  hbm_bytes_per_read = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / reads: the factor 2 is the
+# gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE tallies 128-byte requests at 64 bytes).  Run on the GPU box.
+R=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${1:-$R/gpurun_out/pmc_traffic}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() {   # name counter command...
+  local name=$1 c=$2; shift 2
+  rm -rf /tmp/pt_${name}_$c
+  ( cd $R && timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pt_${name}_$c -o pt -- "$@" ) > $OUT/${name}_$c.log 2>&1
+}
+for c in FETCH_SIZE WRITE_SIZE; do
+  run enc $c python tools/stream_time.py 400000
+  run svb $c python bench.py --svb-only --reads 400000 --steps 3 --warmup 1 --cpu-seconds 0
+  run long $c python bench.py --long --long-reads 16384 --steps 2 --warmup 1 --min-leg-steps-long 2 --cpu-seconds 0
+  run decnp $c python tools/decode_bulk.py 1000000 4000 np 3
+  run decfull $c python tools/decode_bulk.py 1000000 4000 full 3
+done
+python3 - <<PY
+import csv, glob, json, sys, os
+sys.path.insert(0, "$R")
+import bench
+sha = bench.csrc_sha256()
+def per_launch(name, counter, kernels):
+    f = glob.glob("/tmp/pt_%s_%s/**/*counter_collection.csv" % (name, counter), recursive=True)[0]
+    tot = {}
+    for r in csv.DictReader(open(f)):
+        for k in kernels:
+            if k in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                tot.setdefault(k, []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in tot.items()}, {k: len(v) for k, v in tot.items()}
+legs = [("enc", "k_encode_stream", ["k_encode_stream"], 400000, 4000),
+        ("svb", "k_svbzd_encode", ["k_svbzd_encode"], 400000, 4000),
+        ("long", "k_pack+k_deflate_staged", ["k_pack", "k_deflate_staged"], 16384, 100000),
+        ("decnp", "k_inflate_par_np", ["k_inflate_par_np"], 1000000, 4000),
+        ("decfull", "k_inflate_par+k_unpack", ["k_inflate_par<true>"], 1000000, 4000)]
+out = []
+for name, label, kernels, reads, n in legs:
+    try:
+        fe, nf = per_launch(name, "FETCH_SIZE", kernels)
+        wr, nw = per_launch(name, "WRITE_SIZE", kernels)
+        fetch = sum(fe.values()); write = sum(wr.values())
+        b = (2 * fetch + write) * 1024 / reads
+        print("%-26s %8d reads x %6d: FETCH %14.1f KiB  WRITE %14.1f KiB per launch (%s launches) -> %.1f B/read" % (label, reads, n, fetch, write, nf, b))
+        out.append({"kernel": label, "samples_per_read": n, "hbm_bytes_per_read": round(b, 1), "fetch_KiB_per_launch": round(fetch, 1), "write_KiB_per_launch": round(write, 1),
+                    "reads_per_launch": reads, "source": "tools/pmc_traffic_all.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x 2: gfx950 correction)",
+                    "csrc_sha256": sha})
+    except Exception as e:
+        print(label, "failed:", repr(e))
+json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
+print("csrc_sha256", sha)
+PY
