@@ -135,6 +135,21 @@ def cpu_encode_baseline(ob, sig2d, first, n, ref_seconds, sweep_seconds):
         best = max(sweep, key=lambda x: x["GB_per_s"])
         cpu["best_of"] = {"value": best["GB_per_s"], "unit": "GB/s", "t": best["t"], "K": best["K"]}
         cpu["sweep"] = sweep
+        # NOT the reference's shape, for scale only: the same sweep point with one deflate state per worker thread, reset per record
+        # (deflateReset) instead of the reference's slow5_press_init per record — how much of the CPU figure is that allocation + memset
+        try:
+            K_p = 65536                                    # (threads live per batch: a large batch lets a thread's state serve many records)
+            pts = []
+            for t in sorted({best["t"], cores}):
+                r, s_ = 0, 0.0
+                while s_ < max(2.0, sweep_seconds / 2):
+                    tot, sec, _ = ob.encode_batch_mt(sig2d, first, t, K_p, pooled_zstream=True)
+                    r += m; s_ += sec
+                pts.append({"t": t, "K": K_p, "GB_per_s": round(r * 2 * n / s_ / 1e9, 3), "seconds": round(s_, 1)})
+            cpu["pooled_zstream"] = {"what": "one deflate state per worker thread, deflateReset per record: NOT the reference's shape (src/view.c:43-54 allocates per record)",
+                                     "points": pts, "value": max(p["GB_per_s"] for p in pts), "unit": "GB/s"}
+        except Exception as e:
+            cpu["pooled_zstream"] = {"error": repr(e)}
         # the same worker fed with SLOW5 TEXT (BASELINE configs[0]: view in.slow5 -o out.blow5 — the ASCII parse of
         # slow5_rec_depress_parse is part of the reference's compute phase there): a smaller sample, printed by the oracle
         try:

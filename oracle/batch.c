@@ -90,6 +90,7 @@ static void *worker_main(void *arg) {
         encode_one(w->db, i);
     }
     while ((i = steal(w->all, w->n_threads)) >= 0) encode_one(w->db, i);
+    s5o_zlib_pool_release();          /* (threads are created per batch: a pooled deflate state lives as long as its thread) */
     return NULL;
 }
 

@@ -30,6 +30,28 @@ int s5o_zlib_compress(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len
     return 0;
 }
 
+/* NOT the reference's shape: one deflate state per THREAD, reset per record (deflateReset) instead of allocated and cleared per record.
+ * Only the cpu_baseline's "pooled_zstream" point uses it (bench.py), to show how much of the CPU figure is the reference's own
+ * per-record slow5_press_init (src/view.c:43-54: a 256 KiB allocation + memset per record).  Same bytes out. */
+static __thread z_stream t_pool;
+static __thread int t_pool_ok;
+int s5o_pool_zstream = 0;      /* switch for s5o_rec_to_mem (set by s5o_encode_batch_mt's mode argument) */
+int s5o_zlib_compress_pooled(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len) {
+    if (!t_pool_ok) {
+        memset(&t_pool, 0, sizeof t_pool);
+        if (deflateInit2(&t_pool, Z_DEFAULT_COMPRESSION, Z_DEFLATED, MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK) return -1;
+        t_pool_ok = 1;
+    } else if (deflateReset(&t_pool) != Z_OK) return -1;
+    t_pool.next_in = (Bytef *)in;
+    t_pool.avail_in = (uInt)n;
+    t_pool.next_out = out;
+    t_pool.avail_out = (uInt)*out_len;
+    if (deflate(&t_pool, Z_FINISH) != Z_STREAM_END) return -2;
+    *out_len = t_pool.total_out;
+    return 0;
+}
+void s5o_zlib_pool_release(void) { if (t_pool_ok) { deflateEnd(&t_pool); t_pool_ok = 0; } }
+
 int s5o_zlib_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len) {
     z_stream s;
     memset(&s, 0, sizeof s);

@@ -55,7 +55,7 @@ size_t s5o_rec_to_mem(const s5o_rec_t *r, int rec_method, int sig_method, uint8_
     if (rec_method == S5O_REC_ZLIB) {
         size_t plen = s5o_rec_pack(r, sig_method, scratch);
         size_t zl = s5o_zlib_bound(plen);
-        if (s5o_zlib_compress(scratch, plen, out + 8, &zl) != 0) return 0;
+        if ((s5o_pool_zstream ? s5o_zlib_compress_pooled(scratch, plen, out + 8, &zl) : s5o_zlib_compress(scratch, plen, out + 8, &zl)) != 0) return 0;
         sz = zl;
     } else {
         sz = s5o_rec_pack(r, sig_method, out + 8);

@@ -43,6 +43,11 @@ size_t s5o_zlib_bound(size_t n);
 /* per-record deflateInit2/deflate/deflateEnd, as slow5_press_init per record (src/view.c:43-54) */
 int s5o_zlib_compress(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len);
 int s5o_zlib_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len /* in: cap */);
+/* the same bytes from a per-thread deflate state that is reset, not re-allocated, per record: NOT the reference's shape; the
+ * cpu_baseline's "pooled_zstream" point only (s5o_pool_zstream != 0 makes s5o_rec_to_mem use it) */
+extern int s5o_pool_zstream;
+int s5o_zlib_compress_pooled(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len);
+void s5o_zlib_pool_release(void);
 uint32_t s5o_adler32(const uint8_t *p, size_t n);
 
 /* ---- a1 / a4 / a7: the in-memory read and its BLOW5 record ---- */

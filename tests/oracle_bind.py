@@ -220,8 +220,11 @@ def synth_read_id(read_idx):
     return buf.value
 
 
-def encode_batch_mt(sig2d, first_idx, n_threads, batch_size=4096, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD):
+def encode_batch_mt(sig2d, first_idx, n_threads, batch_size=4096, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD, pooled_zstream=False):
+    """pooled_zstream: NOT the reference's shape — one deflate state per worker thread, deflateReset per record (bench: how much of the CPU
+    figure is the reference's per-record slow5_press_init)"""
     sig2d = np.ascontiguousarray(sig2d, dtype=np.int16)
+    C.c_int.in_dll(lib(), "s5o_pool_zstream").value = 1 if pooled_zstream else 0
     secs = C.c_double()
     ck = C.c_uint64()
     total = lib().s5o_encode_batch_mt(_ptr(sig2d), sig2d.shape[0], sig2d.shape[1], first_idx, rec_method, sig_method,
