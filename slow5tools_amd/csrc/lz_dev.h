@@ -92,6 +92,17 @@ __device__ __forceinline__ void lz_dist_sym(uint32_t dist, uint32_t &sym, uint32
     ev = d & ((1u << nb) - 1u);
 }
 
+// length of the match the matcher found at block position pos (d = X.D[pos], not 0)
+template <class C>
+__device__ __forceinline__ uint32_t lz_len_of(const LzSharedT<C> &X, uint32_t d, int pos, int len) {
+    if (!C::HIST) {
+        const uint32_t lc = d >> 13;
+        if (lc < 7u) return lc + 4u;
+        d &= 0x1FFFu;
+    }
+    return lz_match_len(X.win, (uint32_t)C::WOFF + (uint32_t)pos, (uint32_t)C::WOFF + (uint32_t)pos - d, min(258u, (uint32_t)(len - pos)));
+}
+
 // Encode the `len` <= LZ_BLK bytes at X.win + LZ_BLK as one DEFLATE block into the bit buffer.  `hist` = bytes of history in
 // front of them in the window (0 for a record's first block, LZ_BLK afterwards), abs0 = position of the block in the record.
 // Same contract as deflate_block MODE 2: the bit buffer is cleared here and the stream's partial word travels in z.carry.
@@ -127,17 +138,25 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
             h = (w * 2654435761u) >> (32 - C::HBITS);
             const uint32_t maxl = min(258u, (uint32_t)(len - i)), avail = (uint32_t)i + hist;
             const uint2 e = *reinterpret_cast<const uint2 *>(&X.table[h * LZ_WAYS]);
+            // the four bytes in front of mine: the candidates at distances 1..4 come out of (prev4 : w) in registers (one byte-align each)
+            // instead of four more unaligned LDS loads (round 3: a third of the matcher's LDS reads)
+            const uint32_t prev4 = avail >= 4u ? lds_load32u(X.win + widx - 4) : 0u;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t ent = k == 0 ? e.x & 0xFFFFu : k == 1 ? e.x >> 16 : k == 2 ? e.y & 0xFFFFu : e.y >> 16;
                 const uint32_t d = k < 4 ? (p16 - ent) & 0xFFFFu : (uint32_t)(k - 3);
-                if (d >= 1 && d <= avail && d <= 32768u && lds_load32u(X.win + widx - d) == w) {
+                bool hit;
+                if (k < 4) hit = d >= 1 && d <= avail && d <= 32768u && lds_load32u(X.win + widx - d) == w;
+                else hit = avail >= 4u && __builtin_amdgcn_alignbyte(w, prev4, 4u - d) == w;
+                if (hit) {
                     const uint32_t l = lz_match_len(X.win, widx, widx - d, maxl);
                     if (l > best_l || (l == best_l && d < best_d)) { best_l = l; best_d = d; }
                 }
             }
         }
-        if (i < len) X.D[i] = best_l >= (uint32_t)LZ_MINLEN ? (uint16_t)best_d : (uint16_t)0;
+        // LzShort: a distance needs 13 bits, the three above them carry the match length (4 .. 10; 7 = 11 or more: measure again), so the parse and
+        // the passes behind it need not walk the window again for nearly every match (raw signals: matches of 4 - 5 bytes)
+        if (i < len) X.D[i] = best_l >= (uint32_t)LZ_MINLEN ? (uint16_t)(best_d | (C::HIST ? 0u : (min(best_l, 11u) - 4u) << 13)) : (uint16_t)0;
         __syncthreads();
         if (act) X.table[h * LZ_WAYS + wave_id()] = (uint16_t)p16;   // wave k fills way k: see the header note on determinism
         __syncthreads();
@@ -156,7 +175,7 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
                 tok |= bit;
                 if (d) {
                     mat |= bit;
-                    pos += (int)lz_match_len(X.win, WOFF + (uint32_t)pos, WOFF + (uint32_t)pos - d, min(258u, (uint32_t)(len - pos)));
+                    pos += (int)lz_len_of<C>(X, d, pos, len);
                 } else pos++;
             }
             X.entry[tid + 1] = (uint16_t)(pos > base + K ? pos - (base + K) : 0);
@@ -172,7 +191,9 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
             const int pos = base + j;
-            X.D[pos + 1] = (uint16_t)lz_match_len(X.win, WOFF + (uint32_t)pos, WOFF + (uint32_t)pos - X.D[pos], min(258u, (uint32_t)(len - pos)));
+            const uint32_t d = X.D[pos];
+            X.D[pos + 1] = (uint16_t)lz_len_of<C>(X, d, pos, len);
+            if (!C::HIST) X.D[pos] = (uint16_t)(d & 0x1FFFu);              // the plain distance for the passes behind
         }
     }
     __syncthreads();
