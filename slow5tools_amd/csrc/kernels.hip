@@ -333,8 +333,10 @@ __global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list
 // record (LzLong only), 1 = this kernel's share of a batch that runs both (LzShort: payloads <= 8 KiB, LzLong: the others).
 constexpr uint32_t LZ_BYTES = (sizeof(LzSharedT<LzLong>) + 15u) & ~15u;
 constexpr uint32_t LZS_BYTES = (sizeof(LzSharedT<LzShort>) + 15u) & ~15u;
+// build = 1 (LzShort, a batch of short raw-signal records only): the payload head | u64 N | int16 samples | aux is put together right here
+// in the window — no k_pack launch, no parked copy of the payload through HBM
 template <class C>
-__global__ __launch_bounds__(NT) void k_deflate_lz(EncParams p, int use_list, int which) {
+__global__ __launch_bounds__(NT, C::HIST ? 1 : 4) void k_deflate_lz(EncParams p, int use_list, int which, int build) {
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     LzSharedT<C> &X = *reinterpret_cast<LzSharedT<C> *>(smem + S_BYTES + (C::HIST ? 4u * p.obuf_words : 0u));
     uint32_t *obuf = C::HIST ? reinterpret_cast<uint32_t *>(smem + S_BYTES) : X.obuf_alias;
@@ -347,10 +349,39 @@ __global__ __launch_bounds__(NT) void k_deflate_lz(EncParams p, int use_list, in
         // whose record: by the payload size the descriptor implies (signal press none: head + u64 + 2 bytes per sample + aux) — out_len[r]
         // turns from the payload's length into the record's when a kernel is done with it, so it cannot say
         if (which && (d.hdr_len + 8u + 2u * d.n_samples + d.aux_len <= (uint32_t)LzShort::BLK) != !C::HIST) continue;
-        const uint32_t plen = p.a.out_len[r];
+        uint32_t plen = 0;
+        if (!build) plen = p.a.out_len[r];
         uint8_t *out = p.a.slots + d.out_off;
         const uint8_t *src = out + park_offset(d, p.a.sig_method);
         __syncthreads();
+        if constexpr (!C::HIST) {
+            if (build) {
+                uint8_t *w8 = X.win;
+                const uint8_t *hdr = p.a.hdr + d.hdr_off;
+                for (uint32_t i = tid; i < d.hdr_len; i += NT) w8[i] = hdr[i];
+                if (tid < 8) w8[d.hdr_len + tid] = (uint8_t)((uint64_t)d.n_samples >> (8 * tid));
+                // samples: dword loads from the (16-byte aligned) signal, 16-bit stores (the head's 2 + id + 36 + 8 bytes leave the samples 2-byte aligned)
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(p.a.sig + d.sig_off);
+                uint8_t *sp = w8 + d.hdr_len + 8;
+                const bool al2 = ((d.hdr_len + 8u) & 1u) == 0;
+                for (uint32_t i = tid; i < (d.n_samples + 1) / 2; i += NT) {
+                    const uint32_t v = s32[i];
+                    if (al2) {
+                        reinterpret_cast<uint16_t *>(sp)[2 * i] = (uint16_t)v;
+                        if (2 * i + 1 < d.n_samples) reinterpret_cast<uint16_t *>(sp)[2 * i + 1] = (uint16_t)(v >> 16);
+                    } else {
+                        sp[4 * i] = (uint8_t)v; sp[4 * i + 1] = (uint8_t)(v >> 8);
+                        if (2 * i + 1 < d.n_samples) { sp[4 * i + 2] = (uint8_t)(v >> 16); sp[4 * i + 3] = (uint8_t)(v >> 24); }
+                    }
+                }
+                if (d.aux_len) {
+                    const uint8_t *aux = p.a.aux + d.aux_off;
+                    uint8_t *ap = sp + 2 * d.n_samples;
+                    for (uint32_t i = tid; i < d.aux_len; i += NT) ap[i] = aux[i];
+                }
+                plen = d.hdr_len + 8u + 2u * d.n_samples + d.aux_len;
+            }
+        }
         {   // a record starts with an empty table (the output must not depend on what this workgroup encoded before)
             uint4 *t4 = reinterpret_cast<uint4 *>(X.table);
             for (uint32_t i = tid; i < sizeof(X.table) / 16; i += NT) t4[i] = make_uint4(0, 0, 0, 0);
@@ -364,7 +395,7 @@ __global__ __launch_bounds__(NT) void k_deflate_lz(EncParams p, int use_list, in
         do {
             const uint32_t blen = min(plen - done, (uint32_t)C::BLK);
             const bool final = done + blen == plen;
-            {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
+            if (!build) {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
                 const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
                 uint4 *d4 = reinterpret_cast<uint4 *>(X.win + C::WOFF);
                 for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
@@ -1123,7 +1154,7 @@ extern "C" uint64_t s5gpu_slot_bound(uint32_t n, uint32_t hdr_len, uint32_t aux_
     return (z + 16 + 15) & ~15ull;
 }
 
-static void launch_lz(EncParams p, uint32_t n, uint32_t max_payload, hipStream_t st);
+static void launch_lz(EncParams p, uint32_t n, uint32_t max_payload, hipStream_t st, bool build = false);
 static int enc_check(const s5gpu_encode_args_t *a) {
     if (!a || (a->n_reads && (!a->desc || !a->sig || !a->hdr || !a->slots || !a->out_len))) return S5GPU_ERR_ARG;
     if (a->rec_method != S5GPU_REC_NONE && a->rec_method != S5GPU_REC_ZLIB && a->rec_method != S5GPU_REC_ZSTD) return S5GPU_ERR_ARG;
@@ -1204,8 +1235,10 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     if (a->rec_method == S5GPU_REC_ZLIB && a->sig_method == S5GPU_SIG_NONE) {
         // raw int16 samples: the redundancy is repeated sample pairs at any distance, not runs — the LZ77 matcher (lz_dev.h)
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
-        hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
-        launch_lz(p, a->n_reads, a->max_payload, st);
+        // raw-signal records: a batch of short ones (payloads of one 8 KiB block) builds its payloads inside the matcher's kernel
+        const bool all_short = a->max_payload != 0 && a->max_payload <= (uint32_t)LzShort::BLK;
+        if (!all_short) hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
+        launch_lz(p, a->n_reads, a->max_payload, st, all_short);
         HIP_TRY(hipGetLastError());
         return S5GPU_OK;
     }
@@ -1237,14 +1270,15 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
 
 // The LZ77 kernels over parked payloads (out_len[r] = payload length): payloads of at most 8 KiB on LzShort (4 workgroups per CU), the rest on
 // LzLong (1 per CU).  max_payload == 0: unknown (the solo press does not say): both run, each takes its share.
-static void launch_lz(EncParams p, uint32_t n, uint32_t max_payload, hipStream_t st) {
+static void launch_lz(EncParams p, uint32_t n, uint32_t max_payload, hipStream_t st, bool build) {
     p.obuf_words = (DEFL_BLK + 64) / 4;
     const bool any_long = max_payload == 0 || max_payload > (uint32_t)LzShort::BLK;
     const uint32_t gs = n < 8192 ? n : 8192;
-    hipLaunchKernelGGL(k_deflate_lz<LzShort>, dim3(gs), dim3(NT), S_BYTES + LZS_BYTES, st, p, 0, any_long ? 1 : 0 /* which = 0: every record is short */);
+    hipLaunchKernelGGL(k_deflate_lz<LzShort>, dim3(gs), dim3(NT), S_BYTES + LZS_BYTES, st, p, 0, any_long ? 1 : 0 /* which = 0: every record is short */,
+                       build && !any_long ? 1 : 0);
     if (any_long) {
         const uint32_t gl = n < 2048 ? n : 2048;
-        hipLaunchKernelGGL(k_deflate_lz<LzLong>, dim3(gl), dim3(NT), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, st, p, 0, 1);
+        hipLaunchKernelGGL(k_deflate_lz<LzLong>, dim3(gl), dim3(NT), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, st, p, 0, 1, 0);
     }
 }
 

@@ -61,8 +61,8 @@ __device__ __forceinline__ uint32_t lds_load32u(const uint8_t *p) {
     return __builtin_amdgcn_alignbit(q[1], q[0], (uint32_t)(a & 3) * 8u);
 }
 // length of the match between window positions a (current) and b < a, at most maxl; the first LZ_MINLEN bytes are known equal
-__device__ __forceinline__ uint32_t lz_match_len(const uint8_t *win, uint32_t a, uint32_t b, uint32_t maxl) {
-    uint32_t l = LZ_MINLEN;
+__device__ __forceinline__ uint32_t lz_match_len(const uint8_t *win, uint32_t a, uint32_t b, uint32_t maxl, uint32_t from = LZ_MINLEN) {
+    uint32_t l = from;
     while (l + 4 <= maxl) {
         const uint32_t x = lds_load32u(win + a + l) ^ lds_load32u(win + b + l);
         if (x) return l + ((uint32_t)__ffs((int)x) - 1u) / 8u;
@@ -141,6 +141,9 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
             // the four bytes in front of mine: the candidates at distances 1..4 come out of (prev4 : w) in registers (one byte-align each)
             // instead of four more unaligned LDS loads (round 3: a third of the matcher's LDS reads)
             const uint32_t prev4 = avail >= 4u ? lds_load32u(X.win + widx - 4) : 0u;
+            // ... and the four bytes behind mine: a verified candidate's length is settled by ONE more dword compare in nearly every case
+            // (raw signals match over 4 - 5 bytes); only a candidate that agrees over all eight bytes walks on
+            const uint32_t w2 = lds_load32u(X.win + widx + 4);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t ent = k == 0 ? e.x & 0xFFFFu : k == 1 ? e.x >> 16 : k == 2 ? e.y & 0xFFFFu : e.y >> 16;
@@ -149,7 +152,10 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
                 if (k < 4) hit = d >= 1 && d <= avail && d <= 32768u && lds_load32u(X.win + widx - d) == w;
                 else hit = avail >= 4u && __builtin_amdgcn_alignbyte(w, prev4, 4u - d) == w;
                 if (hit) {
-                    const uint32_t l = lz_match_len(X.win, widx, widx - d, maxl);
+                    const uint32_t x = (k < 4 ? lds_load32u(X.win + widx - d + 4) : __builtin_amdgcn_alignbyte(w2, w, 4u - d)) ^ w2;
+                    uint32_t l = x ? 4u + ((uint32_t)__ffs((int)x) - 1u) / 8u : 8u;
+                    if (l >= maxl) l = maxl;                                   // (the bytes behind the block's end do not count)
+                    else if (!x) l = lz_match_len(X.win, widx, widx - d, maxl, 8u);
                     if (l > best_l || (l == best_l && d < best_d)) { best_l = l; best_d = d; }
                 }
             }

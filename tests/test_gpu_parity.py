@@ -504,6 +504,34 @@ def test_lz77_matcher_streams_inflate_with_stock_zlib_and_find_the_redundancy(pr
     _lib.check(_lib.lib().s5gpu_set_option(b"inflate_par", 1))
 
 
+def test_lz77_short_record_shape_builds_its_payloads_and_shares_batches_with_the_long_shape(press):
+    """round 3: raw-signal records whose payload fits one 8 KiB block take LzShort (38 KiB of LDS, the payload put together inside the kernel);
+    a batch that also holds longer records runs both shapes, each on its share.  Ids of odd and even length (the samples then sit 1- or
+    2-byte aligned in the payload), aux tails, empty and one-sample reads, a record of exactly 8192 payload bytes and one of 8193: stock
+    zlib must give back the oracle's payloads, and a short record must come out the same whether or not long ones share its batch"""
+    rng = np.random.default_rng(77)
+    def mk(n, k, aux=b""):
+        sig = ob.synth_read(0x5105, 3000 + k, n)
+        rid = b"r" * (5 + k % 7)
+        return sig, press.pack_hdr(rid, k % 3, 8192.0, 23.0, 1467.61, 4000.0), aux
+    short = [mk(int(rng.integers(0, 4000)), k, bytes(rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8))) for k in range(120)]
+    short += [mk(0, 200), mk(1, 201), mk(2, 202)]
+    hl = len(press.pack_hdr(b"r" * 6, 0, 1.0, 1.0, 1.0, 1.0))                     # 2 + 6 + 36
+    short.append(mk((8192 - hl - 8) // 2, 1))                                   # payload of exactly 8192 bytes (id of 6 characters)
+    longer = [mk((8192 - hl - 8) // 2 + 1, 1), mk(30000, 300), mk(9000, 301)]
+    def run(items):
+        recs = press.encode_records([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], press.REC_ZLIB, press.SIG_NONE)
+        for (sig, hdr, aux), rec in zip(items, recs):
+            assert int.from_bytes(rec[:8], "little") == len(rec) - 8
+            assert zlib.decompress(rec[8:]) == hdr + struct.pack("<Q", sig.size) + sig.tobytes() + aux
+        return recs
+    a = run(short)
+    b = run(short[:60] + longer + short[60:])
+    assert a == b[:60] + b[63:]
+    z6 = sum(len(zlib.compress(i[1] + struct.pack("<Q", i[0].size) + i[0].tobytes() + i[2], 6)) + 8 for i in short)
+    assert sum(map(len, a)) <= 1.04 * z6
+
+
 def test_lz77_matcher_output_is_deterministic_and_independent_of_the_batch(press):
     rng = np.random.default_rng(13)
     sigs = [(500 + 25 * rng.standard_normal(int(n))).astype(np.int16) for n in rng.integers(100, 30000, 40)]

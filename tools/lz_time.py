@@ -39,5 +39,5 @@ for i, rec in zip(idx, b.records(idx)):
     assert zlib.decompress(rec[8:]) == pay
     ref += len(zlib.compress(pay, 6)) + 8
 got = int(b.out_len[torch.tensor(idx)].sum().item())
-print("none + zlib, %d reads x %d samples: k_pack + k_deflate_lz %.2f ms = %.1f GB/s of raw signal, %.2f M reads/s; %.4f B/sample (zlib-6 on the sampled reads: x %.4f)" % (
+print("none + zlib, %d reads x %d samples: (k_pack +) k_deflate_lz %.2f ms = %.1f GB/s of raw signal, %.2f M reads/s; %.4f B/sample (zlib-6 on the sampled reads: x %.4f)" % (
     n_reads, n, ms, n_reads * 2 * n / ms / 1e6, n_reads / ms / 1e3, z / (n_reads * n), got / ref))
