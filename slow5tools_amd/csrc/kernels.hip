@@ -252,7 +252,10 @@ __device__ __forceinline__ uint32_t park_offset(const s5gpu_read_desc_t &d, int 
 // Staged path, step 1: payload straight to HBM.  mode 0: all reads, parked for k_deflate_staged;
 // mode 1: record compression "none" — the payload IS the record: [u64 size][payload] at the slot head;
 // mode 2: like 0 but only the reads on the overflow list.
-__global__ __launch_bounds__(NT) void k_pack(EncParams p, int mode) {
+#ifndef S5_PACK_WG
+#define S5_PACK_WG 8      // (round 3, measured on the long-read leg: 4 / 5 / 6 / 8 workgroups per CU = 23.3 / 22.4 / 22.1 / 22.0 ms)
+#endif
+__global__ __launch_bounds__(NT, S5_PACK_WG) void k_pack(EncParams p, int mode) {
     __shared__ uint32_t ws[16];
     __shared__ uint32_t tile_keys[SVB_TILE / 16 + 4];       // one tile's key bytes (4096 / 4) ...
     __shared__ uint32_t tile_data[3 * SVB_TILE / 4 + 4];    // ... and data bytes (at most 3 per int16 sample), + the copy's look-ahead word
@@ -274,57 +277,67 @@ __global__ __launch_bounds__(NT) void k_pack(EncParams p, int mode) {
     }
 }
 
-// Staged path, step 2: DEFLATE a parked payload, 16 KiB block at a time through LDS.
-__global__ __launch_bounds__(NT) void k_deflate_staged(EncParams p, int use_list) {
+// Staged path, step 2: DEFLATE a parked payload, 16 KiB block at a time through LDS, in place in the read's slot.  Returns the record's
+// length (u64 prefix included; uniform); the prefix and out_len[r] are written here.
+__device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, uint32_t r, DeflShared &S, uint32_t *obuf, BuildScratch &B, uint8_t *stage) {
+    const int tid = threadIdx.x;
+    const s5gpu_read_desc_t d = p.a.desc[r];
+    uint8_t *out = p.a.slots + d.out_off;
+    const uint8_t *src = out + park_offset(d, p.a.sig_method);
+    const uint32_t plen = p.a.out_len[r];
+    __syncthreads();
+    ZOut z;
+    z.bitpos = 80;        // u64 size prefix (words 0, 1: written last) + CMF/FLG 78 9c
+    z.flushed = 2;        // obuf[0] = stream word 2
+    z.carry = 0x9c78u;
+    uint32_t adA = 1, adB = 0, done = 0;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    do {
+        const uint32_t blen = min(plen - done, (uint32_t)DEFL_BLK);
+        const bool final = done + blen == plen;
+        {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
+            uint4 *d4 = reinterpret_cast<uint4 *>(stage);
+            for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
+        }
+        __syncthreads();
+        deflate_block<2, uint64_t>(S, B, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
+        done += blen;
+        if (!final) {
+            flush_words(obuf, out32, z, false);
+            z.carry = obuf[0];      // uniform: every lane reads the same word (flush_words ends on a barrier)
+            __syncthreads();        // ... before the next block's scratch overwrites it
+        }
+    } while (done < plen);
+    z.bitpos = (z.bitpos + 7) & ~7u;
+    if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
+    z.bitpos += 32;
+    __syncthreads();
+    flush_words(obuf, out32, z, true);
+    const uint32_t total = z.bitpos >> 3;
+    __syncthreads();
+    if (tid == 0) {
+        *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
+        p.a.out_len[r] = total;
+    }
+    return total;
+}
+#ifndef S5_STAGED_WG
+#define S5_STAGED_WG 4
+#endif
+__global__ __launch_bounds__(NT, S5_STAGED_WG) void k_deflate_staged(EncParams p, int use_list) {
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     BuildScratch &B = *reinterpret_cast<BuildScratch *>(obuf);   // dead whenever the bit buffer is live (deflate_block MODE 2)
     uint8_t *stage = smem + S_BYTES + 4u * p.obuf_words;
-    const int tid = threadIdx.x;
     const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
-    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
-        const uint32_t r = use_list ? p.a.ovf[1 + it] : it;
-        const s5gpu_read_desc_t d = p.a.desc[r];
-        uint8_t *out = p.a.slots + d.out_off;
-        const uint8_t *src = out + park_offset(d, p.a.sig_method);
-        const uint32_t plen = p.a.out_len[r];
-        __syncthreads();
-        ZOut z;
-        z.bitpos = 80;        // u64 size prefix (words 0, 1: written last) + CMF/FLG 78 9c
-        z.flushed = 2;        // obuf[0] = stream word 2
-        z.carry = 0x9c78u;
-        uint32_t adA = 1, adB = 0, done = 0;
-        uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
-        do {
-            const uint32_t blen = min(plen - done, (uint32_t)DEFL_BLK);
-            const bool final = done + blen == plen;
-            {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
-                const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
-                uint4 *d4 = reinterpret_cast<uint4 *>(stage);
-                for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
-            }
-            __syncthreads();
-            deflate_block<2, uint64_t>(S, B, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
-            done += blen;
-            if (!final) {
-                flush_words(obuf, out32, z, false);
-                z.carry = obuf[0];      // uniform: every lane reads the same word (flush_words ends on a barrier)
-                __syncthreads();        // ... before the next block's scratch overwrites it
-            }
-        } while (done < plen);
-        z.bitpos = (z.bitpos + 7) & ~7u;
-        if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
-        z.bitpos += 32;
-        __syncthreads();
-        flush_words(obuf, out32, z, true);
-        const uint32_t total = z.bitpos >> 3;
-        __syncthreads();
-        if (tid == 0) {
-            *reinterpret_cast<uint64_t *>(out) = (uint64_t)(total - 8);
-            p.a.out_len[r] = total;
-        }
-    }
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x)
+        deflate_staged_record(p, use_list ? p.a.ovf[1 + it] : it, S, obuf, B, stage);
 }
+// (Round 3 tried ORDERED SINGLE-PASS OUTPUT here as well — tickets, compress in place, publish the size, look-back, move the record to its
+// place in the stream, no compaction launch: correct, and 32.3 ms per long-read step against 21.8 + 2.5 for this kernel + k_compact.  A long
+// record's size is only known when it is finished, so a workgroup waits for EVERY predecessor of its dispatch wave to finish before it may
+// move its record and retire: the spread of completion times becomes idle CUs.  k_encode_stream can publish a size before it packs.)
 
 // Staged path with the LZ77 matcher (lz_dev.h): records whose signal press is "none" (raw int16 samples) and byte ranges of the
 // solo zlib press.  LzLong: the parked payload goes through LDS 16 KiB at a time like k_deflate_staged; the previous block stays in
@@ -1308,10 +1321,6 @@ extern "C" int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *a, uint8_t *st
     EncParams p;
     p.a = *a;
     p.dbg = 0; p.zseq = g_zstd_sequences;
-    const uint32_t cap = fused_cap(a);
-    p.pay_cap = cap;
-    p.obuf_words = (cap + 64 > B_BYTES ? cap + 64 : B_BYTES) / 4;
-    const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
     StreamParams sp;
     sp.state = reinterpret_cast<unsigned long long *>(state);
     sp.ctl = ctl;
@@ -1319,6 +1328,10 @@ extern "C" int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *a, uint8_t *st
     sp.rec_off = rec_off;
     HIP_TRY(hipMemsetAsync(state, 0, 8ull * a->n_reads, st));
     HIP_TRY(hipMemsetAsync(ctl, 0, 16, st));
+    const uint32_t cap = fused_cap(a);
+    p.pay_cap = cap;
+    p.obuf_words = (cap + 64 > B_BYTES ? cap + 64 : B_BYTES) / 4;
+    const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
     const bool xz = a->sig_method == S5GPU_SIG_EX_ZD;
     if (cap <= 8192) { if (xz) hipLaunchKernelGGL((k_encode_stream<uint32_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p, sp); else hipLaunchKernelGGL(k_encode_stream<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p, sp); }
     else { if (xz) hipLaunchKernelGGL((k_encode_stream<uint64_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p, sp); else hipLaunchKernelGGL(k_encode_stream<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p, sp); }
