@@ -443,7 +443,10 @@ __global__ __launch_bounds__(NT, C::HIST ? 1 : 4) void k_deflate_lz(EncParams p,
 
 // zstd record press, fused: payload in LDS -> literals-only zstd frame (zstd_enc_dev.h).  Same shape as k_encode_fused.
 template <bool EXZD>
-__global__ __launch_bounds__(NT, 6) void k_zstd_fused(EncParams p) {
+#ifndef S5_ZF_WG
+#define S5_ZF_WG 7      // (round 3, measured: 6 / 7 / 8 workgroups per CU = 8.10 / 7.43 / 7.62 ms per 262 k reads)
+#endif
+__global__ __launch_bounds__(NT, S5_ZF_WG) void k_zstd_fused(EncParams p) {
     const uint32_t r = blockIdx.x;
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
@@ -468,7 +471,10 @@ __global__ __launch_bounds__(NT, 6) void k_zstd_fused(EncParams p) {
     if (threadIdx.x == 0) p.a.out_len[r] = total;
 }
 // ... and staged: a parked payload, 16 KiB block at a time through LDS (k_deflate_staged's twin)
-__global__ __launch_bounds__(NT) void k_zstd_staged(EncParams p, int use_list) {
+#ifndef S5_ZS_WG
+#define S5_ZS_WG 3
+#endif
+__global__ __launch_bounds__(NT, S5_ZS_WG) void k_zstd_staged(EncParams p, int use_list) {
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     uint8_t *stage = smem + S_BYTES + 4u * p.obuf_words;
@@ -764,7 +770,10 @@ __global__ __launch_bounds__(64) void k_zstd_inflate_np(s5gpu_decode_args_t a, N
 static_assert(sizeof(ZstdShared::huf) + sizeof(ZstdShared::ll_e) >= SVB_WSTAGE && offsetof(ZstdShared, ll_e) == sizeof(ZstdShared::huf),
               "the Huffman table and the table behind it double as the svb-zd stage");
 template <bool UNPACK>
-__global__ __launch_bounds__(64) void k_zstd_inflate(s5gpu_decode_args_t a) {
+#ifndef S5_ZI_W
+#define S5_ZI_W 4
+#endif
+__global__ __launch_bounds__(64, S5_ZI_W) void k_zstd_inflate(s5gpu_decode_args_t a) {
     __shared__ __attribute__((aligned(16))) ZstdShared T;
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];
@@ -952,7 +961,10 @@ __device__ __forceinline__ void unpack_record_wg(const s5gpu_decode_args_t &a, u
     }
 }
 
-__global__ __launch_bounds__(NT) void k_unpack(s5gpu_decode_args_t a) {
+#ifndef S5_UNP_WG
+#define S5_UNP_WG 5
+#endif
+__global__ __launch_bounds__(NT, S5_UNP_WG) void k_unpack(s5gpu_decode_args_t a) {
     __shared__ uint32_t ws[16];
     __shared__ __attribute__((aligned(16))) uint8_t svb_stage[SVB_STAGE];
     __shared__ int s_err;
