@@ -62,11 +62,13 @@ constexpr int INF_NEED_FALLBACK = 8;
 constexpr int IP_DBITS = S5_IP_DBITS;  // primary distance lookup bits (>= 7: the code-length code's 7-bit table is built in the same storage)
 static_assert(IP_DBITS >= 7 && IP_DBITS <= INF_DBITS, "");
 
-struct InflParShared {                 // per wave: 6.6 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
+constexpr int IP_WAIT_SVB = 256;       // ... in the instantiation for svb-zd records (below)
+template <int WAIT>
+struct InflParSharedT {                 // per wave: 6.6 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
                                        // LDS per wave = + 33 % time), so nothing here is larger than it has to be
     uint32_t win[IP_SPAN / 4 + 8];     // window; the header parser uses its first INF_IW bytes
     union {
-        uint16_t wq[IP_WAIT];          // waiting match: position in the round's output (< 64 Ki); its length and distance wait in the
+        uint16_t wq[WAIT];             // waiting match: position in the round's output (< 64 Ki); its length and distance wait in the
                                        // first three of the bytes it will produce — a match is at least three bytes long
         uint16_t llut[32];             // (64 bytes of scratch for the header parser's symbol sort; no lit/len lookup table here)
     };
@@ -86,7 +88,16 @@ struct InflParShared {                 // per wave: 6.6 KiB — the kernel's spe
 #ifdef S5_IP_PAD
     uint8_t pad[S5_IP_PAD];            // tools only: how the kernel's time follows the number of resident waves
 #endif
+    static constexpr int N_WAIT = WAIT;
 };
+// Two sizes of the waiting list (round 3).  The kernel's speed follows the number of resident waves, and at 80 VGPRs the register file
+// holds 24 per CU: 7.4 KiB of LDS per wave allow 21, 6.4 KiB all 24 (measured on 1 M own records: 30.9 -> 28.6 ms).  What the list has to
+// hold depends on what was compressed: stock zlib leaves ~110 waiting matches in a 4000-sample svb-zd record (a list of 256 takes a record
+// per round; long reads take a few more rounds in their key bytes), but several hundred per window in a RAW-SIGNAL record (four tokens
+// out of five are far matches: 768 entries, 15.8 ms per 8192 fixture records against 25 with 512).  The caller of s5gpu_decode_dev names
+// the signal press, so svb-zd records get the small list; inflate-only calls and raw-signal records keep the large one.
+using InflParShared = InflParSharedT<IP_WAIT>;
+using InflParSharedSvb = InflParSharedT<IP_WAIT_SVB>;
 static_assert(INF_IW <= IP_SPAN, "the header parser's window is the head of the round window");
 
 // 32 bits of the window starting at bit p (two aligned dwords + one alignbit)
@@ -159,8 +170,8 @@ struct IpLimits { ip_s2 m1[8]; uint32_t base; int np; uint32_t lenmask; };   // 
 // The loop is wave-uniform (it runs while any lane has tokens left) and the length / distance part is entered only in steps in
 // which some lane stands at a length code: a lane that is done, or at a literal, rides along predicated instead of parking
 // behind nested exec masks.
-template <bool WRITE>
-__device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLimits &L, uint32_t st, uint32_t end, uint32_t obase, uint32_t o_abs0,
+template <bool WRITE, class SH>
+__device__ __forceinline__ IpSeg ip_decode_segment(SH &T, const IpLimits &L, uint32_t st, uint32_t end, uint32_t obase, uint32_t o_abs0,
                                                    uint8_t *dst, uint32_t wbase = 0, uint32_t wmax = 0) {
     IpSeg r;
     r.cross = st; r.nout = 0; r.eob = 0; r.eobpos = 0; r.bad = 0; r.nwait = 0;
@@ -284,7 +295,8 @@ __device__ __forceinline__ IpSeg ip_decode_segment(InflParShared &T, const IpLim
 }
 
 // Inflate one zlib stream with one wave.  Returns a status of inflate_dev.h or INF_NEED_FALLBACK (nothing usable was written).
-__device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap,
+template <class SH>
+__device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap,
                                                 uint32_t *out_len, uint32_t *dbg = nullptr) {
     const int lane = lane_id();
     *out_len = 0;
@@ -330,7 +342,7 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             continue;
         }
         int nl, nd;
-        { const int rc = infl_block_tables<InflParShared, 0, true, IP_DBITS>(T, src, total, total_bits, b, type, nl, nd); if (rc != INF_OK) return rc; }
+        { const int rc = infl_block_tables<SH, 0, true, IP_DBITS>(T, src, total, total_bits, b, type, nl, nd); if (rc != INF_OK) return rc; }
         pos = bi_consumed_bits(b);
         if (b.wbase != hdr_wb) win_fresh = false;                             // (the header parser slid its window: never, for a window that starts at the header)
         if (dbg && dbg[3] == 1) return INF_OK;       // tools/par_probe.py cut-off: block header and tables only
@@ -423,7 +435,7 @@ __device__ __forceinline__ int zlib_inflate_par(InflParShared &T, const uint8_t 
             const uint32_t nincl = wave_incl_add(n_all);
             {
                 // (the sums never decrease: the lanes that fit are a prefix; list positions have 16 bits)
-                const uint64_t over = __ballot(wincl > (uint32_t)IP_WAIT || nincl > 0xFFFFu);
+                const uint64_t over = __ballot(wincl > (uint32_t)SH::N_WAIT || nincl > 0xFFFFu);
                 const int mfit = over ? __ffsll((long long)over) - 1 : 64;
                 if (mfit < m) m = mfit;
                 if (m == 0) { if (dbg) dbg[2] = 3; return INF_NEED_FALLBACK; }   // one segment over the list's capacity or with >= 64 KiB of output

@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64) void k_inflate_head(s5gpu_decode_args_t a) {
 // it just wrote is in L2, the window is free as a stage for the data bytes, and the chain of dependent loads a separate kernel
 // starts with (fields -> descriptor -> three length fields of the payload) is gone.  fields.reserved = 1 marks such a record;
 // k_unpack_rest does what is left (records the fallback decoder inflated) and clears the marks.
-static_assert(sizeof(InflParShared::win) >= SVB_WSTAGE, "the inflate window doubles as the svb-zd stage");
+static_assert(sizeof(InflParSharedSvb::win) >= SVB_WSTAGE, "the inflate window doubles as the svb-zd stage");
 // pay: the record's uncompressed bytes — its payload slot, or the workgroup's scratch slot (S5GPU_DEC_NO_PAYLOAD)
 __device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, const s5gpu_rec_desc_t &d, const uint8_t *pay, s5gpu_rec_fields_t &f, uint32_t plen, uint8_t *stage) {
     if (plen < 2) return 7;
@@ -625,7 +625,7 @@ __device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, c
 #endif
 template <bool UNPACK>
 __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_args_t a) {
-    __shared__ InflParShared T;
+    __shared__ typename std::conditional<UNPACK, InflParSharedSvb, InflParShared>::type T;   // svb-zd records: the small waiting list (inflate_par_dev.h)
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
@@ -693,7 +693,7 @@ __device__ __forceinline__ void np_write_fields(const s5gpu_decode_args_t &a, ui
     }
 }
 __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode_args_t a, NpParams np) {
-    __shared__ InflParShared T;
+    __shared__ InflParSharedSvb T;
     uint8_t *pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
     for (;;) {
         uint32_t r = blockIdx.x;
