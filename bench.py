@@ -190,45 +190,71 @@ def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
     total = args.long_reads
     lo, hi = shard.shard_range(total, rank, world)
     mine = hi - lo
-    chunk = max(1, min(args.long_chunk, mine))
+    # at least four chunks per rank, alternating between two sets of output buffers on two streams: the compaction of one chunk
+    # (a copy, HBM-bound) and the drain of its last workgroups run under the next chunk's deflate (VALU-bound).  This is what two
+    # GPU workers of the file pipeline do (examples/s5view.c); 288 GB of HBM hold both sets many times over.
+    chunk = max(1, min(args.long_chunk, -(-mine // 4)))
+    n_sets = 1 if args.long_streams < 2 or mine <= chunk else 2
     chunks = []
-    first_b = None
-    for c0 in range(lo, hi, chunk):
+    sets = []
+    for ci, c0 in enumerate(range(lo, hi, chunk)):
         cn = min(chunk, hi - c0)
-        b = press.DeviceBatch(np.full(cn, n, dtype=np.uint64), device=dev, share=first_b)
-        if first_b is None:
-            first_b = b
+        b = press.DeviceBatch(np.full(cn, n, dtype=np.uint64), device=dev, share=sets[ci % n_sets] if ci >= n_sets else None)
+        if ci < n_sets:
+            sets.append(b)
         b.synth(seed=0x5105, first=c0)
         chunks.append((c0, b))
     torch.cuda.synchronize()
-    st = first_b._stream()
+    # stream 0 deflates chunk after chunk; stream 1 compacts chunk c as soon as its deflate is done, under the deflate of chunk c + 1;
+    # a set of output buffers is taken again once its compaction has finished (events both ways)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_sets)]
+    set_free = [None] * n_sets
 
-    def step(evs=None, k=0):
+    def step(evs=None, k=0, serial=False):
         for ci, (_, b) in enumerate(chunks):
-            if evs is not None:
-                L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3], st)
-            b.encode()
-            if evs is not None:
-                L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3 + 1], st)
-            b.compact()
-            if evs is not None:
-                L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3 + 2], st)
+            two = n_sets == 2 and not serial
+            with torch.cuda.stream(streams[0]):
+                st = b._stream()
+                if two and set_free[ci % 2] is not None:
+                    streams[0].wait_event(set_free[ci % 2])
+                if evs is not None:
+                    L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3], st)
+                b.encode()
+                if evs is not None:
+                    L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3 + 1], st)
+                if two:
+                    done = torch.cuda.Event()
+                    done.record(streams[0])
+            with torch.cuda.stream(streams[1 if two else 0]):
+                st = b._stream()
+                if two:
+                    streams[1].wait_event(done)
+                b.compact()
+                if two:
+                    set_free[ci % 2] = torch.cuda.Event()
+                    set_free[ci % 2].record(streams[1])
+                if evs is not None:
+                    L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3 + 2], st)
 
     for _ in range(W):
         step()
     torch.cuda.synchronize()
     # at least ~1 s of device time: the leg's own step count (the headline's K is kept when it is larger)
     K = max(K, args.min_leg_steps_long)
-    evs = make_events(L, _lib, 3 * K * len(chunks))
-    dt = timed(shard, torch, dev, lambda: [step(evs, k) for k in range(K)])
+    dt = timed(shard, torch, dev, lambda: [step() for k in range(K)])
+    # the kernels' own durations: the same chunk loop on ONE stream (launches that overlap share the device, so events around them
+    # would not time a kernel), right behind the timed region
+    Ks = max(2, K // 4)
+    evs = make_events(L, _lib, 3 * Ks * len(chunks))
+    dt_serial = timed(shard, torch, dev, lambda: [step(evs, k, True) for k in range(Ks)])
     enc_ms = cmp_ms = 0.0
-    for i in range(K * len(chunks)):
+    for i in range(Ks * len(chunks)):
         enc_ms += elapsed_ms(L, _lib, evs[3 * i], evs[3 * i + 1])
         cmp_ms += elapsed_ms(L, _lib, evs[3 * i + 1], evs[3 * i + 2])
     for e in evs:
         L.s5gpu_event_destroy(e)
-    enc_ms /= K
-    cmp_ms /= K
+    enc_ms /= Ks
+    cmp_ms /= Ks
     if rank != 0:
         return None
     # the last chunk's output is still in the shared buffers; sizes of every chunk are in its own out_len
@@ -251,13 +277,15 @@ def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
                     "(a 1/%.1f fraction of the 10 M-read job), read-index space split over %d rank(s) with shard_range, chunks of <= %d reads "
                     "(%.2f GB of signal per launch), generated on device" % (total, n, total * 2 * n / 1e9, LONG_TOTAL_READS_FULL / total, world, chunk, chunk * 2 * n / 1e9),
         "value": round(reads_per_s * 2 * n / 1e9, 3), "unit": "GB/s", "reads_per_s": round(reads_per_s, 1), "scaling": "strong",
-        "n_gpus": world, "steps": K, "ms_per_step": round(dt / K * 1e3, 3), "reads_total": total, "reads_rank0": mine, "chunks_rank0": len(chunks),
+        "n_gpus": world, "steps": K, "ms_per_step": round(dt / K * 1e3, 3), "streams": n_sets,
+        "ms_per_step_one_stream": round(dt_serial / Ks * 1e3, 3), "reads_total": total, "reads_rank0": mine, "chunks_rank0": len(chunks),
         "scale_factor_vs_10M_reads": round(LONG_TOTAL_READS_FULL / total, 3),
         "bytes_per_sample": round(z_bytes / (mine * n), 4), "parity_spot_check": bool(parity),
         "kernel_ms": {"pack+deflate_staged": round(enc_ms, 3), "compact": round(cmp_ms, 3)},
         "roofline": {"bound": "hbm", "kernel": "k_pack+k_deflate_staged", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
-                     "note": "rank 0's shard per step; launch = the chunk loop of one step (k_pack + k_deflate_staged per chunk)"},
+                     "note": "rank 0's shard per step; launch = the chunk loop of one step (k_pack + k_deflate_staged per chunk), durations from %d steps of the "
+                             "same loop on one stream right behind the timed region" % Ks},
     }
 
 
@@ -559,7 +587,8 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the configs[1] and configs[4] legs of the default run")
     ap.add_argument("--long-reads", type=int, default=65536, help="configs[3] leg: size of the read-index space (all ranks together)")
     ap.add_argument("--long-samples", type=int, default=100_000)
-    ap.add_argument("--long-chunk", type=int, default=16384, help="configs[3] leg: reads per launch")
+    ap.add_argument("--long-chunk", type=int, default=16384, help="configs[3] leg: reads per launch (at most; a rank's shard is cut into >= 4 chunks)")
+    ap.add_argument("--long-streams", type=int, default=2, help="configs[3] leg: 2 = chunks alternate between two streams / output buffer sets, 1 = one stream")
     ap.add_argument("--decode", action="store_true", help="configs[4] alone: random get-style decode (inflate + svb-zd unpack)")
     ap.add_argument("--get-reads", type=int, default=100_000, help="configs[4]: random read ids to fetch (seed 1)")
     ap.add_argument("--get-batch", type=int, default=4096, help="configs[4]: ids per batch (-K)")
@@ -599,6 +628,9 @@ def main():
 
     L = _lib.lib()
     _lib.check(L.s5gpu_init(local_rank), "s5gpu_init")
+    for kv in filter(None, os.environ.get("S5BENCH_OPTIONS", "").split(",")):   # tools: library options for A/B runs, e.g. staged_fused=0
+        k, v = kv.split("=")
+        _lib.check(L.s5gpu_set_option(k.encode(), int(v)), "s5gpu_set_option " + kv)
     K = args.steps
     global TIMING_DEV
     TIMING_DEV = "cpu" if alias else dev

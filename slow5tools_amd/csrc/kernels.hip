@@ -279,12 +279,10 @@ __global__ __launch_bounds__(NT, S5_PACK_WG) void k_pack(EncParams p, int mode) 
 
 // Staged path, step 2: DEFLATE a parked payload, 16 KiB block at a time through LDS, in place in the read's slot.  Returns the record's
 // length (u64 prefix included; uniform); the prefix and out_len[r] are written here.
-__device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, uint32_t r, DeflShared &S, uint32_t *obuf, BuildScratch &B, uint8_t *stage) {
+__device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, uint32_t r, const s5gpu_read_desc_t &d, uint32_t plen, DeflShared &S, uint32_t *obuf, BuildScratch &B, uint8_t *stage) {
     const int tid = threadIdx.x;
-    const s5gpu_read_desc_t d = p.a.desc[r];
     uint8_t *out = p.a.slots + d.out_off;
     const uint8_t *src = out + park_offset(d, p.a.sig_method);
-    const uint32_t plen = p.a.out_len[r];
     __syncthreads();
     ZOut z;
     z.bitpos = 80;        // u64 size prefix (words 0, 1: written last) + CMF/FLG 78 9c
@@ -331,9 +329,14 @@ __global__ __launch_bounds__(NT, S5_STAGED_WG) void k_deflate_staged(EncParams p
     BuildScratch &B = *reinterpret_cast<BuildScratch *>(obuf);   // dead whenever the bit buffer is live (deflate_block MODE 2)
     uint8_t *stage = smem + S_BYTES + 4u * p.obuf_words;
     const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
-    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x)
-        deflate_staged_record(p, use_list ? p.a.ovf[1 + it] : it, S, obuf, B, stage);
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const uint32_t r = use_list ? p.a.ovf[1 + it] : it;
+        deflate_staged_record(p, r, p.a.desc[r], p.a.out_len[r], S, obuf, B, stage);
+    }
 }
+// (Round 3 tried steps 1 + 2 in ONE workgroup — park the read's payload, barrier, deflate it from there — so that the streaming of one read
+// would run under the arithmetic of the others: 23.1 ms per long-read step against 21.7 for the two launches.  At this kernel's 128 VGPRs /
+// four workgroups per CU the streaming phase has half the waves k_pack runs with, and what it gains in overlap it loses there.)
 // (Round 3 tried ORDERED SINGLE-PASS OUTPUT here as well — tickets, compress in place, publish the size, look-back, move the record to its
 // place in the stream, no compaction launch: correct, and 32.3 ms per long-read step against 21.8 + 2.5 for this kernel + k_compact.  A long
 // record's size is only known when it is finished, so a workgroup waits for EVERY predecessor of its dispatch wave to finish before it may
