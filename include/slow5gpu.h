@@ -175,6 +175,10 @@ int s5gpu_svbzd_encode_dev(const s5gpu_encode_args_t *args, void *hip_stream);
  * fall back to s5gpu_encode_dev + s5gpu_compact_dev.  stream_out must hold the sum of the slot bounds. */
 int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *args, uint8_t *stream_out, uint64_t *rec_off, uint64_t *state,
                             uint32_t *ctl, void *hip_stream);
+/* The same for the svb-zd stage alone (s5gpu_svbzd_encode_dev + s5gpu_compact_dev in one pass): blobs straight into the contiguous
+ * blob stream; ctl as above (ctl[0]: a blob did not fit the LDS budget).  args->hdr / aux / slots / ovf are not used. */
+int s5gpu_svbzd_encode_stream_dev(const s5gpu_encode_args_t *args, uint8_t *stream_out, uint64_t *rec_off, uint64_t *state,
+                                  uint32_t *ctl, void *hip_stream);
 /* single stages, for the solo press calls (slow5_ptr_compress_solo / slow5_ptr_depress_solo):
  *  deflate_parked: zlib-compress byte ranges already parked in their slots — read i's bytes sit at
  *    slots + out_off + ((slot_cap - s5gpu_payload_bound(desc i)) & ~15), out_len[i] = their length on entry

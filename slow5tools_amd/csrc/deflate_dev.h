@@ -1108,31 +1108,46 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 }
 // wave 0 of the workgroup that owns read r (reads are taken in ticket = start order, so every predecessor is
 // already resident and will publish).  Returns the exclusive prefix (byte offset of this record in the stream).
+// E: state words per lane and step — the window of one look-back step is 64 * E predecessors.  Inclusive prefixes travel one window per
+// step (a store seen by a load on another XCD: about a microsecond), so a kernel that retires R reads per microsecond needs a window wider
+// than R.  (Round 3 measured E = 1, 2, 4 on both stream kernels: no gain on either — k_encode_stream 13.63 / 13.75 / 13.94 ms — so E stays 1;
+// what held the svb-zd stream kernel back was its million tickets on one counter and sizes published only at the end, see there.)
+template <int E = 1>
 __device__ __forceinline__ uint64_t lookback_offset(unsigned long long *st, uint32_t r, uint64_t mysize, uint32_t *err, bool published) {
     const int lane = lane_id();
     if (!published && lane == 0) __hip_atomic_store(&st[r], (1ull << 62) | mysize, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t excl = 0;
+    uint64_t acc = 0;                     // per lane; summed over the wave once at the end
     long long base = (long long)r - 1;
     uint32_t spins = 0;
     for (;;) {
-        const long long idx = base - lane;
-        const uint64_t v = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
-        const uint32_t f = (uint32_t)(v >> 62);
-        const uint64_t m0 = __ballot(f == 0), m2 = __ballot(f == 2);
-        const int first0 = m0 ? __ffsll((long long)m0) - 1 : 64;
-        const int first2 = m2 ? __ffsll((long long)m2) - 1 : 64;
-        if (first2 < first0) {   // a prefix is reachable through published sizes: done
-            excl += wave_sum64(lane <= first2 ? (v & LB_MASK) : 0ull);
-            break;
+        uint64_t v[E];                    // E rows of 64 consecutive words (a row = 512 contiguous bytes), nearest row first
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const long long idx = base - 64 * e - lane;
+            v[e] = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
         }
-        // take the published sizes in front of the first unpublished predecessor, then wait for that one
-        excl += wave_sum64(lane < first0 ? (v & LB_MASK) : 0ull);
-        base -= first0;
-        if (first0 < 64) {
-            if (++spins > (1u << 22)) { if (lane == 0) *err = 1; break; }   // never hang the GPU: report instead
-            __builtin_amdgcn_s_sleep(2);
+        int outcome = 0;                  // 1: reached an inclusive prefix, 2: an unpublished predecessor (wait for it)
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            if (outcome) continue;
+            const uint32_t f = (uint32_t)(v[e] >> 62);
+            const uint64_t m0 = __ballot(f == 0), m2 = __ballot(f == 2);
+            const int first0 = m0 ? __ffsll((long long)m0) - 1 : 64;
+            const int first2 = m2 ? __ffsll((long long)m2) - 1 : 64;
+            if (first2 < first0) {        // a prefix is reachable through published sizes: done
+                acc += lane <= first2 ? (v[e] & LB_MASK) : 0ull;
+                outcome = 1;
+            } else {                      // take the published sizes in front of the first unpublished predecessor
+                acc += lane < first0 ? (v[e] & LB_MASK) : 0ull;
+                if (first0 < 64) { base -= 64 * e + first0; outcome = 2; }
+            }
         }
+        if (outcome == 1) break;
+        if (outcome == 0) { base -= 64 * E; continue; }
+        if (++spins > (1u << 22)) { if (lane == 0) *err = 1; break; }   // never hang the GPU: report instead
+        __builtin_amdgcn_s_sleep(2);
     }
+    const uint64_t excl = wave_sum64(acc);
     if (lane == 0) __hip_atomic_store(&st[r], (2ull << 62) | (excl + mysize), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return excl;
 }

@@ -19,8 +19,14 @@ constexpr int SVB_TILE = NT * 16;   // samples per tile
 // first data byte.  Destinations may be LDS or HBM.  Returns the tile's data byte count (uniform).
 // room: data bytes the destination can still take; if the tile needs more, nothing is written and the
 // (uniform) return value exceeds room — the caller routes the read to the HBM-staged path.
-__device__ __forceinline__ uint32_t svb_encode_tile(const int16_t *__restrict__ sig, uint32_t n, uint32_t t0,
-                                                    uint8_t *keys, uint8_t *data, uint32_t *ws, uint32_t room) {
+// In two halves, so that a caller can learn the sizes of several tiles before it writes any of them (k_svbzd_stream): what a lane
+// holds of a tile between the two is its 16 zig-zag deltas, its 4 key bytes and its byte count.
+struct SvbTileLane {
+    uint32_t z[16];
+    uint32_t key, nbytes;
+    int valid;
+};
+__device__ __forceinline__ void svb_tile_classify(const int16_t *__restrict__ sig, uint32_t n, uint32_t t0, SvbTileLane &T) {
     const int tid = threadIdx.x;
     const uint32_t i0 = t0 + 16u * tid;
     const int valid = i0 >= n ? 0 : (int)min(16u, n - i0);
@@ -41,19 +47,18 @@ __device__ __forceinline__ uint32_t svb_encode_tile(const int16_t *__restrict__ 
     }
     if (valid > 0 && i0 > 0) prev = sig[i0 - 1];
     uint32_t key = 0, nbytes = 0;
-    uint32_t z[16];
     // A lane is almost always full (16 samples) or empty; the full case runs without per-sample predicates.
     const bool full = valid == 16;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int d = x[q] - prev;
         prev = x[q];
-        z[q] = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
+        T.z[q] = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
     }
     if (full) {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const uint32_t code = (z[q] > 0xFFu ? 1u : 0u) + (z[q] >> 16);   // int16 input: z <= 131070, so z >> 16 is 0 or 1
+            const uint32_t code = (T.z[q] > 0xFFu ? 1u : 0u) + (T.z[q] >> 16);   // int16 input: z <= 131070, so z >> 16 is 0 or 1
             key |= code << (2 * q);
             nbytes += code;
         }
@@ -61,40 +66,52 @@ __device__ __forceinline__ uint32_t svb_encode_tile(const int16_t *__restrict__ 
     } else {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const uint32_t code = (z[q] > 0xFFu) + (z[q] > 0xFFFFu);
+            const uint32_t code = (T.z[q] > 0xFFu) + (T.z[q] > 0xFFFFu);
             if (q < valid) {
                 key |= code << (2 * q);
                 nbytes += code + 1;
             }
         }
     }
-    uint32_t total;
-    uint32_t off = block_excl_add(nbytes, ws, total);
-    if (total > room) return total;
-    uint8_t *dp = data + off;
-    if (full) {
+    T.key = key;
+    T.nbytes = nbytes;
+    T.valid = valid;
+}
+// dp: the lane's first data byte (data + its exclusive byte offset in the tile)
+__device__ __forceinline__ void svb_tile_write(const SvbTileLane &T, uint8_t *keys, uint8_t *dp) {
+    const int tid = threadIdx.x;
+    if (T.valid == 16) {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            *dp++ = (uint8_t)z[q];
-            if (z[q] > 0xFFu) {                        // 1.5 % of the samples of a nanopore signal
-                *dp++ = (uint8_t)(z[q] >> 8);
-                if (z[q] > 0xFFFFu) *dp++ = (uint8_t)(z[q] >> 16);
+            *dp++ = (uint8_t)T.z[q];
+            if (T.z[q] > 0xFFu) {                        // 1.5 % of the samples of a nanopore signal
+                *dp++ = (uint8_t)(T.z[q] >> 8);
+                if (T.z[q] > 0xFFFFu) *dp++ = (uint8_t)(T.z[q] >> 16);
             }
         }
     } else {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            if (q < valid) {
-                *dp++ = (uint8_t)z[q];
-                if (z[q] > 0xFFu) *dp++ = (uint8_t)(z[q] >> 8);
-                if (z[q] > 0xFFFFu) *dp++ = (uint8_t)(z[q] >> 16);
+            if (q < T.valid) {
+                *dp++ = (uint8_t)T.z[q];
+                if (T.z[q] > 0xFFu) *dp++ = (uint8_t)(T.z[q] >> 8);
+                if (T.z[q] > 0xFFFFu) *dp++ = (uint8_t)(T.z[q] >> 16);
             }
         }
     }
-    const int nk = (valid + 3) >> 2;
+    const int nk = (T.valid + 3) >> 2;
 #pragma unroll
     for (int q = 0; q < 4; q++)
-        if (q < nk) keys[4 * tid + q] = (uint8_t)(key >> (8 * q));
+        if (q < nk) keys[4 * tid + q] = (uint8_t)(T.key >> (8 * q));
+}
+__device__ __forceinline__ uint32_t svb_encode_tile(const int16_t *__restrict__ sig, uint32_t n, uint32_t t0,
+                                                    uint8_t *keys, uint8_t *data, uint32_t *ws, uint32_t room) {
+    SvbTileLane T;
+    svb_tile_classify(sig, n, t0, T);
+    uint32_t total;
+    const uint32_t off = block_excl_add(T.nbytes, ws, total);
+    if (total > room) return total;
+    svb_tile_write(T, keys, data + off);
     return total;
 }
 

@@ -274,6 +274,16 @@ class DeviceBatch:
                                                  self.lb_state.data_ptr(), self.lb_ctl.data_ptr(), self._stream()),
               "s5gpu_encode_stream_dev")
 
+    def svbzd_encode_stream(self):
+        """svb-zd blobs straight into stream_out / rec_off in one pass (svbzd_encode + compact)"""
+        if not hasattr(self, "lb_state"):
+            t = self.torch
+            self.lb_state = t.zeros(self.n + 1, dtype=t.int64, device=self.dev)
+            self.lb_ctl = t.zeros(4, dtype=t.int32, device=self.dev)
+        check(_lib.lib().s5gpu_svbzd_encode_stream_dev(C.byref(self.args), self.stream_out.data_ptr(), self.rec_off.data_ptr(),
+                                                       self.lb_state.data_ptr(), self.lb_ctl.data_ptr(), self._stream()),
+              "s5gpu_svbzd_encode_stream_dev")
+
     def stream_ok(self):
         """after a synchronise: True if the single-pass stream is valid (no LDS overflow, no look-back timeout)"""
         c = self.lb_ctl.cpu().numpy()

@@ -141,6 +141,20 @@ def test_one_million_reads_svbzd_stage_bit_exact_sample_and_full_round_trip():
     for i in range(0, N_READS, 997):
         blob = b.slots[int(slot_off[i]): int(slot_off[i]) + int(lens[i])].cpu().numpy().tobytes()
         assert blob == ob.svbzd_encode(ob.synth_read(0x5105, i, N)), i
+    # the one-pass form (blobs straight into the stream) against slots + compaction, all 1 M reads: offsets and a hash of the stream
+    del sig, fields
+    b.stream_out = torch.empty(int(lens.sum()) + 64, dtype=torch.uint8, device=dev)
+    b.compact()
+    torch.cuda.synchronize()
+    want_off = b.rec_off.clone()
+    total = int(want_off[N_READS].item())
+    assert total == int(lens.sum())
+    want = b.stream_out[:total].clone()
+    b.stream_out.zero_()
+    b.svbzd_encode_stream()
+    torch.cuda.synchronize()
+    assert b.stream_ok()
+    assert torch.equal(b.rec_off, want_off) and torch.equal(b.stream_out[:total], want)
 
 
 @pytest.mark.gpu

@@ -96,6 +96,34 @@ def test_svbzd_encode_adversarial(press):
         assert blob == ob.svbzd_encode(s)
 
 
+def test_svbzd_stream_one_pass_equals_slots_plus_compaction(press):
+    """s5gpu_svbzd_encode_stream_dev: the blob stream and the offsets of svbzd_encode + compact, in one launch; ragged lengths,
+    empty reads and a read past the LDS budget (ctl[0] tells the caller to take the two-pass route)"""
+    rng = np.random.default_rng(11)
+    lens = [4000, 0, 1, 3, 5, 4096, 4097, 777, 12289, 2, 4000, 16, 9000] + [int(x) for x in rng.integers(0, 6000, 300)]
+    sigs = [(rng.normal(500, 60, n)).astype(np.int16) if i % 3 else rng.integers(-32768, 32768, n, dtype=np.int16) for i, n in enumerate(lens)]
+    b = press.DeviceBatch(lens)
+    b.upload(sigs, [_hdr(press, i) for i in range(len(lens))])
+    b.svbzd_encode()
+    b.compact()
+    want, want_off = b.stream_bytes()
+    b.stream_out.zero_()
+    b.rec_off.zero_()
+    b.svbzd_encode_stream()
+    assert b.stream_ok()
+    got, got_off = b.stream_bytes()
+    assert np.array_equal(got_off, want_off) and got == want
+    blobs = [got[int(got_off[i]):int(got_off[i + 1])] for i in range(len(lens))]
+    for s, blob in zip(sigs[:40], blobs[:40]):
+        assert blob == ob.svbzd_encode(s)
+    # one read that cannot be staged in LDS: the call reports it, nothing hangs
+    big = [4000, 200000, 4000]
+    b2 = press.DeviceBatch(big)
+    b2.upload([rng.integers(-32768, 32768, n, dtype=np.int16) for n in big], [_hdr(press, i) for i in range(3)])
+    b2.svbzd_encode_stream()
+    assert not b2.stream_ok()
+
+
 # ---------------------------------------------------------------- full encode: valid zlib, identical payload
 def test_full_encode_synthetic_4000(press):
     n_reads, n = 1024, 4000
