@@ -1,4 +1,4 @@
-"""Copy the end-of-round profile set (gpurun_out/r02p, made by tools/run_r02_profiles.sh on the GPU box) into profiles/ under
+"""Copy the end-of-round profile set (gpurun_out/r03p, made by tools/run_r03_profiles.sh on the GPU box; r02p / run_r02_profiles.sh in round 2) into profiles/ under
 round-tagged names and rewrite profiles/pmc_traffic.json (HBM bytes per read from the PMC passes, stamped with the hash of the
 kernel sources they were collected on: bench.py prints roofline.traffic only while the hash still matches).
 python tools/install_profiles.py [src_dir] [tag]"""
@@ -21,6 +21,18 @@ for d in sorted(os.listdir(src)):
         shutil.copy(p, os.path.join(P, "%s_bench_line_%s.json.txt" % (tag, d[:-5].replace("bench_", ""))))
     elif d.endswith(".txt"):
         shutil.copy(p, os.path.join(P, "%s_%s" % (tag, d)))
+# traffic: tools/pmc_traffic_all.sh (round 3 on) writes the JSON itself, one entry per leg's dominant kernel, stamped with the source hash
+pj = os.path.join(src, "pmc", "pmc_traffic.json")
+if os.path.exists(pj):
+    entries = json.load(open(pj))
+    stale = [e["kernel"] for e in entries if e.get("csrc_sha256") != bench.csrc_sha256()]
+    if stale:
+        print("WARNING: kernel sources changed since the PMC pass; bench.py will not quote traffic for", stale)
+    for e in entries:
+        e["source"] = "profiles/%s_pmc_traffic.txt; " % tag + e.get("source", "")
+    json.dump(entries, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+    for e in entries: print(e["kernel"], e["samples_per_read"], e["hbm_bytes_per_read"], e["csrc_sha256"])
+    sys.exit(0)
 # traffic: 2 x FETCH_SIZE + WRITE_SIZE (KiB per launch; the x 2 is the gfx950 correction of MI355X_MICROARCH.md) / reads per launch
 txt = open(os.path.join(src, "pmc_k_encode_stream.txt")).read()
 reads = int(re.search(r"over (\d+) reads", txt).group(1))

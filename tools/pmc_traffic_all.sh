@@ -15,6 +15,7 @@ run() {   # name counter command...
 for c in FETCH_SIZE WRITE_SIZE; do
   run enc $c python tools/stream_time.py 400000
   run svb $c python bench.py --svb-only --reads 400000 --steps 3 --warmup 1 --cpu-seconds 0
+  run svbs $c python tools/svb_stream_time.py 400000
   run long $c python bench.py --long --long-reads 16384 --steps 2 --warmup 1 --min-leg-steps-long 2 --cpu-seconds 0
   run decnp $c python tools/decode_bulk.py 1000000 4000 np 3
   run decfull $c python tools/decode_bulk.py 1000000 4000 full 3
@@ -34,7 +35,8 @@ def per_launch(name, counter, kernels):
     return {k: sum(v) / len(v) for k, v in tot.items()}, {k: len(v) for k, v in tot.items()}
 legs = [("enc", "k_encode_stream", ["k_encode_stream"], 400000, 4000),
         ("svb", "k_svbzd_encode", ["k_svbzd_encode"], 400000, 4000),
-        ("long", "k_pack+k_deflate_staged", ["k_pack", "k_deflate_staged"], 16384, 100000),
+        ("svbs", "k_svbzd_stream", ["k_svbzd_stream"], 400000, 4000),
+        ("long", "k_pack+k_deflate_staged", ["k_pack", "k_deflate_staged"], 4096, 100000),   # 16384 reads = 4 chunks of 4096 per step
         ("decnp", "k_inflate_par_np", ["k_inflate_par_np"], 1000000, 4000),
         ("decfull", "k_inflate_par+k_unpack", ["k_inflate_par<true>"], 1000000, 4000)]
 out = []
