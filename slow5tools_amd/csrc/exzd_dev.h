@@ -355,4 +355,200 @@ __device__ __forceinline__ int exzd_decode_wg(const uint8_t *blob, uint64_t L, i
     return 0;
 }
 
+// ---- decode by ONE wave (round 3): the wave that inflated a record decodes its ex-zd blob too (k_inflate_par<2>), as it does for
+// svb-zd — the blob it reads is the payload it just wrote.  Same scheme as exzd_decode_wg on a quarter of the scale: exception chunks
+// of 512 entries (8 per lane), position tiles of 1024 (16 per lane), a 1024-bit flag map; the scratch is the inflate's own LDS, dead
+// by then.  Output: sample i = 1 + position.  A lane whose 16 positions hold no exception (most lanes: 1.5 % of the deltas of a nanopore
+// signal are exceptions) takes its 16 bytes with one load and stores index [p0 + lp, p0 + lp + 16) as two 16-byte words — its
+// carry-in (the sample in front of its first) and its first 15 samples; a lane's 16th sample is the next lane's carry-in, the very
+// last sample is stored behind the loop.
+constexpr uint32_t EXZD_WCHUNK = 512, EXZD_WTILE = 1024;
+struct ExzdWaveScratch {
+    uint32_t epos[EXZD_WCHUNK];
+    uint32_t eval[EXZD_WCHUNK];
+    uint32_t flag[EXZD_WTILE / 32];
+};
+__device__ __forceinline__ uint32_t svb32_decode_chunk_wave(const uint8_t *keys, uint32_t c0, uint32_t cnt, const uint8_t *data,
+                                                            const uint8_t *data_end, uint32_t *vals, int &err) {
+    const int lane = lane_id();
+    const uint32_t i0 = 8u * (uint32_t)lane;
+    const int valid = i0 >= cnt ? 0 : (int)min(8u, cnt - i0);
+    const int nkb = (valid + 3) >> 2;
+    uint32_t key = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+        if (k < nkb) key |= (uint32_t)keys[(c0 >> 2) + 2 * lane + k] << (8 * k);
+    uint32_t nbytes = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (k < valid) nbytes += ((key >> (2 * k)) & 3) + 1;
+    const uint32_t incl = wave_incl_add(nbytes);
+    const uint8_t *dp = data + (incl - nbytes);
+    const bool ok = !(valid > 0 && dp + nbytes > data_end);
+    if (!ok) err = 1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < valid) {
+            uint32_t v = 0;
+            if (ok) {
+                const uint32_t code = (key >> (2 * k)) & 3;
+                for (uint32_t b = 0; b <= code; b++) v |= (uint32_t)dp[b] << (8 * b);
+                dp += code + 1;
+            }
+            vals[i0 + k] = v;
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+}
+// blob (the wave's own payload bytes) -> int16 samples at out (16-byte aligned).  Returns 0 ok, 6 output too small (*n_out = samples
+// needed), 7 malformed; uniform.  Only lane 0's *n_out store matters to the caller (every lane passes the same pointer).
+__device__ __forceinline__ int exzd_decode_wave(const uint8_t *blob, uint64_t L, int16_t *__restrict__ out, uint32_t cap, uint32_t &n_out,
+                                                ExzdWaveScratch &X) {
+    const int lane = lane_id();
+    n_out = 0;
+    if (L < 10 || blob[0] != 0) return 7;
+    uint64_t n64 = 0;
+    for (int b = 0; b < 8; b++) n64 |= (uint64_t)blob[1 + b] << (8 * b);
+    const uint32_t q = blob[9];
+    if (n64 == 0) return L == 10 ? 0 : 7;
+    if (n64 > 0xFFFFFFF0ull || q > 15 || L < 16) return 7;
+    const uint32_t n = (uint32_t)n64, np = n - 1;
+    n_out = n;
+    if (n > cap) return 6;
+    const uint32_t z0 = (uint32_t)blob[10] | ((uint32_t)blob[11] << 8);
+    uint32_t nex = 0;
+    for (int b = 0; b < 4; b++) nex |= (uint32_t)blob[12 + b] << (8 * b);
+    if (nex > np) return 7;
+    const uint32_t nk = (nex + 3) >> 2;
+    const uint8_t *pkeys = nullptr, *pdata = nullptr, *pend = nullptr, *vkeys = nullptr, *vdata = nullptr, *vend = nullptr;
+    uint64_t at = 16;
+    if (nex) {
+        uint32_t sl = 0;
+        if (at + 4 > L) return 7;
+        for (int b = 0; b < 4; b++) sl |= (uint32_t)blob[at + b] << (8 * b);
+        at += 4;
+        if (sl < nk || at + sl > L) return 7;
+        pkeys = blob + at; pdata = pkeys + nk; pend = pkeys + sl;
+        at += sl;
+        if (at + 4 > L) return 7;
+        sl = 0;
+        for (int b = 0; b < 4; b++) sl |= (uint32_t)blob[at + b] << (8 * b);
+        at += 4;
+        if (sl < nk || at + sl > L) return 7;
+        vkeys = blob + at; vdata = vkeys + nk; vend = vkeys + sl;
+        at += sl;
+    }
+    if (L - at != (uint64_t)np - nex) return 7;
+    const uint8_t *rest = blob + at;
+    const uint32_t rest_len = np - nex;
+    const int y0 = (int)(z0 >> 1) ^ -(int)(z0 & 1);
+    int ycarry = y0, err = 0;
+    uint32_t p0 = 0, e0 = 0, rb = 0;            // next position, next exception entry, next byte of `rest`
+    uint32_t cb = 0, cc = 0;                    // exception chunk at hand: entries [cb, cb + cc)
+    uint32_t pd = 0, vd = 0, acarry = 0;        // data bytes consumed of the two lists; last exception position + 1
+    bool broke = false;
+    while (p0 < np) {
+        if (e0 == cb + cc && e0 < nex) {        // all entries of the chunk used: decode the next one
+            cb = e0;
+            cc = min(EXZD_WCHUNK, nex - cb);
+            wave_sync();
+            pd += svb32_decode_chunk_wave(pkeys, cb, cc, pdata + pd, pend, X.epos, err);
+            vd += svb32_decode_chunk_wave(vkeys, cb, cc, vdata + vd, vend, X.eval, err);
+            wave_sync();
+            uint32_t g[8], sum = 0;             // gaps -> absolute positions: abs_e = acarry + sum_{j <= e} (gap_j + 1) - 1
+#pragma unroll
+            for (int k = 0; k < 8; k++) { g[k] = 8u * lane + k < cc ? X.epos[8 * lane + k] + 1u : 0u; sum += g[k]; }
+            const uint32_t incl = wave_incl_add(sum);
+            uint32_t run = acarry + incl - sum;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                run += g[k];
+                if (8u * lane + k < cc) X.epos[8 * lane + k] = run - 1u;
+            }
+            acarry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            wave_sync();
+            if (X.epos[cc - 1] >= np) { broke = true; break; }        // positions must stay inside the signal (uniform read)
+        }
+        // tile [p0, pe): at most EXZD_WTILE positions, and no further than the last exception of the chunk when more follow
+        uint32_t pe = min(p0 + EXZD_WTILE, np);
+        if (cb + cc < nex) pe = min(pe, X.epos[cc - 1] + 1u);
+        if (pe <= p0) { broke = true; break; }                        // cannot happen for a well-formed list
+        if (lane < (int)(EXZD_WTILE / 32)) X.flag[lane] = 0;
+        wave_sync();
+        uint32_t mine = 0;                                            // chunk entries inside the tile
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t ci = 8u * lane + k;
+            if (ci < cc && cb + ci >= e0) {
+                const uint32_t p = X.epos[ci];
+                if (p >= p0 && p < pe) { atomicOr(&X.flag[(p - p0) >> 5], 1u << ((p - p0) & 31)); mine++; }
+            }
+        }
+        const uint32_t in_tile = wave_sum(mine);
+        wave_sync();
+        const uint32_t lp = 16u * (uint32_t)lane;                     // my first position, tile-relative
+        const int valid = p0 + lp >= pe ? 0 : (int)min(16u, pe - p0 - lp);
+        uint32_t fl = (X.flag[lp >> 5] >> (lp & 31)) & 0xFFFFu;
+        if (valid < 16) fl &= (1u << valid) - 1u;
+        const uint32_t pc = (uint32_t)__popc(fl);
+        const uint32_t pincl = wave_incl_add(pc);
+        const uint32_t exb = pincl - pc;                              // exceptions before my first position
+        if ((uint32_t)__builtin_amdgcn_readlane((int)pincl, 63) != in_tile) err = 1;   // two exceptions on one position
+        int d[16], sum = 0;
+        const uint32_t ri0 = rb + lp - exb;
+        if (valid == 16 && fl == 0 && ri0 + 16 <= rest_len) {         // sixteen plain bytes
+            typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(1)));
+            const v4u w = *reinterpret_cast<const v4u *>(rest + ri0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t z = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                d[k] = (int)(z >> 1) ^ -(int)(z & 1);
+                sum += d[k];
+            }
+        } else {
+            uint32_t ei = e0 + exb - cb, ri = ri0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                d[k] = 0;
+                if (k < valid) {
+                    uint32_t z;
+                    if ((fl >> k) & 1u) z = X.eval[ei++] + 256u;
+                    else { z = ri < rest_len ? rest[ri] : 0u; if (ri >= rest_len) err = 1; ri++; }
+                    d[k] = (int)(z >> 1) ^ -(int)(z & 1);
+                }
+                sum += d[k];
+            }
+        }
+        const uint32_t sincl = wave_incl_add((uint32_t)sum);
+        int y = ycarry + (int)(sincl - (uint32_t)sum);                // the sample in front of my first
+        int16_t *o = out + p0 + lp;
+        if (valid == 16 && ((p0 + lp) & 7u) == 0) {
+            uint32_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t lo = ((uint32_t)y << q) & 0xFFFFu;
+                y += d[2 * k];
+                w[k] = lo | (((uint32_t)y << q) << 16);
+                y += d[2 * k + 1];
+            }
+            uint4 *o4 = reinterpret_cast<uint4 *>(o);
+            o4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            o4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        } else if (valid > 0) {
+            o[0] = (int16_t)((uint32_t)y << q);
+#pragma unroll
+            for (int k = 0; k < 15; k++)
+                if (k + 1 < valid) { y += d[k]; o[1 + k] = (int16_t)((uint32_t)y << q); }
+        }
+        ycarry += (int)(uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+        rb += (pe - p0) - in_tile;
+        e0 += in_tile;
+        p0 = pe;
+        wave_sync();
+    }
+    if (lane == 0 && !broke) out[np] = (int16_t)((uint32_t)ycarry << q);   // the last sample (sample 0 when there is no other)
+    if (broke || __ballot(err != 0) || e0 != nex || rb != np - nex) return 7;
+    return 0;
+}
+
 }  // namespace s5

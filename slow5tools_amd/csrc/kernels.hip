@@ -745,12 +745,39 @@ __device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, c
     }
     return 0;
 }
+// ... and an ex-zd one (round 3; exzd_decode_wave): the scratch is the whole table set of the inflate, dead once the record is out
+static_assert(sizeof(ExzdWaveScratch) <= sizeof(InflParSharedSvb), "the ex-zd wave scratch overlays the inflate's LDS");
+__device__ __forceinline__ int unpack_exzd_wave(const s5gpu_decode_args_t &a, const s5gpu_rec_desc_t &d, const uint8_t *pay, s5gpu_rec_fields_t &f, uint32_t plen, ExzdWaveScratch &X) {
+    if (plen < 2) return 7;
+    const uint32_t idl = (uint32_t)ld_le(pay, 2), hl = 2 + idl + 4 + 32;
+    if ((uint64_t)hl + 8 > plen) return 7;
+    const uint64_t L = ld_le(pay + hl, 8);
+    const uint32_t avail = plen - hl - 8;
+    if (L > avail) return 7;
+    uint32_t n = 0;
+    const int st = exzd_decode_wave(pay + hl + 8, L, a.sig_out + d.sig_off, d.sig_cap, n, X);
+    if (st) { if (st == 6 && lane_id() == 0) f.n_samples = n; return st; }
+    if (lane_id() == 0) {
+        f.n_samples = n;
+        f.read_id_len = idl;
+        f.read_group = (uint32_t)ld_le(pay + 2 + idl, 4);
+        uint64_t v[4];
+        for (int q = 0; q < 4; q++) v[q] = ld_le(pay + 2 + idl + 4 + 8 * q, 8);
+        f.digitisation = __longlong_as_double((long long)v[0]);
+        f.offset = __longlong_as_double((long long)v[1]);
+        f.range = __longlong_as_double((long long)v[2]);
+        f.sampling_rate = __longlong_as_double((long long)v[3]);
+        f.aux_off = hl + 8 + (uint32_t)L;
+        f.aux_len = plen - (hl + 8 + (uint32_t)L);
+    }
+    return 0;
+}
 #ifndef S5_IP_WAVES
 #define S5_IP_WAVES 6
 #endif
-template <bool UNPACK>
+template <int UNPACK>      // 0: inflate only; 1: + parse and svb-zd decode; 2: + parse and ex-zd decode
 __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_args_t a) {
-    __shared__ typename std::conditional<UNPACK, InflParSharedSvb, InflParShared>::type T;   // svb-zd records: the small waiting list (inflate_par_dev.h)
+    __shared__ typename std::conditional<UNPACK != 0, InflParSharedSvb, InflParShared>::type T;   // svb-zd / ex-zd records: the small waiting list (inflate_par_dev.h)
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
@@ -764,7 +791,8 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_ar
     if (UNPACK && status == 0) {
         wave_sync();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        status = unpack_svbzd_wave(a, d, a.payload + d.pay_off, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
+        if (UNPACK == 2) status = unpack_exzd_wave(a, d, a.payload + d.pay_off, a.fields[r], olen, *reinterpret_cast<ExzdWaveScratch *>(&T));
+        else status = unpack_svbzd_wave(a, d, a.payload + d.pay_off, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
         mark = 1;
     }
     if (lane_id() == 0) {
@@ -817,6 +845,7 @@ __device__ __forceinline__ void np_write_fields(const s5gpu_decode_args_t &a, ui
         a.fields[r].reserved = 0;
     }
 }
+template <bool EXZD>
 __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode_args_t a, NpParams np) {
     __shared__ InflParSharedSvb T;
     uint8_t *pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
@@ -836,7 +865,8 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode
         if (status == 0) {
             wave_sync();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
+            if (EXZD) status = unpack_exzd_wave(a, d, pay, a.fields[r], olen, *reinterpret_cast<ExzdWaveScratch *>(&T));
+            else status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
         }
         np_write_fields(a, r, status, olen);
         if (!np.ticket) return;
@@ -862,7 +892,8 @@ __global__ __launch_bounds__(64) void k_inflate_fallback_np(s5gpu_decode_args_t 
             if (status == 0) {
                 wave_sync();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, T.ring);
+                if (a.sig_method == S5GPU_SIG_EX_ZD) status = unpack_exzd_wave(a, d, pay, a.fields[r], olen, *reinterpret_cast<ExzdWaveScratch *>(&T));
+                else status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, T.ring);
             }
             np_write_fields(a, r, status, olen);
             wave_sync();
@@ -890,7 +921,7 @@ __global__ __launch_bounds__(64) void k_zstd_inflate_np(s5gpu_decode_args_t a, N
     }
 }
 
-// K4 for the zstd record press: one frame per wave64 (zstd_dev.h).  UNPACK: as k_inflate_par<true> — the wave parses the record and
+// K4 for the zstd record press: one frame per wave64 (zstd_dev.h).  UNPACK: as k_inflate_par<1> — the wave parses the record and
 // decodes its svb-zd signal right away (the Huffman table's storage is the stage), k_unpack_rest clears the marks
 static_assert(sizeof(ZstdShared::huf) + sizeof(ZstdShared::ll_e) >= SVB_WSTAGE && offsetof(ZstdShared, ll_e) == sizeof(ZstdShared::huf),
               "the Huffman table and the table behind it double as the svb-zd stage");
@@ -1095,7 +1126,7 @@ __global__ __launch_bounds__(NT, S5_UNP_WG) void k_unpack(s5gpu_decode_args_t a)
     __shared__ int s_err;
     unpack_record_wg(a, blockIdx.x, ws, svb_stage, s_err);
 }
-// ... behind k_inflate_par<true>: only the records that kernel did not unpack itself (fields.reserved == 0: the ones the fallback
+// ... behind k_inflate_par<1 | 2>: only the records that kernel did not unpack itself (fields.reserved == 0: the ones the fallback
 // decoder inflated); persistent workgroups look at 256 records at a time, and every mark is cleared on the way
 __global__ __launch_bounds__(NT) void k_unpack_rest(s5gpu_decode_args_t a) {
     __shared__ uint32_t ws[16];
@@ -1562,13 +1593,14 @@ void s5kern_release_aux() {   // s5gpu_shutdown (bumps the generation right afte
     g_aux_free.clear();
 }
 
-static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, bool unpack = false) {   // unpack: k_inflate_par also parses + decodes (svb-zd)
+static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpack = 0) {   // unpack: the inflating wave also parses + decodes (1 svb-zd, 2 ex-zd: zlib records only)
     if (a->rec_method == S5GPU_REC_ZSTD) {
-        if (unpack) hipLaunchKernelGGL(k_zstd_inflate<true>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        if (unpack == 1) hipLaunchKernelGGL(k_zstd_inflate<true>, dim3(a->n_recs), dim3(64), 0, st, *a);
         else hipLaunchKernelGGL(k_zstd_inflate<false>, dim3(a->n_recs), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && g_inflate_par) {
-        if (unpack) hipLaunchKernelGGL(k_inflate_par<true>, dim3(a->n_recs), dim3(64), 0, st, *a);
-        else hipLaunchKernelGGL(k_inflate_par<false>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        if (unpack == 2) hipLaunchKernelGGL(k_inflate_par<2>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        else if (unpack == 1) hipLaunchKernelGGL(k_inflate_par<1>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        else hipLaunchKernelGGL(k_inflate_par<0>, dim3(a->n_recs), dim3(64), 0, st, *a);
         const uint32_t g = (a->n_recs + 63) / 64 < 4096 ? (a->n_recs + 63) / 64 : 4096;
         if (g_inflate_par == 1) hipLaunchKernelGGL(k_inflate_fallback, dim3(g), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
@@ -1693,8 +1725,9 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (a->flags & S5GPU_DEC_NO_PAYLOAD) {
         // fields + signals only: persistent workgroups, one reused scratch slot each (k_inflate_par_np)
-        if (a->sig_method != S5GPU_SIG_SVB_ZD || (a->rec_method != S5GPU_REC_ZLIB && a->rec_method != S5GPU_REC_ZSTD)) {
-            s5gpu_set_error("s5gpu_decode_dev: S5GPU_DEC_NO_PAYLOAD serves zlib / zstd records with svb-zd signals");
+        const bool np_xz = a->sig_method == S5GPU_SIG_EX_ZD && a->rec_method == S5GPU_REC_ZLIB;
+        if (!np_xz && (a->sig_method != S5GPU_SIG_SVB_ZD || (a->rec_method != S5GPU_REC_ZLIB && a->rec_method != S5GPU_REC_ZSTD))) {
+            s5gpu_set_error("s5gpu_decode_dev: S5GPU_DEC_NO_PAYLOAD serves zlib / zstd records with svb-zd signals and zlib records with ex-zd signals");
             return S5GPU_ERR_ARG;
         }
         const uint64_t slot = ((uint64_t)a->max_pay_cap + 16 + 15) & ~15ull;
@@ -1713,7 +1746,7 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
             int per_cu = 0, cus = 0, dev = 0;
             HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            if (zl) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_par_np, 64, 0));
+            if (zl) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_par_np<false>, 64, 0));
             else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_zstd_inflate_np, 64, 0));
             res = (uint32_t)(per_cu > 0 && cus > 0 ? per_cu * cus : 4096);
             s_res[zl].store(res, std::memory_order_relaxed);
@@ -1730,7 +1763,8 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         if (zl && a->n_recs <= n_main) np.ticket = nullptr;   // one record per workgroup: no ticket counter, nothing to clear (get batches)
         else HIP_TRY(hipMemsetAsync(a->payload, 0, 64, st));
         if (zl) {
-            hipLaunchKernelGGL(k_inflate_par_np, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
+            if (np_xz) hipLaunchKernelGGL(k_inflate_par_np<true>, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
+            else hipLaunchKernelGGL(k_inflate_par_np<false>, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
             hipLaunchKernelGGL(k_inflate_fallback_np, dim3((uint32_t)n_fb), dim3(64), 0, st, *a, np);
         } else {
             hipLaunchKernelGGL(k_zstd_inflate_np, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
@@ -1739,13 +1773,16 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         return S5GPU_OK;
     }
     // svb-zd records under zlib (default inflate kernel) or zstd: the wave that decompresses a record unpacks it too
-    const bool fused = a->sig_method == S5GPU_SIG_SVB_ZD && g_unpack_fused &&
-                       ((a->rec_method == S5GPU_REC_ZLIB && g_inflate_par == 1) || a->rec_method == S5GPU_REC_ZSTD);
+    // ... and ex-zd records under zlib (round 3)
+    const int fused = !g_unpack_fused ? 0
+                    : a->sig_method == S5GPU_SIG_SVB_ZD && ((a->rec_method == S5GPU_REC_ZLIB && g_inflate_par == 1) || a->rec_method == S5GPU_REC_ZSTD) ? 1
+                    : a->sig_method == S5GPU_SIG_EX_ZD && a->rec_method == S5GPU_REC_ZLIB && g_inflate_par == 1 ? 2 : 0;
     int rc = launch_inflate(a, st, fused);
     if (rc) return rc;
-    // the ex-zd decoder keeps one chunk of exceptions and a flag map in (dynamic) LDS; the other signal formats need none
-    if (fused) hipLaunchKernelGGL(k_unpack_rest, dim3((a->n_recs + NT - 1) / NT < 2048 ? (a->n_recs + NT - 1) / NT : 2048), dim3(NT), 0, st, *a);
-    else hipLaunchKernelGGL(k_unpack, dim3(a->n_recs), dim3(NT), a->sig_method == S5GPU_SIG_EX_ZD ? sizeof(ExzdScratch) : 0, st, *a);
+    // the workgroup form of the ex-zd decoder keeps one chunk of exceptions and a flag map in (dynamic) LDS; the other signal formats need none
+    const size_t xlds = a->sig_method == S5GPU_SIG_EX_ZD ? sizeof(ExzdScratch) : 0;
+    if (fused) hipLaunchKernelGGL(k_unpack_rest, dim3((a->n_recs + NT - 1) / NT < 2048 ? (a->n_recs + NT - 1) / NT : 2048), dim3(NT), xlds, st, *a);
+    else hipLaunchKernelGGL(k_unpack, dim3(a->n_recs), dim3(NT), xlds, st, *a);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }

@@ -96,7 +96,7 @@ def decode_records(records, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD, raise_on
     return out
 
 
-def decode_signals_dev(records, rec_method=REC_ZLIB, max_pay_cap=None, sig_caps=None, scratch_bytes=None, device="cuda:0"):
+def decode_signals_dev(records, rec_method=REC_ZLIB, max_pay_cap=None, sig_caps=None, scratch_bytes=None, device="cuda:0", sig_method=SIG_SVB_ZD):
     """s5gpu_decode_dev with S5GPU_DEC_NO_PAYLOAD: fields + signals only, the uncompressed records stay in reused scratch slots
     (what `get` needs of /root/reference/src/get.c:37-66 when the caller holds the read ids).  records: bytes without the u64 prefix.
     Returns (fields as a numpy REC_FIELDS array, list of int16 arrays — empty where status != 0)."""
@@ -128,7 +128,7 @@ def decode_signals_dev(records, rec_method=REC_ZLIB, max_pay_cap=None, sig_caps=
         scratch_bytes = int(L.s5gpu_decode_scratch_bytes(max_pay_cap))
     t_scr = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
     a = _lib.DecodeArgs()
-    a.n_recs, a.rec_method, a.sig_method, a.flags = n, rec_method, SIG_SVB_ZD, _lib.DEC_NO_PAYLOAD
+    a.n_recs, a.rec_method, a.sig_method, a.flags = n, rec_method, sig_method, _lib.DEC_NO_PAYLOAD
     a.desc, a.in_, a.payload, a.sig_out, a.fields = t_desc.data_ptr(), t_in.data_ptr(), t_scr.data_ptr(), t_sig.data_ptr(), t_fields.data_ptr()
     a.payload_bytes, a.max_pay_cap = scratch_bytes, max_pay_cap
     check(L.s5gpu_decode_dev(C.byref(a), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "s5gpu_decode_dev")

@@ -127,6 +127,54 @@ def test_decode_rejects_malformed_exzd_blobs(press):
             assert len(g["signal"]) == len(sig)
 
 
+def test_wave_decoder_behind_the_inflate_equals_the_workgroup_decoder(press):
+    """zlib records with ex-zd signals are unpacked by the wave that inflated them (exzd_decode_wave: chunks of 512 exceptions, tiles of
+    1024 positions) — every shape of _signals, damaged blobs included, must come out as from the two-kernel form (unpack_fused = 0:
+    exzd_decode_wg) and as from the call without payload output (S5GPU_DEC_NO_PAYLOAD), status for status and sample for sample."""
+    from slow5tools_amd import _lib
+    rng = np.random.default_rng(33)
+    sigs = _signals(rng)
+    hdrs = [press.pack_hdr(ob.synth_read_id(i), *HDR_ARGS) for i in range(len(sigs))]
+    auxs = [b"" if i % 3 else bytes([i % 251] * (i % 40)) for i in range(len(sigs))]
+    pays = [_payload(press, h, s, a) for h, s, a in zip(hdrs, sigs, auxs)]
+    # damaged blobs inside intact zlib streams: header fields, section lengths, truncation, 120 random hits
+    sig = rng.integers(-2000, 2000, 9000).astype(np.int16)
+    hdr = press.pack_hdr(b"r", *HDR_ARGS)
+    good = _payload(press, hdr, sig)
+    at = len(hdr) + 8
+    for off, val in ((0, 1), (9, 16), (12, 0xFF), (13, 0xFF), (16, 0), (1, 0x7F)):
+        b = bytearray(good); b[at + off] = val; pays.append(bytes(b))
+    b = bytearray(good); b[at + 12:at + 16] = struct.pack("<I", 5); pays.append(bytes(b))
+    b = bytearray(good[:-7]); struct.pack_into("<Q", b, len(hdr), len(b) - at); pays.append(bytes(b))
+    for v in range(120):
+        b = bytearray(good)
+        p = int(rng.integers(at, len(b)))
+        if v % 2:
+            b[p] ^= 1 << int(rng.integers(0, 8))
+        else:
+            b[p:p + 4] = rng.integers(0, 256, 4, dtype=np.uint8).tobytes()
+        pays.append(bytes(b))
+    recs = [zlib.compress(p, 6 if i % 2 else 1) for i, p in enumerate(pays)]
+    L = _lib.lib()
+    fused = press.decode_records(recs, press.REC_ZLIB, press.SIG_EX_ZD, raise_on_error=False)
+    _lib.check(L.s5gpu_set_option(b"unpack_fused", 0))
+    try:
+        split = press.decode_records(recs, press.REC_ZLIB, press.SIG_EX_ZD, raise_on_error=False)
+    finally:
+        _lib.check(L.s5gpu_set_option(b"unpack_fused", 1))
+    f_np, s_np = press.decode_signals_dev(recs, press.REC_ZLIB, max_pay_cap=max(len(p) for p in pays) + 64,
+                                          sig_caps=[max(len(s) for s in sigs) + 16] * len(recs), sig_method=press.SIG_EX_ZD)
+    assert [g["status"] for g in fused[:len(sigs)]] == [0] * len(sigs)
+    for i, (a, b) in enumerate(zip(fused, split)):
+        assert a["status"] == b["status"] == int(f_np["status"][i]), (i, a["status"], b["status"], int(f_np["status"][i]))
+        if a["status"] == 0:
+            assert np.array_equal(a["signal"], b["signal"]) and np.array_equal(a["signal"], s_np[i]), i
+            assert a["aux"] == b["aux"] and a["read_id"] == b["read_id"]
+            if i < len(sigs):
+                assert np.array_equal(a["signal"], sigs[i]), i
+    assert sum(1 for g in fused[len(sigs):] if g["status"] == 7) >= 8
+
+
 def test_view_to_and_from_exzd_files(tmp_path):
     """s5view: the reference's zlib+svb-zd file -> zlib+ex-zd reproduces the reference's ex-zd payloads; and back"""
     out = tmp_path / "x.blow5"

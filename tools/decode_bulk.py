@@ -1,7 +1,7 @@
 """One bulk decode call (the whole index in one s5gpu_decode_dev) a few times, nothing else: the driver of tools/pmc_decode_traffic.sh and of
 quick A/B timings.   python tools/decode_bulk.py [reads] [samples] [np|full] [reps]
 np   = S5GPU_DEC_NO_PAYLOAD (k_inflate_par_np: persistent workgroups, scratch slots, fields + signals out)
-full = payload slots written out as well (k_inflate_par<true> + k_inflate_fallback + k_unpack_rest)"""
+full = payload slots written out as well (k_inflate_par<1> + k_inflate_fallback + k_unpack_rest)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

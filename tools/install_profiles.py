@@ -51,7 +51,7 @@ if os.path.exists(dt):      # bulk decode: the inflating wave also unpacks, so o
         recs = int(f2.group(2)) // 64
         entries.append({"kernel": "k_inflate_par+k_unpack", "samples_per_read": 4000,
                         "hbm_bytes_per_read": round((2 * float(f2.group(1)) + float(w2.group(1))) * 1024 / recs, 1),
-                        "source": "profiles/%s_pmc_decode_traffic.txt (k_inflate_par<true> over %d records; FETCH x 2: gfx950 correction)" % (tag, recs),
+                        "source": "profiles/%s_pmc_decode_traffic.txt (k_inflate_par<1> over %d records; FETCH x 2: gfx950 correction)" % (tag, recs),
                         "csrc_sha256": bench.csrc_sha256()})
 json.dump(entries, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 for e in entries: print(e)
