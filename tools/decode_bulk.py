@@ -34,9 +34,25 @@ else:
     pay = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device="cuda")
     a.payload = pay.data_ptr()
 ts = []
-for _ in range(reps):
+soak = os.environ.get("S5_SOAK", "") not in ("", "0")     # check every repetition (signals cleared in between): a soak for rare wrong decodes
+soak_bad = 0
+want = b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]
+for rep in range(reps):
+    if soak:
+        sig.zero_(); fields.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); _lib.check(L.s5gpu_decode_dev(C.byref(a), None), "decode"); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    if soak:
+        st_ = fields.view(torch.int32).view(n_reads, 16)[:, 0]
+        good = bool((st_ == 0).all().item()) and bool(torch.equal(sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n], want))
+        if not good:
+            soak_bad += 1
+            neq = (sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n] != want).any(dim=1)
+            bad = torch.nonzero(neq).flatten().cpu().numpy()
+            print("   rep %d WRONG: %d reads differ, first %s; nonzero statuses %d" % (rep, len(bad), bad[:12], int((st_ != 0).sum().item())))
+if soak:
+    print("soak %s: %d repetitions, %d wrong" % (mode, reps, soak_bad))
+    ts = ts[:8]
 st = fields.view(torch.int32).view(n_reads, 16)[:, 0]
 ok = bool((st == 0).all().item()) and bool(torch.equal(sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n], b.sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n]))
 if not ok:
