@@ -190,9 +190,9 @@ def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
     total = args.long_reads
     lo, hi = shard.shard_range(total, rank, world)
     mine = hi - lo
-    # at least four chunks per rank, alternating between two sets of output buffers on two streams: the compaction of one chunk
-    # (a copy, HBM-bound) and the drain of its last workgroups run under the next chunk's deflate (VALU-bound).  This is what two
-    # GPU workers of the file pipeline do (examples/s5view.c); 288 GB of HBM hold both sets many times over.
+    # at least four chunks per rank, alternating between two sets of output buffers: the streaming steps of one chunk (park the payloads;
+    # compact the records) run under the arithmetic of another (below).  This is what several GPU workers of the file pipeline do
+    # (examples/s5view.c); 288 GB of HBM hold both sets many times over.
     chunk = max(1, min(args.long_chunk, -(-mine // 4)))
     n_sets = 1 if args.long_streams < 2 or mine <= chunk else 2
     chunks = []
@@ -205,34 +205,45 @@ def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
         b.synth(seed=0x5105, first=c0)
         chunks.append((c0, b))
     torch.cuda.synchronize()
-    # stream 0 deflates chunk after chunk; stream 1 compacts chunk c as soon as its deflate is done, under the deflate of chunk c + 1;
-    # a set of output buffers is taken again once its compaction has finished (events both ways)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_sets)]
+    # Three streams, two sets of output buffers: the staged encode of a chunk is two calls (s5gpu_pack_parked_dev: streaming, HBM-bound;
+    # s5gpu_deflate_parked_dev: arithmetic, VALU-bound) and the compaction a third (a copy).  Stream D deflates chunk after chunk; stream P
+    # parks chunk c + 1 and stream C compacts chunk c - 1 meanwhile; a buffer set is taken again once its compaction is done.
+    # Small chunks (a rank's shard of the strong-scaling job at N = 8: 2048 reads = two rounds of workgroups) take two deflate streams in
+    # turn, so that a chunk's last workgroups drain beside the next chunk's first (8192 reads on one GPU: 548 against 518 GB/s); large
+    # chunks do better with one (65 536 reads: 582 against 567).
+    alt_deflate = chunk < 8192
+    streams = [torch.cuda.Stream(device=dev) for _ in range((4 if alt_deflate else 3) if n_sets == 2 else 1)]
     set_free = [None] * n_sets
 
     def step(evs=None, k=0, serial=False):
         for ci, (_, b) in enumerate(chunks):
-            two = n_sets == 2 and not serial
+            if n_sets == 2 and not serial:
+                sp, sc, sd = streams[0], streams[1], streams[2 + (ci % 2 if alt_deflate else 0)]
+                with torch.cuda.stream(sp):
+                    if set_free[ci % 2] is not None:
+                        sp.wait_event(set_free[ci % 2])
+                    b.pack_parked()
+                    parked = torch.cuda.Event()
+                    parked.record(sp)
+                with torch.cuda.stream(sd):
+                    sd.wait_event(parked)
+                    b.deflate_parked()
+                    done = torch.cuda.Event()
+                    done.record(sd)
+                with torch.cuda.stream(sc):
+                    sc.wait_event(done)
+                    b.compact()
+                    set_free[ci % 2] = torch.cuda.Event()
+                    set_free[ci % 2].record(sc)
+                continue
             with torch.cuda.stream(streams[0]):
                 st = b._stream()
-                if two and set_free[ci % 2] is not None:
-                    streams[0].wait_event(set_free[ci % 2])
                 if evs is not None:
                     L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3], st)
                 b.encode()
                 if evs is not None:
                     L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3 + 1], st)
-                if two:
-                    done = torch.cuda.Event()
-                    done.record(streams[0])
-            with torch.cuda.stream(streams[1 if two else 0]):
-                st = b._stream()
-                if two:
-                    streams[1].wait_event(done)
                 b.compact()
-                if two:
-                    set_free[ci % 2] = torch.cuda.Event()
-                    set_free[ci % 2].record(streams[1])
                 if evs is not None:
                     L.s5gpu_event_record(evs[(k * len(chunks) + ci) * 3 + 2], st)
 
@@ -277,7 +288,7 @@ def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
                     "(a 1/%.1f fraction of the 10 M-read job), read-index space split over %d rank(s) with shard_range, chunks of <= %d reads "
                     "(%.2f GB of signal per launch), generated on device" % (total, n, total * 2 * n / 1e9, LONG_TOTAL_READS_FULL / total, world, chunk, chunk * 2 * n / 1e9),
         "value": round(reads_per_s * 2 * n / 1e9, 3), "unit": "GB/s", "reads_per_s": round(reads_per_s, 1), "scaling": "strong",
-        "n_gpus": world, "steps": K, "ms_per_step": round(dt / K * 1e3, 3), "streams": n_sets,
+        "n_gpus": world, "steps": K, "ms_per_step": round(dt / K * 1e3, 3), "streams": len(streams), "buffer_sets": n_sets,
         "ms_per_step_one_stream": round(dt_serial / Ks * 1e3, 3), "reads_total": total, "reads_rank0": mine, "chunks_rank0": len(chunks),
         "scale_factor_vs_10M_reads": round(LONG_TOTAL_READS_FULL / total, 3),
         "bytes_per_sample": round(z_bytes / (mine * n), 4), "parity_spot_check": bool(parity),
@@ -618,7 +629,7 @@ def main():
     ap.add_argument("--long-reads", type=int, default=65536, help="configs[3] leg: size of the read-index space (all ranks together)")
     ap.add_argument("--long-samples", type=int, default=100_000)
     ap.add_argument("--long-chunk", type=int, default=16384, help="configs[3] leg: reads per launch (at most; a rank's shard is cut into >= 4 chunks)")
-    ap.add_argument("--long-streams", type=int, default=2, help="configs[3] leg: 2 = chunks alternate between two streams / output buffer sets, 1 = one stream")
+    ap.add_argument("--long-streams", type=int, default=2, help="configs[3] leg: 2 = two output buffer sets, pack / deflate / compaction of successive chunks on three streams; 1 = one stream, one set")
     ap.add_argument("--decode", action="store_true", help="configs[4] alone: random get-style decode (inflate + svb-zd unpack)")
     ap.add_argument("--get-reads", type=int, default=100_000, help="configs[4]: random read ids to fetch (seed 1)")
     ap.add_argument("--get-batch", type=int, default=4096, help="configs[4]: ids per batch (-K)")

@@ -186,6 +186,11 @@ int s5gpu_svbzd_encode_stream_dev(const s5gpu_encode_args_t *args, uint8_t *stre
  *  inflate: zlib streams -> payload slots, fields[i].status / payload_len (Adler-32 verified)
  *  svbzd_decode: svb-zd blobs (desc.in_off/in_len) -> sig_out, fields[i].status / n_samples */
 int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *args, void *hip_stream);   /* rec_method zstd: the zstd twin */
+/* pack_parked: the step in front of it for whole reads — signal press + record layout, every payload parked where deflate_parked
+ *    expects it, out_len[i] = its length.  pack_parked + deflate_parked = s5gpu_encode_dev on a batch of long reads, as two calls a
+ *    caller may put on different streams (bench.py's configs[3] leg: the next chunk's pack and the previous chunk's compaction run
+ *    beside a chunk's deflate). */
+int s5gpu_pack_parked_dev(const s5gpu_encode_args_t *args, void *hip_stream);
 int s5gpu_inflate_dev(const s5gpu_decode_args_t *args, void *hip_stream);
 int s5gpu_svbzd_decode_dev(const s5gpu_decode_args_t *args, void *hip_stream);
 /* inflate_head: only the first desc[i].pay_cap bytes of every zlib record (a record's head: u16 read_id_len | read_id | ...; what

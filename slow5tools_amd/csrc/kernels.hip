@@ -1508,6 +1508,23 @@ extern "C" int s5gpu_encode_stream_dev(const s5gpu_encode_args_t *a, uint8_t *st
     return S5GPU_OK;
 }
 
+// step 1 of the staged path on its own (k_pack, mode 0): every read's payload parked in its slot's tail, out_len = payload length — what
+// s5gpu_deflate_parked_dev takes.  A caller that works through a long job chunk by chunk can put the two steps of successive chunks on
+// different streams: the streaming step of one chunk and the compaction of another run under the arithmetic of a third.
+extern "C" int s5gpu_pack_parked_dev(const s5gpu_encode_args_t *a, void *stream_) {
+    int rc = enc_check(a);
+    if (rc) { s5gpu_set_error("s5gpu_pack_parked_dev: bad arguments"); return rc; }
+    if (a->n_reads == 0) return S5GPU_OK;
+    EncParams p;
+    p.a = *a;
+    p.dbg = 0; p.zseq = g_zstd_sequences;
+    p.obuf_words = (DEFL_BLK + 64) / 4;
+    p.pay_cap = DEFL_BLK;
+    hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, (hipStream_t)stream_, p, 0);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
 extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stream_) {
     int rc = enc_check(a);
     if (rc) { s5gpu_set_error("s5gpu_deflate_parked_dev: bad arguments"); return rc; }

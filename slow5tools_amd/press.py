@@ -264,6 +264,14 @@ class DeviceBatch:
     def encode(self):
         check(_lib.lib().s5gpu_encode_dev(C.byref(self.args), self._stream()), "s5gpu_encode_dev")
 
+    def pack_parked(self):
+        """step 1 of the staged (long-read) encode alone: payloads parked in the slots' tails"""
+        check(_lib.lib().s5gpu_pack_parked_dev(C.byref(self.args), self._stream()), "s5gpu_pack_parked_dev")
+
+    def deflate_parked(self):
+        """step 2: the parked payloads compressed in place (pack_parked + deflate_parked = encode on long reads)"""
+        check(_lib.lib().s5gpu_deflate_parked_dev(C.byref(self.args), self._stream()), "s5gpu_deflate_parked_dev")
+
     def encode_stream(self):
         """ordered single-pass encode straight into stream_out / rec_off (no slots, no compaction pass)"""
         if not hasattr(self, "lb_state"):

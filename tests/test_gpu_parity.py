@@ -213,6 +213,27 @@ def test_encode_long_reads_staged_path(press):
     assert tg <= 1.02 * tr
 
 
+def test_staged_encode_as_two_calls_equals_the_one_call(press):
+    """s5gpu_pack_parked_dev + s5gpu_deflate_parked_dev (the two steps of the staged path, as a chunked job puts them on different
+    streams) leave the same records in the slots as s5gpu_encode_dev on a batch of long reads"""
+    rng = np.random.default_rng(29)
+    lens = [70000, 100000, 65537, 131072, 90001]
+    sigs = [ob.synth_read(0x5105, 9000 + i, n) if i % 2 == 0 else (500 + rng.integers(-300, 300, n)).astype(np.int16) for i, n in enumerate(lens)]
+    hdrs = [_hdr(press, 9000 + i) for i in range(len(lens))]
+    auxs = [b"", bytes(range(40)), b"", b"\x01" * 7, b""]
+    b = press.DeviceBatch(lens, aux_len=[len(a) for a in auxs])
+    b.upload(sigs, hdrs, auxs)
+    b.encode()
+    one = b.records()
+    b.slots.zero_()
+    b.out_len.zero_()
+    b.pack_parked()
+    b.deflate_parked()
+    two = b.records()
+    assert one == two
+    _check_records(press, sigs, hdrs, auxs, two, press.REC_ZLIB, press.SIG_SVB_ZD)
+
+
 @pytest.mark.parametrize("cap", [0, 2048, 5000, 5400])
 def test_lds_overflow_reads_take_the_staged_path(press, cap):
     """reads whose payload exceeds the fused kernel's LDS budget (incompressible signal, or a forced
