@@ -32,6 +32,7 @@ python tools/exzd_time.py > $O/exzd_time.txt 2>&1
 python tools/lz_time.py 16384 100000 > $O/lz_time_long_reads.txt 2>&1
 python tools/e2e_view.py 400000 > $O/e2e_view.txt 2>&1
 python tools/get_bench.py > $O/get_bench.txt 2>&1
+python tools/get_bench.py 1000000 1000000 > $O/get_bench_1M_ids.txt 2>&1
 python tools/pcie_rate.py > $O/pcie_rate.txt 2>&1
 bash tools/stages.sh > $O/encode_stages.txt 2>&1
 bash tools/pmc_inflate.sh 65536 4000 > $O/pmc_k_inflate_par.txt 2>&1
