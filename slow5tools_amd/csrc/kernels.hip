@@ -925,10 +925,11 @@ __global__ __launch_bounds__(64) void k_zstd_inflate_np(s5gpu_decode_args_t a, N
 // decodes its svb-zd signal right away (the Huffman table's storage is the stage), k_unpack_rest clears the marks
 static_assert(sizeof(ZstdShared::huf) + sizeof(ZstdShared::ll_e) >= SVB_WSTAGE && offsetof(ZstdShared, ll_e) == sizeof(ZstdShared::huf),
               "the Huffman table and the table behind it double as the svb-zd stage");
-template <bool UNPACK>
 #ifndef S5_ZI_W
 #define S5_ZI_W 4
 #endif
+static_assert(sizeof(ExzdWaveScratch) <= sizeof(ZstdShared), "the ex-zd wave scratch overlays the zstd decoder's LDS");
+template <int UNPACK>      // 0: decompress only; 1: + parse and svb-zd decode; 2: + parse and ex-zd decode
 __global__ __launch_bounds__(64, S5_ZI_W) void k_zstd_inflate(s5gpu_decode_args_t a) {
     __shared__ __attribute__((aligned(16))) ZstdShared T;
     const uint32_t r = blockIdx.x;
@@ -939,7 +940,8 @@ __global__ __launch_bounds__(64, S5_ZI_W) void k_zstd_inflate(s5gpu_decode_args_
     if (UNPACK && status == 0) {
         wave_sync();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        status = unpack_svbzd_wave(a, d, a.payload + d.pay_off, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.huf));
+        if (UNPACK == 2) status = unpack_exzd_wave(a, d, a.payload + d.pay_off, a.fields[r], olen, *reinterpret_cast<ExzdWaveScratch *>(&T));
+        else status = unpack_svbzd_wave(a, d, a.payload + d.pay_off, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.huf));
         mark = 1;
     }
     if (lane_id() == 0) {
@@ -1610,10 +1612,11 @@ void s5kern_release_aux() {   // s5gpu_shutdown (bumps the generation right afte
     g_aux_free.clear();
 }
 
-static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpack = 0) {   // unpack: the inflating wave also parses + decodes (1 svb-zd, 2 ex-zd: zlib records only)
+static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpack = 0) {   // unpack: the inflating wave also parses + decodes (1 svb-zd, 2 ex-zd)
     if (a->rec_method == S5GPU_REC_ZSTD) {
-        if (unpack == 1) hipLaunchKernelGGL(k_zstd_inflate<true>, dim3(a->n_recs), dim3(64), 0, st, *a);
-        else hipLaunchKernelGGL(k_zstd_inflate<false>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        if (unpack == 2) hipLaunchKernelGGL(k_zstd_inflate<2>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        else if (unpack == 1) hipLaunchKernelGGL(k_zstd_inflate<1>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        else hipLaunchKernelGGL(k_zstd_inflate<0>, dim3(a->n_recs), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && g_inflate_par) {
         if (unpack == 2) hipLaunchKernelGGL(k_inflate_par<2>, dim3(a->n_recs), dim3(64), 0, st, *a);
         else if (unpack == 1) hipLaunchKernelGGL(k_inflate_par<1>, dim3(a->n_recs), dim3(64), 0, st, *a);
@@ -1790,10 +1793,10 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         return S5GPU_OK;
     }
     // svb-zd records under zlib (default inflate kernel) or zstd: the wave that decompresses a record unpacks it too
-    // ... and ex-zd records under zlib (round 3)
+    // ... and ex-zd records (round 3)
     const int fused = !g_unpack_fused ? 0
                     : a->sig_method == S5GPU_SIG_SVB_ZD && ((a->rec_method == S5GPU_REC_ZLIB && g_inflate_par == 1) || a->rec_method == S5GPU_REC_ZSTD) ? 1
-                    : a->sig_method == S5GPU_SIG_EX_ZD && a->rec_method == S5GPU_REC_ZLIB && g_inflate_par == 1 ? 2 : 0;
+                    : a->sig_method == S5GPU_SIG_EX_ZD && ((a->rec_method == S5GPU_REC_ZLIB && g_inflate_par == 1) || a->rec_method == S5GPU_REC_ZSTD) ? 2 : 0;
     int rc = launch_inflate(a, st, fused);
     if (rc) return rc;
     // the workgroup form of the ex-zd decoder keeps one chunk of exceptions and a flag map in (dynamic) LDS; the other signal formats need none

@@ -116,6 +116,14 @@ def test_svbzd_stream_one_pass_equals_slots_plus_compaction(press):
     blobs = [got[int(got_off[i]):int(got_off[i + 1])] for i in range(len(lens))]
     for s, blob in zip(sigs[:40], blobs[:40]):
         assert blob == ob.svbzd_encode(s)
+    for k in (1, 2, 3, 5):                          # fewer reads than a group of four, and a last group that is not full
+        bk = press.DeviceBatch(lens[:k] if k < 5 else [4000, 4000, 17, 4000, 3999])
+        sk = sigs[:k] if k < 5 else [rng.integers(-500, 500, n).astype(np.int16) for n in (4000, 4000, 17, 4000, 3999)]
+        bk.upload(sk, [_hdr(press, i) for i in range(k)])
+        bk.svbzd_encode_stream()
+        assert bk.stream_ok()
+        gk, ok_ = bk.stream_bytes()
+        assert [gk[int(ok_[i]):int(ok_[i + 1])] for i in range(k)] == [ob.svbzd_encode(x) for x in sk]
     # one read that cannot be staged in LDS: the call reports it, nothing hangs
     big = [4000, 200000, 4000]
     b2 = press.DeviceBatch(big)
