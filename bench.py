@@ -416,7 +416,7 @@ def decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, want_c
         if payload_t is None:
             a.flags, a.payload, a.payload_bytes, a.max_pay_cap = _lib.DEC_NO_PAYLOAD, scratch.data_ptr(), scratch_bytes, pay_cap
         else:
-            a.payload = payload_t.data_ptr()
+            a.payload, a.max_pay_cap = payload_t.data_ptr(), pay_cap     # (the hint that the records are short: the kernel's 24-wave shape)
         return a
 
     def descs(sel, with_payload):

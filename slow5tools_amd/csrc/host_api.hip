@@ -520,6 +520,7 @@ static int decode_batch_dev(int slot, uint32_t n, const void *const *rec, const 
         a.n_recs = m; a.rec_method = rec_method; a.sig_method = sig_method;
         a.desc = (const s5gpu_rec_desc_t *)c->d_desc.p; a.in = (const uint8_t *)c->d_in.p;
         a.payload = (uint8_t *)c->d_pay.p; a.sig_out = (int16_t *)c->d_sig.p; a.fields = (s5gpu_rec_fields_t *)c->d_fields.p;
+        for (uint32_t k = 0; k < m; k++) if (desc[k].pay_cap > a.max_pay_cap) a.max_pay_cap = desc[k].pay_cap;   // (short records: the inflate kernel's 24-wave shape)
         if ((rc = s5gpu_decode_dev(&a, c->st))) return rc;
         uint8_t *hp = (uint8_t *)c->h_out.p, *hsg = hp + up(po + 64, 64), *hf = hsg + up(so * 2 + 64, 64);
         HIP_TRY(hipMemcpyAsync(hf, c->d_fields.p, sizeof(s5gpu_rec_fields_t) * m, hipMemcpyDeviceToHost, c->st));
@@ -774,6 +775,7 @@ static int decode_resident_impl(Ctx *c, uint32_t n, const void *const *rec, cons
         da.n_recs = n; da.rec_method = from_rec; da.sig_method = from_sig;
         da.desc = (const s5gpu_rec_desc_t *)c->d_desc2.p; da.in = (const uint8_t *)c->d_in.p;
         da.payload = (uint8_t *)c->d_pay.p; da.sig_out = (int16_t *)c->d_sig2.p; da.fields = (s5gpu_rec_fields_t *)c->d_fields.p;
+        for (uint32_t i = 0; i < n; i++) if (rd[i].pay_cap > da.max_pay_cap) da.max_pay_cap = rd[i].pay_cap;
         if ((rc = s5gpu_decode_dev(&da, c->st))) return rc;
         HIP_TRY(hipMemcpyAsync(ff.data(), c->d_fields.p, sizeof(s5gpu_rec_fields_t) * n, hipMemcpyDeviceToHost, c->st));
         HIP_TRY(hipStreamSynchronize(c->st));

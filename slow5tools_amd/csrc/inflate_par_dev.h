@@ -62,7 +62,10 @@ constexpr int INF_NEED_FALLBACK = 8;
 constexpr int IP_DBITS = S5_IP_DBITS;  // primary distance lookup bits (>= 7: the code-length code's 7-bit table is built in the same storage)
 static_assert(IP_DBITS >= 7 && IP_DBITS <= INF_DBITS, "");
 
-constexpr int IP_WAIT_SVB = 256;       // ... in the instantiation for svb-zd records (below)
+#ifndef S5_IP_WAIT_SVB
+#define S5_IP_WAIT_SVB 256
+#endif
+constexpr int IP_WAIT_SVB = S5_IP_WAIT_SVB;       // ... in the instantiation for svb-zd records (below)
 template <int WAIT>
 struct InflParSharedT {                 // per wave: 6.6 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
                                        // LDS per wave = + 33 % time), so nothing here is larger than it has to be

@@ -775,9 +775,13 @@ __device__ __forceinline__ int unpack_exzd_wave(const s5gpu_decode_args_t &a, co
 #ifndef S5_IP_WAVES
 #define S5_IP_WAVES 6
 #endif
-template <int UNPACK>      // 0: inflate only; 1: + parse and svb-zd decode; 2: + parse and ex-zd decode
+// SHORT: the caller's batch holds short records (s5gpu_decode_args.max_pay_cap <= S5_IP_SHORT_PAY): the 256-entry waiting list, 24 waves per CU
+#ifndef S5_IP_SHORT_PAY
+#define S5_IP_SHORT_PAY 32768u
+#endif
+template <int UNPACK, bool SHORT = true>      // UNPACK 0: inflate only; 1: + parse and svb-zd decode; 2: + parse and ex-zd decode
 __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_args_t a) {
-    __shared__ typename std::conditional<UNPACK != 0, InflParSharedSvb, InflParShared>::type T;   // svb-zd / ex-zd records: the small waiting list (inflate_par_dev.h)
+    __shared__ typename std::conditional<UNPACK != 0 && SHORT, InflParSharedSvb, InflParShared>::type T;   // short svb-zd / ex-zd records: the small waiting list (inflate_par_dev.h)
     const uint32_t r = blockIdx.x;
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
@@ -845,9 +849,9 @@ __device__ __forceinline__ void np_write_fields(const s5gpu_decode_args_t &a, ui
         a.fields[r].reserved = 0;
     }
 }
-template <bool EXZD>
+template <bool EXZD, bool SHORT = true>
 __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode_args_t a, NpParams np) {
-    __shared__ InflParSharedSvb T;
+    __shared__ typename std::conditional<SHORT, InflParSharedSvb, InflParShared>::type T;
     uint8_t *pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
     for (;;) {
         uint32_t r = blockIdx.x;
@@ -1618,9 +1622,14 @@ static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpa
         else if (unpack == 1) hipLaunchKernelGGL(k_zstd_inflate<1>, dim3(a->n_recs), dim3(64), 0, st, *a);
         else hipLaunchKernelGGL(k_zstd_inflate<0>, dim3(a->n_recs), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && g_inflate_par) {
-        if (unpack == 2) hipLaunchKernelGGL(k_inflate_par<2>, dim3(a->n_recs), dim3(64), 0, st, *a);
-        else if (unpack == 1) hipLaunchKernelGGL(k_inflate_par<1>, dim3(a->n_recs), dim3(64), 0, st, *a);
-        else hipLaunchKernelGGL(k_inflate_par<0>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        // the waiting list's size follows what was compressed and how long the records are (inflate_par_dev.h): short svb-zd / ex-zd
+        // records take the 256-entry list; long ones (several hundred waiting matches per window in their key bytes: 14.7 ms per 8192
+        // records of merged_expected_zlib_svb.blow5 with 768 entries, 23.3 with 256), raw-signal records and callers that do not say
+        // (max_pay_cap = 0) the 768-entry one
+        const bool shortrec = a->max_pay_cap != 0 && a->max_pay_cap <= S5_IP_SHORT_PAY;
+        if (unpack == 2) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<2, true>), dim3(a->n_recs), dim3(64), 0, st, *a); else hipLaunchKernelGGL((k_inflate_par<2, false>), dim3(a->n_recs), dim3(64), 0, st, *a); }
+        else if (unpack == 1) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<1, true>), dim3(a->n_recs), dim3(64), 0, st, *a); else hipLaunchKernelGGL((k_inflate_par<1, false>), dim3(a->n_recs), dim3(64), 0, st, *a); }
+        else hipLaunchKernelGGL((k_inflate_par<0, true>), dim3(a->n_recs), dim3(64), 0, st, *a);
         const uint32_t g = (a->n_recs + 63) / 64 < 4096 ? (a->n_recs + 63) / 64 : 4096;
         if (g_inflate_par == 1) hipLaunchKernelGGL(k_inflate_fallback, dim3(g), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
@@ -1766,7 +1775,7 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
             int per_cu = 0, cus = 0, dev = 0;
             HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            if (zl) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_par_np<false>, 64, 0));
+            if (zl) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_inflate_par_np<false, true>), 64, 0));
             else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_zstd_inflate_np, 64, 0));
             res = (uint32_t)(per_cu > 0 && cus > 0 ? per_cu * cus : 4096);
             s_res[zl].store(res, std::memory_order_relaxed);
@@ -1783,8 +1792,9 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         if (zl && a->n_recs <= n_main) np.ticket = nullptr;   // one record per workgroup: no ticket counter, nothing to clear (get batches)
         else HIP_TRY(hipMemsetAsync(a->payload, 0, 64, st));
         if (zl) {
-            if (np_xz) hipLaunchKernelGGL(k_inflate_par_np<true>, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
-            else hipLaunchKernelGGL(k_inflate_par_np<false>, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
+            const bool shortrec = a->max_pay_cap <= S5_IP_SHORT_PAY;
+            if (np_xz) { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<true, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<true, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
+            else { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<false, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<false, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
             hipLaunchKernelGGL(k_inflate_fallback_np, dim3((uint32_t)n_fb), dim3(64), 0, st, *a, np);
         } else {
             hipLaunchKernelGGL(k_zstd_inflate_np, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);

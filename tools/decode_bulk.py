@@ -32,7 +32,7 @@ if mode == "np":
     a.flags, a.payload, a.payload_bytes, a.max_pay_cap = _lib.DEC_NO_PAYLOAD, scr.data_ptr(), sb, pay_cap
 else:
     pay = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device="cuda")
-    a.payload = pay.data_ptr()
+    a.payload, a.max_pay_cap = pay.data_ptr(), pay_cap
 ts = []
 soak = os.environ.get("S5_SOAK", "") not in ("", "0")     # check every repetition (signals cleared in between): a soak for rare wrong decodes
 soak_bad = 0

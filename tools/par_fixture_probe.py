@@ -56,6 +56,26 @@ for name in ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES:
             cuts.append(min(tt))
         a.sig_method = keep
         print("    sync passes per record %s, rounds %s; cumulative ms: header %.2f, + sync %.2f, + output / runs / waiting %.2f, + Adler %.2f" % (ff["n_samples"].tolist(), ff["read_id_len"].tolist(), *cuts))
+    if f.sig_method == 1:   # svb-zd records: the whole decode as s5gpu_decode_dev runs it (the inflating wave unpacks; its waiting list is the small one)
+        _lib.check(L.s5gpu_set_option(b"inflate_par", 1), "opt")
+        sig_cap = 8 * ((plen + 7) // 8)          # (samples <= payload bytes)
+        d2 = d.copy()
+        d2["sig_off"] = np.arange(batch, dtype=np.uint64) * sig_cap; d2["sig_cap"] = sig_cap
+        desc2 = torch.from_numpy(d2.view(np.uint8).copy()).cuda()
+        sig = torch.empty(batch * sig_cap + 64, dtype=torch.int16, device="cuda")
+        a2 = _lib.DecodeArgs(); a2.n_recs, a2.rec_method, a2.sig_method = batch, 1, 1
+        a2.desc, a2.in_, a2.payload, a2.fields, a2.sig_out = desc2.data_ptr(), inp.data_ptr(), pay.data_ptr(), fields.data_ptr(), sig.data_ptr()
+        a2.max_pay_cap = pay_cap          # what the host calls pass: short records get the 24-wave shape of the kernel
+        ts = []
+        for _ in range(4):
+            fields.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); _lib.check(L.s5gpu_decode_dev(C.byref(a2), None), "decode"); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+        ff = fields.cpu().numpy().view(_lib.REC_FIELDS)[:len(streams)]
+        ok = all(int(x) == 0 for x in ff["status"])
+        nsamp = int(fields.cpu().numpy().view(_lib.REC_FIELDS)["n_samples"][:batch].astype(np.int64).sum())
+        print("    whole decode (s5gpu_decode_dev: inflate + parse + svb-zd unpack by the same wave): %.2f ms = %.2f G samples/s, statuses ok %s" % (min(ts[1:]), nsamp / min(ts[1:]) / 1e6, ok))
+        del sig
     print("%-44s %2d records (%d..%d B) x %d:  " % (name, len(streams), lens.min(), lens.max(), batch) +
           "   ".join("par=%d %.2f ms (%.1f GB/s of zlib stream) %s" % (m, t, zbytes / t / 1e6, s) for m, t, s in out))
 _lib.check(L.s5gpu_set_option(b"inflate_par", 1), "opt")
