@@ -1626,7 +1626,8 @@ static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpa
         // records take the 256-entry list; long ones (several hundred waiting matches per window in their key bytes: 14.7 ms per 8192
         // records of merged_expected_zlib_svb.blow5 with 768 entries, 23.3 with 256), raw-signal records and callers that do not say
         // (max_pay_cap = 0) the 768-entry one
-        const bool shortrec = a->max_pay_cap != 0 && a->max_pay_cap <= S5_IP_SHORT_PAY;
+        // (an ex-zd slot is sized for its worst case, 9.5 bytes per sample against svb-zd's 3.25: the same reads, three times the slot)
+        const bool shortrec = a->max_pay_cap != 0 && a->max_pay_cap <= S5_IP_SHORT_PAY * (a->sig_method == S5GPU_SIG_EX_ZD ? 3u : 1u);
         if (unpack == 2) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<2, true>), dim3(a->n_recs), dim3(64), 0, st, *a); else hipLaunchKernelGGL((k_inflate_par<2, false>), dim3(a->n_recs), dim3(64), 0, st, *a); }
         else if (unpack == 1) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<1, true>), dim3(a->n_recs), dim3(64), 0, st, *a); else hipLaunchKernelGGL((k_inflate_par<1, false>), dim3(a->n_recs), dim3(64), 0, st, *a); }
         else hipLaunchKernelGGL((k_inflate_par<0, true>), dim3(a->n_recs), dim3(64), 0, st, *a);
@@ -1792,7 +1793,7 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         if (zl && a->n_recs <= n_main) np.ticket = nullptr;   // one record per workgroup: no ticket counter, nothing to clear (get batches)
         else HIP_TRY(hipMemsetAsync(a->payload, 0, 64, st));
         if (zl) {
-            const bool shortrec = a->max_pay_cap <= S5_IP_SHORT_PAY;
+            const bool shortrec = a->max_pay_cap <= S5_IP_SHORT_PAY * (np_xz ? 3u : 1u);
             if (np_xz) { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<true, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<true, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
             else { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<false, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<false, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
             hipLaunchKernelGGL(k_inflate_fallback_np, dim3((uint32_t)n_fb), dim3(64), 0, st, *a, np);

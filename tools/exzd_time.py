@@ -45,7 +45,7 @@ for sm, name in ((press.SIG_EX_ZD, "ex-zd"), (press.SIG_SVB_ZD, "svb-zd (two-pas
     d["sig_off"] = np.arange(n_reads, dtype=np.uint64) * sig_cap; d["sig_cap"] = sig_cap
     desc = torch.from_numpy(d.view(np.uint8).copy()).to(dev)
     a = _lib.DecodeArgs()
-    a.n_recs, a.rec_method, a.sig_method = n_reads, 1, sm
+    a.n_recs, a.rec_method, a.sig_method, a.max_pay_cap = n_reads, 1, sm, pay_cap     # (max_pay_cap: short records, the kernel's 24-wave shape)
     a.desc, a.in_, a.payload, a.sig_out, a.fields = desc.data_ptr(), b.stream_out.data_ptr(), payload.data_ptr(), sig.data_ptr(), fields.data_ptr()
 
     def dec():

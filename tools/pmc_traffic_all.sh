@@ -38,7 +38,7 @@ legs = [("enc", "k_encode_stream", ["k_encode_stream"], 400000, 4000),
         ("svbs", "k_svbzd_stream", ["k_svbzd_stream"], 400000, 4000),
         ("long", "k_pack+k_deflate_staged", ["k_pack", "k_deflate_staged"], 4096, 100000),   # 16384 reads = 4 chunks of 4096 per step
         ("decnp", "k_inflate_par_np", ["k_inflate_par_np"], 1000000, 4000),
-        ("decfull", "k_inflate_par+k_unpack", ["k_inflate_par<1>"], 1000000, 4000)]
+        ("decfull", "k_inflate_par+k_unpack", ["k_inflate_par<1"], 1000000, 4000)]
 out = []
 for name, label, kernels, reads, n in legs:
     try:

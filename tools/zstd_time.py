@@ -55,7 +55,7 @@ for rec, name in ((press.REC_ZSTD, "zstd"), (press.REC_ZLIB, "zlib")):
     sig = torch.empty(n_reads * ((n_samp + 7) // 8 * 8) + 64, dtype=torch.int16, device=dev)
     fields = torch.zeros(n_reads * _lib.REC_FIELDS.itemsize, dtype=torch.uint8, device=dev)
     a = _lib.DecodeArgs()
-    a.n_recs, a.rec_method, a.sig_method = n_reads, rec, press.SIG_SVB_ZD
+    a.n_recs, a.rec_method, a.sig_method, a.max_pay_cap = n_reads, rec, press.SIG_SVB_ZD, pcap - 16
     a.desc, a.in_, a.payload, a.sig_out, a.fields = t_desc.data_ptr(), b.stream_out.data_ptr(), pay.data_ptr(), sig.data_ptr(), fields.data_ptr()
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     ms_i = timed(lambda: _lib.check(L.s5gpu_inflate_dev(C.byref(a), st), "inflate"))
