@@ -108,11 +108,11 @@ typedef struct s5gpu_rec_fields {
 
 /* s5gpu_decode_args.flags */
 enum {
-    /* s5gpu_decode_dev, zlib or zstd records with svb-zd signals: the caller wants fields + signals only (what `get` and the
+    /* s5gpu_decode_dev, zlib or zstd records with svb-zd signals and zlib records with ex-zd signals: the caller wants fields + signals only (what `get` and the
      * decode half of a signal consumer need; read_id / aux bytes live in the uncompressed record and are NOT kept).  `payload` is then
      * SCRATCH of payload_bytes bytes (s5gpu_decode_scratch_bytes() says how much is useful): the kernel runs as persistent
      * workgroups, each with one scratch slot of max_pay_cap bytes that it reuses record after record, so an uncompressed record
-     * never has to reach HBM (measured traffic: DESIGN.md 4.7).  desc[i].pay_off / pay_cap are ignored; a record whose payload
+     * needs no slot of its own (n x pay_cap bytes saved; the HBM traffic is that of the full form: DESIGN.md 4.8).  desc[i].pay_off / pay_cap are ignored; a record whose payload
      * exceeds max_pay_cap reports status 5 with the size needed.  fields[i].aux_off / aux_len are still reported. */
     S5GPU_DEC_NO_PAYLOAD = 1
 };
