@@ -182,6 +182,7 @@ int s5host::for_each_device_range(uint32_t n, const std::function<int(int, uint3
 
 using s5host::encode_and_collect;
 void s5kern_release_aux();   // kernels.hip
+void s5kern_release_order();
 
 extern "C" void s5gpu_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -205,6 +206,7 @@ extern "C" void s5gpu_shutdown(void) {
     }
     g_ndev = 0;
     s5kern_release_aux();
+    s5kern_release_order();
     s5host_generation++;
 }
 

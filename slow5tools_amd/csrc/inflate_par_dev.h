@@ -483,6 +483,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             // does, I wait until every entry up to it is done.  Stock zlib leaves ~110 such matches in an svb-zd record of 4000
             // samples (half of them in the key bytes); nearly all copy literals from far back and go in the first round.
             for (uint32_t c0 = 0; c0 < wtot; c0 += 64) {
+                if (dbg && dbg[3] == 4) break;                   // probe cut-off: what the waiting matches cost (the output is wrong without them)
                 const uint32_t j = c0 + (uint32_t)lane;
                 const bool have = j < wtot;
                 const int op = have ? (int)T.wq[j] : 0;
@@ -520,7 +521,9 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                     wave_sync();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     donem |= __ballot(ready);
+                    if (dbg) dbg[2] += 0x10000u;                 // (probe builds: dependency steps of the waiting matches in the high half, ...
                 }
+                if (dbg) dbg[2] += 1u;                           // ... batches of 64 in the low half)
             }
             o += round_out;
             // where the round ended: behind the end-of-block code, or at the last emitted lane's last token

@@ -704,6 +704,70 @@ __global__ __launch_bounds__(64) void k_inflate_head(s5gpu_decode_args_t a) {
     }
 }
 
+// ---- launch order of the wave-per-record kernels: the longest records first (round 3) ----
+// One wave decodes one record, so a batch ends when its longest record does — and a record of 300 k samples takes a wave ~15 ms however
+// idle the rest of the device is.  In file order it starts wherever it happens to stand: 262 144 records with the read lengths of a real
+// run decode in 23.7 ms, 16.6 ms with the longest first (tools/mixed_lengths.py: the rate per sample of a batch of equal reads).  So batches
+// larger than the device holds at once are counting-sorted by compressed length first — 128 buckets, four per octave, descending; the
+// k_route_* kernels' scheme with its scratch in a buffer of the library's own: ord[0..127] bucket counts, then cursors; ord[129] != 0: one
+// length class, no list (file order is as good); the list from ord[132] on.
+constexpr uint32_t ORD_FLAG = 129, ORD_LIST = 132;
+__device__ __forceinline__ uint32_t order_at(const uint32_t *ord, uint32_t i) {
+    return ord && !ord[ORD_FLAG] ? ord[ORD_LIST + i] : i;
+}
+__device__ __forceinline__ uint32_t order_bucket(uint32_t len) {
+    if (len < 4) return len;
+    const uint32_t hb = 31u - (uint32_t)__clz((int)len);
+    return hb * 4 + ((len >> (hb - 2)) & 3u);
+}
+__global__ __launch_bounds__(NT) void k_order_zero(uint32_t *ord) {
+    if (threadIdx.x < ORD_LIST) ord[threadIdx.x] = 0;
+}
+__global__ __launch_bounds__(NT) void k_order_count(const s5gpu_rec_desc_t *desc, uint32_t n, uint32_t *ord) {
+    __shared__ uint32_t h[128];
+    if (threadIdx.x < 128) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * NT + threadIdx.x;
+    if (i < n) atomicAdd(&h[order_bucket(desc[i].in_len)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 128 && h[threadIdx.x]) atomicAdd(&ord[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(128) void k_order_scan(uint32_t *ord) {   // one workgroup of 128: thread t owns bucket 127 - t
+    __shared__ uint32_t ws[2];
+    __shared__ uint64_t su[2];
+    const uint32_t b = 127u - threadIdx.x;
+    const uint32_t c = ord[b];
+    const uint32_t incl = wave_incl_add(c);
+    if (lane_id() == 63) ws[wave_id()] = incl;
+    const uint64_t used = __ballot(c != 0);
+    if (lane_id() == 0) su[wave_id()] = used;
+    __syncthreads();
+    ord[b] = incl - c + (wave_id() ? ws[0] : 0u);                       // cursor of the bucket in the descending list
+    if (threadIdx.x == 0) {
+        // su[0] bit i = bucket 127 - i, su[1] bit i = bucket 63 - i: at most three neighbouring buckets in use = one length class
+        const int nb = __popcll((unsigned long long)su[0]) + __popcll((unsigned long long)su[1]);
+        int first = -1, last = -1;
+        for (int t = 0; t < 128; t++) {
+            const bool u = ((t < 64 ? su[0] >> t : su[1] >> (t - 64)) & 1ull) != 0;
+            if (u) { if (first < 0) first = t; last = t; }
+        }
+        ord[ORD_FLAG] = nb == 0 || last - first <= 2 ? 1u : 0u;
+    }
+}
+__global__ __launch_bounds__(NT) void k_order_scatter(const s5gpu_rec_desc_t *desc, uint32_t n, uint32_t *ord) {   // a workgroup reserves one range per bucket
+    __shared__ uint32_t h[128], base[128];
+    if (ord[ORD_FLAG]) return;
+    if (threadIdx.x < 128) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * NT + threadIdx.x;
+    uint32_t b = 0, rank = 0;
+    if (i < n) { b = order_bucket(desc[i].in_len); rank = atomicAdd(&h[b], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 128 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&ord[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (i < n) ord[ORD_LIST + base[b] + rank] = i;
+}
+
 // K4, parallel inside the record (inflate_par_dev.h): one record per wave64, 64 self-synchronising segment decoders.  Default for
 // every batch size; what it declines (status INF_NEED_FALLBACK) the wave-per-record decoder redoes right behind it.
 // UNPACK (s5gpu_decode_dev on svb-zd records): the wave that inflated a record also parses it and decodes its signal — the payload
@@ -780,9 +844,9 @@ __device__ __forceinline__ int unpack_exzd_wave(const s5gpu_decode_args_t &a, co
 #define S5_IP_SHORT_PAY 32768u
 #endif
 template <int UNPACK, bool SHORT = true>      // UNPACK 0: inflate only; 1: + parse and svb-zd decode; 2: + parse and ex-zd decode
-__global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_args_t a) {
+__global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_args_t a, const uint32_t *ord) {
     __shared__ typename std::conditional<UNPACK != 0 && SHORT, InflParSharedSvb, InflParShared>::type T;   // short svb-zd / ex-zd records: the small waiting list (inflate_par_dev.h)
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = order_at(ord, blockIdx.x);
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
 #ifdef S5_PAR_PROBE   // tools/par_probe.py only (a variant build, tools/variant.sh probe -DS5_PAR_PROBE): cut-offs 91..93 and counters (99) keyed on sig_method
@@ -841,6 +905,7 @@ struct NpParams {
     uint32_t cap;          // payload bytes a slot takes (slot - 16)
     uint32_t *ticket;      // [0]: next record of the main kernel
     uint32_t first_fb;     // first slot of the fallback kernel's workgroups
+    const uint32_t *ord;   // launch order (longest records first), or nullptr
 };
 __device__ __forceinline__ void np_write_fields(const s5gpu_decode_args_t &a, uint32_t r, int status, uint32_t olen) {
     if (lane_id() == 0) {
@@ -860,6 +925,7 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode
             r = __builtin_amdgcn_readfirstlane(r);
         }
         if (r >= a.n_recs) return;
+        r = order_at(np.ord, r);
         const s5gpu_rec_desc_t d = a.desc[r];
         uint32_t olen = 0;
         int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
@@ -934,9 +1000,9 @@ static_assert(sizeof(ZstdShared::huf) + sizeof(ZstdShared::ll_e) >= SVB_WSTAGE &
 #endif
 static_assert(sizeof(ExzdWaveScratch) <= sizeof(ZstdShared), "the ex-zd wave scratch overlays the zstd decoder's LDS");
 template <int UNPACK>      // 0: decompress only; 1: + parse and svb-zd decode; 2: + parse and ex-zd decode
-__global__ __launch_bounds__(64, S5_ZI_W) void k_zstd_inflate(s5gpu_decode_args_t a) {
+__global__ __launch_bounds__(64, S5_ZI_W) void k_zstd_inflate(s5gpu_decode_args_t a, const uint32_t *ord) {
     __shared__ __attribute__((aligned(16))) ZstdShared T;
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = order_at(ord, blockIdx.x);
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
     int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
@@ -1553,6 +1619,7 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
 // Small batches (a single slow5_get) take the wave-per-record decoder (lowest latency); from
 // g_inflate_simt_min records on, the lane-per-record decoder (highest throughput).
 static uint32_t g_unpack_fused = 1;            // s5gpu_decode_dev, zlib + svb-zd: k_inflate_par unpacks the records it inflates (0: always k_unpack)
+static uint32_t g_order_min = 8192;            // zlib batches of at least this many records are launched longest first (option "order_min"; 0 = never)
 static uint32_t g_inflate_par = 1;             // zlib records: the decoder that is parallel inside a record (0: the two older kernels, chosen by batch size)
 static uint32_t g_inflate_route = 1;           // big zlib batches: sort by length, long records to the wave kernel (below)
 static uint32_t g_inflate_simt_min = 24576;   // measured crossover on 4000-sample reads: 16384 wave 3.0 ms vs lane 4.2 ms, 32768 wave 5.8 vs lane 4.5
@@ -1562,6 +1629,7 @@ extern "C" int s5gpu_set_option(const char *key, long value) {
     if (key && strcmp(key, "zstd_sequences") == 0 && (value == 0 || value == 1)) { g_zstd_sequences = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "unpack_fused") == 0 && (value == 0 || value == 1)) { g_unpack_fused = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_par") == 0 && value >= 0 && value <= 2) { g_inflate_par = (uint32_t)value; return S5GPU_OK; }   // 2 (tools): no fallback pass, declined records keep status 8
+    if (key && strcmp(key, "order_min") == 0 && value >= 0) { g_order_min = (uint32_t)value; return S5GPU_OK; }   // big zlib batches: longest records first from this many records on (0: never)
     if (s5host_set_option(key, value) == S5GPU_OK) return S5GPU_OK;
     s5gpu_set_error("s5gpu_set_option: unknown option");
     return S5GPU_ERR_ARG;
@@ -1616,11 +1684,59 @@ void s5kern_release_aux() {   // s5gpu_shutdown (bumps the generation right afte
     g_aux_free.clear();
 }
 
+// Scratch of the launch-order list: one buffer per (device, stream) — work on one stream is ordered, so the buffer of a stream is free again
+// when the next call on that stream is enqueued — grown on demand (hipFree waits for the device), released by s5gpu_shutdown.
+struct OrderBuf {
+    uint32_t *p = nullptr;
+    size_t words = 0;
+    int dev = -1;
+    hipStream_t st = nullptr;
+};
+static std::mutex g_ord_mu;
+static std::vector<OrderBuf> g_ord;
+void s5kern_release_order() {                 // s5gpu_shutdown
+    std::lock_guard<std::mutex> lk(g_ord_mu);
+    for (OrderBuf &b : g_ord) if (b.p) (void)hipFree(b.p);
+    g_ord.clear();
+}
+// builds the list for this batch on `st`; *out = nullptr when the batch is too small for the order to matter
+static int launch_order(const s5gpu_decode_args_t *a, hipStream_t st, const uint32_t **out) {
+    *out = nullptr;
+    if (!g_order_min || a->n_recs < g_order_min) return S5GPU_OK;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const size_t need = (size_t)ORD_LIST + a->n_recs;
+    uint32_t *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ord_mu);
+        OrderBuf *hit = nullptr;
+        for (OrderBuf &b : g_ord) if (b.dev == dev && b.st == st) { hit = &b; break; }
+        if (!hit) { g_ord.emplace_back(); hit = &g_ord.back(); hit->dev = dev; hit->st = st; }
+        if (hit->words < need) {
+            if (hit->p) (void)hipFree(hit->p);
+            hit->p = nullptr; hit->words = 0;
+            const size_t w = need + need / 4;
+            if (hipMalloc((void **)&hit->p, w * sizeof(uint32_t)) != hipSuccess) { hit->p = nullptr; s5gpu_set_error("no device memory for the launch-order list"); return S5GPU_ERR_NOMEM; }
+            hit->words = w;
+        }
+        p = hit->p;
+    }
+    const uint32_t nb = (a->n_recs + NT - 1) / NT;
+    hipLaunchKernelGGL(k_order_zero, dim3(1), dim3(NT), 0, st, p);
+    hipLaunchKernelGGL(k_order_count, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(128), 0, st, p);
+    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
+    *out = p;
+    return S5GPU_OK;
+}
+
 static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpack = 0) {   // unpack: the inflating wave also parses + decodes (1 svb-zd, 2 ex-zd)
     if (a->rec_method == S5GPU_REC_ZSTD) {
-        if (unpack == 2) hipLaunchKernelGGL(k_zstd_inflate<2>, dim3(a->n_recs), dim3(64), 0, st, *a);
-        else if (unpack == 1) hipLaunchKernelGGL(k_zstd_inflate<1>, dim3(a->n_recs), dim3(64), 0, st, *a);
-        else hipLaunchKernelGGL(k_zstd_inflate<0>, dim3(a->n_recs), dim3(64), 0, st, *a);
+        const uint32_t *ord = nullptr;
+        { const int rc = launch_order(a, st, &ord); if (rc) return rc; }
+        if (unpack == 2) hipLaunchKernelGGL(k_zstd_inflate<2>, dim3(a->n_recs), dim3(64), 0, st, *a, ord);
+        else if (unpack == 1) hipLaunchKernelGGL(k_zstd_inflate<1>, dim3(a->n_recs), dim3(64), 0, st, *a, ord);
+        else hipLaunchKernelGGL(k_zstd_inflate<0>, dim3(a->n_recs), dim3(64), 0, st, *a, ord);
     } else if (a->rec_method == S5GPU_REC_ZLIB && g_inflate_par) {
         // the waiting list's size follows what was compressed and how long the records are (inflate_par_dev.h): short svb-zd / ex-zd
         // records take the 256-entry list; long ones (several hundred waiting matches per window in their key bytes: 14.7 ms per 8192
@@ -1628,9 +1744,11 @@ static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpa
         // (max_pay_cap = 0) the 768-entry one
         // (an ex-zd slot is sized for its worst case, 9.5 bytes per sample against svb-zd's 3.25: the same reads, three times the slot)
         const bool shortrec = a->max_pay_cap != 0 && a->max_pay_cap <= S5_IP_SHORT_PAY * (a->sig_method == S5GPU_SIG_EX_ZD ? 3u : 1u);
-        if (unpack == 2) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<2, true>), dim3(a->n_recs), dim3(64), 0, st, *a); else hipLaunchKernelGGL((k_inflate_par<2, false>), dim3(a->n_recs), dim3(64), 0, st, *a); }
-        else if (unpack == 1) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<1, true>), dim3(a->n_recs), dim3(64), 0, st, *a); else hipLaunchKernelGGL((k_inflate_par<1, false>), dim3(a->n_recs), dim3(64), 0, st, *a); }
-        else hipLaunchKernelGGL((k_inflate_par<0, true>), dim3(a->n_recs), dim3(64), 0, st, *a);
+        const uint32_t *ord = nullptr;
+        { const int rc = launch_order(a, st, &ord); if (rc) return rc; }
+        if (unpack == 2) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<2, true>), dim3(a->n_recs), dim3(64), 0, st, *a, ord); else hipLaunchKernelGGL((k_inflate_par<2, false>), dim3(a->n_recs), dim3(64), 0, st, *a, ord); }
+        else if (unpack == 1) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<1, true>), dim3(a->n_recs), dim3(64), 0, st, *a, ord); else hipLaunchKernelGGL((k_inflate_par<1, false>), dim3(a->n_recs), dim3(64), 0, st, *a, ord); }
+        else hipLaunchKernelGGL((k_inflate_par<0, true>), dim3(a->n_recs), dim3(64), 0, st, *a, ord);
         const uint32_t g = (a->n_recs + 63) / 64 < 4096 ? (a->n_recs + 63) / 64 : 4096;
         if (g_inflate_par == 1) hipLaunchKernelGGL(k_inflate_fallback, dim3(g), dim3(64), 0, st, *a);
     } else if (a->rec_method == S5GPU_REC_ZLIB && a->n_recs >= g_inflate_simt_min) {
@@ -1790,8 +1908,12 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         np.slot = (uint32_t)slot;
         np.cap = (uint32_t)slot - 16;
         np.first_fb = (uint32_t)n_main;
+        np.ord = nullptr;
         if (zl && a->n_recs <= n_main) np.ticket = nullptr;   // one record per workgroup: no ticket counter, nothing to clear (get batches)
-        else HIP_TRY(hipMemsetAsync(a->payload, 0, 64, st));
+        else {
+            HIP_TRY(hipMemsetAsync(a->payload, 0, 64, st));
+            if (zl) { const int rc = launch_order(a, st, &np.ord); if (rc) return rc; }     // tickets in the order of the list: the longest records first
+        }
         if (zl) {
             const bool shortrec = a->max_pay_cap <= S5_IP_SHORT_PAY * (np_xz ? 3u : 1u);
             if (np_xz) { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<true, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<true, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }

@@ -651,6 +651,32 @@ def test_fused_unpack_and_the_records_it_leaves_to_the_second_kernel(press):
     assert any(g["status"] == 8 for g in alone)
 
 
+def test_big_mixed_batch_is_launched_longest_first_and_decodes_the_same(press):
+    """batches of >= 8192 zlib records are counting-sorted by compressed length on the device and launched longest first (one wave per
+    record: the batch ends with its longest one); the order must not show in the results — full form, no-payload form and file order
+    (option order_min = 0) agree record for record on 9000 reads of 1 .. 60000 samples"""
+    from slow5tools_amd import _lib
+    rng = np.random.default_rng(41)
+    n_rec = 9000
+    lens = np.clip(np.exp(rng.normal(np.log(1500), 1.1, n_rec)), 1, 60000).astype(np.int64)
+    lens[:4] = (60000, 1, 2, 45000)
+    sigs = [(500 + rng.integers(-60, 60, int(n))).astype(np.int16) for n in lens]
+    hdrs = [_hdr(press, i) for i in range(n_rec)]
+    recs = [r[8:] for r in press.encode_records(sigs, hdrs)]
+    f_np, s_np = press.decode_signals_dev(recs, press.REC_ZLIB, max_pay_cap=int(lens.max()) * 13 // 4 + 512, sig_caps=[int(n) + 8 for n in lens])
+    assert (f_np["status"] == 0).all()
+    L = _lib.lib()
+    full = press.decode_records(recs)
+    _lib.check(L.s5gpu_set_option(b"order_min", 0))
+    try:
+        f_fo, s_fo = press.decode_signals_dev(recs, press.REC_ZLIB, max_pay_cap=int(lens.max()) * 13 // 4 + 512, sig_caps=[int(n) + 8 for n in lens])
+    finally:
+        _lib.check(L.s5gpu_set_option(b"order_min", 8192))
+    for i in range(n_rec):
+        assert np.array_equal(s_np[i], sigs[i]) and np.array_equal(s_fo[i], sigs[i]) and np.array_equal(full[i]["signal"], sigs[i]), i
+        assert int(f_np["read_group"][i]) == int(f_fo["read_group"][i]) == full[i]["read_group"]
+
+
 @pytest.mark.parametrize("scratch", ["default", "three-slots"])
 def test_decode_without_payload_output_equals_the_full_decode(press, scratch):
     """S5GPU_DEC_NO_PAYLOAD (fields + signals only; persistent workgroups inflate into a reused scratch slot and unpack out of it):

@@ -50,3 +50,12 @@ _lib.check(L.s5gpu_set_option(b"inflate_route", 1), "opt")
 run("routed: sorted lanes + long on waves", ident, 0)
 _lib.check(L.s5gpu_set_option(b"inflate_par", 1), "opt")
 run("parallel inside the record (default)", ident, 0)
+# the same with the descriptors sorted by compressed length, longest first, on the host: what launch order is worth (one wave per record:
+# the batch ends when its longest record does, and that one should not start last)
+run("parallel, longest first (host-sorted)", np.argsort(-il.astype(np.int64), kind="stable"), 0)
+run("parallel, shortest first (host-sorted)", np.argsort(il.astype(np.int64), kind="stable"), 0)
+# ... and what the library does by itself (batches of >= 8192 records are counting-sorted by compressed length on the device): the default
+# line above IS that; with the option off, file order
+_lib.check(L.s5gpu_set_option(b"order_min", 0), "opt")
+run("parallel, file order (order_min = 0)", ident, 0)
+_lib.check(L.s5gpu_set_option(b"order_min", 8192), "opt")

@@ -47,7 +47,7 @@ for name in ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES:
         fields.zero_(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); torch.cuda.synchronize()
         ff = fields.cpu().numpy().view(_lib.REC_FIELDS)[:len(streams)]
         cuts = []
-        for cut in (91, 92, 93, 1):
+        for cut in (91, 92, 94, 93, 1):
             a.sig_method = cut
             tt = []
             for _ in range(3):
@@ -55,7 +55,8 @@ for name in ZLIB_SVB_FIXTURES + ZLIB_NONE_FIXTURES:
                 e0.record(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); e1.record(); torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
             cuts.append(min(tt))
         a.sig_method = keep
-        print("    sync passes per record %s, rounds %s; cumulative ms: header %.2f, + sync %.2f, + output / runs / waiting %.2f, + Adler %.2f" % (ff["n_samples"].tolist(), ff["read_id_len"].tolist(), *cuts))
+        print("    waiting matches: batches of 64 per record %s, dependency steps %s" % ([int(x) & 0xFFFF for x in ff["read_group"]], [int(x) >> 16 for x in ff["read_group"]]))
+        print("    sync passes per record %s, rounds %s; cumulative ms: header %.2f, + sync %.2f, + output pass / runs %.2f, + waiting matches %.2f, + Adler %.2f" % (ff["n_samples"].tolist(), ff["read_id_len"].tolist(), *cuts))
     if f.sig_method == 1:   # svb-zd records: the whole decode as s5gpu_decode_dev runs it (the inflating wave unpacks; its waiting list is the small one)
         _lib.check(L.s5gpu_set_option(b"inflate_par", 1), "opt")
         sig_cap = 8 * ((plen + 7) // 8)          # (samples <= payload bytes)
