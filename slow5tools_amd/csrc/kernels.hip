@@ -1699,16 +1699,18 @@ void s5kern_release_order() {                 // s5gpu_shutdown
     for (OrderBuf &b : g_ord) if (b.p) (void)hipFree(b.p);
     g_ord.clear();
 }
-// builds the list for this batch on `st`; *out = nullptr when the batch is too small for the order to matter
-static int launch_order(const s5gpu_decode_args_t *a, hipStream_t st, const uint32_t **out) {
+// builds the list for this batch on `st`; *out = nullptr when the batch is too small for the order to matter.  `hold` keeps the pool locked
+// until the caller has enqueued the kernel that reads the list: two threads that share a stream (the default stream, say) must not
+// interleave "build my list" / "build yours" / "read mine".
+static int launch_order(const s5gpu_decode_args_t *a, hipStream_t st, const uint32_t **out, std::unique_lock<std::mutex> &hold) {
     *out = nullptr;
     if (!g_order_min || a->n_recs < g_order_min) return S5GPU_OK;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const size_t need = (size_t)ORD_LIST + a->n_recs;
     uint32_t *p = nullptr;
+    hold = std::unique_lock<std::mutex>(g_ord_mu);
     {
-        std::lock_guard<std::mutex> lk(g_ord_mu);
         OrderBuf *hit = nullptr;
         for (OrderBuf &b : g_ord) if (b.dev == dev && b.st == st) { hit = &b; break; }
         if (!hit) { g_ord.emplace_back(); hit = &g_ord.back(); hit->dev = dev; hit->st = st; }
@@ -1731,9 +1733,10 @@ static int launch_order(const s5gpu_decode_args_t *a, hipStream_t st, const uint
 }
 
 static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpack = 0) {   // unpack: the inflating wave also parses + decodes (1 svb-zd, 2 ex-zd)
+    std::unique_lock<std::mutex> hold;            // (launch_order's: released when the kernels that read the list are enqueued)
     if (a->rec_method == S5GPU_REC_ZSTD) {
         const uint32_t *ord = nullptr;
-        { const int rc = launch_order(a, st, &ord); if (rc) return rc; }
+        { const int rc = launch_order(a, st, &ord, hold); if (rc) return rc; }
         if (unpack == 2) hipLaunchKernelGGL(k_zstd_inflate<2>, dim3(a->n_recs), dim3(64), 0, st, *a, ord);
         else if (unpack == 1) hipLaunchKernelGGL(k_zstd_inflate<1>, dim3(a->n_recs), dim3(64), 0, st, *a, ord);
         else hipLaunchKernelGGL(k_zstd_inflate<0>, dim3(a->n_recs), dim3(64), 0, st, *a, ord);
@@ -1745,7 +1748,7 @@ static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpa
         // (an ex-zd slot is sized for its worst case, 9.5 bytes per sample against svb-zd's 3.25: the same reads, three times the slot)
         const bool shortrec = a->max_pay_cap != 0 && a->max_pay_cap <= S5_IP_SHORT_PAY * (a->sig_method == S5GPU_SIG_EX_ZD ? 3u : 1u);
         const uint32_t *ord = nullptr;
-        { const int rc = launch_order(a, st, &ord); if (rc) return rc; }
+        { const int rc = launch_order(a, st, &ord, hold); if (rc) return rc; }
         if (unpack == 2) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<2, true>), dim3(a->n_recs), dim3(64), 0, st, *a, ord); else hipLaunchKernelGGL((k_inflate_par<2, false>), dim3(a->n_recs), dim3(64), 0, st, *a, ord); }
         else if (unpack == 1) { if (shortrec) hipLaunchKernelGGL((k_inflate_par<1, true>), dim3(a->n_recs), dim3(64), 0, st, *a, ord); else hipLaunchKernelGGL((k_inflate_par<1, false>), dim3(a->n_recs), dim3(64), 0, st, *a, ord); }
         else hipLaunchKernelGGL((k_inflate_par<0, true>), dim3(a->n_recs), dim3(64), 0, st, *a, ord);
@@ -1903,6 +1906,7 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         if (n_main > resident) n_main = resident;
         if (n_main > a->n_recs) n_main = a->n_recs;
         NpParams np;
+        std::unique_lock<std::mutex> hold;
         np.ticket = reinterpret_cast<uint32_t *>(a->payload);
         np.scratch = a->payload + 64;
         np.slot = (uint32_t)slot;
@@ -1912,7 +1916,7 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         if (zl && a->n_recs <= n_main) np.ticket = nullptr;   // one record per workgroup: no ticket counter, nothing to clear (get batches)
         else {
             HIP_TRY(hipMemsetAsync(a->payload, 0, 64, st));
-            if (zl) { const int rc = launch_order(a, st, &np.ord); if (rc) return rc; }     // tickets in the order of the list: the longest records first
+            if (zl) { const int rc = launch_order(a, st, &np.ord, hold); if (rc) return rc; }     // tickets in the order of the list: the longest records first
         }
         if (zl) {
             const bool shortrec = a->max_pay_cap <= S5_IP_SHORT_PAY * (np_xz ? 3u : 1u);
