@@ -730,6 +730,8 @@ def main():
         n_reads = args.reads if args.reads != 1_000_000 else 262144
         rng = np.random.default_rng(5)
         ns = np.clip(np.exp(rng.normal(np.log(6000), 0.9, n_reads)), 200, 400000).astype(np.uint64)
+        if os.environ.get("S5BENCH_MIXED_SORT"):          # tools: what the order of the reads is worth (longest first / shortest first)
+            ns = np.sort(ns)[::-1].copy() if os.environ["S5BENCH_MIXED_SORT"] == "desc" else np.sort(ns)
         # the device entry point only knows the longest read; the host batch calls name this budget from the lengths themselves
         b = press.DeviceBatch(ns, device=dev, lds_payload_cap=args.fused_cap)
         tot = b.sig.numel()
