@@ -129,7 +129,7 @@ typedef struct s5gpu_decode_args {
     s5gpu_rec_fields_t *fields;      /* device, out                                                  */
     uint64_t payload_bytes;          /* S5GPU_DEC_NO_PAYLOAD: bytes of scratch at `payload`          */
     uint32_t max_pay_cap;            /* largest uncompressed record to expect (0 = not known).  S5GPU_DEC_NO_PAYLOAD: the scratch slot
-                                      * size.  Any form: a batch of short records (<= 32 KiB, i.e. reads of up to ~20 k samples) with
+                                      * size.  Any form: a batch of short records (<= 32 KiB of slot, i.e. reads of up to ~10 k samples) with
                                       * svb-zd / ex-zd signals runs the inflate kernel in its 24-waves-per-CU shape (a 256-entry list
                                       * of waiting matches); longer or unknown ones in the 21-wave shape with 768 entries, which long
                                       * reads written by stock zlib need in their key bytes */
