@@ -26,6 +26,13 @@
 #include "slow5_compat.h"
 #include "slow5gpu.h"
 
+/* S5VIEW_TIMING=1: where the wall time of the whole process goes (stderr, seconds since main() was entered) */
+static double g_t_main;
+static int g_timing;
+static double now_s(void);
+static void stamp(const char *what) { if (g_timing) fprintf(stderr, "s5view[t] %8.3f  %s\n", now_s() - g_t_main, what); }
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static int die(const char *what) {
     fprintf(stderr, "s5view: %s (slow5_errno %d; %s)\n", what, slow5_errno, s5gpu_last_error());
     return EXIT_FAILURE;
@@ -136,6 +143,7 @@ typedef struct {
     uint64_t *rec_pos, *out_off;
     uint32_t *rec_len;
     uint32_t *nl, nl_cap;       /* SLOW5 text: newline positions found by the pread threads (16 equal shares) */
+    int ready;                  /* its buffers are allocated (slots behind the first are pinned while the first chunk is already on its way) */
 } fslot_t;
 typedef struct {
     pthread_mutex_t mu;
@@ -217,7 +225,7 @@ static void *freader_main(void *arg) {
     for (int64_t s = 0;; s++) {
         fslot_t *b = &P->slot[s % FSLOT];
         pthread_mutex_lock(&P->mu);
-        while (!P->failed && b->state != ST_EMPTY) pthread_cond_wait(&P->cv, &P->mu);
+        while (!P->failed && (b->state != ST_EMPTY || !b->ready)) pthread_cond_wait(&P->cv, &P->mu);
         const int stop = P->failed;
         pthread_mutex_unlock(&P->mu);
         if (stop) return NULL;
@@ -244,6 +252,7 @@ static void *freader_main(void *arg) {
             for (int t = 0; t < used; t++) if (!job[t].ok) { fpipe_fail(P, "read failed"); return NULL; }
         }
         P->pos += want;
+        if (s == 0) stamp("first chunk read");
         const size_t have = carry + want;
         size_t p = 0;
         uint32_t n = 0;
@@ -328,13 +337,51 @@ static void *fworker_main(void *arg) {
             return NULL;
         }
         b->out_total = (size_t)b->out_off[b->n];
+        if (s == 0) stamp("first chunk through the GPU call");
         pthread_mutex_lock(&P->mu);
         b->state = ST_DONE;
         pthread_cond_broadcast(&P->cv);
         pthread_mutex_unlock(&P->mu);
     }
 }
-static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+/* buffers of one chunk slot.  Output room: what the conversion usually needs (a chunk that outgrows it is redone with the room it asked for) */
+static int fslot_alloc(fpipe_t *P, int i) {
+    fslot_t *b = &P->slot[i];
+    const char *e;
+    b->cap = (uint32_t)(P->chunk / 48) + 1;                      /* descriptors per chunk; a chunk of smaller records than that is framed in two rounds */
+    e = getenv("S5VIEW_SLOT_RECS");                             /* tests: fewer descriptors than a chunk holds records */
+    if (e && atoi(e) > 0) b->cap = (uint32_t)atoi(e);
+    b->in = (uint8_t *)s5gpu_host_alloc(P->chunk + 64);
+    /* text in: ~4.5 text bytes per sample against ~0.9 record bytes; text out: ~4.5 against 0.9 the other way; BLOW5 to BLOW5: about the
+     * same size unless a compressed file is written out uncompressed */
+    const int expands = P->from.record_method != SLOW5_COMPRESS_NONE && P->to.record_method == SLOW5_COMPRESS_NONE;
+    b->out_cap = P->ascii ? P->chunk / 2 : P->ascii_out ? P->chunk * 6 : expands ? P->chunk * 3 : P->chunk + P->chunk / 4;
+    if (b->out_cap < (1u << 16)) b->out_cap = 1u << 16;
+    b->out = (uint8_t *)s5gpu_host_alloc(b->out_cap);
+    b->rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * b->cap);
+    b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * b->cap);
+    b->out_off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)b->cap + 1));
+    if (P->ascii) { b->nl_cap = 16 * (uint32_t)(P->chunk / 16 / 64 + 64); b->nl = (uint32_t *)malloc(sizeof(uint32_t) * b->nl_cap); }
+    if (!b->in || !b->out || !b->rec_pos || !b->rec_len || !b->out_off || (P->ascii && !b->nl)) return -1;
+    pthread_mutex_lock(&P->mu);
+    b->ready = 1;
+    pthread_cond_broadcast(&P->cv);
+    pthread_mutex_unlock(&P->mu);
+    return 0;
+}
+static void *fslot_alloc_rest(void *arg) {
+    fpipe_t *P = (fpipe_t *)arg;
+    for (int i = 1; i < FSLOT; i++) {
+        /* a file that fits the slots already there needs no more of them */
+        pthread_mutex_lock(&P->mu);
+        const int done = P->failed || P->total_batches >= 0;
+        pthread_mutex_unlock(&P->mu);
+        if (done) break;
+        if (fslot_alloc(P, i) != 0) { fpipe_fail(P, "cannot allocate the chunk buffers"); break; }
+    }
+    stamp("all chunk slots pinned");
+    return NULL;
+}
 /* returns 0 and the record count, -1, or -2: a record does not fit a chunk (an uncompressed ultra-long read) — the caller redoes the
  * file with the per-record pipeline */
 static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slow5_press_method_t to, int ascii_out, int workers, uint64_t *total) {
@@ -364,23 +411,14 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     P.readers = e ? atoi(e) : (in->format == SLOW5_FORMAT_ASCII ? 8 : 4);   /* (text is twice the bytes per sample: more copy threads) */
     P.from = from; P.to = to; P.total_batches = -1;
     const double t_alloc = now_s();
-    for (int i = 0; i < FSLOT; i++) {
-        fslot_t *b = &P.slot[i];
-        b->cap = (uint32_t)(P.chunk / 48) + 1;                      /* descriptors per chunk; a chunk of smaller records than that is framed in two rounds */
-        e = getenv("S5VIEW_SLOT_RECS");                             /* tests: fewer descriptors than a chunk holds records */
-        if (e && atoi(e) > 0) b->cap = (uint32_t)atoi(e);
-        b->in = (uint8_t *)s5gpu_host_alloc(P.chunk + 64);
-        b->out_cap = P.ascii ? P.chunk : P.ascii_out ? P.chunk * 6 : P.chunk * 3;   /* (a chunk that outgrows it is redone with the room it asked for) */
-        b->out = (uint8_t *)s5gpu_host_alloc(b->out_cap);
-        b->rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * b->cap);
-        b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * b->cap);
-        b->out_off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)b->cap + 1));
-        if (P.ascii) { b->nl_cap = 16 * (uint32_t)(P.chunk / 16 / 64 + 64); b->nl = (uint32_t *)malloc(sizeof(uint32_t) * b->nl_cap); }
-        if (!b->in || !b->out || !b->rec_pos || !b->rec_len || !b->out_off || (P.ascii && !b->nl)) { fprintf(stderr, "s5view: cannot allocate the chunk buffers (%s)\n", s5gpu_last_error()); return -1; }
-    }
+    /* slot 0 is pinned here; the others by a helper thread while the first chunk is read and sent (a pinned buffer of tens of MB costs
+     * 5-15 ms, and a short job is over before four slots' worth of that would have been spent up front) */
+    if (fslot_alloc(&P, 0) != 0) { fprintf(stderr, "s5view: cannot allocate the chunk buffers (%s)\n", s5gpu_last_error()); return -1; }
+    stamp("first chunk slot pinned");
     const double t0 = now_s();
-    pthread_t rd, wk[8];
+    pthread_t rd, wk[8], al;
     const int W = workers > 8 ? 8 : workers;
+    pthread_create(&al, NULL, fslot_alloc_rest, &P);
     pthread_create(&rd, NULL, freader_main, &P);
     for (int i = 0; i < W; i++) pthread_create(&wk[i], NULL, fworker_main, &P);
     uint64_t out_bytes = 0;
@@ -406,7 +444,9 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     }
     pthread_join(rd, NULL);
     for (int i = 0; i < W; i++) pthread_join(wk[i], NULL);
+    pthread_join(al, NULL);
     const double t1 = now_s();
+    stamp("last write");
     for (int i = 0; i < FSLOT; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); free(b->nl); }
     if (P.failed && P.oversize) return -2;
     if (P.failed) { fprintf(stderr, "s5view: %s\n", P.why); return -1; }
@@ -415,7 +455,15 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     return 0;
 }
 
+static void *early_init_main(void *arg) {
+    (void)arg;
+    if (s5gpu_init(0) == S5GPU_OK) s5gpu_host_free(s5gpu_host_alloc(4096));   /* (the first pinned allocation brings up its own machinery) */
+    stamp("early device initialisation done");
+    return NULL;
+}
 int main(int argc, char **argv) {
+    g_t_main = now_s();
+    g_timing = getenv("S5VIEW_TIMING") && atoi(getenv("S5VIEW_TIMING"));
     if (argc >= 3 && strcmp(argv[1], "--index") == 0) {
         slow5_file_t *s = slow5_open(argv[2], "r");
         if (!s) return die("cannot open input");
@@ -449,8 +497,13 @@ int main(int argc, char **argv) {
         const char *dm = getenv("S5VIEW_DEV_MASK");
         if (dm && strtoull(dm, NULL, 0) && s5gpu_init_mask(strtoull(dm, NULL, 0)) != S5GPU_OK) return die("cannot initialise the devices of S5VIEW_DEV_MASK");
     }
+    /* the HIP runtime and the device context come up (~0.15 s) while the input's header is read and the output is created */
+    pthread_t init_th;
+    const int early_init = !(getenv("S5VIEW_DEV_MASK") && strtoull(getenv("S5VIEW_DEV_MASK"), NULL, 0));
+    if (early_init) pthread_create(&init_th, NULL, early_init_main, NULL);
     slow5_file_t *in = slow5_open(argv[1], "r");
     if (!in) return die("cannot open input");
+    stamp("input opened, header read");
     FILE *out = fopen(argv[2], "wb");
     if (!out) return die("cannot open output");
     const size_t ol = strlen(argv[2]);
@@ -460,6 +513,8 @@ int main(int argc, char **argv) {
 
     const int workers = argc > 6 ? atoi(argv[6]) : 1;
     uint64_t total = 0;
+    if (early_init) pthread_join(init_th, NULL);
+    stamp("device ready");
     const char *nofast = getenv("S5VIEW_PER_RECORD");
     /* chunked pipeline: BLOW5 -> BLOW5, SLOW5 -> BLOW5 (the conversion BASELINE configs[0] names) and BLOW5 -> SLOW5; text to text takes the per-record one */
     int fast = workers > 0 && (fmt_out == SLOW5_FORMAT_BINARY || in->format == SLOW5_FORMAT_BINARY) && !(nofast && atoi(nofast));
@@ -541,6 +596,8 @@ int main(int argc, char **argv) {
     fclose(out);
     slow5_close(in);
     fprintf(stderr, "s5view: %llu records\n", (unsigned long long)total);
+    stamp("output closed");
     s5gpu_shutdown();
+    stamp("library shut down");
     return EXIT_SUCCESS;
 }

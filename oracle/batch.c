@@ -286,3 +286,221 @@ uint64_t s5o_convert_ascii_batch_mt(const char *text, const uint64_t *line_off, 
     if (checksum) *checksum = ck;
     return db.failed ? 0 : total;
 }
+
+/* =====================================================================================================================
+ * END-TO-END twins: the WHOLE loop of `slow5tools view` and `slow5tools get --benchmark` on files, for bench.py's `e2e` object.
+ * Same shape as the reference: a serial read phase of K records (src/view.c:265-278: slow5_get_next_mem — one getline / one
+ * fread + one malloc per record), the work_db compute phase above (src/view.c:292), a serial ordered write phase (src/view.c:296-299:
+ * one fwrite + one free per record); the three phases one after the other per batch.  phases[0..2] = seconds spent in read /
+ * compute / write, phases[3] = first read to last write.  TEST / BENCH infrastructure like the rest of this file.
+ * ===================================================================================================================== */
+#include <stdio.h>
+#include <unistd.h>
+#include <fcntl.h>
+
+typedef struct {
+    batch_t db;               /* db.out / db.out_len: the batch's outputs */
+    char **mem;               /* the batch's input records (lines, or BLOW5 record bytes) */
+    size_t *bytes;
+    int from_blow5;
+    uint8_t aux_types[256];   /* text input: the aux columns' types (the header's "#char*..." line) */
+    int n_aux;
+} view_db_t;
+
+static void view_one(void *dbv, int32_t i) {
+    view_db_t *v = (view_db_t *)dbv;            /* (batch_t is the first member) */
+    batch_t *db = &v->db;
+    db->out[i] = NULL;
+    db->out_len[i] = 0;
+    s5o_rec_t r;
+    uint8_t *pay = NULL;
+    size_t plen = 0;
+    int from_sig = S5O_SIG_NONE;
+    if (!v->from_blow5) {                       /* slow5_rec_depress_parse of an ASCII line */
+        pay = (uint8_t *)malloc(v->bytes[i] + 128);
+        plen = pay ? s5o_ascii_line_to_payload(v->mem[i], v->bytes[i], v->n_aux ? v->aux_types : NULL, (unsigned)v->n_aux, pay) : 0;
+    } else {                                    /* ... of a zlib + svb-zd record */
+        size_t cap = v->bytes[i] * 4 + 4096;
+        for (int attempt = 0; attempt < 4 && !plen; attempt++) {
+            pay = (uint8_t *)malloc(cap);
+            size_t l = cap;
+            if (pay && s5o_zlib_decompress((const uint8_t *)v->mem[i], v->bytes[i], pay, &l) == 0) { plen = l; break; }
+            free(pay); pay = NULL; cap *= 4;
+        }
+        from_sig = S5O_SIG_SVB_ZD;
+    }
+    if (!plen || s5o_rec_parse(pay, plen, from_sig, &r, NULL) != 0) { free(pay); db->failed = 1; return; }
+    int16_t *sig = (int16_t *)malloc(r.len_raw_signal ? 2 * (size_t)r.len_raw_signal : 2);
+    if (!sig || s5o_rec_parse(pay, plen, from_sig, &r, sig) != 0) { free(pay); free(sig); db->failed = 1; return; }
+    uint8_t *scratch = (uint8_t *)malloc(s5o_payload_bound(&r, db->sig_method));
+    uint8_t *out = (uint8_t *)malloc(s5o_rec_to_mem_bound(&r, db->sig_method));
+    db->out_len[i] = s5o_rec_to_mem(&r, db->rec_method, db->sig_method, scratch, out);
+    db->out[i] = out;
+    free(scratch); free(sig); free(pay);
+}
+
+/* in: a .slow5 (text) file or a BLOW5 file with zlib + svb-zd records (sniffed); out: BLOW5, zlib + svb-zd.  max_reads = 0: the whole file.
+ * Returns the number of records written, 0 on failure. */
+uint64_t s5o_view_file(const char *in_path, const char *out_path, int n_threads, int batch_size, uint64_t max_reads, double phases[4]) {
+    FILE *in = fopen(in_path, "rb"), *out = fopen(out_path, "wb");
+    if (!in || !out) { if (in) fclose(in); if (out) fclose(out); return 0; }
+    static char ibuf[1 << 20], obuf[1 << 20];
+    setvbuf(in, ibuf, _IOFBF, sizeof ibuf);
+    setvbuf(out, obuf, _IOFBF, sizeof obuf);
+    view_db_t V;
+    memset(&V, 0, sizeof V);
+    uint8_t head[64];
+    char *hdr_text = NULL;
+    size_t hdr_len = 0;
+    int c0 = fgetc(in);
+    ungetc(c0, in);
+    V.from_blow5 = c0 == 'B';
+    if (V.from_blow5) {
+        uint32_t hl;
+        if (fread(head, 1, 64, in) != 64 || fread(&hl, 4, 1, in) != 1) goto fail;
+        hdr_text = (char *)malloc(hl ? hl : 1);
+        if (fread(hdr_text, 1, hl, in) != hl) goto fail;
+        hdr_len = hl;
+    } else {
+        /* header lines (#..., @...) up to the first record line; #slow5_version / #num_read_groups go into the binary head */
+        memset(head, 0, 64);
+        memcpy(head, "BLOW5\1", 6);
+        head[6] = 0; head[7] = 2; head[8] = 0;
+        uint32_t nrg = 1;
+        size_t cap = 0;
+        char *line = NULL;
+        for (;;) {
+            int c = fgetc(in);
+            if (c == EOF) break;
+            ungetc(c, in);
+            if (c != '#' && c != '@') break;
+            ssize_t l = getline(&line, &cap, in);
+            if (l <= 0) break;
+            if (strncmp(line, "#slow5_version\t", 15) == 0) { int a = 0, b = 0, c2 = 0; sscanf(line + 15, "%d.%d.%d", &a, &b, &c2); head[6] = (uint8_t)a; head[7] = (uint8_t)b; head[8] = (uint8_t)c2; continue; }
+            if (strncmp(line, "#num_read_groups\t", 17) == 0) { nrg = (uint32_t)strtoul(line + 17, NULL, 10); continue; }
+            if (strncmp(line, "#char*\t", 7) == 0) { const int na = s5o_aux_types(line, (size_t)l, V.aux_types, sizeof V.aux_types); V.n_aux = na > 0 ? na : 0; }
+            hdr_text = (char *)realloc(hdr_text, hdr_len + (size_t)l);
+            memcpy(hdr_text + hdr_len, line, (size_t)l);
+            hdr_len += (size_t)l;
+        }
+        free(line);
+        memcpy(head + 10, &nrg, 4);
+    }
+    head[9] = 1;  /* record press zlib */
+    head[14] = 1; /* signal press svb-zd */
+    {
+        uint32_t hl = (uint32_t)hdr_len;
+        fwrite(head, 1, 64, out); fwrite(&hl, 4, 1, out); fwrite(hdr_text, 1, hdr_len, out);
+    }
+    V.db.rec_method = S5O_REC_ZLIB;
+    V.db.sig_method = S5O_SIG_SVB_ZD;
+    V.db.one = view_one;
+    V.db.out = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)batch_size);
+    V.db.out_len = (size_t *)malloc(sizeof(size_t) * (size_t)batch_size);
+    V.mem = (char **)malloc(sizeof(char *) * (size_t)batch_size);
+    V.bytes = (size_t *)malloc(sizeof(size_t) * (size_t)batch_size);
+    uint64_t total = 0;
+    double tr = 0, tc = 0, tw = 0;
+    const double t_first = now_s();
+    int eof = 0;
+    while (!eof && (!max_reads || total < max_reads)) {
+        double t0 = now_s();
+        int64_t n = 0;
+        while (n < batch_size && (!max_reads || total + (uint64_t)n < max_reads)) {     /* read phase */
+            if (V.from_blow5) {
+                uint64_t sz;
+                if (fread(&sz, 8, 1, in) != 1 || memcmp(&sz, "5WOLB", 5) == 0) { eof = 1; break; }
+                V.mem[n] = (char *)malloc((size_t)sz ? (size_t)sz : 1);
+                if (fread(V.mem[n], 1, (size_t)sz, in) != (size_t)sz) { free(V.mem[n]); eof = 1; break; }
+                V.bytes[n] = (size_t)sz;
+            } else {
+                char *line = NULL;
+                size_t cap = 0;
+                ssize_t l = getline(&line, &cap, in);
+                if (l <= 0) { free(line); eof = 1; break; }
+                if (l && line[l - 1] == '\n') l--;
+                V.mem[n] = line;
+                V.bytes[n] = (size_t)l;
+            }
+            n++;
+        }
+        if (n == 0) break;
+        double t1 = now_s();
+        V.db.n_batch = n;
+        work_batch(&V.db, n_threads);                                                   /* compute phase */
+        double t2 = now_s();
+        for (int64_t i = 0; i < n; i++) {                                               /* ordered write phase */
+            if (V.db.out[i]) fwrite(V.db.out[i], 1, V.db.out_len[i], out);
+            free(V.db.out[i]);
+            free(V.mem[i]);
+        }
+        double t3 = now_s();
+        tr += t1 - t0; tc += t2 - t1; tw += t3 - t2;
+        total += (uint64_t)n;
+    }
+    fwrite("5WOLB", 1, 5, out);
+    fflush(out);
+    const double t_last = now_s();
+    if (phases) { phases[0] = tr; phases[1] = tc; phases[2] = tw; phases[3] = t_last - t_first; }
+    free(V.db.out); free(V.db.out_len); free(V.mem); free(V.bytes); free(hdr_text);
+    fclose(in); fclose(out);
+    return V.db.failed ? 0 : total;
+fail:
+    free(hdr_text); fclose(in); fclose(out);
+    return 0;
+}
+
+/* `get --benchmark -t T -K B` on a file (src/get.c:52, 321-386): per id the worker itself preads the record (slow5_get does), inflates,
+ * parses and decodes it; nothing is written.  pos / len: file extents of the records to fetch ([u64 size][bytes]: pos points at the size
+ * prefix), in fetch order.  Returns samples decoded (0 on failure); *secs = first batch to last. */
+typedef struct { batch_t db; int fd; const uint64_t *pos; const uint32_t *len; } get_db_t;
+static void get_one(void *dbv, int32_t i) {
+    get_db_t *g = (get_db_t *)dbv;
+    batch_t *db = &g->db;
+    const uint64_t k = db->base + (uint64_t)i;
+    db->out[i] = NULL;
+    db->out_len[i] = 0;
+    const size_t zl = g->len[k] - 8;
+    uint8_t *rec = (uint8_t *)malloc(g->len[k]);
+    if (!rec || pread(g->fd, rec, g->len[k], (off_t)g->pos[k]) != (ssize_t)g->len[k]) { free(rec); db->failed = 1; return; }
+    size_t cap = zl * 4 + 4096, plen = 0;
+    uint8_t *pay = NULL;
+    for (int attempt = 0; attempt < 4 && !plen; attempt++) {
+        pay = (uint8_t *)malloc(cap);
+        size_t l = cap;
+        if (pay && s5o_zlib_decompress(rec + 8, zl, pay, &l) == 0) { plen = l; break; }
+        free(pay); pay = NULL; cap *= 4;
+    }
+    free(rec);
+    s5o_rec_t r;
+    if (!plen || s5o_rec_parse(pay, plen, db->sig_method, &r, NULL) != 0) { free(pay); db->failed = 1; return; }
+    int16_t *sig = (int16_t *)malloc(r.len_raw_signal ? 2 * (size_t)r.len_raw_signal : 2);
+    if (!sig || s5o_rec_parse(pay, plen, db->sig_method, &r, sig) != 0) { free(pay); free(sig); db->failed = 1; return; }
+    free(pay);
+    db->out[i] = (uint8_t *)sig;
+    db->out_len[i] = (size_t)r.len_raw_signal;
+}
+uint64_t s5o_get_file(const char *path, const uint64_t *pos, const uint32_t *len, uint64_t n_ids, int n_threads, int batch_size, double *secs) {
+    get_db_t G;
+    memset(&G, 0, sizeof G);
+    G.fd = open(path, O_RDONLY);
+    if (G.fd < 0) return 0;
+    G.pos = pos; G.len = len;
+    G.db.rec_method = S5O_REC_ZLIB;
+    G.db.sig_method = S5O_SIG_SVB_ZD;
+    G.db.one = get_one;
+    G.db.out = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)batch_size);
+    G.db.out_len = (size_t *)malloc(sizeof(size_t) * (size_t)batch_size);
+    uint64_t total = 0;
+    const double t0 = now_s();
+    for (uint64_t base = 0; base < n_ids; base += (uint64_t)batch_size) {
+        G.db.base = base;
+        G.db.n_batch = (int64_t)(n_ids - base < (uint64_t)batch_size ? n_ids - base : (uint64_t)batch_size);
+        work_batch(&G.db, n_threads);
+        for (int64_t i = 0; i < G.db.n_batch; i++) { total += G.db.out_len[i]; free(G.db.out[i]); }
+    }
+    if (secs) *secs = now_s() - t0;
+    free(G.db.out); free(G.db.out_len);
+    close(G.fd);
+    return G.db.failed ? 0 : total;
+}

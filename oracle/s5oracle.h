@@ -98,6 +98,14 @@ uint64_t s5o_decode_batch_mt(const uint8_t *stream, const uint64_t *rec_off, con
 uint64_t s5o_convert_ascii_batch_mt(const char *text, const uint64_t *line_off, uint64_t n_lines, int rec_method, int sig_method,
                                     int n_threads, int batch_size, double *secs, uint64_t *checksum);
 
+/* END-TO-END twins on files (bench.py `e2e`): the whole batch loop of `view` (serial read of K records, work_db, serial ordered write:
+ * src/view.c:241-323) from a .slow5 or a zlib + svb-zd BLOW5 file to a zlib + svb-zd BLOW5 file; phases = {read, compute, write, first read
+ * to last write} seconds.  Returns records written (0 on failure). */
+uint64_t s5o_view_file(const char *in_path, const char *out_path, int n_threads, int batch_size, uint64_t max_reads, double phases[4]);
+/* ... and of `get --benchmark` (src/get.c:52,321-386): per id pread + inflate + parse + svb-zd decode inside the worker, nothing written;
+ * pos / len = file extents of the records ([u64 size][bytes]).  Returns samples decoded (0 on failure). */
+uint64_t s5o_get_file(const char *path, const uint64_t *pos, const uint32_t *len, uint64_t n_ids, int n_threads, int batch_size, double *secs);
+
 /* ---- §8f row 2: SLOW5 ASCII record lines <-> uncompressed payloads (ascii.c) ---- */
 /* aux type codes: low 4 bits 0..11 = int8,int16,int32,int64,uint8,uint16,uint32,uint64,float,double,char,enum; 0x80 = array */
 int s5o_aux_types(const char *types_line, size_t len, uint8_t *types, unsigned cap);

@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <string>
 
 #include "host_ctx.h"
@@ -370,10 +371,10 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
     const int G = s5host::n_devices();
     if (G == 0) return S5GPU_ERR_NODEV;
     s5host::ShareGather sg(G);
-    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
+    auto share = [&](int slot, uint32_t lo, uint32_t hi) -> int {
         s5host::CtxHold hold;
         int r = hold.acquire(slot);
-        if (r) return sg.fail(r);
+        if (r) return sg.fail(r, slot);
         Ctx *c = hold.c;
         const uint32_t m = hi - lo;
         const char *base_p = (const char *)chunk;
@@ -393,7 +394,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         bool bad = false;
         for (uint32_t i = 0; i < m; i++)
             if (L[i].status) { bad = true; if (status) status[lo + i] = L[i].status; }
-        if (bad) { s5gpu_set_error("s5gpu_ascii_to_blow5_stream: at least one line is malformed (see status[i])"); return sg.fail(S5GPU_ERR_DATA); }
+        if (bad) { s5gpu_set_error("s5gpu_ascii_to_blow5_stream: at least one line is malformed (see status[i])"); return sg.fail(S5GPU_ERR_DATA, slot); }
         std::vector<s5gpu_read_desc_t> desc(m);
         std::vector<s5gpu_txt_desc_t> td(m);
         uint64_t so = 0, ho = 0, ao = 0, oo = 0;
@@ -406,7 +407,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
             d.aux_len = (uint32_t)L[i].aux.size();
             const uint64_t pb = s5gpu_payload_bound(d.n_samples, d.hdr_len, d.aux_len, to_sig);
             const uint64_t sb = s5gpu_slot_bound(d.n_samples, d.hdr_len, d.aux_len, to_rec, to_sig);
-            if (pb > 0xFFFFFF00ull) { s5gpu_set_error("read %u: record larger than 4 GiB", lo + i); return sg.fail(S5GPU_ERR_ARG); }
+            if (pb > 0xFFFFFF00ull) { s5gpu_set_error("read %u: record larger than 4 GiB", lo + i); return sg.fail(S5GPU_ERR_ARG, slot); }
             d.slot_cap = (uint32_t)sb;
             if (pb > max_payload) max_payload = (uint32_t)pb;
             s5gpu_txt_desc_t &t = td[i];
@@ -419,7 +420,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         if ((r = c->h_in.reserve(h_hdr + h_aux + h_desc + h_td)) || (r = c->d_txt.reserve(tbytes + 64)) || (r = c->d_sig.reserve(so * 2 + 64)) ||
             (r = c->d_hdr.reserve(ho + 64)) || (r = c->d_aux.reserve(ao + 64)) || (r = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * m)) ||
             (r = c->d_tdesc.reserve(h_td + 4ull * m)) || (r = c->h_out.reserve(4ull * m + 64)))
-            return sg.fail(r);
+            return sg.fail(r, slot);
         uint8_t *hh = (uint8_t *)c->h_in.p, *ha = hh + h_hdr, *hd = ha + h_aux, *htd = hd + h_desc;
         for (uint32_t i = 0; i < m; i++) {
             memcpy(hh + desc[i].hdr_off, L[i].head.data(), desc[i].hdr_len);
@@ -430,7 +431,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         auto hip = [&](hipError_t e, const char *what) -> int {
             if (e == hipSuccess) return 0;
             s5gpu_set_error("%s failed: %s", what, hipGetErrorString(e));
-            return sg.fail(S5GPU_ERR_HIP);
+            return sg.fail(S5GPU_ERR_HIP, slot);
         };
         if ((r = hip(hipMemcpyAsync(c->d_txt.p, (const uint8_t *)chunk + b0, tbytes, hipMemcpyHostToDevice, c->st), "upload of the chunk"))) return r;
         if ((r = hip(hipMemcpyAsync(c->d_hdr.p, hh, ho, hipMemcpyHostToDevice, c->st), "upload"))) return r;
@@ -438,13 +439,13 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         if ((r = hip(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_read_desc_t) * m, hipMemcpyHostToDevice, c->st), "upload"))) return r;
         if ((r = hip(hipMemcpyAsync(c->d_tdesc.p, htd, h_td, hipMemcpyHostToDevice, c->st), "upload"))) return r;
         int32_t *d_status = (int32_t *)((uint8_t *)c->d_tdesc.p + h_td);
-        if ((r = s5gpu_ascii_parse_dev(m, (const s5gpu_txt_desc_t *)c->d_tdesc.p, (const uint8_t *)c->d_txt.p, (int16_t *)c->d_sig.p, d_status, c->st))) return sg.fail(r);
+        if ((r = s5gpu_ascii_parse_dev(m, (const s5gpu_txt_desc_t *)c->d_tdesc.p, (const uint8_t *)c->d_txt.p, (int16_t *)c->d_sig.p, d_status, c->st))) return sg.fail(r, slot);
         if ((r = hip(hipMemcpyAsync(c->h_out.p, d_status, 4ull * m, hipMemcpyDeviceToHost, c->st), "status download"))) return r;
         if ((r = hip(hipStreamSynchronize(c->st), "synchronise"))) return r;
         const int32_t *hs = (const int32_t *)c->h_out.p;
         for (uint32_t i = 0; i < m; i++)
             if (hs[i]) { bad = true; if (status) status[lo + i] = hs[i]; }
-        if (bad) { s5gpu_set_error("s5gpu_ascii_to_blow5_stream: raw_signal text of at least one line is malformed (see status[i])"); return sg.fail(S5GPU_ERR_DATA); }
+        if (bad) { s5gpu_set_error("s5gpu_ascii_to_blow5_stream: raw_signal text of at least one line is malformed (see status[i])"); return sg.fail(S5GPU_ERR_DATA, slot); }
         s5gpu_encode_args_t a;
         memset(&a, 0, sizeof a);
         a.n_reads = m; a.rec_method = to_rec; a.sig_method = to_sig;
@@ -452,7 +453,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         a.sig = (const int16_t *)c->d_sig.p; a.hdr = (const uint8_t *)c->d_hdr.p; a.aux = (const uint8_t *)c->d_aux.p;
         a.max_payload = max_payload;
         std::vector<uint64_t> off;
-        if ((r = s5host::encode_stream_resident(c, m, desc, a, oo, off))) return sg.fail(r);
+        if ((r = s5host::encode_stream_resident(c, m, desc, a, oo, off))) return sg.fail(r, slot);
         uint64_t base = 0;
         bool copy = false;
         if ((r = sg.place(slot, off[m], out_cap, &base, &copy))) return r;
@@ -462,8 +463,10 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         if (hi == n) out_off[n] = base + off[m];
         HIP_TRY(hipStreamSynchronize(c->st));
         return S5GPU_OK;
-    });
-    if (rc) return rc;
+    };
+    // any way a share gives up releases the shares waiting behind it (ShareGather::place)
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int { const int r = share(slot, lo, hi); if (r) sg.fail(r, slot); return r; });
+    if (rc) return sg.report(rc);   // the share that failed first, not the lowest slot that noticed
     if (sg.overflow) {
         const uint64_t need = sg.need();
         out_off[0] = need;
@@ -602,10 +605,10 @@ extern "C" int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t
     const int G = s5host::n_devices();
     if (G == 0) return S5GPU_ERR_NODEV;
     s5host::ShareGather sg(G);
-    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
+    auto share = [&](int slot, uint32_t lo, uint32_t hi) -> int {
         s5host::CtxHold hold;
         int r = hold.acquire(slot);
-        if (r) return sg.fail(r);
+        if (r) return sg.fail(r, slot);
         Ctx *c = hold.c;
         const uint32_t m = hi - lo;
         uint64_t b0 = UINT64_MAX, e1 = 0;
@@ -621,11 +624,11 @@ extern "C" int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t
         std::vector<s5gpu_rec_fields_t> ff;
         if ((r = s5host::decode_resident_framed(c, m, rec.data(), len.data(), from_rec, from_sig, rd, ff, status ? status + lo : nullptr,
                                                 (const uint8_t *)chunk + b0, (size_t)(e1 - b0))))
-            return sg.fail(r);
+            return sg.fail(r, slot);
         auto hip = [&](hipError_t e, const char *what) -> int {
             if (e == hipSuccess) return 0;
             s5gpu_set_error("%s failed: %s", what, hipGetErrorString(e));
-            return sg.fail(S5GPU_ERR_HIP);
+            return sg.fail(S5GPU_ERR_HIP, slot);
         };
         // 1. signal text into worst-case slots; ids and aux bytes gathered for the host
         std::vector<s5gpu_read_desc_t> slots(m);
@@ -635,7 +638,7 @@ extern "C" int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t
         uint64_t to = 0, go = 0;
         for (uint32_t i = 0; i < m; i++) {
             const uint64_t cap = up(7ull * ff[i].n_samples + 16, 16);
-            if (cap > 0xFFFFFF00ull) { s5gpu_set_error("read %u: signal text larger than 4 GiB", lo + i); return sg.fail(S5GPU_ERR_ARG); }
+            if (cap > 0xFFFFFF00ull) { s5gpu_set_error("read %u: signal text larger than 4 GiB", lo + i); return sg.fail(S5GPU_ERR_ARG, slot); }
             memset(&td[i], 0, sizeof td[i]);
             td[i].txt_off = to; td[i].sig_off = rd[i].sig_off; td[i].txt_len = (uint32_t)cap; td[i].n_samples = ff[i].n_samples;
             memset(&slots[i], 0, sizeof slots[i]);
@@ -651,7 +654,7 @@ extern "C" int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t
         const size_t b_all = o_p + 2 * b_g8 + b_g4 + up(8ull * m, 64);
         if ((r = c->d_tdesc.reserve(b_all)) || (r = c->d_txt.reserve(to + 64)) || (r = c->d_gather.reserve(go + 64)) || (r = c->h_in.reserve(b_all)) ||
             (r = c->h_out.reserve(go + 64)))
-            return sg.fail(r);
+            return sg.fail(r, slot);
         uint8_t *h = (uint8_t *)c->h_in.p, *dv = (uint8_t *)c->d_tdesc.p;
         memcpy(h, td.data(), sizeof(s5gpu_txt_desc_t) * m);
         memcpy(h + o_rd, slots.data(), sizeof(s5gpu_read_desc_t) * m);
@@ -661,10 +664,10 @@ extern "C" int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t
         if ((r = hip(hipMemcpyAsync(dv, h, o_tl, hipMemcpyHostToDevice, c->st), "upload"))) return r;
         uint32_t *d_tl = (uint32_t *)(dv + o_tl);
         int32_t *d_st = (int32_t *)(dv + o_st);
-        if ((r = s5gpu_ascii_format_dev(m, (const s5gpu_txt_desc_t *)dv, (const int16_t *)c->d_sig2.p, (uint8_t *)c->d_txt.p, d_tl, d_st, c->st))) return sg.fail(r);
+        if ((r = s5gpu_ascii_format_dev(m, (const s5gpu_txt_desc_t *)dv, (const int16_t *)c->d_sig2.p, (uint8_t *)c->d_txt.p, d_tl, d_st, c->st))) return sg.fail(r, slot);
         if ((r = s5gpu_gather_dev(2 * m, (const uint64_t *)(dv + o_src), (const uint32_t *)(dv + o_len), (const uint64_t *)(dv + o_dst),
                                   (const uint8_t *)c->d_pay.p, (uint8_t *)c->d_gather.p, c->st)))
-            return sg.fail(r);
+            return sg.fail(r, slot);
         std::vector<uint32_t> tl(m);
         std::vector<int32_t> fs(m);
         uint8_t *h_g = (uint8_t *)c->h_out.p;
@@ -674,7 +677,7 @@ extern "C" int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t
         if ((r = hip(hipStreamSynchronize(c->st), "synchronise"))) return r;
         // 2. the other columns on the host: prefix and suffix of every line, back to back in one blob
         std::vector<std::string> pre(m), suf(m);
-        int fail = 0;
+        std::atomic<int> fail{0};   // written by the parallel_for workers
         parallel_for(m, to / 4, [&](uint32_t a, uint32_t b) {
             for (uint32_t i = a; i < b; i++) {
                 const s5gpu_rec_fields_t &f = ff[i];
@@ -693,8 +696,8 @@ extern "C" int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t
                 suf[i].push_back('\n');
             }
         });
-        if (fail == 1) { s5gpu_set_error("s5gpu_blow5_to_ascii_stream: signal formatting failed"); return sg.fail(S5GPU_ERR_HIP); }
-        if (fail == 2) { s5gpu_set_error("s5gpu_blow5_to_ascii_stream: aux bytes of at least one record do not match the header's aux types"); return sg.fail(S5GPU_ERR_DATA); }
+        if (fail == 1) { s5gpu_set_error("s5gpu_blow5_to_ascii_stream: signal formatting failed"); return sg.fail(S5GPU_ERR_HIP, slot); }
+        if (fail == 2) { s5gpu_set_error("s5gpu_blow5_to_ascii_stream: aux bytes of at least one record do not match the header's aux types"); return sg.fail(S5GPU_ERR_DATA, slot); }
         std::vector<uint64_t> off(m + 1), p_src(2ull * m), p_dst(2ull * m), s_dst(m);
         std::vector<uint32_t> p_len(2ull * m);
         uint64_t bo = 0;
@@ -735,8 +738,10 @@ extern "C" int s5gpu_blow5_to_ascii_stream(uint32_t n, const void *chunk, size_t
         if (hi == n) out_off[n] = base + off[m];
         HIP_TRY(hipStreamSynchronize(c->st));
         return S5GPU_OK;
-    });
-    if (rc) return rc;
+    };
+    // any way a share gives up releases the shares waiting behind it (ShareGather::place)
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int { const int r = share(slot, lo, hi); if (r) sg.fail(r, slot); return r; });
+    if (rc) return sg.report(rc);   // the share that failed first, not the lowest slot that noticed
     if (sg.overflow) {
         const uint64_t need = sg.need();
         out_off[0] = need;

@@ -376,6 +376,8 @@ static struct slow5_idx *idx_scan(slow5_file_t *s) {
     const int rec_code = rec_to_code(s->compress->record_press->method);
     uint64_t pos = s->meta.start_rec_offset;
     const uint64_t end = (uint64_t)fst.st_size - 5;
+    /* the work buffers follow the chunk size (chunk / 48 descriptors, 256 id bytes each): a small file gets small ones */
+    if (chunk > end - pos) chunk = (size_t)(end - pos) > 4096 ? (size_t)(end - pos) : 4096;
     uint8_t *buf = (uint8_t *)malloc(chunk + 64);
     uint32_t cap = (uint32_t)(chunk / 48) + 16;
     uint64_t *rpos = (uint64_t *)malloc(sizeof(uint64_t) * cap), *ent = (uint64_t *)malloc(sizeof(uint64_t) * cap);
@@ -403,7 +405,7 @@ static struct slow5_idx *idx_scan(slow5_file_t *s) {
         while (p + 8 <= have && n < cap) {
             uint64_t sz;
             memcpy(&sz, buf + p, 8);
-            if (sz > 0xFFFFFF00ull) { err = SLOW5_ERR_TRUNC; break; }
+            if (sz > 0xFFFFFF00ull || sz > end - (file_base + p + 8)) { err = SLOW5_ERR_TRUNC; break; }   /* the record would leave the file: nothing is grown for it */
             if (sz > chunk - 8) {                                         /* a record larger than the chunk: grow the chunk and start this round over */
                 const size_t nc = (size_t)sz + 8 + (chunk >> 1);
                 uint8_t *nb = (uint8_t *)realloc(buf, nc + 64);

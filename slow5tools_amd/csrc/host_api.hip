@@ -888,10 +888,10 @@ extern "C" int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_b
     const int G = s5host::n_devices();
     if (G == 0) return S5GPU_ERR_NODEV;
     s5host::ShareGather sg(G);
-    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
+    auto share = [&](int slot, uint32_t lo, uint32_t hi) -> int {
         s5host::CtxHold hold;
         int r = hold.acquire(slot);
-        if (r) return sg.fail(r);
+        if (r) return sg.fail(r, slot);
         Ctx *c = hold.c;
         const uint32_t m = hi - lo;
         uint64_t b0 = UINT64_MAX, e1 = 0;
@@ -911,7 +911,7 @@ extern "C" int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_b
         if (r == S5GPU_ERR_DATA) {                     // corrupt records are the caller's to look at: fields[i].status says which
             for (uint32_t i = 0; i < m; i++) { fields[lo + i] = ff[i]; if (st[i]) { fields[lo + i].status = st[i]; fields[lo + i].n_samples = 0; } }
         }
-        if (r) return sg.fail(r);
+        if (r) return sg.fail(r, slot);
         // compact the signals (each sits in its own guessed slot) into one block on the device, then one D2H
         std::vector<uint64_t> src(m), dst(m), off(m + 1);
         std::vector<uint32_t> gl(m);
@@ -938,8 +938,10 @@ extern "C" int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_b
         if (hi == n) sig_off[n] = base + off[m];
         HIP_TRY(hipStreamSynchronize(c->st));
         return S5GPU_OK;
-    });
-    if (rc) return rc;
+    };
+    // any way a share gives up releases the shares waiting behind it (ShareGather::place)
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int { const int r = share(slot, lo, hi); if (r) sg.fail(r, slot); return r; });
+    if (rc) return sg.report(rc);   // the share that failed first, not the lowest slot that noticed
     if (sg.overflow) {
         sig_off[0] = sg.need();
         s5gpu_set_error("s5gpu_decode_stream: signal buffer too small (%llu samples needed)", (unsigned long long)sig_off[0]);
@@ -1055,10 +1057,10 @@ extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chu
     const int G = s5host::n_devices();
     if (G == 0) return S5GPU_ERR_NODEV;
     s5host::ShareGather sg(G);
-    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int {
+    auto share = [&](int slot, uint32_t lo, uint32_t hi) -> int {
         s5host::CtxHold hold;
         int r = hold.acquire(slot);
-        if (r) return sg.fail(r);
+        if (r) return sg.fail(r, slot);
         Ctx *c = hold.c;
         const uint32_t m = hi - lo;
         // the extent of this share of the chunk (the records of a share are contiguous in a file chunk)
@@ -1074,8 +1076,8 @@ extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chu
         std::vector<s5gpu_rec_desc_t> rd;
         std::vector<s5gpu_rec_fields_t> ff;
         std::vector<uint64_t> off;
-        if ((r = decode_resident_impl(c, m, rec.data(), len.data(), from_rec, from_sig, rd, ff, status ? status + lo : nullptr, &fs))) return sg.fail(r);
-        if ((r = recompress_encode_half(c, m, rd, ff, to_rec, to_sig, new_read_group ? new_read_group + lo : nullptr, drop_aux, nullptr, nullptr, &off))) return sg.fail(r);
+        if ((r = decode_resident_impl(c, m, rec.data(), len.data(), from_rec, from_sig, rd, ff, status ? status + lo : nullptr, &fs))) return sg.fail(r, slot);
+        if ((r = recompress_encode_half(c, m, rd, ff, to_rec, to_sig, new_read_group ? new_read_group + lo : nullptr, drop_aux, nullptr, nullptr, &off))) return sg.fail(r, slot);
         uint64_t base = 0;
         bool copy = false;
         if ((r = sg.place(slot, off[m], out_cap, &base, &copy))) return r;
@@ -1085,8 +1087,10 @@ extern "C" int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chu
         if (hi == n) out_off[n] = base + off[m];
         HIP_TRY(hipStreamSynchronize(c->st));
         return S5GPU_OK;
-    });
-    if (rc) return rc;
+    };
+    // any way a share gives up releases the shares waiting behind it (ShareGather::place)
+    const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) -> int { const int r = share(slot, lo, hi); if (r) sg.fail(r, slot); return r; });
+    if (rc) return sg.report(rc);   // the share that failed first, not the lowest slot that noticed
     if (sg.overflow) {
         const uint64_t need = sg.need();
         out_off[0] = need;   // the size the caller has to bring (the sum over ALL shares)

@@ -9,12 +9,14 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/slow5gpu.h"
 
 extern "C" void s5gpu_set_error(const char *fmt, ...);
+extern "C" const char *s5gpu_last_error(void);
 
 #define HIP_TRY(x)                                                                                   \
     do {                                                                                             \
@@ -92,31 +94,47 @@ struct ShareGather {
     std::condition_variable cv;
     std::vector<int64_t> totals;
     bool failed = false, overflow = false;
+    int fail_rc = S5GPU_OK, fail_slot = -1;   // the FIRST failure: what the call reports, whichever share's thread returns first
+    std::string fail_msg;
     explicit ShareGather(int G) : totals((size_t)G, -1) {}
-    int fail(int rc) {
+    // a share gives up with rc (its message is this thread's s5gpu_last_error()); shares waiting behind it are released
+    int fail(int rc, int slot = -1) {
         std::lock_guard<std::mutex> g(mu);
+        if (!failed) { fail_rc = rc; fail_slot = slot; fail_msg = s5gpu_last_error(); }
         failed = true;
         cv.notify_all();
         return rc;
     }
-    // 0 and *base (where this share starts) / *copy (false: the output does not fit, skip the copy); S5GPU_ERR_HIP if a share in front failed
+    // 0 and *base (where this share starts) / *copy (false: the output does not fit, skip the copy).  A share whose predecessors have
+    // all published goes on whatever happened behind it; one that waits on a failed share returns that share's code (report() below
+    // names the share that failed, not the one that waited)
     int place(int slot, uint64_t total, size_t out_cap, uint64_t *base, bool *copy) {
         std::unique_lock<std::mutex> g(mu);
         totals[(size_t)slot] = (int64_t)total;
         cv.notify_all();
         uint64_t b = 0;
+        bool ready = false;
         for (;;) {
-            bool ready = true;
+            ready = true;
             b = 0;
             for (int q = 0; q < slot; q++) { if (totals[(size_t)q] < 0) ready = false; else b += (uint64_t)totals[(size_t)q]; }
             if (ready || failed) break;
             cv.wait(g);
         }
-        if (failed) return S5GPU_ERR_HIP;
+        if (!ready) return fail_rc;
         if (b + total > out_cap) overflow = true;
         *base = b;
         *copy = !overflow;
         return S5GPU_OK;
+    }
+    // after the device threads have joined: the code and message of the share that failed first (rc = what for_each_device_range
+    // returned: the lowest slot's code, which may be a share that merely waited on the failing one)
+    int report(int rc) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!failed) return rc;
+        if (fail_slot >= 0 && totals.size() > 1) s5gpu_set_error("device slot %d: %s", fail_slot, fail_msg.c_str());
+        else s5gpu_set_error("%s", fail_msg.c_str());
+        return fail_rc;
     }
     uint64_t need() const {
         uint64_t s = 0;

@@ -374,6 +374,14 @@ __global__ __launch_bounds__(NT, C::HIST ? 1 : 4) void k_deflate_lz(EncParams p,
         if (which && (d.hdr_len + 8u + 2u * d.n_samples + d.aux_len <= (uint32_t)LzShort::BLK) != !C::HIST) continue;
         uint32_t plen = 0;
         if (!build) plen = p.a.out_len[r];
+        if constexpr (!C::HIST) {
+            // build mode assembles the payload in the 8 KiB window: a descriptor that implies more than the caller's max_payload promised
+            // (s5gpu_encode_dev is a public call) must not overrun LDS — the read goes on the overflow list and the long shape redoes it
+            if (build && d.hdr_len + 8u + 2u * d.n_samples + d.aux_len > (uint32_t)C::BLK) {
+                if (tid == 0) { const uint32_t at = atomicAdd(&p.a.ovf[0], 1u); p.a.ovf[1 + at] = r; }
+                continue;
+            }
+        }
         uint8_t *out = p.a.slots + d.out_off;
         const uint8_t *src = out + park_offset(d, p.a.sig_method);
         __syncthreads();
@@ -907,6 +915,49 @@ struct NpParams {
     uint32_t first_fb;     // first slot of the fallback kernel's workgroups
     const uint32_t *ord;   // launch order (longest records first), or nullptr
 };
+#ifdef S5_NP_TRIPWIRE
+// Tripwire of the no-payload decode (tools only): an independent Adler-32 of the scratch slot — byte loads, one lane's running sums at a time
+// folded by a wave reduction, nothing shared with the inflate's dword / dot-product pass — and the record's trailer.
+__device__ __forceinline__ uint32_t np_trailer(const uint8_t *in, uint32_t in_len) {
+    const uint8_t *t = in + in_len - 4;
+    return ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+}
+template <bool BYPASS>     // BYPASS: agent-scope atomic byte loads (around this CU's L1); otherwise the plain loads the unpack uses
+__device__ __forceinline__ uint32_t np_slot_adler(const uint8_t *pay, uint32_t n) {
+    // lane l owns bytes [l * c, (l + 1) * c): A_l = sum x, B_l = sum (len_l - i) x_i; the lanes combine as Adler-32 concatenation
+    const uint32_t c = (n + 63u) / 64u, lo = min(n, (uint32_t)lane_id() * c), hi = min(n, lo + c);
+    uint64_t sa = 0, sb = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t x = BYPASS ? (uint32_t)__hip_atomic_load(pay + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)pay[i];
+        sa += x; sb += (uint64_t)(n - i) * x;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+    const uint32_t A = (uint32_t)((1 + sa) % 65521u), B = (uint32_t)((n + sb) % 65521u);
+    return (B << 16) | A;
+}
+// decode the svb-zd blob of the slot again, one lane per 64th of the samples, scalar code, and compare with what the unpack wrote
+__device__ __forceinline__ int np_signal_check(const s5gpu_decode_args_t &a, const s5gpu_rec_desc_t &d, const uint8_t *pay, uint32_t plen) {
+    const uint32_t idl = (uint32_t)ld_le(pay, 2), hl = 2 + idl + 4 + 32;
+    const uint8_t *sigp = pay + hl + 8;
+    const uint32_t n = (uint32_t)ld_le(sigp, 4), nk = (n + 3) >> 2;
+    const uint8_t *keys = sigp + 4, *data = keys + nk;
+    const int16_t *out = a.sig_out + d.sig_off;
+    int bad = 0;
+    if (lane_id() == 0) {       // one lane, the whole read: slow and independent of every wave primitive
+        int acc = 0;
+        uint32_t at = 0;
+        for (uint32_t i = 0; i < n && !bad; i++) {
+            const uint32_t code = (keys[i >> 2] >> (2 * (i & 3))) & 3u;
+            uint32_t zz = 0;
+            for (uint32_t k = 0; k <= code; k++) zz |= (uint32_t)data[at + k] << (8 * k);
+            at += code + 1;
+            acc += (int)(zz >> 1) ^ -(int)(zz & 1);
+            if (__hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int16_t)acc) bad = 1;
+        }
+    }
+    return __ballot(bad != 0) ? 1 : 0;
+}
+#endif
 __device__ __forceinline__ void np_write_fields(const s5gpu_decode_args_t &a, uint32_t r, int status, uint32_t olen) {
     if (lane_id() == 0) {
         a.fields[r].status = status;
@@ -935,8 +986,27 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode
         if (status == 0) {
             wave_sync();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (EXZD) status = unpack_exzd_wave(a, d, pay, a.fields[r], olen, *reinterpret_cast<ExzdWaveScratch *>(&T));
-            else status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
+#ifdef S5_NP_TRIPWIRE   // tools/np_tripwire.py (a variant build): is the slot still what the inflate verified when the unpack reads it, and afterwards?
+            const uint32_t want_ad = np_trailer(a.in + d.in_off, d.in_len);
+            {   // 20: the slot differs from what the inflate verified, seen through L1 and around it; 23: only through L1 (stale lines of
+                // the slot's previous record); 24: only around it
+                const bool bad_l1 = np_slot_adler<false>(pay, olen) != want_ad, bad_l2 = np_slot_adler<true>(pay, olen) != want_ad;
+                if (bad_l1 || bad_l2) status = bad_l1 && bad_l2 ? 20 : bad_l1 ? 23 : 24;
+            }
+#endif
+            if (status == 0) {
+                if (EXZD) status = unpack_exzd_wave(a, d, pay, a.fields[r], olen, *reinterpret_cast<ExzdWaveScratch *>(&T));
+                else status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
+            }
+#ifdef S5_NP_TRIPWIRE
+            if (status == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                      // the samples just stored are read back around L1
+                wave_sync();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (np_slot_adler<false>(pay, olen) != want_ad || np_slot_adler<true>(pay, olen) != want_ad) status = 21;   // changed while the unpack was reading it
+                else if (!EXZD && np_signal_check(a, d, pay, olen)) status = 22;       // the slot is intact and the samples written differ from it: the unpack read wrong
+            }
+#endif
         }
         np_write_fields(a, r, status, olen);
         if (!np.ticket) return;
@@ -1492,7 +1562,13 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         // raw-signal records: a batch of short ones (payloads of one 8 KiB block) builds its payloads inside the matcher's kernel
         const bool all_short = a->max_payload != 0 && a->max_payload <= (uint32_t)LzShort::BLK;
         if (!all_short) hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
+        else HIP_TRY(hipMemsetAsync(a->ovf, 0, 4, st));
         launch_lz(p, a->n_reads, a->max_payload, st, all_short);
+        if (all_short) {   // reads whose descriptors belie max_payload (the short shape put them on the overflow list): parked + the long shape; usually none
+            const uint32_t g = a->n_reads < 1024 ? a->n_reads : 1024;
+            hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2);
+            hipLaunchKernelGGL(k_deflate_lz<LzLong>, dim3(g), dim3(NT), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, st, p, 1, 0, 0);
+        }
         HIP_TRY(hipGetLastError());
         return S5GPU_OK;
     }
@@ -1685,40 +1761,60 @@ void s5kern_release_aux() {   // s5gpu_shutdown (bumps the generation right afte
 }
 
 // Scratch of the launch-order list: one buffer per (device, stream) — work on one stream is ordered, so the buffer of a stream is free again
-// when the next call on that stream is enqueued — grown on demand (hipFree waits for the device), released by s5gpu_shutdown.
+// when the next call on that stream is enqueued — grown on demand, released by s5gpu_shutdown.  One pool and one lock PER DEVICE: the
+// multi-device batch calls run one host thread per device, and those must not serialise on each other's list builds.  A buffer that is
+// outgrown is retired, not freed (hipFree waits for the device — and an earlier launch on the stream may still read the old list): the
+// retired ones go with the pool at shutdown; growth is geometric, so they add up to less than the live buffer.
 struct OrderBuf {
     uint32_t *p = nullptr;
     size_t words = 0;
-    int dev = -1;
     hipStream_t st = nullptr;
 };
-static std::mutex g_ord_mu;
-static std::vector<OrderBuf> g_ord;
+constexpr int ORD_MAX_DEV = 64;
+struct OrderPool {
+    std::mutex mu;
+    std::vector<OrderBuf> live;
+    std::vector<uint32_t *> retired;
+};
+static OrderPool g_ord[ORD_MAX_DEV];
 void s5kern_release_order() {                 // s5gpu_shutdown
-    std::lock_guard<std::mutex> lk(g_ord_mu);
-    for (OrderBuf &b : g_ord) if (b.p) (void)hipFree(b.p);
-    g_ord.clear();
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int dev = 0; dev < ORD_MAX_DEV; dev++) {
+        OrderPool &P = g_ord[dev];
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (P.live.empty() && P.retired.empty()) continue;
+        (void)hipSetDevice(dev);
+        for (OrderBuf &b : P.live) if (b.p) (void)hipFree(b.p);
+        for (uint32_t *q : P.retired) (void)hipFree(q);
+        P.live.clear();
+        P.retired.clear();
+    }
+    if (have_cur) (void)hipSetDevice(cur);
 }
-// builds the list for this batch on `st`; *out = nullptr when the batch is too small for the order to matter.  `hold` keeps the pool locked
-// until the caller has enqueued the kernel that reads the list: two threads that share a stream (the default stream, say) must not
+// builds the list for this batch on `st`; *out = nullptr when the batch is too small for the order to matter.  `hold` keeps the device's pool
+// locked until the caller has enqueued the kernel that reads the list: two threads that share a stream (the default stream, say) must not
 // interleave "build my list" / "build yours" / "read mine".
 static int launch_order(const s5gpu_decode_args_t *a, hipStream_t st, const uint32_t **out, std::unique_lock<std::mutex> &hold) {
     *out = nullptr;
     if (!g_order_min || a->n_recs < g_order_min) return S5GPU_OK;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= ORD_MAX_DEV) return S5GPU_OK;          // (file order is always correct)
+    OrderPool &P = g_ord[dev];
     const size_t need = (size_t)ORD_LIST + a->n_recs;
     uint32_t *p = nullptr;
-    hold = std::unique_lock<std::mutex>(g_ord_mu);
+    hold = std::unique_lock<std::mutex>(P.mu);
     {
         OrderBuf *hit = nullptr;
-        for (OrderBuf &b : g_ord) if (b.dev == dev && b.st == st) { hit = &b; break; }
-        if (!hit) { g_ord.emplace_back(); hit = &g_ord.back(); hit->dev = dev; hit->st = st; }
+        for (OrderBuf &b : P.live) if (b.st == st) { hit = &b; break; }
+        if (!hit) { P.live.emplace_back(); hit = &P.live.back(); hit->st = st; }
         if (hit->words < need) {
-            if (hit->p) (void)hipFree(hit->p);
-            hit->p = nullptr; hit->words = 0;
-            const size_t w = need + need / 4;
-            if (hipMalloc((void **)&hit->p, w * sizeof(uint32_t)) != hipSuccess) { hit->p = nullptr; s5gpu_set_error("no device memory for the launch-order list"); return S5GPU_ERR_NOMEM; }
+            const size_t w = need + need / 2;
+            uint32_t *q = nullptr;
+            if (hipMalloc((void **)&q, w * sizeof(uint32_t)) != hipSuccess) { hold.unlock(); s5gpu_set_error("no device memory for the launch-order list"); return S5GPU_ERR_NOMEM; }
+            if (hit->p) P.retired.push_back(hit->p);
+            hit->p = q;
             hit->words = w;
         }
         p = hit->p;
@@ -1763,6 +1859,7 @@ static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpa
             AuxStream *ax;
             const uint32_t aux_gen = s5host_generation;
             { const int rc = aux_acquire(&ax); if (rc) return rc; }
+            struct AuxGuard { AuxStream *a; uint32_t gen; ~AuxGuard() { aux_release(a, gen); } } aux_guard{ax, aux_gen};   // back to the pool on every way out
             AuxStream &t_aux = *ax;
             const uint32_t nbt = (a->n_recs + NT - 1) / NT;
             hipLaunchKernelGGL(k_route_zero, dim3(1), dim3(NT), 0, st, *a);
@@ -1776,7 +1873,6 @@ static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpa
             HIP_TRY(hipEventRecord(t_aux.join, t_aux.st));
             hipLaunchKernelGGL(k_inflate_simt<true>, dim3(nb64), dim3(64), 64 * sizeof(LaneTables), st, *a);
             HIP_TRY(hipStreamWaitEvent(st, t_aux.join, 0));
-            aux_release(ax, aux_gen);
         }
     } else {
         hipLaunchKernelGGL(k_inflate, dim3(a->n_recs), dim3(64), 0, st, *a);
@@ -1890,17 +1986,25 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         const bool zl = a->rec_method == S5GPU_REC_ZLIB;
         uint64_t n_fb = zl ? (n_slots / 16 < 1 ? 1 : n_slots / 16 > 256 ? 256 : n_slots / 16) : 0;
         uint64_t n_main = n_slots - n_fb;
-        // more workgroups than the device holds at once buy nothing: they would only spread the scratch over more of L2
-        static std::atomic<uint32_t> s_res[2] = {{0}, {0}};
-        uint32_t res = s_res[zl].load(std::memory_order_relaxed);
+        // more workgroups than the device holds at once buy nothing: they would only spread the scratch over more of L2.  The count is
+        // asked for the template variant that is launched (the two waiting-list sizes differ in LDS: 24 and 21 waves per CU)
+        const bool shortrec_np = a->max_pay_cap <= S5_IP_SHORT_PAY * (np_xz ? 3u : 1u);
+        const int variant = !zl ? 4 : (np_xz ? 2 : 0) + (shortrec_np ? 1 : 0);
+        static std::atomic<uint32_t> s_res[5] = {{0}, {0}, {0}, {0}, {0}};
+        uint32_t res = s_res[variant].load(std::memory_order_relaxed);
         if (!res) {
             int per_cu = 0, cus = 0, dev = 0;
             HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            if (zl) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_inflate_par_np<false, true>), 64, 0));
-            else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_zstd_inflate_np, 64, 0));
+            switch (variant) {
+            case 0: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_inflate_par_np<false, false>), 64, 0)); break;
+            case 1: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_inflate_par_np<false, true>), 64, 0)); break;
+            case 2: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_inflate_par_np<true, false>), 64, 0)); break;
+            case 3: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_inflate_par_np<true, true>), 64, 0)); break;
+            default: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_zstd_inflate_np, 64, 0)); break;
+            }
             res = (uint32_t)(per_cu > 0 && cus > 0 ? per_cu * cus : 4096);
-            s_res[zl].store(res, std::memory_order_relaxed);
+            s_res[variant].store(res, std::memory_order_relaxed);
         }
         const uint64_t resident = res;
         if (n_main > resident) n_main = resident;
@@ -1919,7 +2023,7 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
             if (zl) { const int rc = launch_order(a, st, &np.ord, hold); if (rc) return rc; }     // tickets in the order of the list: the longest records first
         }
         if (zl) {
-            const bool shortrec = a->max_pay_cap <= S5_IP_SHORT_PAY * (np_xz ? 3u : 1u);
+            const bool shortrec = shortrec_np;
             if (np_xz) { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<true, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<true, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
             else { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<false, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<false, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
             hipLaunchKernelGGL(k_inflate_fallback_np, dim3((uint32_t)n_fb), dim3(64), 0, st, *a, np);

@@ -255,6 +255,28 @@ def convert_ascii_batch_mt(text, line_off, n_threads, batch_size=4096, rec_metho
     return total, secs.value, ck.value
 
 
+def view_file(in_path, out_path, n_threads, batch_size=4096, max_reads=0):
+    """the CPU twin of the whole `view` loop on files (oracle/batch.c s5o_view_file): returns (records, dict of phase seconds)"""
+    ph = (C.c_double * 4)()
+    L = lib()
+    L.s5o_view_file.restype = C.c_uint64
+    L.s5o_view_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_double)]
+    n = L.s5o_view_file(str(in_path).encode(), str(out_path).encode(), n_threads, batch_size, max_reads, ph)
+    return int(n), dict(read=ph[0], compute=ph[1], write=ph[2], first_read_to_last_write=ph[3])
+
+
+def get_file(path, pos, length, n_threads, batch_size=4096):
+    """the CPU twin of `get --benchmark` on a file: returns (samples decoded, seconds)"""
+    pos = np.ascontiguousarray(pos, dtype=np.uint64)
+    length = np.ascontiguousarray(length, dtype=np.uint32)
+    secs = C.c_double()
+    L = lib()
+    L.s5o_get_file.restype = C.c_uint64
+    L.s5o_get_file.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    n = L.s5o_get_file(str(path).encode(), pos.ctypes.data, length.ctypes.data, pos.size, n_threads, batch_size, C.byref(secs))
+    return int(n), secs.value
+
+
 # ---- §8f row 2: SLOW5 ASCII ----
 def aux_types(types_line):
     buf = (C.c_uint8 * 1024)()
