@@ -664,6 +664,9 @@ def main():
     ap.add_argument("--decode", action="store_true", help="configs[4] alone: random get-style decode (inflate + svb-zd unpack)")
     ap.add_argument("--get-reads", type=int, default=100_000, help="configs[4]: random read ids to fetch (seed 1)")
     ap.add_argument("--get-batch", type=int, default=4096, help="configs[4]: ids per batch (-K)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file to file) object of the default run")
+    ap.add_argument("--e2e-reads", type=int, default=1_000_000, help="e2e: reads in the files (4000 samples each; /dev/shm)")
+    ap.add_argument("--e2e-cpu-reads", type=int, default=262_144, help="e2e: records of the same files the CPU twins convert per point")
     ap.add_argument("--min-leg-seconds", type=float, default=1.2, help="every GPU leg keeps the device busy for about this long at least")
     ap.add_argument("--min-leg-steps-svb", type=int, default=300, help="configs[1] leg: steps (2.8 ms each on 1 M reads)")
     ap.add_argument("--min-leg-steps-long", type=int, default=40, help="configs[3] leg: steps (28 ms each on 65536 reads)")
@@ -835,6 +838,20 @@ def main():
     if rank != 0:
         return finish(None)
 
+    # ---- end to end through files + the host-buffer (PCIe-inclusive) batch call: N = 1 figures, like the CPU baseline ----
+    e2e_obj = pcie_obj = None
+    if default_shape and world == 1 and not args.no_e2e:
+        import bench_e2e
+        torch.cuda.empty_cache()
+        try:
+            e2e_obj = bench_e2e.e2e(args, L, _lib, press, torch, dev, ob, want_cpu=args.cpu_seconds > 0)
+        except Exception as e:      # (never fatal for the line)
+            e2e_obj = {"error": repr(e)}
+        try:
+            pcie_obj = bench_e2e.pcie_inclusive(L, _lib, press, n_reads, n)
+        except Exception as e:
+            pcie_obj = {"error": repr(e)}
+
     # ---- results, rank 0 ----
     z_bytes = int(main_out_len.sum())
     total_reads = n_reads * world
@@ -907,6 +924,8 @@ def main():
         "configs1": leg1,
         "configs3": leg3,
         "configs4": leg4,
+        "e2e": e2e_obj,
+        "pcie_inclusive": pcie_obj,
     }
     finish(line)
 

@@ -70,6 +70,21 @@ static void gfail(gpipe_t *P, const char *what, const char *arg) {
     pthread_mutex_unlock(&P->mu);
 }
 
+/* A slot's buffers are pinned by the reader thread that fills it first: the readers run side by side, so the slots come up in parallel
+ * with the first preads, and a list of a few batches never pays for eight slots (640 MB of pinned memory up front was a third of a
+ * 100 k-id job). */
+static int gslot_alloc(gpipe_t *P, gslot_t *b) {
+    b->in_cap = (size_t)P->K * 4096 + 65536;
+    b->in = (uint8_t *)s5gpu_host_alloc(b->in_cap);
+    b->out_cap = (size_t)P->K * (P->benchmark ? 16384 : 6144) + 65536;     /* decoded samples / re-encoded records; a batch that outgrows it is redone */
+    b->out = (uint8_t *)s5gpu_host_alloc(b->out_cap);
+    b->rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)P->K);
+    b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)P->K);
+    b->off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)P->K + 1));
+    b->fields = (s5gpu_rec_fields_t *)malloc(sizeof(s5gpu_rec_fields_t) * (size_t)P->K);
+    return b->in && b->out && b->rec_pos && b->rec_len && b->off && b->fields ? 0 : -1;
+}
+
 /* read phase (get.c:335-361): one reader thread fills one whole batch; several batches are being filled at once */
 static void *greader_main(void *arg) {
     gpipe_t *P = (gpipe_t *)arg;
@@ -83,6 +98,7 @@ static void *greader_main(void *arg) {
         const int stop = P->failed;
         pthread_mutex_unlock(&P->mu);
         if (stop) return NULL;
+        if (!b->in && gslot_alloc(P, b) != 0) { gfail(P, "cannot allocate the batch buffers", NULL); return NULL; }
         const uint64_t i0 = (uint64_t)s * (uint64_t)P->K, i1 = i0 + (uint64_t)P->K < P->n_ids ? i0 + (uint64_t)P->K : P->n_ids;
         size_t at = 0;
         uint32_t n = 0;
@@ -191,6 +207,11 @@ static char **read_ids(const char *path, uint64_t *n_out) {
     return ids;
 }
 
+static void *early_init_main(void *arg) {
+    (void)arg;
+    if (s5gpu_init(0) == S5GPU_OK) s5gpu_host_free(s5gpu_host_alloc(4096));
+    return NULL;
+}
 int main(int argc, char **argv) {
     if (argc >= 6 && strcmp(argv[1], "--random") == 0) {
         slow5_file_t *s = slow5_open(argv[2], "r");
@@ -227,6 +248,10 @@ int main(int argc, char **argv) {
     pthread_mutex_init(&P.mu, NULL);
     pthread_cond_init(&P.cv, NULL);
     P.benchmark = benchmark;
+    /* the HIP runtime and the device context come up (~0.15 s) while the index is loaded (~0.13 s per million reads) and the ids are read */
+    pthread_t init_th;
+    const int early_init = !(getenv("S5VIEW_DEV_MASK") && strtoull(getenv("S5VIEW_DEV_MASK"), NULL, 0));     /* (a device mask has initialised the library already) */
+    if (early_init) pthread_create(&init_th, NULL, early_init_main, NULL);
     P.in = slow5_open(av[1], "r");
     if (!P.in || P.in->format != SLOW5_FORMAT_BINARY) return die("cannot open input (an indexed BLOW5 file)");
     const double t_idx0 = now_s();
@@ -234,6 +259,7 @@ int main(int argc, char **argv) {
     const double t_idx = now_s() - t_idx0;
     P.ids = read_ids(av[2], &P.n_ids);
     if (!P.ids) return die("cannot read the id list");
+    if (early_init) pthread_join(init_th, NULL);
     P.from.record_method = P.in->compress->record_press->method; P.from.signal_method = P.in->compress->signal_press->method;
     P.to.record_method = SLOW5_COMPRESS_ZLIB; P.to.signal_method = SLOW5_COMPRESS_SVB_ZD;
     int argk = benchmark ? 3 : 6;
@@ -252,19 +278,7 @@ int main(int argc, char **argv) {
     { const char *e = getenv("S5GET_SKIP"); P.skip = e && atoi(e); }
     P.fd = fileno(P.in->fp);
     P.n_batches = (int64_t)((P.n_ids + (uint64_t)P.K - 1) / (uint64_t)P.K);
-    for (int i = 0; i < GSLOT; i++) {
-        gslot_t *b = &P.slot[i];
-        b->seq = (int64_t)i - GSLOT;
-        b->in_cap = (size_t)P.K * 4096 + 65536;
-        b->in = (uint8_t *)s5gpu_host_alloc(b->in_cap);
-        b->out_cap = (size_t)P.K * 16384 + 65536;
-        b->out = (uint8_t *)s5gpu_host_alloc(b->out_cap);
-        b->rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)P.K);
-        b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)P.K);
-        b->off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)P.K + 1));
-        b->fields = (s5gpu_rec_fields_t *)malloc(sizeof(s5gpu_rec_fields_t) * (size_t)P.K);
-        if (!b->in || !b->out || !b->rec_pos || !b->rec_len || !b->off || !b->fields) return die("cannot allocate the batch buffers");
-    }
+    for (int i = 0; i < GSLOT; i++) P.slot[i].seq = (int64_t)i - GSLOT;     /* (a slot's buffers are pinned by the reader that first fills it: gslot_alloc) */
     double *lat = (double *)malloc(sizeof(double) * (size_t)(P.n_batches ? P.n_batches : 1));
     const double t0 = now_s();
     pthread_t rd[32], wk[4];

@@ -256,19 +256,58 @@ __device__ __forceinline__ uint32_t park_offset(const s5gpu_read_desc_t &d, int 
     return (d.slot_cap - payload_bound_dev(d, sig_method)) & ~15u;
 }
 
+constexpr uint32_t ORD_FLAG = 129, ORD_LIST = 132;
+__device__ __forceinline__ uint32_t order_at(const uint32_t *ord, uint32_t i) {
+    return ord && !ord[ORD_FLAG] ? ord[ORD_LIST + i] : i;
+}
+__device__ __forceinline__ uint32_t order_bucket(uint32_t len) {
+    if (len < 4) return len;
+    const uint32_t hb = 31u - (uint32_t)__clz((int)len);
+    return hb * 4 + ((len >> (hb - 2)) & 3u);
+}
+// ... and for the ENCODE side (round 4): the reads on the overflow list of a mixed batch (the ones the staged kernels redo) by their
+// number of samples, longest first — a 300 k-sample read keeps one workgroup busy for most of a millisecond, and in list order (the order
+// in which the fused kernel's workgroups happened to give up) it starts wherever it stands.  The list holds read indices.
+__global__ __launch_bounds__(NT) void k_eorder_count(const s5gpu_read_desc_t *desc, const uint32_t *ovf, uint32_t *ord) {
+    __shared__ uint32_t h[128];
+    if (threadIdx.x < 128) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * NT + threadIdx.x;
+    if (i < ovf[0]) atomicAdd(&h[order_bucket(desc[ovf[1 + i]].n_samples)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 128 && h[threadIdx.x]) atomicAdd(&ord[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(NT) void k_eorder_scatter(const s5gpu_read_desc_t *desc, const uint32_t *ovf, uint32_t *ord) {
+    __shared__ uint32_t h[128], base[128];
+    if (ord[ORD_FLAG]) return;
+    if (threadIdx.x < 128) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * NT + threadIdx.x;
+    uint32_t b = 0, rank = 0, r = 0;
+    if (i < ovf[0]) { r = ovf[1 + i]; b = order_bucket(desc[r].n_samples); rank = atomicAdd(&h[b], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 128 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&ord[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (i < ovf[0]) ord[ORD_LIST + base[b] + rank] = r;
+}
+// entry `it` of the overflow list, in launch order when there is one
+__device__ __forceinline__ uint32_t ovf_at(const uint32_t *ovf, const uint32_t *ord, uint32_t it) {
+    return ord && !ord[ORD_FLAG] ? ord[ORD_LIST + it] : ovf[1 + it];
+}
+
 // Staged path, step 1: payload straight to HBM.  mode 0: all reads, parked for k_deflate_staged;
 // mode 1: record compression "none" — the payload IS the record: [u64 size][payload] at the slot head;
 // mode 2: like 0 but only the reads on the overflow list.
 #ifndef S5_PACK_WG
 #define S5_PACK_WG 8      // (round 3, measured on the long-read leg: 4 / 5 / 6 / 8 workgroups per CU = 23.3 / 22.4 / 22.1 / 22.0 ms)
 #endif
-__global__ __launch_bounds__(NT, S5_PACK_WG) void k_pack(EncParams p, int mode) {
+__global__ __launch_bounds__(NT, S5_PACK_WG) void k_pack(EncParams p, int mode, const uint32_t *ord) {
     __shared__ uint32_t ws[16];
     __shared__ uint32_t tile_keys[SVB_TILE / 16 + 4];       // one tile's key bytes (4096 / 4) ...
     __shared__ uint32_t tile_data[3 * SVB_TILE / 4 + 4];    // ... and data bytes (at most 3 per int16 sample), + the copy's look-ahead word
     const uint32_t count = mode == 2 ? p.a.ovf[0] : p.a.n_reads;
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
-        const uint32_t r = mode == 2 ? p.a.ovf[1 + it] : it;
+        const uint32_t r = mode == 2 ? ovf_at(p.a.ovf, ord, it) : it;
         const s5gpu_read_desc_t d = p.a.desc[r];
         uint8_t *dst = p.a.slots + d.out_off + (mode == 1 ? 8u : park_offset(d, p.a.sig_method));
         const uint32_t plen = build_payload_hbm(p.a, d, dst, ws, tile_keys, tile_data);
@@ -330,14 +369,14 @@ __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, ui
 #ifndef S5_STAGED_WG
 #define S5_STAGED_WG 4
 #endif
-__global__ __launch_bounds__(NT, S5_STAGED_WG) void k_deflate_staged(EncParams p, int use_list) {
+__global__ __launch_bounds__(NT, S5_STAGED_WG) void k_deflate_staged(EncParams p, int use_list, const uint32_t *ord) {
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     BuildScratch &B = *reinterpret_cast<BuildScratch *>(obuf);   // dead whenever the bit buffer is live (deflate_block MODE 2)
     uint8_t *stage = smem + S_BYTES + 4u * p.obuf_words;
     const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
-        const uint32_t r = use_list ? p.a.ovf[1 + it] : it;
+        const uint32_t r = use_list ? ovf_at(p.a.ovf, ord, it) : it;
         deflate_staged_record(p, r, p.a.desc[r], p.a.out_len[r], S, obuf, B, stage);
     }
 }
@@ -719,15 +758,6 @@ __global__ __launch_bounds__(64) void k_inflate_head(s5gpu_decode_args_t a) {
 // larger than the device holds at once are counting-sorted by compressed length first — 128 buckets, four per octave, descending; the
 // k_route_* kernels' scheme with its scratch in a buffer of the library's own: ord[0..127] bucket counts, then cursors; ord[129] != 0: one
 // length class, no list (file order is as good); the list from ord[132] on.
-constexpr uint32_t ORD_FLAG = 129, ORD_LIST = 132;
-__device__ __forceinline__ uint32_t order_at(const uint32_t *ord, uint32_t i) {
-    return ord && !ord[ORD_FLAG] ? ord[ORD_LIST + i] : i;
-}
-__device__ __forceinline__ uint32_t order_bucket(uint32_t len) {
-    if (len < 4) return len;
-    const uint32_t hb = 31u - (uint32_t)__clz((int)len);
-    return hb * 4 + ((len >> (hb - 2)) & 3u);
-}
 __global__ __launch_bounds__(NT) void k_order_zero(uint32_t *ord) {
     if (threadIdx.x < ORD_LIST) ord[threadIdx.x] = 0;
 }
@@ -935,25 +965,39 @@ __device__ __forceinline__ uint32_t np_slot_adler(const uint8_t *pay, uint32_t n
     const uint32_t A = (uint32_t)((1 + sa) % 65521u), B = (uint32_t)((n + sb) % 65521u);
     return (B << 16) | A;
 }
-// decode the svb-zd blob of the slot again, one lane per 64th of the samples, scalar code, and compare with what the unpack wrote
+// decode the svb-zd blob of the slot again — lane l the l-th 64th of the samples, scalar code per lane: its first data byte from a plain
+// sum over the keys in front of it, its first sample from the deltas in front of it (a wave prefix sum is the one primitive shared with the
+// unpack) — and compare with what the unpack stored
 __device__ __forceinline__ int np_signal_check(const s5gpu_decode_args_t &a, const s5gpu_rec_desc_t &d, const uint8_t *pay, uint32_t plen) {
     const uint32_t idl = (uint32_t)ld_le(pay, 2), hl = 2 + idl + 4 + 32;
     const uint8_t *sigp = pay + hl + 8;
     const uint32_t n = (uint32_t)ld_le(sigp, 4), nk = (n + 3) >> 2;
     const uint8_t *keys = sigp + 4, *data = keys + nk;
     const int16_t *out = a.sig_out + d.sig_off;
-    int bad = 0;
-    if (lane_id() == 0) {       // one lane, the whole read: slow and independent of every wave primitive
-        int acc = 0;
-        uint32_t at = 0;
-        for (uint32_t i = 0; i < n && !bad; i++) {
+    const uint32_t c = ((n + 63u) / 64u + 3u) & ~3u;                 // samples per lane, a multiple of 4: lanes start on a key byte
+    const uint32_t lo = min(n, (uint32_t)lane_id() * c), hi = min(n, lo + c);
+    uint32_t at = 0;
+    for (uint32_t k = 0; k < (lo >> 2); k++) { const uint32_t kb = keys[k]; at += 4u + (kb & 3u) + ((kb >> 2) & 3u) + ((kb >> 4) & 3u) + (kb >> 6); }
+    int sum = 0;
+    {
+        uint32_t q = at;
+        for (uint32_t i = lo; i < hi; i++) {
             const uint32_t code = (keys[i >> 2] >> (2 * (i & 3))) & 3u;
             uint32_t zz = 0;
-            for (uint32_t k = 0; k <= code; k++) zz |= (uint32_t)data[at + k] << (8 * k);
-            at += code + 1;
-            acc += (int)(zz >> 1) ^ -(int)(zz & 1);
-            if (__hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int16_t)acc) bad = 1;
+            for (uint32_t k = 0; k <= code; k++) zz |= (uint32_t)data[q + k] << (8 * k);
+            q += code + 1;
+            sum += (int)(zz >> 1) ^ -(int)(zz & 1);
         }
+    }
+    int acc = (int)(wave_incl_add((uint32_t)sum) - (uint32_t)sum);
+    int bad = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t code = (keys[i >> 2] >> (2 * (i & 3))) & 3u;
+        uint32_t zz = 0;
+        for (uint32_t k = 0; k <= code; k++) zz |= (uint32_t)data[at + k] << (8 * k);
+        at += code + 1;
+        acc += (int)(zz >> 1) ^ -(int)(zz & 1);
+        if (__hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int16_t)acc) bad = 1;
     }
     return __ballot(bad != 0) ? 1 : 0;
 }
@@ -1477,6 +1521,94 @@ extern "C" uint64_t s5gpu_slot_bound(uint32_t n, uint32_t hdr_len, uint32_t aux_
     return (z + 16 + 15) & ~15ull;
 }
 
+static uint32_t g_order_min = 8192;            // batches of at least this many records are launched longest first (option "order_min"; 0 = never)
+// Scratch of the launch-order list: one buffer per (device, stream) — work on one stream is ordered, so the buffer of a stream is free again
+// when the next call on that stream is enqueued — grown on demand, released by s5gpu_shutdown.  One pool and one lock PER DEVICE: the
+// multi-device batch calls run one host thread per device, and those must not serialise on each other's list builds.  A buffer that is
+// outgrown is retired, not freed (hipFree waits for the device — and an earlier launch on the stream may still read the old list): the
+// retired ones go with the pool at shutdown; growth is geometric, so they add up to less than the live buffer.
+struct OrderBuf {
+    uint32_t *p = nullptr;
+    size_t words = 0;
+    hipStream_t st = nullptr;
+};
+constexpr int ORD_MAX_DEV = 64;
+struct OrderPool {
+    std::mutex mu;
+    std::vector<OrderBuf> live;
+    std::vector<uint32_t *> retired;
+};
+static OrderPool g_ord[ORD_MAX_DEV];
+void s5kern_release_order() {                 // s5gpu_shutdown
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int dev = 0; dev < ORD_MAX_DEV; dev++) {
+        OrderPool &P = g_ord[dev];
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (P.live.empty() && P.retired.empty()) continue;
+        (void)hipSetDevice(dev);
+        for (OrderBuf &b : P.live) if (b.p) (void)hipFree(b.p);
+        for (uint32_t *q : P.retired) (void)hipFree(q);
+        P.live.clear();
+        P.retired.clear();
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+}
+// the (device, stream)'s scratch with room for `need` words, and the pool's lock in `hold`
+static int order_scratch(hipStream_t st, size_t need, uint32_t **out, std::unique_lock<std::mutex> &hold) {
+    *out = nullptr;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= ORD_MAX_DEV) return S5GPU_OK;          // (file order is always correct)
+    OrderPool &P = g_ord[dev];
+    hold = std::unique_lock<std::mutex>(P.mu);
+    OrderBuf *hit = nullptr;
+    for (OrderBuf &b : P.live) if (b.st == st) { hit = &b; break; }
+    if (!hit) { P.live.emplace_back(); hit = &P.live.back(); hit->st = st; }
+    if (hit->words < need) {
+        const size_t w = need + need / 2;
+        uint32_t *q = nullptr;
+        if (hipMalloc((void **)&q, w * sizeof(uint32_t)) != hipSuccess) { hold.unlock(); s5gpu_set_error("no device memory for the launch-order list"); return S5GPU_ERR_NOMEM; }
+        if (hit->p) P.retired.push_back(hit->p);
+        hit->p = q;
+        hit->words = w;
+    }
+    *out = hit->p;
+    return S5GPU_OK;
+}
+// builds the list for this batch on `st`; *out = nullptr when the batch is too small for the order to matter.  `hold` keeps the device's pool
+// locked until the caller has enqueued the kernel that reads the list: two threads that share a stream (the default stream, say) must not
+// interleave "build my list" / "build yours" / "read mine".
+static int launch_order(const s5gpu_decode_args_t *a, hipStream_t st, const uint32_t **out, std::unique_lock<std::mutex> &hold) {
+    *out = nullptr;
+    if (!g_order_min || a->n_recs < g_order_min) return S5GPU_OK;
+    uint32_t *p = nullptr;
+    { const int rc = order_scratch(st, (size_t)ORD_LIST + a->n_recs, &p, hold); if (rc) return rc; }
+    if (!p) return S5GPU_OK;
+    const uint32_t nb = (a->n_recs + NT - 1) / NT;
+    hipLaunchKernelGGL(k_order_zero, dim3(1), dim3(NT), 0, st, p);
+    hipLaunchKernelGGL(k_order_count, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(128), 0, st, p);
+    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
+    *out = p;
+    return S5GPU_OK;
+}
+// ... the encode side's: the overflow list of a mixed batch (how many reads are on it is only known on the device: the grids cover n_reads)
+static int launch_eorder(const s5gpu_encode_args_t *a, hipStream_t st, const uint32_t **out, std::unique_lock<std::mutex> &hold) {
+    *out = nullptr;
+    if (!g_order_min || a->n_reads < g_order_min) return S5GPU_OK;
+    uint32_t *p = nullptr;
+    { const int rc = order_scratch(st, (size_t)ORD_LIST + a->n_reads, &p, hold); if (rc) return rc; }
+    if (!p) return S5GPU_OK;
+    const uint32_t nb = (a->n_reads + NT - 1) / NT;
+    hipLaunchKernelGGL(k_order_zero, dim3(1), dim3(NT), 0, st, p);
+    hipLaunchKernelGGL(k_eorder_count, dim3(nb), dim3(NT), 0, st, a->desc, a->ovf, p);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(128), 0, st, p);
+    hipLaunchKernelGGL(k_eorder_scatter, dim3(nb), dim3(NT), 0, st, a->desc, a->ovf, p);
+    *out = p;
+    return S5GPU_OK;
+}
+
 static void launch_lz(EncParams p, uint32_t n, uint32_t max_payload, hipStream_t st, bool build = false);
 static int enc_check(const s5gpu_encode_args_t *a) {
     if (!a || (a->n_reads && (!a->desc || !a->sig || !a->hdr || !a->slots || !a->out_len))) return S5GPU_ERR_ARG;
@@ -1530,7 +1662,7 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     p.zseq = g_zstd_sequences;
     if (a->rec_method == S5GPU_REC_NONE) {
         p.obuf_words = 0; p.pay_cap = 0;
-        hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 1);
+        hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 1, nullptr);
         HIP_TRY(hipGetLastError());
         return S5GPU_OK;
     }
@@ -1561,12 +1693,12 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
         // raw-signal records: a batch of short ones (payloads of one 8 KiB block) builds its payloads inside the matcher's kernel
         const bool all_short = a->max_payload != 0 && a->max_payload <= (uint32_t)LzShort::BLK;
-        if (!all_short) hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
+        if (!all_short) hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0, nullptr);
         else HIP_TRY(hipMemsetAsync(a->ovf, 0, 4, st));
         launch_lz(p, a->n_reads, a->max_payload, st, all_short);
         if (all_short) {   // reads whose descriptors belie max_payload (the short shape put them on the overflow list): parked + the long shape; usually none
             const uint32_t g = a->n_reads < 1024 ? a->n_reads : 1024;
-            hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2);
+            hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2, nullptr);
             hipLaunchKernelGGL(k_deflate_lz<LzLong>, dim3(g), dim3(NT), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, st, p, 1, 0, 0);
         }
         HIP_TRY(hipGetLastError());
@@ -1585,14 +1717,18 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         // overflow reads (usually none: the two launches below then exit at once)
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
         const uint32_t g = a->n_reads < 8192 ? a->n_reads : 8192;   // persistent loops over the list; enough workgroups for the CUs to balance
-        hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2);
+        // the reads on the list, longest first (a caller that names an LDS budget has a mixed batch; otherwise the list is usually empty)
+        const uint32_t *eord = nullptr;
+        std::unique_lock<std::mutex> hold;
+        if (a->lds_payload_cap) { const int rc2 = launch_eorder(a, st, &eord, hold); if (rc2) return rc2; }
+        hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2, eord);
         if (zs) hipLaunchKernelGGL(k_zstd_staged, dim3(g), dim3(NT), st_lds, st, p, 1);
-        else hipLaunchKernelGGL(k_deflate_staged, dim3(g), dim3(NT), st_lds, st, p, 1);
+        else hipLaunchKernelGGL(k_deflate_staged, dim3(g), dim3(NT), st_lds, st, p, 1, eord);
     } else {
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
-        hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0);
+        hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0, nullptr);
         if (a->rec_method == S5GPU_REC_ZSTD) hipLaunchKernelGGL(k_zstd_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0);
-        else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0);
+        else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0, nullptr);
     }
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
@@ -1668,7 +1804,7 @@ extern "C" int s5gpu_pack_parked_dev(const s5gpu_encode_args_t *a, void *stream_
     p.dbg = 0; p.zseq = g_zstd_sequences;
     p.obuf_words = (DEFL_BLK + 64) / 4;
     p.pay_cap = DEFL_BLK;
-    hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, (hipStream_t)stream_, p, 0);
+    hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, (hipStream_t)stream_, p, 0, nullptr);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }
@@ -1687,7 +1823,7 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
     if (a->rec_method == S5GPU_REC_ZSTD) hipLaunchKernelGGL(k_zstd_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
     else if (a->sig_method == S5GPU_SIG_NONE)   // byte ranges of unknown kind (the solo zlib press): the LZ77 matcher
         launch_lz(p, a->n_reads, a->max_payload, (hipStream_t)stream_);
-    else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
+    else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0, nullptr);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }
@@ -1695,7 +1831,6 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
 // Small batches (a single slow5_get) take the wave-per-record decoder (lowest latency); from
 // g_inflate_simt_min records on, the lane-per-record decoder (highest throughput).
 static uint32_t g_unpack_fused = 1;            // s5gpu_decode_dev, zlib + svb-zd: k_inflate_par unpacks the records it inflates (0: always k_unpack)
-static uint32_t g_order_min = 8192;            // zlib batches of at least this many records are launched longest first (option "order_min"; 0 = never)
 static uint32_t g_inflate_par = 1;             // zlib records: the decoder that is parallel inside a record (0: the two older kernels, chosen by batch size)
 static uint32_t g_inflate_route = 1;           // big zlib batches: sort by length, long records to the wave kernel (below)
 static uint32_t g_inflate_simt_min = 24576;   // measured crossover on 4000-sample reads: 16384 wave 3.0 ms vs lane 4.2 ms, 32768 wave 5.8 vs lane 4.5
@@ -1758,74 +1893,6 @@ void s5kern_release_aux() {   // s5gpu_shutdown (bumps the generation right afte
     }
     g_aux_all.clear();
     g_aux_free.clear();
-}
-
-// Scratch of the launch-order list: one buffer per (device, stream) — work on one stream is ordered, so the buffer of a stream is free again
-// when the next call on that stream is enqueued — grown on demand, released by s5gpu_shutdown.  One pool and one lock PER DEVICE: the
-// multi-device batch calls run one host thread per device, and those must not serialise on each other's list builds.  A buffer that is
-// outgrown is retired, not freed (hipFree waits for the device — and an earlier launch on the stream may still read the old list): the
-// retired ones go with the pool at shutdown; growth is geometric, so they add up to less than the live buffer.
-struct OrderBuf {
-    uint32_t *p = nullptr;
-    size_t words = 0;
-    hipStream_t st = nullptr;
-};
-constexpr int ORD_MAX_DEV = 64;
-struct OrderPool {
-    std::mutex mu;
-    std::vector<OrderBuf> live;
-    std::vector<uint32_t *> retired;
-};
-static OrderPool g_ord[ORD_MAX_DEV];
-void s5kern_release_order() {                 // s5gpu_shutdown
-    int cur = 0;
-    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
-    for (int dev = 0; dev < ORD_MAX_DEV; dev++) {
-        OrderPool &P = g_ord[dev];
-        std::lock_guard<std::mutex> lk(P.mu);
-        if (P.live.empty() && P.retired.empty()) continue;
-        (void)hipSetDevice(dev);
-        for (OrderBuf &b : P.live) if (b.p) (void)hipFree(b.p);
-        for (uint32_t *q : P.retired) (void)hipFree(q);
-        P.live.clear();
-        P.retired.clear();
-    }
-    if (have_cur) (void)hipSetDevice(cur);
-}
-// builds the list for this batch on `st`; *out = nullptr when the batch is too small for the order to matter.  `hold` keeps the device's pool
-// locked until the caller has enqueued the kernel that reads the list: two threads that share a stream (the default stream, say) must not
-// interleave "build my list" / "build yours" / "read mine".
-static int launch_order(const s5gpu_decode_args_t *a, hipStream_t st, const uint32_t **out, std::unique_lock<std::mutex> &hold) {
-    *out = nullptr;
-    if (!g_order_min || a->n_recs < g_order_min) return S5GPU_OK;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= ORD_MAX_DEV) return S5GPU_OK;          // (file order is always correct)
-    OrderPool &P = g_ord[dev];
-    const size_t need = (size_t)ORD_LIST + a->n_recs;
-    uint32_t *p = nullptr;
-    hold = std::unique_lock<std::mutex>(P.mu);
-    {
-        OrderBuf *hit = nullptr;
-        for (OrderBuf &b : P.live) if (b.st == st) { hit = &b; break; }
-        if (!hit) { P.live.emplace_back(); hit = &P.live.back(); hit->st = st; }
-        if (hit->words < need) {
-            const size_t w = need + need / 2;
-            uint32_t *q = nullptr;
-            if (hipMalloc((void **)&q, w * sizeof(uint32_t)) != hipSuccess) { hold.unlock(); s5gpu_set_error("no device memory for the launch-order list"); return S5GPU_ERR_NOMEM; }
-            if (hit->p) P.retired.push_back(hit->p);
-            hit->p = q;
-            hit->words = w;
-        }
-        p = hit->p;
-    }
-    const uint32_t nb = (a->n_recs + NT - 1) / NT;
-    hipLaunchKernelGGL(k_order_zero, dim3(1), dim3(NT), 0, st, p);
-    hipLaunchKernelGGL(k_order_count, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
-    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(128), 0, st, p);
-    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
-    *out = p;
-    return S5GPU_OK;
 }
 
 static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpack = 0) {   // unpack: the inflating wave also parses + decodes (1 svb-zd, 2 ex-zd)
