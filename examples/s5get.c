@@ -209,7 +209,7 @@ static char **read_ids(const char *path, uint64_t *n_out) {
 
 static void *early_init_main(void *arg) {
     (void)arg;
-    if (s5gpu_init(0) == S5GPU_OK) s5gpu_host_free(s5gpu_host_alloc(4096));
+    if (s5gpu_warmup() == S5GPU_OK) s5gpu_host_free(s5gpu_host_alloc(4096));
     return NULL;
 }
 int main(int argc, char **argv) {

@@ -149,6 +149,10 @@ int s5gpu_init(int device);              /* select device; S5GPU_ERR_NODEV if it
  * affected: their caller picks the device (hipSetDevice) and passes buffers of that device. */
 int s5gpu_init_mask(uint64_t dev_mask);
 int s5gpu_devices_in_use(void);          /* devices the batch calls run on (0 before initialisation) */
+/* Brings up, on the first device in use, what the first batch call would otherwise pay for: the HIP runtime and context, the kernels'
+ * code objects (loaded on first launch) and one set of streams.  A tool calls it from a helper thread at start-up, under its own file
+ * opening / index loading (examples/s5view.c, s5get.c: the first GPU call of a 100 k-id `get` was 175 ms of a 230 ms job).  Optional. */
+int s5gpu_warmup(void);
 void s5gpu_shutdown(void);
 const char *s5gpu_last_error(void);
 int s5gpu_device_count(void);

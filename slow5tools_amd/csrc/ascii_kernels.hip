@@ -169,6 +169,12 @@ __global__ __launch_bounds__(NT) void k_gather(const uint64_t *src_off, const ui
     for (uint32_t i = threadIdx.x; i < l; i += NT) o[i] = s[i];
 }
 
+__global__ void k_ascii_noop(uint32_t *p) { if (p) p[0] = 0; }
+int s5ascii_warm(hipStream_t st) {             // s5gpu_warmup (kernels.hip): this file's code object
+    hipLaunchKernelGGL(k_ascii_noop, dim3(1), dim3(64), 0, st, (uint32_t *)nullptr);
+    return hipGetLastError() == hipSuccess ? S5GPU_OK : S5GPU_ERR_HIP;
+}
+
 extern "C" int s5gpu_ascii_parse_dev(uint32_t n, const s5gpu_txt_desc_t *desc, const uint8_t *text, int16_t *sig, int32_t *status,
                                      void *stream_) {
     if (n == 0) return S5GPU_OK;

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -331,24 +332,36 @@ static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, con
 static int encode_batch_dev(int slot, uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
                             const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
                             int sig_method, void **out, size_t *out_len) {
-    // A big batch is cut in two halves that run on two contexts at once: one half's H2D overlaps the other's kernels and
-    // D2H (PCIe is full duplex, and the host-side packing of one half hides behind the copies of the other).
+    // A big batch is cut in pieces that run on two contexts at once: one piece's H2D overlaps the other's kernels and D2H (PCIe is
+    // full duplex, and the host-side packing of one piece hides behind the copies of the other).  Two halves up to 131072 reads; beyond that
+    // pieces of about 65536 reads, two host threads taking them in turn — the pinned staging stays at a few hundred MB whatever the batch
+    // (round 4: 1 M reads in one call went through two 4 GB halves at 4.1 GB/s; 65536-read pieces run at 20+).
     const char *e = getenv("S5GPU_SPLIT");
     const bool split = n >= 16384 && (!e || atoi(e) != 0);
     if (!split) return encode_batch_one(slot, n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
-    const uint32_t h = n / 2;
-    int rc2 = S5GPU_OK;
-    char err2[512] = "";
-    std::thread t([&]() {
-        rc2 = encode_batch_one(slot, n - h, sig + h, n_samples + h, hdr + h, hdr_len + h, aux ? aux + h : nullptr, aux_len ? aux_len + h : nullptr,
-                               rec_method, sig_method, out + h, out_len + h);
-        if (rc2) snprintf(err2, sizeof err2, "%s", s5gpu_last_error());   // the message lives in that thread
-    });
-    const int rc1 = encode_batch_one(slot, h, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
+    const char *pe = getenv("S5GPU_PIECE");
+    const uint32_t piece = pe && atoi(pe) >= 1024 ? (uint32_t)atoi(pe) : 65536u;
+    const uint32_t P = n <= 2 * piece ? 2u : (n + piece - 1) / piece;
+    std::atomic<uint32_t> next{0};
+    int rcs[2] = {S5GPU_OK, S5GPU_OK};
+    char errs[2][512] = {"", ""};
+    auto body = [&](int w) {
+        for (;;) {
+            const uint32_t k = next.fetch_add(1);
+            if (k >= P || rcs[0] || rcs[1]) return;
+            const uint32_t lo = (uint32_t)((uint64_t)n * k / P), hi = (uint32_t)((uint64_t)n * (k + 1) / P);
+            const int rc = encode_batch_one(slot, hi - lo, sig + lo, n_samples + lo, hdr + lo, hdr_len + lo, aux ? aux + lo : nullptr, aux_len ? aux_len + lo : nullptr,
+                                            rec_method, sig_method, out + lo, out_len + lo);
+            if (rc) { rcs[w] = rc; snprintf(errs[w], sizeof errs[w], "%s", s5gpu_last_error()); return; }   // the message lives in that thread
+        }
+    };
+    std::thread t(body, 1);
+    body(0);
     t.join();
-    if (rc1 || rc2) {
-        if (!rc1) s5gpu_set_error("%s", err2);
-        return rc1 ? rc1 : rc2;
+    if (rcs[0] || rcs[1]) {
+        const int w = rcs[0] ? 0 : 1;
+        s5gpu_set_error("%s", errs[w]);
+        return rcs[w];
     }
     return S5GPU_OK;
 }

@@ -2147,6 +2147,20 @@ extern "C" int s5gpu_patch_u32_dev(uint8_t *base, const uint64_t *off, const uin
     return S5GPU_OK;
 }
 
+// ---- s5gpu_warmup: the code objects of this file and of ascii_kernels.hip are loaded by their first launch ----
+__global__ void k_noop(uint32_t *p) { if (p) p[0] = 0; }
+int s5ascii_warm(hipStream_t st);              // ascii_kernels.hip
+extern "C" int s5gpu_warmup(void) {
+    int rc;
+    if (s5gpu_devices_in_use() == 0 && (rc = s5gpu_init(0))) return rc;
+    if ((rc = set_lds_attrs())) return rc;     // (the function attributes need the functions: this loads the code object)
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, nullptr, (uint32_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    if ((rc = s5ascii_warm(nullptr))) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return S5GPU_OK;
+}
+
 extern "C" int s5gpu_synth_dev(int16_t *sig, uint64_t n_reads, uint64_t n, uint64_t stride, uint64_t seed, uint64_t first,
                                void *stream_) {
     if (!sig || stride < n) return S5GPU_ERR_ARG;
