@@ -300,6 +300,73 @@ def long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, W):
     }
 
 
+def mixed_leg(args, L, _lib, press, shard, rank, world, dev):
+    """The read lengths of a real run (what a PromethION DNA flow cell writes: log-normal, median ~6000 samples, a tail past 300 k) as a leg of the
+    default line: --mixed-reads reads per GPU (weak scaling), full BLOW5 encode through s5gpu_encode_dev with an 8 KiB fused budget — short reads
+    in the fused kernel, the rest through the overflow list (launched longest first) and the staged kernels — then the compaction into the record
+    stream.  /root/reference/src/thread.c:19-37 (work stealing) exists for exactly this imbalance."""
+    import zlib
+
+    import numpy as np
+    import torch
+
+    n_reads = args.mixed_reads
+    rng = np.random.default_rng(5 + rank)
+    ns = np.clip(np.exp(rng.normal(np.log(6000), 0.9, n_reads)), 200, 400000).astype(np.uint64)
+    b = press.DeviceBatch(ns, device=dev, lds_payload_cap=args.fused_cap)
+    tot = b.sig.numel()
+    _lib.check(L.s5gpu_synth_dev(b.sig.data_ptr(), 1, tot - 64, tot, 0x5105 + rank, 0, b._stream()), "synth")     # one long trace cut into the reads
+    _lib.check(L.s5gpu_synth_hdr_dev(b.hdr.data_ptr(), n_reads, rank * n_reads, b._stream()), "hdr")
+    raw_bytes = int(2 * ns.sum())
+    torch.cuda.synchronize()
+    st = b._stream()
+    for _ in range(2):
+        b.encode()
+        b.compact()
+    torch.cuda.synchronize()
+    K = max(4, int(args.min_leg_seconds / 0.012))
+    evs = make_events(L, _lib, 3 * K)
+
+    def steps():
+        for k in range(K):
+            L.s5gpu_event_record(evs[3 * k], st)
+            b.encode()
+            L.s5gpu_event_record(evs[3 * k + 1], st)
+            b.compact()
+            L.s5gpu_event_record(evs[3 * k + 2], st)
+
+    dt = timed(shard, torch, dev, steps)
+    enc_ms = float(np.mean([elapsed_ms(L, _lib, evs[3 * k], evs[3 * k + 1]) for k in range(K)]))
+    cmp_ms = float(np.mean([elapsed_ms(L, _lib, evs[3 * k + 1], evs[3 * k + 2]) for k in range(K)]))
+    for e in evs:
+        L.s5gpu_event_destroy(e)
+    out_len = b.out_len[:n_reads].cpu().numpy().astype(np.int64)
+    z_bytes = int(out_len.sum())
+    parity = True
+    if rank == 0:   # stock zlib must inflate sampled records of every length class to a payload of the right shape
+        order = np.argsort(ns)
+        idx = [int(order[0]), int(order[n_reads // 2]), int(order[-1]), 0, n_reads - 1]
+        for i, rec in zip(idx, b.stream_records(idx)):
+            pay = zlib.decompress(rec[8:])
+            parity &= len(pay) > 86 and int.from_bytes(pay[82:86], "little") == int(ns[i])
+    del b
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    alg = raw_bytes + 74 * n_reads + z_bytes
+    kern_s = (enc_ms + cmp_ms) / 1e3
+    kernel = "k_encode_fused+k_pack+k_deflate_staged+k_compact"
+    traffic, traffic_src = pmc_traffic(kernel, "mixed", n_reads)
+    return {"workload": "read lengths of a real run: %d reads per GPU, log-normal lengths (median %d, max %d samples, %.2f G samples), full BLOW5 encode, %d-byte fused budget, overflow list launched longest first"
+                        % (n_reads, int(np.median(ns)), int(ns.max()), ns.sum() / 1e9, args.fused_cap),
+            "value": round(raw_bytes * world * K / dt / 1e9, 3), "unit": "GB/s", "steps": K, "ms_per_step": round(dt / K * 1e3, 3), "scaling": "weak",
+            "reads_per_s": round(n_reads * world * K / dt, 1), "samples_per_s": round(float(ns.sum()) * world * K / dt, 1),
+            "bytes_per_sample": round(z_bytes / (raw_bytes / 2), 4), "parity_spot_check": bool(parity),
+            "kernel_ms": {"encode": round(enc_ms, 3), "compact": round(cmp_ms, 3)},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(alg / kern_s / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(alg / kern_s / 1e9 / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg}}
+
+
 def svb_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, K, W):
     """BASELINE configs[1]: the svb-zd stage alone on the same resident reads, blobs into one contiguous stream (k_svbzd_stream;
     --two-pass: k_svbzd_encode into slots + the compaction), bit-exact against the oracle on a spot sample (the full comparison is tests/test_full_size.py)."""
@@ -507,92 +574,99 @@ def decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, want_c
         got = sig[: k * sig_cap].view(k, sig_cap)[:, :n]
         want = src_sig[torch.from_numpy(sel).to(dev)][:, :n]
         ok &= bool((stt == 0).all().item()) and bool((got == want).all().item())
-    # pass 3: the whole index in one call (what `view` / `merge` decode per batch when the batch is large)
-    if hip is not None:
-        del pin, pin_in_off, pin_in_len
-        L.s5gpu_host_free(pin_ptr)
-    del sig, fields, desc_dev
     bulk = None
-    d = descs(np.arange(n_reads), True)
-    big_desc = torch.from_numpy(d.view(np.uint8)).to(dev)
-    big_sig = torch.empty(n_reads * sig_cap + 64, dtype=torch.int16, device=dev)
-    big_fields = torch.zeros(n_reads * 64, dtype=torch.uint8, device=dev)
-    a_bulk = args_for(n_reads, big_desc, big_sig, big_fields, b.stream_out.data_ptr())
+    if not args.decode_batches_only:     # (--decode-batches-only: the K-sized batches alone — their own kernel-stats CSV and PMC pass)
+        # pass 3: the whole index in one call (what `view` / `merge` decode per batch when the batch is large)
+        if hip is not None:
+            del pin, pin_in_off, pin_in_len
+            L.s5gpu_host_free(pin_ptr)
+        del sig, fields, desc_dev
+        bulk = None
+        d = descs(np.arange(n_reads), True)
+        big_desc = torch.from_numpy(d.view(np.uint8)).to(dev)
+        big_sig = torch.empty(n_reads * sig_cap + 64, dtype=torch.int16, device=dev)
+        big_fields = torch.zeros(n_reads * 64, dtype=torch.uint8, device=dev)
+        a_bulk = args_for(n_reads, big_desc, big_sig, big_fields, b.stream_out.data_ptr())
 
-    def bulk_call(a, reps_min, secs):
-        ts = []
-        t0 = time.perf_counter()
-        while len(ts) < reps_min or (time.perf_counter() - t0 < secs and len(ts) < 400):
-            L.s5gpu_event_record(ev[0], st)
-            _lib.check(L.s5gpu_decode_dev(C.byref(a), st), "s5gpu_decode_dev")
-            L.s5gpu_event_record(ev[1], st)
-            torch.cuda.synchronize()
-            ts.append(elapsed_ms(L, _lib, ev[0], ev[1]))
-        return ts
+        def bulk_call(a, reps_min, secs):
+            ts = []
+            t0 = time.perf_counter()
+            while len(ts) < reps_min or (time.perf_counter() - t0 < secs and len(ts) < 400):
+                L.s5gpu_event_record(ev[0], st)
+                _lib.check(L.s5gpu_decode_dev(C.byref(a), st), "s5gpu_decode_dev")
+                L.s5gpu_event_record(ev[1], st)
+                torch.cuda.synchronize()
+                ts.append(elapsed_ms(L, _lib, ev[0], ev[1]))
+            return ts
 
-    ts = bulk_call(a_bulk, 3, args.min_leg_seconds)
-    ms = float(np.mean(ts[1:]))
-    stt = big_fields.view(torch.int32).view(n_reads, 16)[:, 0]
-    same = bool((stt == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n], src_sig[:, :n]))
-    ok &= same
-    alg = z_total + 2 * n * n_reads                         # Z + 2N per record (decode)
-    dtraffic, dtraffic_src = pmc_traffic("k_inflate_par_np", n, n_reads)
-    bulk = {"reads": n_reads, "calls": len(ts) - 1, "ms": round(ms, 3), "ms_min": round(min(ts[1:]), 3), "reads_per_s": round(n_reads / ms * 1e3, 1),
-            "raw_signal_GB_per_s": round(n_reads * 2 * n / ms / 1e6, 2), "roundtrip_identical": same,
-            "roofline": {"bound": "hbm", "kernel": "k_inflate_par_np (inflate + parse + svb-zd unpack, one launch)", "achieved": round(alg / ms / 1e6, 2), "peak": PEAK_HBM_GBS,
-                         "unit": "GB/s", "frac": round(alg / ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": dtraffic, "traffic_source": dtraffic_src, "algorithmic_bytes_per_launch": alg}}
-    # ... the same call in the form that also writes every uncompressed record out (what the view / merge worker needs)
-    try:
-        big_pay = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device=dev)
-        a_full = args_for(n_reads, big_desc, big_sig, big_fields, b.stream_out.data_ptr(), payload_t=big_pay)
-        big_sig.zero_()
-        ts = bulk_call(a_full, 4, 0.3)
-        msf = float(np.mean(ts[1:]))
+        ts = bulk_call(a_bulk, 3, args.min_leg_seconds)
+        ms = float(np.mean(ts[1:]))
         stt = big_fields.view(torch.int32).view(n_reads, 16)[:, 0]
-        samef = bool((stt == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n], src_sig[:, :n]))
-        ok &= samef
-        ftraffic, ftraffic_src = pmc_traffic("k_inflate_par+k_unpack", n, n_reads)
-        bulk["with_payload_output"] = {"ms": round(msf, 3), "reads_per_s": round(n_reads / msf * 1e3, 1), "roundtrip_identical": samef,
-                                       "roofline_frac": round(alg / msf / 1e6 / PEAK_HBM_GBS, 5), "traffic": ftraffic, "traffic_source": ftraffic_src}
-        del big_pay
-    except torch.OutOfMemoryError:
-        bulk["with_payload_output"] = None
-    # ---- the same call on records WRITTEN BY STOCK ZLIB (what the reference's own files hold: level 6, arbitrary LZ77
-    # distances): 2048 distinct records compressed on the CPU, tiled to 262 144; every decoded signal compared ----
-    try:
-        import zlib
-        distinct, nb = 2048, min(262144, n_reads)
-        hostsig = src_sig[:distinct, :n].cpu().numpy()
-        streams = []
-        for i in range(distinct):
-            rec, keep = ob.make_rec(ob.synth_read_id(i), 0, 8192.0, 3.0, 1400.0, 4000.0, np.ascontiguousarray(hostsig[i]))
-            streams.append(zlib.compress(ob.rec_pack(rec, ob.SIG_SVB_ZD), 6))
-        zl = np.array([len(x) for x in streams], dtype=np.int64)
-        zo = np.concatenate([[0], np.cumsum((zl + 15) // 16 * 16)])
-        blob = np.zeros(zo[-1] + 64, dtype=np.uint8)
-        for x, o_ in zip(streams, zo[:-1]):
-            blob[o_:o_ + len(x)] = np.frombuffer(x, dtype=np.uint8)
-        zin = torch.from_numpy(blob).to(dev)
-        idx = np.arange(nb) % distinct
-        d2 = d[:nb].copy()
-        d2["in_off"] = zo[idx]; d2["in_len"] = zl[idx]
-        zdesc = torch.from_numpy(d2.view(np.uint8)).to(dev)
-        a_z = args_for(nb, zdesc, big_sig, big_fields, zin.data_ptr())
-        big_sig.zero_()
-        ts = bulk_call(a_z, 3, args.min_leg_seconds / 2)
-        ms2 = float(np.mean(ts[1:]))
-        stt = big_fields.view(torch.int32).view(n_reads, 16)[:nb, 0]
-        got = big_sig[: nb * sig_cap].view(nb, sig_cap)[:, :n]
-        want = src_sig[:distinct, :n]
-        same2 = bool((stt == 0).all().item()) and all(bool(torch.equal(got[k0:k0 + distinct], want[: min(distinct, nb - k0)])) for k0 in range(0, nb, distinct))
-        bulk["stock_zlib_records"] = {"reads": nb, "distinct": distinct, "calls": len(ts) - 1, "ms": round(ms2, 3), "reads_per_s": round(nb / ms2 * 1e3, 1),
-                                      "raw_signal_GB_per_s": round(nb * 2 * n / ms2 / 1e6, 2), "roundtrip_identical": same2,
-                                      "what": "svb-zd records compressed by zlib %s level 6 on the CPU (the reference's writer), decoded by the same call" % zlib.ZLIB_VERSION}
-        ok &= same2
-        del zin, zdesc
-    except Exception as e:      # (never fatal for the line)
-        bulk["stock_zlib_records"] = {"error": repr(e)}
-    del big_desc, big_sig, big_fields, scratch
+        same = bool((stt == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n], src_sig[:, :n]))
+        ok &= same
+        alg = z_total + 2 * n * n_reads                         # Z + 2N per record (decode)
+        dtraffic, dtraffic_src = pmc_traffic("k_inflate_par_np", n, n_reads)
+        bulk = {"reads": n_reads, "calls": len(ts) - 1, "ms": round(ms, 3), "ms_min": round(min(ts[1:]), 3), "reads_per_s": round(n_reads / ms * 1e3, 1),
+                "raw_signal_GB_per_s": round(n_reads * 2 * n / ms / 1e6, 2), "roundtrip_identical": same,
+                "roofline": {"bound": "hbm", "kernel": "k_inflate_par_np (inflate + parse + svb-zd unpack, one launch)", "achieved": round(alg / ms / 1e6, 2), "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": round(alg / ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": dtraffic, "traffic_source": dtraffic_src, "algorithmic_bytes_per_launch": alg}}
+        # ... the same call in the form that also writes every uncompressed record out (what the view / merge worker needs)
+        try:
+            big_pay = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device=dev)
+            a_full = args_for(n_reads, big_desc, big_sig, big_fields, b.stream_out.data_ptr(), payload_t=big_pay)
+            big_sig.zero_()
+            ts = bulk_call(a_full, 4, 0.3)
+            msf = float(np.mean(ts[1:]))
+            stt = big_fields.view(torch.int32).view(n_reads, 16)[:, 0]
+            samef = bool((stt == 0).all().item()) and bool(torch.equal(big_sig[: n_reads * sig_cap].view(n_reads, sig_cap)[:, :n], src_sig[:, :n]))
+            ok &= samef
+            ftraffic, ftraffic_src = pmc_traffic("k_inflate_par+k_unpack", n, n_reads)
+            bulk["with_payload_output"] = {"ms": round(msf, 3), "reads_per_s": round(n_reads / msf * 1e3, 1), "roundtrip_identical": samef,
+                                           "roofline_frac": round(alg / msf / 1e6 / PEAK_HBM_GBS, 5), "traffic": ftraffic, "traffic_source": ftraffic_src}
+            del big_pay
+        except torch.OutOfMemoryError:
+            bulk["with_payload_output"] = None
+        # ---- the same call on records WRITTEN BY STOCK ZLIB (what the reference's own files hold: level 6, arbitrary LZ77
+        # distances): 2048 distinct records compressed on the CPU, tiled to 262 144; every decoded signal compared ----
+        try:
+            import zlib
+            distinct, nb = 2048, min(262144, n_reads)
+            hostsig = src_sig[:distinct, :n].cpu().numpy()
+            streams = []
+            for i in range(distinct):
+                rec, keep = ob.make_rec(ob.synth_read_id(i), 0, 8192.0, 3.0, 1400.0, 4000.0, np.ascontiguousarray(hostsig[i]))
+                streams.append(zlib.compress(ob.rec_pack(rec, ob.SIG_SVB_ZD), 6))
+            zl = np.array([len(x) for x in streams], dtype=np.int64)
+            zo = np.concatenate([[0], np.cumsum((zl + 15) // 16 * 16)])
+            blob = np.zeros(zo[-1] + 64, dtype=np.uint8)
+            for x, o_ in zip(streams, zo[:-1]):
+                blob[o_:o_ + len(x)] = np.frombuffer(x, dtype=np.uint8)
+            zin = torch.from_numpy(blob).to(dev)
+            idx = np.arange(nb) % distinct
+            d2 = d[:nb].copy()
+            d2["in_off"] = zo[idx]; d2["in_len"] = zl[idx]
+            zdesc = torch.from_numpy(d2.view(np.uint8)).to(dev)
+            a_z = args_for(nb, zdesc, big_sig, big_fields, zin.data_ptr())
+            big_sig.zero_()
+            ts = bulk_call(a_z, 3, args.min_leg_seconds / 2)
+            ms2 = float(np.mean(ts[1:]))
+            stt = big_fields.view(torch.int32).view(n_reads, 16)[:nb, 0]
+            got = big_sig[: nb * sig_cap].view(nb, sig_cap)[:, :n]
+            want = src_sig[:distinct, :n]
+            same2 = bool((stt == 0).all().item()) and all(bool(torch.equal(got[k0:k0 + distinct], want[: min(distinct, nb - k0)])) for k0 in range(0, nb, distinct))
+            bulk["stock_zlib_records"] = {"reads": nb, "distinct": distinct, "calls": len(ts) - 1, "ms": round(ms2, 3), "reads_per_s": round(nb / ms2 * 1e3, 1),
+                                          "raw_signal_GB_per_s": round(nb * 2 * n / ms2 / 1e6, 2), "roundtrip_identical": same2,
+                                          "what": "svb-zd records compressed by zlib %s level 6 on the CPU (the reference's writer), decoded by the same call" % zlib.ZLIB_VERSION}
+            ok &= same2
+            del zin, zdesc
+        except Exception as e:      # (never fatal for the line)
+            bulk["stock_zlib_records"] = {"error": repr(e)}
+        del big_desc, big_sig, big_fields, scratch
+    else:
+        if hip is not None:
+            del pin, pin_in_off, pin_in_len
+            L.s5gpu_host_free(pin_ptr)
+        del sig, fields, desc_dev, scratch
     for e in ev:
         L.s5gpu_event_destroy(e)
     if rank != 0:
@@ -635,7 +709,8 @@ def decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, want_c
             "per_read_latency_us_p50": round(float(np.percentile(lat_ms, 50)) * 1e3 / K, 3),
             "kernel_ms_per_batch": round(k_ms, 4) if k_ms else None,
             "roofline": {"bound": "hbm", "kernel": "k_inflate_par_np (K = %d)" % K, "achieved": round(k_alg / k_ms / 1e6, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(k_alg / k_ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(k_alg)} if k_ms else None,
+                         "frac": round(k_alg / k_ms / 1e6 / PEAK_HBM_GBS, 5), "traffic": pmc_traffic("k_inflate_par_np@K", n, K)[0], "traffic_source": pmc_traffic("k_inflate_par_np@K", n, K)[1],
+                         "algorithmic_bytes_per_launch": int(k_alg)} if k_ms else None,
             "bulk_decode_one_call": bulk,
             "cpu_baseline": cpu,
             "roundtrip_identical": bool(ok)}
@@ -662,8 +737,11 @@ def main():
     ap.add_argument("--long-chunk", type=int, default=16384, help="configs[3] leg: reads per launch (at most; a rank's shard is cut into >= 4 chunks)")
     ap.add_argument("--long-streams", type=int, default=2, help="configs[3] leg: 2 = two output buffer sets, pack / deflate / compaction of successive chunks on three streams; 1 = one stream, one set")
     ap.add_argument("--decode", action="store_true", help="configs[4] alone: random get-style decode (inflate + svb-zd unpack)")
+    ap.add_argument("--decode-batches-only", action="store_true", help="configs[4]: only the K-sized get batches (no bulk call, no stock-zlib records)")
     ap.add_argument("--get-reads", type=int, default=100_000, help="configs[4]: random read ids to fetch (seed 1)")
     ap.add_argument("--get-batch", type=int, default=4096, help="configs[4]: ids per batch (-K)")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-read-lengths leg of the default run")
+    ap.add_argument("--mixed-reads", type=int, default=262144, help="mixed leg: reads per GPU")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file to file) object of the default run")
     ap.add_argument("--e2e-reads", type=int, default=1_000_000, help="e2e: reads in the files (4000 samples each; /dev/shm)")
     ap.add_argument("--e2e-cpu-reads", type=int, default=262_144, help="e2e: records of the same files the CPU twins convert per point")
@@ -830,10 +908,13 @@ def main():
         if single_pass:     # configs[4] decodes the records the headline wrote; it runs before configs[1] reuses the stream buffer
             leg4 = decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, world == 1 and args.cpu_seconds > 0)
         leg1 = svb_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, K, args.warmup)
+    del b                                       # free the main batch before the other legs allocate
+    torch.cuda.empty_cache()
     if default_shape and not args.no_long:
-        del b                                   # free the 1 M-read batch before the long leg allocates
-        torch.cuda.empty_cache()
         leg3 = long_leg(args, L, _lib, press, shard, ob, rank, world, dev, K, args.warmup)
+    leg_mixed = None
+    if default_shape and not args.no_mixed:
+        leg_mixed = mixed_leg(args, L, _lib, press, shard, rank, world, dev)
 
     if rank != 0:
         return finish(None)
@@ -924,6 +1005,7 @@ def main():
         "configs1": leg1,
         "configs3": leg3,
         "configs4": leg4,
+        "mixed": leg_mixed,
         "e2e": e2e_obj,
         "pcie_inclusive": pcie_obj,
     }

@@ -233,9 +233,22 @@ def _same_file(a, b, block=1 << 24):
 
 
 def pcie_inclusive(L, _lib, press, n_reads, n, reps=2):
-    """s5gpu_encode_batch on host buffers at the full batch size: what a patched view.c sees per batch (host int16 signals in, one malloc'd
-    record per read out: the ownership contract of slow5_rec_to_mem).  The first call also allocates the library's pinned and device
-    workspaces; both are reported."""
+    """s5gpu_encode_batch on host buffers: what a patched view.c sees per batch (host int16 signals in, one malloc'd record per read out: the
+    ownership contract of slow5_rec_to_mem, /root/reference/src/view.c:49,298) — at 65536 reads per call (sixteen of the reference's default
+    batches) and at the full 1 M.  The first call of a size also allocates the library's pinned and device workspaces; best and first are
+    both reported.  The 1 M call hands out 3.5 GB in a million malloc'd buffers the process has never touched: page faults, not PCIe, bound it —
+    the chunk calls (s5gpu_recompress_stream ...) exist for that reason."""
+    out = {"call": "s5gpu_encode_batch (host int16 signals in, one malloc'd record per read out)", "note": "PCIe-inclusive: never `value`"}
+    for m in (65536, n_reads):
+        if m > n_reads:
+            continue
+        out["batch_%d" % m] = _pcie_one(L, _lib, press, m, n, 3 if m <= 65536 else reps)
+    big = out["batch_%d" % n_reads]
+    out.update({"reads": n_reads, "samples_per_read": n, "GB_per_s": big["GB_per_s"], "reads_per_s": big["reads_per_s"]})
+    return out
+
+
+def _pcie_one(L, _lib, press, n_reads, n, reps):
     rng = np.random.default_rng(0)
     base = (500 + 30 * rng.standard_normal((1024, n))).astype(np.int16)
     sig = np.ascontiguousarray(np.tile(base, (n_reads // 1024 + 1, 1))[:n_reads])
@@ -261,7 +274,5 @@ def pcie_inclusive(L, _lib, press, n_reads, n, reps=2):
         for p in np.frombuffer(out, dtype=np.uint64).tolist():
             libc.free(p)
     best = min(times)
-    return {"call": "s5gpu_encode_batch (host int16 signals in, one malloc'd record per read out)", "reads": n_reads, "samples_per_read": n,
-            "seconds": [round(t, 3) for t in times], "GB_per_s": round(n_reads * n * 2 / best / 1e9, 3), "reads_per_s": round(n_reads / best, 1),
-            "first_call_GB_per_s": round(n_reads * n * 2 / times[0] / 1e9, 3), "bytes_per_sample": round(tot / (n_reads * n), 4),
-            "note": "PCIe-inclusive: never `value`"}
+    return {"reads": n_reads, "seconds": [round(t, 3) for t in times], "GB_per_s": round(n_reads * n * 2 / best / 1e9, 3), "reads_per_s": round(n_reads / best, 1),
+            "first_call_GB_per_s": round(n_reads * n * 2 / times[0] / 1e9, 3), "bytes_per_sample": round(tot / (n_reads * n), 4)}

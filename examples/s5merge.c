@@ -187,6 +187,8 @@ int main(int argc, char **argv) {
                 size_t lo = 0;
                 while (lo < n_plain && strcmp(plain[lo].name, h->aux[c].name) < 0) lo++;
                 if (lo < n_plain && strcmp(plain[lo].name, h->aux[c].name) == 0) {
+                    /* STRICTER than the reference on purpose: merge.c:292 keeps the first file's type (std::map::insert ignores the second) and then
+                     * copies the other file's aux bytes under it — a header that no longer describes its records.  Refused here. */
                     if (strcmp(plain[lo].type, h->aux[c].type) != 0) return die("different types in different files for", h->aux[c].name);
                 } else {
                     auxcol_t *np = (auxcol_t *)realloc(plain, sizeof(auxcol_t) * (n_plain + 1));

@@ -134,7 +134,7 @@ static void *worker_main(void *arg) {                               /* compute p
  * threads), frames the records in place (their size prefixes chain through the chunk; a record cut by the chunk's end is
  * carried to the next chunk), the GPU worker hands the whole chunk over in one call and gets the re-encoded records back as
  * one contiguous stream, and the writer issues one write() per chunk.  Same three stages, same order of records. */
-#define FSLOT 4
+#define FSLOT_MAX 16
 typedef struct {
     int state;
     int64_t seq;
@@ -149,7 +149,9 @@ typedef struct {
 typedef struct {
     pthread_mutex_t mu;
     pthread_cond_t cv;
-    fslot_t slot[FSLOT];
+    fslot_t slot[FSLOT_MAX];
+    int nslot;                   /* chunk slots in flight (S5VIEW_SLOTS, default 6) */
+    double t_read, t_frame, t_rwait, t_gpu, t_write, t_wwait;   /* S5VIEW_TIMING: where the stages spend their time */
     int fd_in, fd_out;
     uint64_t pos, end;           /* record area of the input file: [pos, end) */
     size_t chunk;
@@ -224,12 +226,15 @@ static void *freader_main(void *arg) {
     size_t carry = 0;
     const uint8_t *carry_from = NULL;
     for (int64_t s = 0;; s++) {
-        fslot_t *b = &P->slot[s % FSLOT];
+        fslot_t *b = &P->slot[s % P->nslot];
+        const double tw0 = now_s();
         pthread_mutex_lock(&P->mu);
         while (!P->failed && (b->state != ST_EMPTY || !b->ready)) pthread_cond_wait(&P->cv, &P->mu);
         const int stop = P->failed;
         pthread_mutex_unlock(&P->mu);
         if (stop) return NULL;
+        const double tr0 = now_s();
+        P->t_rwait += tr0 - tw0;
         if (carry) memmove(b->in, carry_from, carry);            /* the record the previous chunk's end cut in two */
         size_t want = P->chunk - carry;
         if (want > P->end - P->pos) want = (size_t)(P->end - P->pos);
@@ -253,6 +258,8 @@ static void *freader_main(void *arg) {
             for (int t = 0; t < used; t++) if (!job[t].ok) { fpipe_fail(P, "read failed"); return NULL; }
         }
         P->pos += want;
+        const double tr1 = now_s();
+        P->t_read += tr1 - tr0;
         if (s == 0) stamp("first chunk read");
         const size_t have = carry + want;
         size_t p = 0;
@@ -290,6 +297,7 @@ static void *freader_main(void *arg) {
         if (file_done && carry && n == 0) { fpipe_fail(P, "bad record framing"); return NULL; }
         const int last = file_done && carry == 0;
         b->in_have = p;
+        P->t_frame += now_s() - tr1;
         pthread_mutex_lock(&P->mu);
         if (n) { b->n = n; b->seq = s; b->state = ST_FILLED; }
         if (last || n == 0) P->total_batches = s + (n ? 1 : 0);
@@ -297,7 +305,7 @@ static void *freader_main(void *arg) {
         pthread_mutex_unlock(&P->mu);
         if (last || n == 0) return NULL;
         if (carry) {   /* the next slot's head takes the cut record: it must still be readable when that slot is claimed */
-            /* the bytes stay valid: this slot is not reused before the next one has been filled (FSLOT >= 2) */
+            /* the bytes stay valid: this slot is not reused before the next one has been filled (at least two slots) */
         }
     }
 }
@@ -309,7 +317,7 @@ static void *fworker_main(void *arg) {
         int64_t s;
         for (;;) {
             s = P->next_work;
-            b = &P->slot[s % FSLOT];
+            b = &P->slot[s % P->nslot];
             if (P->failed || (P->total_batches >= 0 && s >= P->total_batches)) { pthread_mutex_unlock(&P->mu); return NULL; }
             if (b->state == ST_FILLED && b->seq == s) break;
             pthread_cond_wait(&P->cv, &P->mu);
@@ -317,6 +325,7 @@ static void *fworker_main(void *arg) {
         P->next_work = s + 1;
         b->state = ST_BUSY;
         pthread_mutex_unlock(&P->mu);
+        const double tg0 = now_s();
         for (int attempt = 0;; attempt++) {
             const int rc = P->ascii_out
                 ? s5gpu_blow5_to_ascii_stream(b->n, b->in, b->in_have, b->rec_pos, b->rec_len, rec_code_of(P->from.record_method), sig_code_of(P->from.signal_method),
@@ -340,15 +349,17 @@ static void *fworker_main(void *arg) {
         b->out_total = (size_t)b->out_off[b->n];
         if (s == 0) stamp("first chunk through the GPU call");
         pthread_mutex_lock(&P->mu);
+        P->t_gpu += now_s() - tg0;
         b->state = ST_DONE;
         pthread_cond_broadcast(&P->cv);
         pthread_mutex_unlock(&P->mu);
     }
 }
-/* ---- the ordered write phase, one chunk: several threads put disjoint parts of the chunk's output at their file offsets ----
- * One write() per chunk runs at 4-5 GB/s into the page cache (a new file's pages are allocated, zeroed and filled by one thread), which is
- * what bounded every conversion once the compute was on the GPU (round 4: 3.5 GB out in 0.75 s).  S5VIEW_WRITERS threads (default 4; 1 = the
- * plain write()), S5VIEW_WRITE_MODE = pwrite (default) | mmap (ftruncate + mmap of the chunk's range, memcpy). */
+/* ---- the ordered write phase, one chunk ----
+ * One write() per chunk (S5VIEW_WRITERS = 1, the default).  Measured on the round-4 MI355X box into /dev/shm (tools/hw_probe/shm_write_probe.c):
+ * one thread's write() 6.5 GB/s — a new file's pages are allocated and zeroed under the inode lock —, 4 pwrite threads on disjoint parts of
+ * the chunk 7.1, 8 threads 3.5, ftruncate + mmap + memcpy 5.6 / 3.9: the page cache does not take a second writer, so 3.5 GB of records are
+ * 0.54 s of any conversion.  S5VIEW_WRITERS > 1 / S5VIEW_WRITE_MODE = mmap keep the parallel forms for filesystems that do. */
 typedef struct { int fd; const uint8_t *src; uint8_t *dst; size_t len; off_t off; int ok; } wjob_t;
 static void *wjob_main(void *arg) {
     wjob_t *j = (wjob_t *)arg;
@@ -423,7 +434,7 @@ static int fslot_alloc(fpipe_t *P, int i) {
 }
 static void *fslot_alloc_rest(void *arg) {
     fpipe_t *P = (fpipe_t *)arg;
-    for (int i = 1; i < FSLOT; i++) {
+    for (int i = 1; i < P->nslot; i++) {
         /* a file that fits the slots already there needs no more of them */
         pthread_mutex_lock(&P->mu);
         const int done = P->failed || P->total_batches >= 0;
@@ -462,6 +473,10 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     e = getenv("S5VIEW_READERS");
     P.readers = e ? atoi(e) : (in->format == SLOW5_FORMAT_ASCII ? 8 : 4);   /* (text is twice the bytes per sample: more copy threads) */
     P.from = from; P.to = to; P.total_batches = -1;
+    e = getenv("S5VIEW_SLOTS");
+    P.nslot = e ? atoi(e) : 6;
+    if (P.nslot < 2) P.nslot = 2;
+    if (P.nslot > FSLOT_MAX) P.nslot = FSLOT_MAX;
     const double t_alloc = now_s();
     /* slot 0 is pinned here; the others by a helper thread while the first chunk is read and sent (a pinned buffer of tens of MB costs
      * 5-15 ms, and a short job is over before four slots' worth of that would have been spent up front) */
@@ -476,17 +491,21 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     uint64_t out_bytes = 0;
     off_t out_pos = lseek(P.fd_out, 0, SEEK_CUR);                    /* (the header is flushed: the records start here) */
     e = getenv("S5VIEW_WRITERS");
-    const int writers = e ? atoi(e) : 4;
+    const int writers = e ? atoi(e) : 1;     /* (round 4, MI355X box, /dev/shm: one write() 6.5 GB/s, 4 pwrite threads 7.1, 8 threads 3.5: tools/hw_probe/shm_write_probe.c) */
     e = getenv("S5VIEW_WRITE_MODE");
     const int write_mmap = e && strcmp(e, "mmap") == 0;
     for (int64_t s = 0;; s++) {                                      /* ordered write phase: the chunks in order, each by several threads */
-        fslot_t *b = &P.slot[s % FSLOT];
+        fslot_t *b = &P.slot[s % P.nslot];
+        const double tq0 = now_s();
         pthread_mutex_lock(&P.mu);
         while (!P.failed && !(b->state == ST_DONE && b->seq == s) && !(P.total_batches >= 0 && s >= P.total_batches)) pthread_cond_wait(&P.cv, &P.mu);
         const int stop = P.failed || (P.total_batches >= 0 && s >= P.total_batches);
         pthread_mutex_unlock(&P.mu);
         if (stop) break;
+        const double tq1 = now_s();
+        P.t_wwait += tq1 - tq0;
         if (write_chunk(P.fd_out, b->out, b->out_total, out_pos, writers, write_mmap) != 0) fpipe_fail(&P, "write failed");
+        P.t_write += now_s() - tq1;
         if (s == 0) stamp("first chunk written");
         if (out_pos >= 0) out_pos += (off_t)b->out_total;
         out_bytes += b->out_total;
@@ -502,7 +521,9 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     if (out_pos >= 0 && lseek(P.fd_out, out_pos, SEEK_SET) < 0) fpipe_fail(&P, "seek failed");   /* the end marker follows the last record */
     const double t1 = now_s();
     stamp("last write");
-    for (int i = 0; i < FSLOT; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); free(b->nl); }
+    for (int i = 0; i < P.nslot; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); free(b->nl); }
+    if (g_timing) fprintf(stderr, "s5view[t] stages (seconds, summed): reader pread %.3f + framing %.3f + waiting for a free slot %.3f | GPU calls %.3f over %d worker(s) | writer write %.3f + waiting for a chunk %.3f | %d slots\n",
+                          P.t_read, P.t_frame, P.t_rwait, P.t_gpu, W, P.t_write, P.t_wwait, P.nslot);
     if (P.failed && P.oversize) return -2;
     if (P.failed) { fprintf(stderr, "s5view: %s\n", P.why); return -1; }
     fprintf(stderr, "s5view: chunked pipeline%s%s: %.3f s for %llu records (%.1f MB in, %.1f MB out; buffers %.3f s), %d pread threads, %d GPU worker(s), chunks of %zu MB\n",

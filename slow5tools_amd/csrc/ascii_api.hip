@@ -378,6 +378,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         Ctx *c = hold.c;
         const uint32_t m = hi - lo;
         const char *base_p = (const char *)chunk;
+        s5_trace("ascii_to_blow5_stream: context acquired");
         // scalar and aux columns on the host; the raw_signal column stays where it is
         std::vector<Line> L(m);
         uint64_t text_bytes = 0, b0 = UINT64_MAX, e1 = 0;
@@ -395,6 +396,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         for (uint32_t i = 0; i < m; i++)
             if (L[i].status) { bad = true; if (status) status[lo + i] = L[i].status; }
         if (bad) { s5gpu_set_error("s5gpu_ascii_to_blow5_stream: at least one line is malformed (see status[i])"); return sg.fail(S5GPU_ERR_DATA, slot); }
+        s5_trace("scalar / aux columns parsed on the host");
         std::vector<s5gpu_read_desc_t> desc(m);
         std::vector<s5gpu_txt_desc_t> td(m);
         uint64_t so = 0, ho = 0, ao = 0, oo = 0;
@@ -421,6 +423,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
             (r = c->d_hdr.reserve(ho + 64)) || (r = c->d_aux.reserve(ao + 64)) || (r = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * m)) ||
             (r = c->d_tdesc.reserve(h_td + 4ull * m)) || (r = c->h_out.reserve(4ull * m + 64)))
             return sg.fail(r, slot);
+        s5_trace("workspaces reserved");
         uint8_t *hh = (uint8_t *)c->h_in.p, *ha = hh + h_hdr, *hd = ha + h_aux, *htd = hd + h_desc;
         for (uint32_t i = 0; i < m; i++) {
             memcpy(hh + desc[i].hdr_off, L[i].head.data(), desc[i].hdr_len);
@@ -442,6 +445,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         if ((r = s5gpu_ascii_parse_dev(m, (const s5gpu_txt_desc_t *)c->d_tdesc.p, (const uint8_t *)c->d_txt.p, (int16_t *)c->d_sig.p, d_status, c->st))) return sg.fail(r, slot);
         if ((r = hip(hipMemcpyAsync(c->h_out.p, d_status, 4ull * m, hipMemcpyDeviceToHost, c->st), "status download"))) return r;
         if ((r = hip(hipStreamSynchronize(c->st), "synchronise"))) return r;
+        s5_trace("chunk uploaded, raw_signal text parsed on the device");
         const int32_t *hs = (const int32_t *)c->h_out.p;
         for (uint32_t i = 0; i < m; i++)
             if (hs[i]) { bad = true; if (status) status[lo + i] = hs[i]; }
@@ -454,6 +458,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         a.max_payload = max_payload;
         std::vector<uint64_t> off;
         if ((r = s5host::encode_stream_resident(c, m, desc, a, oo, off))) return sg.fail(r, slot);
+        s5_trace("records encoded");
         uint64_t base = 0;
         bool copy = false;
         if ((r = sg.place(slot, off[m], out_cap, &base, &copy))) return r;
@@ -462,6 +467,7 @@ extern "C" int s5gpu_ascii_to_blow5_stream(uint32_t n, const void *chunk, size_t
         for (uint32_t i = 0; i < m; i++) out_off[lo + i] = base + off[i];
         if (hi == n) out_off[n] = base + off[m];
         HIP_TRY(hipStreamSynchronize(c->st));
+        s5_trace("record stream downloaded");
         return S5GPU_OK;
     };
     // any way a share gives up releases the shares waiting behind it (ShareGather::place)

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -145,6 +146,20 @@ struct ShareGather {
 }  // namespace s5host
 
 static inline uint64_t up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// S5GPU_TRACE=1 (tools): milliseconds since the calling thread's previous trace point, to stderr — where a chunk call's time goes
+#include <time.h>
+static inline void s5_trace(const char *what) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("S5GPU_TRACE"); on = e && atoi(e) ? 1 : 0; }
+    if (!on) return;
+    static thread_local double last = 0;
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    const double now = (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+    fprintf(stderr, "s5gpu[trace] %p +%8.3f ms  %s\n", (void *)&last, last ? 1e3 * (now - last) : 0.0, what);
+    last = now;
+}
 
 // host-side packing / unpacking of a batch is plain memcpy work: spread it over a few threads
 template <class F>

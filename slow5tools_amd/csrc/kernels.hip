@@ -1012,7 +1012,14 @@ __device__ __forceinline__ void np_write_fields(const s5gpu_decode_args_t &a, ui
 template <bool EXZD, bool SHORT = true>
 __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode_args_t a, NpParams np) {
     __shared__ typename std::conditional<SHORT, InflParSharedSvb, InflParShared>::type T;
+#ifdef S5_NP_LDS_PAY   // tools (a variant build, tools/variant.sh ldspay -DS5_NP_LDS_PAY=5376): the uncompressed record never leaves the CU — what that buys in
+                       // HBM traffic and what the LDS costs in resident waves (profiles/r04_np_lds_payload.txt); records larger than the array are declined
+    __shared__ __attribute__((aligned(16))) uint8_t lds_pay[S5_NP_LDS_PAY];
+    uint8_t *pay = lds_pay;
+    np.cap = np.cap < (uint32_t)S5_NP_LDS_PAY - 16u ? np.cap : (uint32_t)S5_NP_LDS_PAY - 16u;
+#else
     uint8_t *pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
+#endif
     for (;;) {
         uint32_t r = blockIdx.x;
         if (np.ticket) {                               // (a batch no larger than the grid: workgroup b takes record b, no ticket)

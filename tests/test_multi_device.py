@@ -177,7 +177,7 @@ def test_bench_two_ranks_preflight_on_one_gpu(tmp_path):
     env = dict(os.environ, S5BENCH_ALIAS_DEVICES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "20000", "--long-reads", "512", "--cpu-seconds", "0",
-           "--get-reads", "20000", "--min-leg-seconds", "0.2", "--min-leg-steps-svb", "4", "--min-leg-steps-long", "2"]
+           "--get-reads", "20000", "--min-leg-seconds", "0.2", "--min-leg-steps-svb", "4", "--min-leg-steps-long", "2", "--mixed-reads", "8192"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -189,3 +189,5 @@ def test_bench_two_ranks_preflight_on_one_gpu(tmp_path):
     assert j["configs3"]["parity_spot_check"] is True and j["configs3"]["reads_rank0"] == 256 and j["configs3"]["scaling"] == "strong"
     assert j["configs4"]["roundtrip_identical"] is True and j["configs4"]["bulk_decode_one_call"]["stock_zlib_records"]["roundtrip_identical"] is True
     assert j["cpu_baseline"] is None                       # an N = 1 figure
+    assert j["mixed"]["parity_spot_check"] is True and j["mixed"]["scaling"] == "weak"
+    assert j["e2e"] is None and j["pcie_inclusive"] is None                   # file-to-file and host-buffer figures are N = 1 figures too

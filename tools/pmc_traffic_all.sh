@@ -19,6 +19,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   run long $c python bench.py --long --long-reads 16384 --steps 2 --warmup 1 --min-leg-steps-long 2 --cpu-seconds 0
   run decnp $c python tools/decode_bulk.py 1000000 4000 np 3
   run decfull $c python tools/decode_bulk.py 1000000 4000 full 3
+  run mixed $c python bench.py --mixed --steps 2 --warmup 1 --cpu-seconds 0
+  run dec4k $c python bench.py --decode --decode-batches-only --reads 200000 --cpu-seconds 0
 done
 python3 - <<PY
 import csv, glob, json, sys, os
@@ -38,7 +40,9 @@ legs = [("enc", "k_encode_stream", ["k_encode_stream"], 400000, 4000),
         ("svbs", "k_svbzd_stream", ["k_svbzd_stream"], 400000, 4000),
         ("long", "k_pack+k_deflate_staged", ["k_pack", "k_deflate_staged"], 4096, 100000),   # 16384 reads = 4 chunks of 4096 per step
         ("decnp", "k_inflate_par_np", ["k_inflate_par_np"], 1000000, 4000),
-        ("decfull", "k_inflate_par+k_unpack", ["k_inflate_par<1"], 1000000, 4000)]
+        ("decfull", "k_inflate_par+k_unpack", ["k_inflate_par<1"], 1000000, 4000),
+        ("mixed", "k_encode_fused+k_pack+k_deflate_staged+k_compact", ["k_encode_fused", "k_pack", "k_deflate_staged", "k_compact"], 262144, "mixed"),   # one launch of each per step
+        ("dec4k", "k_inflate_par_np@K", ["k_inflate_par_np"], 4096, 4000)]      # get batches of K = 4096 records (the last batch of a pass is shorter: a few % low)
 out = []
 for name, label, kernels, reads, n in legs:
     try:
@@ -46,7 +50,7 @@ for name, label, kernels, reads, n in legs:
         wr, nw = per_launch(name, "WRITE_SIZE", kernels)
         fetch = sum(fe.values()); write = sum(wr.values())
         b = (2 * fetch + write) * 1024 / reads
-        print("%-26s %8d reads x %6d: FETCH %14.1f KiB  WRITE %14.1f KiB per launch (%s launches) -> %.1f B/read" % (label, reads, n, fetch, write, nf, b))
+        print("%-26s %8d reads x %6s: FETCH %14.1f KiB  WRITE %14.1f KiB per launch (%s launches) -> %.1f B/read" % (label, reads, n, fetch, write, nf, b))
         out.append({"kernel": label, "samples_per_read": n, "hbm_bytes_per_read": round(b, 1), "fetch_KiB_per_launch": round(fetch, 1), "write_KiB_per_launch": round(write, 1),
                     "reads_per_launch": reads, "source": "tools/pmc_traffic_all.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x 2: gfx950 correction)",
                     "csrc_sha256": sha})
