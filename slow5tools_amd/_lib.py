@@ -121,5 +121,5 @@ EXPORTS = [
     "s5gpu_synth_hdr_dev", "s5gpu_event_create", "s5gpu_event_record", "s5gpu_event_elapsed_ms", "s5gpu_event_destroy",
     "s5gpu_encode_batch", "s5gpu_decode_batch", "s5gpu_solo_batch", "s5gpu_deflate_parked_dev", "s5gpu_inflate_dev",
     "s5gpu_svbzd_decode_dev", "s5gpu_set_option", "s5gpu_recompress_batch", "s5gpu_patch_u32_dev", "s5gpu_encode_stream_dev",
-    "s5gpu_svbzd_encode_stream_dev", "s5gpu_pack_parked_dev",
+    "s5gpu_svbzd_encode_stream_dev", "s5gpu_pack_parked_dev", "s5gpu_warmup",
 ]

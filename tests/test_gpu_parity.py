@@ -801,3 +801,40 @@ def test_parallel_inflate_on_awkward_zlib_streams(press, inflate_kernel):
     got = press.decode_records(streams, 1, 0)
     for g, s in zip(got, sigs):
         assert g["status"] == 0 and np.array_equal(g["signal"], s)
+
+
+def test_mixed_batch_overflow_list_is_launched_longest_first_and_encodes_the_same(press):
+    """encode side of the launch order (round 4): a mixed batch with an LDS budget sends its long reads through the overflow list, which is
+    counting-sorted by read length on the device (longest first) for batches of >= 8192 reads; the order must not show in the output —
+    every record byte-identical to the file-order run (option order_min = 0), every sampled record inflated by stock zlib to the oracle's
+    payload"""
+    from slow5tools_amd import _lib
+    import torch
+    rng = np.random.default_rng(77)
+    n_rec = 9000
+    ns = np.clip(np.exp(rng.normal(np.log(5000), 1.0, n_rec)), 1, 90000).astype(np.uint64)
+    ns[:3] = (90000, 1, 70000)
+    sigs = [(520 + rng.integers(-70, 70, int(n))).astype(np.int16) for n in ns]
+    hdrs = [_hdr(press, i) for i in range(n_rec)]
+    L = _lib.lib()
+    out = {}
+    for order_min in (8192, 0):
+        _lib.check(L.s5gpu_set_option(b"order_min", order_min))
+        try:
+            b = press.DeviceBatch(ns, hdr_len=[len(h) for h in hdrs], lds_payload_cap=8192)
+            b.upload(sigs, hdrs)
+            b.encode()
+            b.compact()
+            stream, off = b.stream_bytes()
+            assert int(b.ovf[0].item()) > 1000          # the list really carries the long reads
+            out[order_min] = (stream, off.copy())
+            del b
+            torch.cuda.empty_cache()
+        finally:
+            _lib.check(L.s5gpu_set_option(b"order_min", 8192))
+    assert out[8192][0] == out[0][0] and np.array_equal(out[8192][1], out[0][1])
+    stream, off = out[8192]
+    for i in list(range(0, n_rec, 450)) + [0, 1, 2]:
+        rec = stream[int(off[i]):int(off[i + 1])]
+        want, _ = _oracle_payload(hdrs[i], sigs[i], b"", 1)
+        assert zlib.decompress(rec[8:]) == want, i

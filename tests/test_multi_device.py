@@ -76,6 +76,18 @@ assert rc == 0 and off[n] == full and raw[:full] == b"".join(plain[i][:8] + ob.r
 for cap in (full // 5, full // 2, full - 1):          # overflow in the first, the second and the last share
     rc, off, raw = stream(cap)
     assert rc == -3 and off[0] == full, (cap, rc, off[0], full)
+# a corrupt record in the LAST share (ADVICE round 3): the call must come back with the data error of the share that holds it — not with
+# a secondary code of a share in front that merely noticed — and status[] must name the record
+bad_i = n - 2
+broken = bytearray(chunk)
+broken[int(pos[bad_i]) + 20] ^= 0x55
+ob_ = C.create_string_buffer(full + 64); off = (C.c_uint64 * (n + 1))(); st = (C.c_int32 * n)()
+rc = L.s5gpu_recompress_stream(n, bytes(broken), len(chunk) - 64, pos.ctypes.data, ln32.ctypes.data, 1, 1, 0, 0, None, 0, ob_, full + 64, off, st)
+msg = L.s5gpu_last_error()
+assert rc == -5, (rc, msg)                               # S5GPU_ERR_DATA
+assert st[bad_i] != 0 and sum(1 for x in st if x) == 1, list(st)[-6:]
+ndev = L.s5gpu_devices_in_use()
+assert ndev == 1 or (b"device slot %%d" %% (ndev - 1)) in msg, msg
 L.s5gpu_shutdown()
 assert L.s5gpu_devices_in_use() == 0
 print("multi ok", len(b"".join(recs)))
