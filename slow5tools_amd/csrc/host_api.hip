@@ -343,25 +343,25 @@ static int encode_batch_dev(int slot, uint32_t n, const int16_t *const *sig, con
     const uint32_t piece = pe && atoi(pe) >= 1024 ? (uint32_t)atoi(pe) : 65536u;
     const uint32_t P = n <= 2 * piece ? 2u : (n + piece - 1) / piece;
     std::atomic<uint32_t> next{0};
-    int rcs[2] = {S5GPU_OK, S5GPU_OK};
+    std::atomic<int> rcs[2] = {{S5GPU_OK}, {S5GPU_OK}};            // (each written by its own thread, read by both)
     char errs[2][512] = {"", ""};
     auto body = [&](int w) {
         for (;;) {
             const uint32_t k = next.fetch_add(1);
-            if (k >= P || rcs[0] || rcs[1]) return;
+            if (k >= P || rcs[0].load() || rcs[1].load()) return;
             const uint32_t lo = (uint32_t)((uint64_t)n * k / P), hi = (uint32_t)((uint64_t)n * (k + 1) / P);
             const int rc = encode_batch_one(slot, hi - lo, sig + lo, n_samples + lo, hdr + lo, hdr_len + lo, aux ? aux + lo : nullptr, aux_len ? aux_len + lo : nullptr,
                                             rec_method, sig_method, out + lo, out_len + lo);
-            if (rc) { rcs[w] = rc; snprintf(errs[w], sizeof errs[w], "%s", s5gpu_last_error()); return; }   // the message lives in that thread
+            if (rc) { snprintf(errs[w], sizeof errs[w], "%s", s5gpu_last_error()); rcs[w].store(rc); return; }   // the message lives in that thread
         }
     };
     std::thread t(body, 1);
     body(0);
     t.join();
-    if (rcs[0] || rcs[1]) {
-        const int w = rcs[0] ? 0 : 1;
+    if (rcs[0].load() || rcs[1].load()) {
+        const int w = rcs[0].load() ? 0 : 1;
         s5gpu_set_error("%s", errs[w]);
-        return rcs[w];
+        return rcs[w].load();
     }
     return S5GPU_OK;
 }
