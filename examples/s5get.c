@@ -82,7 +82,10 @@ static int gslot_alloc(gpipe_t *P, gslot_t *b) {
     b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)P->K);
     b->off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)P->K + 1));
     b->fields = (s5gpu_rec_fields_t *)malloc(sizeof(s5gpu_rec_fields_t) * (size_t)P->K);
-    return b->in && b->out && b->rec_pos && b->rec_len && b->off && b->fields ? 0 : -1;
+    if (b->in && b->out && b->rec_pos && b->rec_len && b->off && b->fields) return 0;
+    s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->off); free(b->fields);      /* (all or nothing) */
+    b->in = b->out = NULL; b->rec_pos = b->off = NULL; b->rec_len = NULL; b->fields = NULL;
+    return -1;
 }
 
 /* read phase (get.c:335-361): one reader thread fills one whole batch; several batches are being filled at once */

@@ -356,6 +356,16 @@ def test_chunked_view_pipeline_equals_the_per_record_pipeline(tmp_path, chunk_kb
         r = subprocess.run([S5VIEW, str(src), str(c), "zlib", "svb-zd", "4096", "2"], capture_output=True, text=True, timeout=300, env=env3)
         assert r.returncode == 0 and "chunked pipeline" in r.stderr, r.stderr
         assert c.read_bytes() == a.read_bytes()
+    if chunk_kb == 517:                                               # round 4: the pipeline's knobs change no byte — slot count, parallel chunk writer (pwrite / mmap), full exit
+        for k, extra in enumerate(({"S5VIEW_SLOTS": "2"}, {"S5VIEW_SLOTS": "16", "S5VIEW_WRITERS": "4", "S5VIEW_CHUNK_KB": "8192"},      # (a chunk's output must exceed 1 MiB for several writers)
+                                   {"S5VIEW_WRITERS": "3", "S5VIEW_WRITE_MODE": "mmap", "S5VIEW_CHUNK_KB": "8192"},
+                                   {"S5_FULL_EXIT": "1", "S5VIEW_TIMING": "1"})):
+            d = tmp_path / ("knob%d.blow5" % k)
+            r = subprocess.run([S5VIEW, str(src), str(d), "zlib", "svb-zd", "4096", "3"], capture_output=True, text=True, timeout=300, env=dict(env, **extra))
+            assert r.returncode == 0 and "chunked pipeline" in r.stderr, r.stderr
+            assert d.read_bytes() == a.read_bytes(), extra
+            if "S5VIEW_TIMING" in extra:
+                assert "s5view[t]" in r.stderr and "stages (seconds, summed)" in r.stderr
     back = tmp_path / "back.blow5"                                   # and back: zlib + svb-zd -> none, through the chunks again
     r = subprocess.run([S5VIEW, str(a), str(back), "none", "none", "4096", "1"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
