@@ -129,16 +129,28 @@ __device__ __forceinline__ void ip_load_window(uint32_t *win, const uint8_t *src
     wave_sync();
 }
 
-// n bytes from s to d, the two ranges disjoint, any alignment (one lane; global memory takes unaligned dwords)
-__device__ __forceinline__ void ip_copy_disjoint(uint8_t *d, const uint8_t *s, int n) {
+// n bytes from s to d, the two ranges disjoint, any alignment (one lane; global memory takes unaligned dwords).  The waiting matches it
+// serves are mostly 3-8 bytes: both ends of the piece are loaded before anything is stored and the two halves overlap in the middle —
+// one round trip to memory whatever the length, at most one of four short paths per lane (8.92 -> 8.62 ms per 262 144 stock-zlib records
+// against the 16 / 8 / 4 / byte-loop ladder, profiles/r04_wait_matches.txt)
+__device__ __forceinline__ void ip_copy_ends(uint8_t *d, const uint8_t *s, int n) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(1)));
     typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
     typedef uint32_t u1 __attribute__((aligned(1)));
-    int k = 0;
-    for (; k + 16 <= n; k += 16) *reinterpret_cast<u4 *>(d + k) = *reinterpret_cast<const u4 *>(s + k);
-    if (k + 8 <= n) { *reinterpret_cast<u2 *>(d + k) = *reinterpret_cast<const u2 *>(s + k); k += 8; }
-    if (k + 4 <= n) { *reinterpret_cast<u1 *>(d + k) = *reinterpret_cast<const u1 *>(s + k); k += 4; }
-    for (; k < n; k++) d[k] = s[k];
+    if (n >= 16) {
+        const u4 e = *reinterpret_cast<const u4 *>(s + n - 16);
+        for (int k = 0; k + 16 < n; k += 16) *reinterpret_cast<u4 *>(d + k) = *reinterpret_cast<const u4 *>(s + k);
+        *reinterpret_cast<u4 *>(d + n - 16) = e;
+    } else if (n >= 8) {
+        const u2 a = *reinterpret_cast<const u2 *>(s), e = *reinterpret_cast<const u2 *>(s + n - 8);
+        *reinterpret_cast<u2 *>(d) = a; *reinterpret_cast<u2 *>(d + n - 8) = e;
+    } else if (n >= 4) {
+        const u1 a = *reinterpret_cast<const u1 *>(s), e = *reinterpret_cast<const u1 *>(s + n - 4);
+        *reinterpret_cast<u1 *>(d) = a; *reinterpret_cast<u1 *>(d + n - 4) = e;
+    } else if (n > 0) {
+        const uint8_t a = s[0], b = s[n >> 1], e = s[n - 1];
+        d[0] = a; d[n >> 1] = b; d[n - 1] = e;
+    }
 }
 
 struct IpSeg {            // what a lane learns about its segment
@@ -467,10 +479,11 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                         const uint32_t a = T.fill_a[f0 + lane], op = a & 0xFFFFFu, mlen = a >> 20;
                         const uint32_t x = T.fill_x[f0 + lane], x4 = x * 0x01010101u;
                         uint8_t *q = dst + op;
-                        uint32_t k = 0;
-                        while (k < mlen && ((uintptr_t)(q + k) & 3)) q[k++] = (uint8_t)x;
-                        for (; k + 4 <= mlen; k += 4) *reinterpret_cast<uint32_t *>(q + k) = x4;
-                        for (; k < mlen; k++) q[k] = (uint8_t)x;
+                        typedef uint32_t u1 __attribute__((aligned(1)));
+                        if (mlen >= 4) {                                     // dwords wherever they start; the last one overlaps
+                            for (uint32_t k = 0; k + 4 < mlen; k += 4) *reinterpret_cast<u1 *>(q + k) = x4;
+                            *reinterpret_cast<u1 *>(q + mlen - 4) = x4;
+                        } else if (mlen) { q[0] = (uint8_t)x; q[mlen >> 1] = (uint8_t)x; q[mlen - 1] = (uint8_t)x; }
                     }
                 }
             }
@@ -478,10 +491,11 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             wave_sync();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             // ---- waiting matches: 64 at a time, each copied by ITS lane as soon as nothing it reads is still to come.  The list is
-            // in stream order, so the destinations are ascending and disjoint: the only entry whose destination can reach into my
-            // source is the last one that starts in front of my source's end (binary search over the lanes in front of me); if it
-            // does, I wait until every entry up to it is done.  Stock zlib leaves ~110 such matches in an svb-zd record of 4000
-            // samples (half of them in the key bytes); nearly all copy literals from far back and go in the first round.
+            // in stream order, so the destinations — starts and ends — are ascending and disjoint: the entries that reach into my
+            // source are a contiguous range of the lanes in front of me, from the first whose end lies behind my source's start to
+            // the last that starts in front of my source's end (two binary searches over the lanes); I go as soon as exactly those
+            // are done.  Stock zlib leaves ~110 such matches in an svb-zd record of 4000 samples (half of them in the key bytes):
+            // ~7 dependency steps per 64 entries (waiting for everything in front of the last one, as rounds 2-3 did, took 13).
             for (uint32_t c0 = 0; c0 < wtot; c0 += 64) {
                 if (dbg && dbg[3] == 4) break;                   // probe cut-off: what the waiting matches cost (the output is wrong without them)
                 const uint32_t j = c0 + (uint32_t)lane;
@@ -499,12 +513,18 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                     if (lo < hi) { if (v < se) lo = mid + 1; else hi = mid; }
                 }
                 const int cand = lo - 1;                                          // the last entry in front of me that starts before se
-                const int c_op = __builtin_amdgcn_ds_bpermute(max(cand, 0) << 2, op), c_len = __builtin_amdgcn_ds_bpermute(max(cand, 0) << 2, mlen);
-                const int dep = have && cand >= 0 && c_op + c_len > ss ? cand : -1;
+                int lo2 = 0, hi2 = lane;                                          // the first one that ends behind ss
+                const int e_op = op + mlen;
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const int mid = (lo2 + hi2) >> 1;
+                    const int v = __builtin_amdgcn_ds_bpermute(mid << 2, e_op);
+                    if (lo2 < hi2) { if (v <= ss) lo2 = mid + 1; else hi2 = mid; }
+                }
+                const uint64_t need = cand >= lo2 ? (2ull << cand) - (1ull << lo2) : 0ull;
                 uint64_t donem = ~__ballot(have);
                 while (~donem) {
-                    const int u = __ffsll((long long)~donem) - 1;                 // first entry not done: everything in front of it is
-                    const bool ready = !((donem >> lane) & 1ull) && dep < u;
+                    const bool ready = !((donem >> lane) & 1ull) && !(need & ~donem);
                     if (ready) {
                         // the bytes in front of q are periodic with period dist; every step copies as much as is known without
                         // reading what it writes, and then twice as much is known (a run at distance 1 takes 9 steps, not 258)
@@ -512,7 +532,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                         int k = 0, d = (int)dist;
                         while (k < mlen) {
                             const int nb = min(mlen - k, d);
-                            ip_copy_disjoint(q + k, q + k - d, nb);
+                            ip_copy_ends(q + k, q + k - d, nb);
                             k += nb;
                             d += d;
                         }

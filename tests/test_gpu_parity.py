@@ -803,6 +803,72 @@ def test_parallel_inflate_on_awkward_zlib_streams(press, inflate_kernel):
         assert g["status"] == 0 and np.array_equal(g["signal"], s)
 
 
+def test_waiting_matches_copy_in_dependency_order(press, inflate_kernel):
+    """matches whose source is another waiting match's output, in chains of every shape: each waits for exactly the entries that reach into its
+    source (two binary searches over the list, inflate_par_dev.h), not for everything in front of it — phrases that quote the phrase before
+    (chains as long as the list), quotes of quotes at shrinking lengths (one source spanning several earlier destinations), a quote that
+    overlaps its own output, far quotes between near ones (entries that may overtake their neighbours), at zlib levels 1 - 9; the payload is
+    a raw-signal record so that any byte pattern is a valid signal (reference decode: /root/reference/src/view.c + zlib inflate)"""
+    rng = np.random.default_rng(2024)
+    def rnd(n):
+        return bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    def chain(total, lo, hi):                          # every phrase = the tail of what precedes it + a few fresh bytes
+        out = bytearray(rnd(64))
+        while len(out) < total:
+            k = min(int(rng.integers(lo, hi)), len(out))
+            back = int(rng.integers(k, min(len(out), 4 * hi) + 1))
+            out += out[len(out) - back: len(out) - back + k] + rnd(int(rng.integers(1, 4)))
+        return bytes(out[:total])
+    def nested(total):                                 # quotes of quotes: a source that spans several earlier quotes and the literals between
+        out = bytearray(rnd(200))
+        while len(out) < total:
+            for k in (37, 23, 11, 7, 5, 3):
+                out += out[-(k + 9): -9] + rnd(1)
+            out += out[-150:-20]                       # one long quote across all of them
+        return bytes(out[:total])
+    def far_and_near(total):
+        base = rnd(3000)
+        out = bytearray(base)
+        while len(out) < total:
+            p = int(rng.integers(0, 2900))
+            out += base[p: p + int(rng.integers(4, 60))]          # far: literals of the first window
+            out += out[-int(rng.integers(3, 12)):] * 2            # near: overlaps what was just written
+            out += out[-40:-30] + rnd(2)
+        return bytes(out[:total])
+    blobs = [chain(9000, 3, 9), chain(9000, 3, 40), chain(60000, 5, 258), nested(9000), nested(70000), far_and_near(9000), far_and_near(40000),
+             (b"ab" * 3 + b"c") * 2000, chain(3000, 3, 5) * 20]
+    streams, sigs = [], []
+    for i, blob in enumerate(blobs):
+        blob = blob[: len(blob) // 2 * 2]
+        sig = np.frombuffer(blob, dtype=np.int16).copy()
+        payload, _ = _oracle_payload(_hdr(press, i), sig, b"", 0)
+        for level in range(1, 10):
+            v = zlib.compress(payload, level)
+            streams.append(v); sigs.append(sig)
+        c = zlib.compressobj(9, zlib.DEFLATED, 15, 9, zlib.Z_FILTERED)
+        streams.append(c.compress(payload) + c.flush()); sigs.append(sig)
+    got = press.decode_records(streams, 1, 0)
+    for k, (g, s) in enumerate(zip(got, sigs)):
+        assert g["status"] == 0 and np.array_equal(g["signal"], s), (k // 10, k % 10)
+    if inflate_kernel == "parallel-in-record":
+        # and without the fallback pass behind it: what the parallel decoder does not decline (status 8: a segment over the list's capacity)
+        # it must decode right by itself — and it takes the ones whose matches are not too dense for the list (37 of 90 when this was written)
+        from slow5tools_amd import _lib
+        L = _lib.lib()
+        _lib.check(L.s5gpu_set_option(b"inflate_par", 2))
+        try:
+            got = press.decode_records(streams, 1, 0, raise_on_error=False)
+        finally:
+            _lib.check(L.s5gpu_set_option(b"inflate_par", 1))
+        taken = 0
+        for k, (g, s) in enumerate(zip(got, sigs)):
+            assert g["status"] in (0, 8), (k, g["status"])
+            if g["status"] == 0:
+                taken += 1
+                assert np.array_equal(g["signal"], s), (k // 10, k % 10)
+        assert taken >= len(streams) // 4, taken
+
+
 def test_mixed_batch_overflow_list_is_launched_longest_first_and_encodes_the_same(press):
     """encode side of the launch order (round 4): a mixed batch with an LDS budget sends its long reads through the overflow list, which is
     counting-sorted by read length on the device (longest first) for batches of >= 8192 reads; the order must not show in the output —
