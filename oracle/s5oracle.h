@@ -124,6 +124,7 @@ int s5o_exzd_decode(const uint8_t *in, size_t len, int16_t *out, uint64_t *n_out
 size_t s5o_zstd_restated_decompress(const uint8_t *in, size_t len, uint8_t *out, size_t cap);   /* (size_t)-1 on error */
 /* the frame layout of the device encoder (zstd_enc.c): literals-only blocks of <= 16 KiB */
 int s5o_zstd_seq_ctable(int which, uint16_t *next, int32_t *dnb, int32_t *dfs);
+int s5o_zstd_seq_dtable(int which, uint32_t *cells);   /* decode cells of a predefined distribution, packed as csrc/zstd_seq_tables.h has them */
 size_t s5o_zstd_literals_bound(size_t n);
 size_t s5o_zstd_literals_compress(const uint8_t *in, size_t n, uint8_t *out);
 

@@ -244,6 +244,17 @@ static int64_t seq_table(int mode, const uint8_t *p, size_t len, fse_ent *t, int
 }
 
 /* returns the decompressed size, or (size_t)-1 on error.  out must hold cap bytes. */
+/* decode cells of a predefined distribution (0 literal lengths, 1 offsets, 2 match lengths; RFC 8878 3.1.1.3.2.2 and appendix A), packed as
+ * the device keeps them in csrc/zstd_seq_tables.h: symbol | (bits | baseline << 4) << 8; returns the number of cells (0: no such table) */
+int s5o_zstd_seq_dtable(int which, uint32_t *cells) {
+    fse_ent t[64];
+    const int16_t *def = which == 0 ? LL_DEF : which == 1 ? OF_DEF : which == 2 ? ML_DEF : NULL;
+    const int n = which == 0 ? 36 : which == 1 ? 29 : 53, log = which == 1 ? 5 : 6;
+    if (!def || fse_build(t, def, n - 1, log, NULL, NULL)) return 0;
+    for (int i = 0; i < (1 << log); i++) cells[i] = (uint32_t)t[i].sym | (((uint32_t)t[i].nb | (((uint32_t)t[i].base & 0xFFFu) << 4)) << 8);
+    return 1 << log;
+}
+
 size_t s5o_zstd_restated_decompress(const uint8_t *in, size_t len, uint8_t *out, size_t cap) {
     const size_t ERR = (size_t)-1;
     if (len < 6 || in[0] != 0x28 || in[1] != 0xB5 || in[2] != 0x2F || in[3] != 0xFD) return ERR;

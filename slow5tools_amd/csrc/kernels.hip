@@ -1091,7 +1091,15 @@ __global__ __launch_bounds__(64) void k_inflate_fallback_np(s5gpu_decode_args_t 
         }
     }
 }
-__global__ __launch_bounds__(64) void k_zstd_inflate_np(s5gpu_decode_args_t a, NpParams np) {
+// zstd records, a pass in front of the decoders: the first Huffman tree description of every frame, one frame per lane (zstd_dev.h)
+__global__ __launch_bounds__(64) void k_zstd_weights(s5gpu_decode_args_t a, uint8_t *ws) {
+    __shared__ uint32_t L[64 * ZW_LANE_DW];
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= a.n_recs) return;
+    const s5gpu_rec_desc_t d = a.desc[r];
+    zstd_first_tree_lane(L + threadIdx.x * ZW_LANE_DW, a.in + d.in_off, d.in_len, ws + (uint64_t)r * ZW_REC);
+}
+__global__ __launch_bounds__(64) void k_zstd_inflate_np(s5gpu_decode_args_t a, NpParams np, const uint8_t *ws) {
     __shared__ __attribute__((aligned(16))) ZstdShared T;
     uint8_t *pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
     for (;;) {
@@ -1101,7 +1109,7 @@ __global__ __launch_bounds__(64) void k_zstd_inflate_np(s5gpu_decode_args_t a, N
         if (r >= a.n_recs) return;
         const s5gpu_rec_desc_t d = a.desc[r];
         uint32_t olen = 0;
-        int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
+        int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen, ws ? ws + (uint64_t)r * ZW_REC : nullptr);
         if (status == 0) {
             wave_sync();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1121,12 +1129,12 @@ static_assert(sizeof(ZstdShared::huf) + sizeof(ZstdShared::ll_e) >= SVB_WSTAGE &
 #endif
 static_assert(sizeof(ExzdWaveScratch) <= sizeof(ZstdShared), "the ex-zd wave scratch overlays the zstd decoder's LDS");
 template <int UNPACK>      // 0: decompress only; 1: + parse and svb-zd decode; 2: + parse and ex-zd decode
-__global__ __launch_bounds__(64, S5_ZI_W) void k_zstd_inflate(s5gpu_decode_args_t a, const uint32_t *ord) {
+__global__ __launch_bounds__(64, S5_ZI_W) void k_zstd_inflate(s5gpu_decode_args_t a, const uint32_t *ord, const uint8_t *ws) {
     __shared__ __attribute__((aligned(16))) ZstdShared T;
     const uint32_t r = order_at(ord, blockIdx.x);
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
-    int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+    int status = zstd_decode_wave(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, ws ? ws + (uint64_t)r * ZW_REC : nullptr);
     uint32_t mark = 0;
     if (UNPACK && status == 0) {
         wave_sync();
@@ -1586,19 +1594,34 @@ static int order_scratch(hipStream_t st, size_t need, uint32_t **out, std::uniqu
 // builds the list for this batch on `st`; *out = nullptr when the batch is too small for the order to matter.  `hold` keeps the device's pool
 // locked until the caller has enqueued the kernel that reads the list: two threads that share a stream (the default stream, say) must not
 // interleave "build my list" / "build yours" / "read mine".
-static int launch_order(const s5gpu_decode_args_t *a, hipStream_t st, const uint32_t **out, std::unique_lock<std::mutex> &hold) {
+// `extra_words` more words of the same scratch (16-byte aligned, behind the list) come back in *extra — the zstd decoders' weights pass; they are
+// handed out whether or not the batch is big enough for a list (want_order = false: no list at all)
+static int launch_order(const s5gpu_decode_args_t *a, hipStream_t st, const uint32_t **out, std::unique_lock<std::mutex> &hold,
+                        size_t extra_words = 0, uint32_t **extra = nullptr, bool want_order = true) {
     *out = nullptr;
-    if (!g_order_min || a->n_recs < g_order_min) return S5GPU_OK;
+    if (extra) *extra = nullptr;
+    const bool order = want_order && g_order_min && a->n_recs >= g_order_min;
+    if (!order && !(extra && extra_words)) return S5GPU_OK;
+    const size_t list_words = order ? (((size_t)ORD_LIST + a->n_recs + 3) & ~(size_t)3) : 0;
     uint32_t *p = nullptr;
-    { const int rc = order_scratch(st, (size_t)ORD_LIST + a->n_recs, &p, hold); if (rc) return rc; }
+    { const int rc = order_scratch(st, list_words + (extra ? extra_words : 0), &p, hold); if (rc) return rc; }
     if (!p) return S5GPU_OK;
-    const uint32_t nb = (a->n_recs + NT - 1) / NT;
-    hipLaunchKernelGGL(k_order_zero, dim3(1), dim3(NT), 0, st, p);
-    hipLaunchKernelGGL(k_order_count, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
-    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(128), 0, st, p);
-    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
-    *out = p;
+    if (order) {
+        const uint32_t nb = (a->n_recs + NT - 1) / NT;
+        hipLaunchKernelGGL(k_order_zero, dim3(1), dim3(NT), 0, st, p);
+        hipLaunchKernelGGL(k_order_count, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
+        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(128), 0, st, p);
+        hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(NT), 0, st, a->desc, a->n_recs, p);
+        *out = p;
+    }
+    if (extra && extra_words) *extra = p + list_words;
     return S5GPU_OK;
+}
+// zstd batches of at least this many frames get the weights pass (k_zstd_weights: the first tree description of every frame, a frame per lane)
+// in front of the decoder; smaller ones (a `get` of a few reads) are not worth the extra launch.  Option "zstd_pre_min"; 0 = never.
+static uint32_t g_zstd_pre_min = 256;
+static size_t zstd_pre_words(const s5gpu_decode_args_t *a) {
+    return g_zstd_pre_min && a->n_recs >= g_zstd_pre_min ? (size_t)a->n_recs * (ZW_REC / 4) : 0;
 }
 // ... the encode side's: the overflow list of a mixed batch (how many reads are on it is only known on the device: the grids cover n_reads)
 static int launch_eorder(const s5gpu_encode_args_t *a, hipStream_t st, const uint32_t **out, std::unique_lock<std::mutex> &hold) {
@@ -1847,6 +1870,7 @@ extern "C" int s5gpu_set_option(const char *key, long value) {
     if (key && strcmp(key, "zstd_sequences") == 0 && (value == 0 || value == 1)) { g_zstd_sequences = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "unpack_fused") == 0 && (value == 0 || value == 1)) { g_unpack_fused = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_par") == 0 && value >= 0 && value <= 2) { g_inflate_par = (uint32_t)value; return S5GPU_OK; }   // 2 (tools): no fallback pass, declined records keep status 8
+    if (key && strcmp(key, "zstd_pre_min") == 0 && value >= 0) { g_zstd_pre_min = (uint32_t)value; return S5GPU_OK; }   // zstd batches: weights pass from this many frames on (0: never)
     if (key && strcmp(key, "order_min") == 0 && value >= 0) { g_order_min = (uint32_t)value; return S5GPU_OK; }   // big zlib batches: longest records first from this many records on (0: never)
     if (s5host_set_option(key, value) == S5GPU_OK) return S5GPU_OK;
     s5gpu_set_error("s5gpu_set_option: unknown option");
@@ -1906,10 +1930,13 @@ static int launch_inflate(const s5gpu_decode_args_t *a, hipStream_t st, int unpa
     std::unique_lock<std::mutex> hold;            // (launch_order's: released when the kernels that read the list are enqueued)
     if (a->rec_method == S5GPU_REC_ZSTD) {
         const uint32_t *ord = nullptr;
-        { const int rc = launch_order(a, st, &ord, hold); if (rc) return rc; }
-        if (unpack == 2) hipLaunchKernelGGL(k_zstd_inflate<2>, dim3(a->n_recs), dim3(64), 0, st, *a, ord);
-        else if (unpack == 1) hipLaunchKernelGGL(k_zstd_inflate<1>, dim3(a->n_recs), dim3(64), 0, st, *a, ord);
-        else hipLaunchKernelGGL(k_zstd_inflate<0>, dim3(a->n_recs), dim3(64), 0, st, *a, ord);
+        uint32_t *ws32 = nullptr;
+        { const int rc = launch_order(a, st, &ord, hold, zstd_pre_words(a), &ws32); if (rc) return rc; }
+        uint8_t *ws = reinterpret_cast<uint8_t *>(ws32);
+        if (ws) hipLaunchKernelGGL(k_zstd_weights, dim3((a->n_recs + 63) / 64), dim3(64), 0, st, *a, ws);
+        if (unpack == 2) hipLaunchKernelGGL(k_zstd_inflate<2>, dim3(a->n_recs), dim3(64), 0, st, *a, ord, ws);
+        else if (unpack == 1) hipLaunchKernelGGL(k_zstd_inflate<1>, dim3(a->n_recs), dim3(64), 0, st, *a, ord, ws);
+        else hipLaunchKernelGGL(k_zstd_inflate<0>, dim3(a->n_recs), dim3(64), 0, st, *a, ord, ws);
     } else if (a->rec_method == S5GPU_REC_ZLIB && g_inflate_par) {
         // the waiting list's size follows what was compressed and how long the records are (inflate_par_dev.h): short svb-zd / ex-zd
         // records take the 256-entry list; long ones (several hundred waiting matches per window in their key bytes: 14.7 ms per 8192
@@ -2102,7 +2129,12 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
             else { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<false, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<false, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
             hipLaunchKernelGGL(k_inflate_fallback_np, dim3((uint32_t)n_fb), dim3(64), 0, st, *a, np);
         } else {
-            hipLaunchKernelGGL(k_zstd_inflate_np, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
+            uint32_t *ws32 = nullptr;
+            const uint32_t *none = nullptr;
+            { const int rc = launch_order(a, st, &none, hold, zstd_pre_words(a), &ws32, false); if (rc) return rc; }
+            uint8_t *ws = reinterpret_cast<uint8_t *>(ws32);
+            if (ws) hipLaunchKernelGGL(k_zstd_weights, dim3((a->n_recs + 63) / 64), dim3(64), 0, st, *a, ws);
+            hipLaunchKernelGGL(k_zstd_inflate_np, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np, ws);
         }
         HIP_TRY(hipGetLastError());
         return S5GPU_OK;

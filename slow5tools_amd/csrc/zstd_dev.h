@@ -23,6 +23,7 @@
 
 #include "dev_common.h"
 #include "inflate_dev.h"   // INF_* status codes
+#include "zstd_seq_tables.h"   // decode cells of the predefined sequence distributions
 
 namespace s5 {
 
@@ -41,6 +42,11 @@ struct ZstdShared {                  // per wave
     uint8_t slot[512];               // FSE build: symbol of every spread slot
     uint32_t x[8];                   // lane 0 -> wave mailbox
 };
+
+// the weights scratch of k_zstd_weights (zstd_first_tree_lane below): one record per frame
+constexpr uint32_t ZW_NIB = 128;                 // bytes of nibbles in a record of the weights scratch ...
+constexpr uint32_t ZW_REC = 144;                 // ... then u32 offset of the description in the frame (0: none), u32 weights sent; 16-byte stride
+constexpr int ZW_LANE_DW = 45;                   // LDS dwords per lane (odd: the lanes' tables start in different banks)
 
 struct ZFse { uint16_t *e; uint8_t *s; };                       // one FSE decode table
 __device__ __forceinline__ uint32_t zfse_get(const ZFse &t, uint32_t i) {   // symbol | bits << 8 | baseline << 16
@@ -190,11 +196,6 @@ __device__ __forceinline__ int z_fse_build_wave(ZstdShared &T, const ZFse &t, in
     return 0;
 }
 
-__device__ const int16_t Z_LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
-__device__ const int16_t Z_ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-                                         1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
-__device__ const int16_t Z_OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
-
 // extra bits | base << 8 of the literal-length / match-length codes (RFC 8878 3.1.1.3.2.1.1)
 __device__ __forceinline__ uint32_t z_ll_sym(uint32_t c) {
     if (c < 16) return c << 8;
@@ -215,13 +216,12 @@ __device__ __forceinline__ uint32_t z_ml_sym(uint32_t c) {
 }
 
 // one of the three sequence tables (all lanes; the count header is read by lane 0): bytes of description consumed, -1 on error
-__device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_t *p, uint32_t len, const ZFse &t, int *log, const int16_t *def,
-                                           int def_n, int def_log, int max_log, int max_sym) {
+__device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_t *p, uint32_t len, const ZFse &t, int *log, const uint32_t *def,
+                                           int def_log, int max_log, int max_sym) {
     const int lane = lane_id();
-    if (mode == 0) {
-        if (lane < def_n) T.norm[lane] = def[lane];
+    if (mode == 0) {                                               // predefined: the cells are constants (zstd_seq_tables.h), one per lane
+        if (lane < (1 << def_log)) { const uint32_t v = def[lane]; t.s[lane] = (uint8_t)v; t.e[lane] = (uint16_t)(v >> 8); }
         wave_sync();
-        if (z_fse_build_wave(T, t, def_n - 1, def_log)) return -1;
         *log = def_log;
         return 0;
     }
@@ -249,7 +249,8 @@ __device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_
 }
 
 // Huffman weights of a tree description: bytes consumed (0 on error); T.w[0..*nsym_out)
-__device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *p, uint32_t len, uint32_t *nsym_out) {   // all lanes
+// `pre` (or nullptr): what k_zstd_weights left for this frame — if it names the description at frame offset `at`, the weights are there
+__device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *p, uint32_t len, uint32_t *nsym_out, const uint8_t *pre, uint32_t at) {   // all lanes
     const int lane = lane_id();
     if (len < 1) return 0;
     const uint32_t hb = p[0];
@@ -264,6 +265,18 @@ __device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *
     // FSE-compressed: count header by lane 0, table by the wave, the two interleaved states walked by lane 0
     const uint32_t used = 1 + hb;
     if (used > len || hb < 1) return 0;
+    if (pre) {
+        const uint32_t *m = reinterpret_cast<const uint32_t *>(pre + ZW_NIB);
+        const uint32_t pn = m[1];
+        if (m[0] == at && pn) {                                   // four weights per lane, a nibble each
+            const uint32_t v = reinterpret_cast<const uint16_t *>(pre)[lane];
+#pragma unroll
+            for (int k = 0; k < 4; k++) T.w[4 * lane + k] = (uint8_t)((v >> (4 * k)) & 15u);
+            wave_sync();
+            *nsym_out = pn;
+            return used;
+        }
+    }
     if (lane == 0) {
         int maxsym = 0, log = 0;
         const uint32_t h = z_ncount(p + 1, hb, T.norm, &maxsym, &log, 6, 12);
@@ -317,6 +330,93 @@ __device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *
     if (!T.x[4]) return 0;
     *nsym_out = T.x[4];
     return used;
+}
+
+// ---- the first Huffman tree description of a frame, one frame per LANE (k_zstd_weights, a pass in front of the decoder) ----
+// An FSE-compressed tree description is a serial chain of up to 255 dependent table steps (plus the count header and the table behind it):
+// walked inside the frame's wave it keeps 63 lanes waiting for ~a quarter of the frame's time (9 + 2 of 43 ms per 1 M frames, round 2's
+// cut-offs).  The chain is tiny — <= 127 bytes in, <= 255 nibbles out, a 64-cell table — so 64 frames' chains fit one wave: each lane
+// parses its frame's header, first block header and literals header (the same checks as zstd_decode_wave), reads the count header, builds
+// the table serially (oracle/zstd_dec.c fse_build) in its own 45 dwords of LDS, walks the two states and leaves the weights, a nibble
+// each, with the description's offset in the frame.  Anything irregular leaves "none": the frame's wave then does it all itself and is
+// the one that reports the error.  Only the FIRST tree of a frame is served (a record of up to 16 KiB as this library writes it, of up
+// to 128 KiB as libzstd does, has one).
+__device__ __forceinline__ void zstd_first_tree_lane(uint32_t *lds, const uint8_t *in, uint32_t len, uint8_t *rec) {
+    uint16_t *cell = reinterpret_cast<uint16_t *>(lds);                       // 64 cells: symbol | bits << 4 | baseline << 8
+    int16_t *norm = reinterpret_cast<int16_t *>(lds + 32);                    // 13 counts
+    uint8_t *next = reinterpret_cast<uint8_t *>(lds + 39);                    // 13 next-state counters
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(rec);
+    uint32_t at = 0, nsym = 0;
+    do {
+        if (len < 6 || in[0] != 0x28 || in[1] != 0xB5 || in[2] != 0x2F || in[3] != 0xFD) break;
+        const uint32_t fhd = in[4];
+        if ((fhd & 8) || (fhd & 3)) break;
+        const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1;
+        uint32_t p = 5 + (single ? 0u : 1u) + (fcs_flag == 0 ? single : fcs_flag == 1 ? 2u : fcs_flag == 2 ? 4u : 8u);
+        if (p + 3 > len) break;
+        const uint32_t bh = in[p] | (in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16);
+        p += 3;
+        const uint32_t bsize = bh >> 3;
+        if (((bh >> 1) & 3) != 2 || bsize < 5 || bsize > 128 * 1024 || p + bsize > len) break;
+        const uint8_t *b = in + p;
+        if ((b[0] & 3) != 2) break;                                              // literals with a tree of their own
+        const uint32_t sf = (b[0] >> 2) & 3;
+        const uint64_t v = (uint64_t)b[0] | ((uint64_t)b[1] << 8) | ((uint64_t)b[2] << 16) | ((uint64_t)b[3] << 24) | ((uint64_t)b[4] << 32);
+        const uint32_t q = sf < 2 ? 3u : sf == 2 ? 4u : 5u;
+        const uint32_t csize = sf < 2 ? (uint32_t)(v >> 14) & 0x3FF : sf == 2 ? (uint32_t)(v >> 18) & 0x3FFF : (uint32_t)(v >> 22) & 0x3FFFF;
+        if (q + csize > bsize || csize < 1) break;
+        const uint8_t *t = b + q;
+        const uint32_t hb = t[0];
+        if (hb >= 128 || hb < 1 || 1 + hb > csize) break;                       // (nibble descriptions cost the frame's wave nothing)
+        int maxsym = 0, log = 0;
+        const uint32_t h = z_ncount(t + 1, hb, norm, &maxsym, &log, 6, 12);
+        if (!h || h >= hb) break;
+        const int size = 1 << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+        int high = size - 1;
+        for (int sy = 0; sy <= maxsym; sy++) {
+            const int n = norm[sy];
+            if (n == -1) { cell[high--] = (uint16_t)sy; next[sy] = 1; } else next[sy] = (uint8_t)n;
+        }
+        int pos = 0;
+        for (int sy = 0; sy <= maxsym; sy++)
+            for (int i = 0; i < (int)norm[sy]; i++) {
+                cell[pos] = (uint16_t)sy;
+                do { pos = (pos + step) & mask; } while (pos > high);
+            }
+        if (pos != 0) break;
+        for (int i = 0; i < size; i++) {
+            const uint32_t sy = cell[i];
+            const uint32_t ns = next[sy]++;
+            const uint32_t nb = (uint32_t)(log - z_highbit(ns));
+            cell[i] = (uint16_t)(sy | (nb << 4) | ((((ns << nb) - (uint32_t)size) & 63u) << 8));
+        }
+        ZBits br;
+        if (!br.init(t + 1 + h, hb - h)) break;
+        if (br.left() < 2u * (uint32_t)log) break;
+        br.need(12);
+        uint32_t s1 = br.get((uint32_t)log), s2 = br.get((uint32_t)log);
+        uint32_t acc = 0, n = 0;
+        bool ok = true;
+#define ZW_EMIT(sym_) { acc |= ((sym_) & 15u) << (4u * (n & 7u)); if ((n & 7u) == 7u) { out32[n >> 3] = acc; acc = 0; } n++; }
+        for (;;) {
+            if (n >= 254) { ok = false; break; }
+            const uint32_t e1 = cell[s1], e2 = cell[s2];
+            const uint32_t n1 = (e1 >> 4) & 15u, n2 = (e2 >> 4) & 15u;
+            ZW_EMIT(e1); ZW_EMIT(e2);
+            br.need(12);
+            if (br.left() < n1) break;
+            s1 = (e1 >> 8) + br.get(n1);
+            if (br.left() < n2) { const uint32_t e = cell[s1]; ZW_EMIT(e); break; }
+            s2 = (e2 >> 8) + br.get(n2);
+        }
+#undef ZW_EMIT
+        if (!ok || n > 255) break;
+        if (n & 7u) out32[n >> 3] = acc;
+        at = (uint32_t)(t - in);
+        nsym = n;
+    } while (false);
+    out32[ZW_NIB / 4] = nsym ? at : 0u;
+    out32[ZW_NIB / 4 + 1] = nsym;
 }
 
 // From the weights T.w[0..nsym) to the table layout, all 64 lanes: the implied last weight, the code length limit, and
@@ -439,6 +539,47 @@ struct ZPre {
     }
     __device__ __forceinline__ uint32_t peek(uint32_t n) const { return used < 64 ? (uint32_t)(((c << used) >> 1) >> (63 - n)) : 0u; }
 };
+// one lane's range of its stream, from the reader position `st` (bits in front of it) down to seg_lo: symbols that START above seg_lo are
+// the lane's; cross = where the last one ends.  The unread bits ride on top of one 64-bit word: a symbol is one 32-bit shift for the table
+// index and one 64-bit shift to drop its code; four symbols (<= 44 bits) per refill, and every lane refills at the same place — a lane
+// that refilled when it ran dry would make the wave wait for a global load in nearly every step.  WRITE: the symbols go to q, four at a
+// time as one (unaligned) dword while the lane has four.
+#ifndef S5_ZH_TAIL
+#define S5_ZH_TAIL 128           // bits of a range the first pass decodes to find where the next range really starts
+#endif
+template <bool WRITE>
+__device__ __forceinline__ void z_huf_range(const uint16_t *huf, uint32_t L, const uint8_t *p, int st, int seg_lo, int &cross, uint32_t &cnt, uint8_t *q) {
+    ZPre b;
+    b.at(p, st);
+    int hi = st;
+    const uint32_t sh = 32u - L;
+    cnt = 0;
+    while (__ballot(hi > seg_lo)) {
+        b.refill();
+        uint64_t w = b.used < 64 ? b.c << b.used : 0ull;               // (bits before the start of the stream read as zero)
+        uint32_t took = 0, v = 0, nv = 0;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            const uint32_t e = huf[(uint32_t)(w >> 32) >> sh];
+            const uint32_t nb = max(e >> 8, 1u);                         // (a complete table has no empty cell; never stall on one)
+            if (hi > seg_lo) {
+                took += nb;
+                hi -= (int)nb;
+                if (WRITE) v |= (e & 255u) << (8 * q4);
+                nv++;
+            }
+            w <<= nb;
+        }
+        b.used += took;
+        cnt += nv;
+        if (WRITE) {
+            if (nv == 4) *(z_u32u *)q = v;
+            else for (uint32_t k = 0; k < nv; k++) q[k] = (uint8_t)(v >> (8 * k));
+            q += nv;
+        }
+    }
+    cross = hi;
+}
 __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t L, const uint8_t *p, uint32_t sl, uint8_t *dst, uint32_t ns, int G) {
     const int lane = lane_id(), j = lane & (G - 1), g0 = lane & ~(G - 1);
     const uint32_t last = sl ? p[sl - 1] : 0u;
@@ -446,29 +587,15 @@ __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t 
     const int Bs = 8 * (int)(sl - 1) + z_highbit(last);                                  // bits below the end mark
     const int B = max((Bs + G - 1) / G, 1);
     const int seg_hi = Bs - j * B, seg_lo = max(seg_hi - B, 0);                          // my symbols start at hi in (seg_lo, seg_hi]
-    int st = seg_hi, cross = seg_hi;
+    int st, cross = seg_hi;
     uint32_t cnt = 0;
+    // first only the tail of every range, from wherever: after a few codes the decoder is in step, and where it leaves the range is
+    // (nearly always) where the next lane really starts — a full pass from guessed starts would be decoded for that alone
+    z_huf_range<false>(huf, L, p, min(seg_hi, seg_lo + S5_ZH_TAIL), seg_lo, cross, cnt, nullptr);
+    st = __shfl(cross, max(lane - 1, 0));
+    if (j == 0) st = Bs;
     for (int pass = 0; pass <= G; pass++) {
-        ZPre b;
-        b.at(p, st);
-        int hi = st;
-        cnt = 0;
-        while (__ballot(hi > seg_lo)) {
-            // four symbols (<= 44 bits) per refill, and every lane refills HERE: a lane that refilled when it ran dry would make
-            // the wave wait for a global load in nearly every step (64 lanes, each dry every fifth step)
-            b.refill();
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                if (hi > seg_lo) {
-                    const uint32_t e = huf[b.peek(L)];
-                    const uint32_t nb = max(e >> 8, 1u);                                 // (a complete table has no empty cell; never stall on one)
-                    b.used += nb;
-                    hi -= (int)nb;
-                    cnt++;
-                }
-            }
-        }
-        cross = hi;
+        z_huf_range<false>(huf, L, p, st, seg_lo, cross, cnt, nullptr);
         int nst = __shfl(cross, max(lane - 1, 0));
         if (j == 0) nst = Bs;
         const bool moved = nst != st;
@@ -482,25 +609,9 @@ __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t 
     const uint32_t total = (uint32_t)__shfl((int)incl, g0 + G - 1) - before;
     const int fin = __shfl(cross, g0 + G - 1);
     if (__ballot(total != ns || fin != 0)) return false;
-    {   // ---- output ----
-        uint8_t *q = dst + (incl - cnt - before);
-        ZPre b;
-        b.at(p, st);
-        int hi = st;
-        while (__ballot(hi > seg_lo)) {
-            b.refill();
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                if (hi > seg_lo) {
-                    const uint32_t e = huf[b.peek(L)];
-                    const uint32_t nb = max(e >> 8, 1u);
-                    b.used += nb;
-                    hi -= (int)nb;
-                    *q++ = (uint8_t)e;
-                }
-            }
-        }
-    }
+    uint32_t cnt2;
+    int cross2;
+    z_huf_range<true>(huf, L, p, st, seg_lo, cross2, cnt2, dst + (incl - cnt - before));
     return true;
 }
 
@@ -522,7 +633,8 @@ __device__ __forceinline__ void z_wave_move_down(uint8_t *d, const uint8_t *s, u
 }
 
 // One frame -> out (olen bytes).  INF_OK, or INF_ERR_HEADER / DATA / TRUNC / OVERFLOW (olen = bytes needed when the frame says).
-__device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out) {
+// `pre`: this frame's record of the weights scratch (k_zstd_weights ran over the batch), or nullptr
+__device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out, const uint8_t *pre = nullptr) {
     const int lane = lane_id();
     *olen_out = 0;
     if (len < 6) return INF_ERR_TRUNC;
@@ -584,6 +696,9 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             else { lsize = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; q = 5; streams = 4; }
         }
         if (lsize > 128 * 1024) { status = INF_ERR_DATA; break; }
+#if defined(S5_ZCUT) && S5_ZCUT == 1   // variant builds (tools/zstd_cuts.sh): where a frame's time goes, by leaving early
+        break;
+#endif
         const uint8_t *lit = nullptr;                             // where literal li lives (raw: in the input; Huffman: parked in `out`)
         uint32_t lit_fill = 0;
         bool lit_parked = false;
@@ -597,7 +712,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             q = cend;
             if (ltype == 2) {
                 uint32_t nw = 0;
-                const uint32_t u = z_huf_weights(T, b + c, cend - c, &nw);
+                const uint32_t u = z_huf_weights(T, b + c, cend - c, &nw, pre, (uint32_t)(b + c - in));
                 if (!u) { status = INF_ERR_DATA; break; }
                 const uint32_t nsym = z_huf_ranks(T, nw, &huf_log);
                 if (!nsym) { huf_log = 0; status = INF_ERR_DATA; break; }
@@ -622,6 +737,9 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 }
                 wave_sync();
             } else if (!huf_log) { status = INF_ERR_DATA; break; }
+#if defined(S5_ZCUT) && S5_ZCUT == 2
+            break;
+#endif
             uint8_t *park = out + (E - lsize);
             bool ok = true;
             if (streams == 1) {
@@ -648,6 +766,9 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             lit = park;
             lit_parked = true;
         }
+#if defined(S5_ZCUT) && S5_ZCUT == 3
+        break;
+#endif
         // ---- sequences section ----
         if (q >= bend) { status = INF_ERR_DATA; break; }
         uint32_t nseq = b[q++];
@@ -663,14 +784,17 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             {
                 int u, bad = 0;
                 uint32_t qq = q;
-                if ((u = z_seq_table(T, (int)(modes >> 6), b + qq, bend - qq, tll, &ll_log, Z_LL_DEF, 36, 6, 9, 35)) < 0) bad = 1; else qq += (uint32_t)u;
-                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 4) & 3), b + qq, bend - qq, tof, &of_log, Z_OF_DEF, 29, 5, 8, 31)) < 0) bad = 1; else qq += (uint32_t)u; }
-                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 2) & 3), b + qq, bend - qq, tml, &ml_log, Z_ML_DEF, 53, 6, 9, 52)) < 0) bad = 1; else qq += (uint32_t)u; }
+                if ((u = z_seq_table(T, (int)(modes >> 6), b + qq, bend - qq, tll, &ll_log, ZSEQ_LL_DEC, 6, 9, 35)) < 0) bad = 1; else qq += (uint32_t)u;
+                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 4) & 3), b + qq, bend - qq, tof, &of_log, ZSEQ_OF_DEC, 5, 8, 31)) < 0) bad = 1; else qq += (uint32_t)u; }
+                if (!bad) { if ((u = z_seq_table(T, (int)((modes >> 2) & 3), b + qq, bend - qq, tml, &ml_log, ZSEQ_ML_DEC, 6, 9, 52)) < 0) bad = 1; else qq += (uint32_t)u; }
                 if (lane == 0) { T.x[0] = (uint32_t)bad; T.x[1] = qq; }
             }
             wave_sync();
             if (T.x[0]) { status = INF_ERR_DATA; break; }
             q = T.x[1];
+#if defined(S5_ZCUT) && S5_ZCUT == 4
+            break;
+#endif
             ZBits br;
             br.base = b; br.ptr = 0; br.used = 64; br.c = 0;
             uint32_t sl = 0, so = 0, sm = 0;
@@ -721,6 +845,9 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 // room: the output may not run into the parked literals still unread, nor past the end of the slot
                 const uint32_t lim = lit_parked ? E - lsize + li + llen : E;
                 if ((uint64_t)o + llen + mlen > lim) { status = fcs_bytes ? INF_ERR_DATA : INF_ERR_OVERFLOW; break; }
+#if defined(S5_ZCUT) && S5_ZCUT == 5   // the chains without the copies
+                o += llen + mlen; li += llen;
+#else
                 if (lit) { if (llen > 64) z_wave_move_down(out + o, lit + li, llen); else if ((uint32_t)lane < llen) out[o + lane] = lit[li + lane]; }
                 else { for (uint32_t k = lane; k < llen; k += 64) out[o + k] = (uint8_t)lit_fill; }
                 o += llen; li += llen;
@@ -730,6 +857,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 else { for (uint32_t k = lane; k < mlen; k += 64) out[o + k] = src[k % offset]; }
                 o += mlen;
                 wave_sync();
+#endif
             }
             if (status != INF_OK) break;
             if (__shfl((int)(br.done() && !br.overrun()), 0) == 0) { status = INF_ERR_DATA; break; }

@@ -447,6 +447,17 @@ def test_zstd_sequence_tables_of_the_device_are_the_predefined_ones():
         n = L.s5o_zstd_seq_ctable(which, nx, dnb, dfs)
         a, b, c = g.ctable(norm)
         assert n == len(norm) and list(nx) == a and list(dnb)[:n] == b and list(dfs)[:n] == c
+    # ... and the decode cells the device decoder copies for a block in predefined mode: the oracle's fse_build over the same distributions,
+    # and the first rows of RFC 8878 appendix A (state: symbol, bits, baseline)
+    for which, norm, log in ((0, g.LL, 6), (1, g.OF, 5), (2, g.ML, 6)):
+        cells = (C.c_uint32 * 64)()
+        assert L.s5o_zstd_seq_dtable(which, cells) == 1 << log
+        assert list(cells)[: 1 << log] == g.dtable(norm, log)
+    def rows(v):
+        return [(x & 255, (x >> 8) & 15, x >> 12) for x in v]
+    assert rows(g.dtable(g.LL, 6))[:6] == [(0, 4, 0), (0, 4, 16), (1, 5, 32), (3, 5, 0), (4, 5, 0), (6, 5, 0)]
+    assert rows(g.dtable(g.OF, 5))[:6] == [(0, 5, 0), (6, 4, 0), (9, 5, 0), (15, 5, 0), (21, 5, 0), (3, 5, 0)]
+    assert rows(g.dtable(g.ML, 6))[:6] == [(0, 6, 0), (1, 4, 0), (2, 5, 32), (3, 5, 0), (5, 5, 0), (6, 5, 0)]
 
 
 @needs_zstd

@@ -20,6 +20,17 @@ def press():
     return p
 
 
+@pytest.fixture(autouse=True, params=["weights-pass", "in-wave"])
+def first_tree(request, press):
+    """every test of this file twice: with the pass that decodes the first tree description of every frame a frame per lane
+    (k_zstd_weights, by default from 256 frames on) forced on for any batch, and without it (the frame's wave walks the chain itself)"""
+    from slow5tools_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.s5gpu_set_option(b"zstd_pre_min", 1 if request.param == "weights-pass" else 0))
+    yield request.param
+    _lib.check(L.s5gpu_set_option(b"zstd_pre_min", 256))
+
+
 def zstd_solo(frames):
     """s5gpu_solo_batch(stage 4): whole frames in, payloads (or None) and per-frame status out"""
     from slow5tools_amd import _lib

@@ -50,7 +50,7 @@ a.sig_method = 99
 fields.zero_(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); torch.cuda.synchronize()
 f = fields.cpu().numpy().view(_lib.REC_FIELDS)
 print("  sync passes per record: mean %.1f max %d; rounds mean %.2f; decline reasons %s" % (f["n_samples"].mean(), f["n_samples"].max(), f["read_id_len"].mean(), dict(collections.Counter(f["read_group"].tolist()))))
-for cut, what in ((91, "block header + tables"), (92, "+ window, sync passes"), (93, "+ output pass, runs, waiting matches"), (1, "+ Adler-32 (whole kernel)")):
+for cut, what in ((91, "block header + tables"), (92, "+ window, sync passes"), (93, "+ output pass, runs, waiting matches"), (1, "+ Adler-32 (whole kernel)"), (94, "whole kernel without the waiting matches")):
     a.sig_method = cut
     tt = []
     for _ in range(3):
