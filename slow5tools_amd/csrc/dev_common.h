@@ -18,6 +18,30 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// n bytes from s to d, the two ranges disjoint, any alignment (one lane; global memory takes unaligned dwords).  The waiting matches it
+// serves are mostly 3-8 bytes: both ends of the piece are loaded before anything is stored and the two halves overlap in the middle —
+// one round trip to memory whatever the length, at most one of four short paths per lane (8.92 -> 8.62 ms per 262 144 stock-zlib records
+// against the 16 / 8 / 4 / byte-loop ladder, profiles/r04_wait_matches.txt)
+__device__ __forceinline__ void copy_ends(uint8_t *d, const uint8_t *s, int n) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(1)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
+    typedef uint32_t u1 __attribute__((aligned(1)));
+    if (n >= 16) {
+        const u4 e = *reinterpret_cast<const u4 *>(s + n - 16);
+        for (int k = 0; k + 16 < n; k += 16) *reinterpret_cast<u4 *>(d + k) = *reinterpret_cast<const u4 *>(s + k);
+        *reinterpret_cast<u4 *>(d + n - 16) = e;
+    } else if (n >= 8) {
+        const u2 a = *reinterpret_cast<const u2 *>(s), e = *reinterpret_cast<const u2 *>(s + n - 8);
+        *reinterpret_cast<u2 *>(d) = a; *reinterpret_cast<u2 *>(d + n - 8) = e;
+    } else if (n >= 4) {
+        const u1 a = *reinterpret_cast<const u1 *>(s), e = *reinterpret_cast<const u1 *>(s + n - 4);
+        *reinterpret_cast<u1 *>(d) = a; *reinterpret_cast<u1 *>(d + n - 4) = e;
+    } else if (n > 0) {
+        const uint8_t a = s[0], b = s[n >> 1], e = s[n - 1];
+        d[0] = a; d[n >> 1] = b; d[n - 1] = e;
+    }
+}
+
 // ---- wave-level scans (64 lanes) ----
 // Prefix scans and reductions run on the DPP data path (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast:15 and
 // row_bcast:31 carry the row totals up): six VALU instructions, no LDS crossbar traffic and no address arithmetic, against

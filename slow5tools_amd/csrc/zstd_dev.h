@@ -34,12 +34,20 @@ struct ZstdShared {                  // per wave
     uint16_t ll_e[512], ml_e[512], of_e[256];
     uint8_t ll_s[512], ml_s[512], of_s[256];
     uint32_t llsym[36], mlsym[53];   // extra bits | base << 8
-    uint8_t w[256];                  // Huffman weights
-    uint16_t start[256];             // first table cell of each symbol / FSE spread cells (as bytes)
-    int16_t norm[64];
-    uint16_t wt_e[64];               // FSE table of the Huffman weights
-    uint8_t wt_s[64];
-    uint8_t slot[512];               // FSE build: symbol of every spread slot
+    union {
+        struct {                     // while tables are built ...
+            uint8_t w[256];          // Huffman weights
+            uint16_t start[256];     // first table cell of each symbol / FSE spread cells (as bytes)
+            int16_t norm[64];
+            uint16_t wt_e[64];       // FSE table of the Huffman weights
+            uint8_t wt_s[64];
+            uint8_t slot[512];       // FSE build: symbol of every spread slot
+        };
+        struct {                     // ... and while sequences are executed, 64 at a time: what lane 0's chain decoded, and where the literals go
+            uint32_t sq_ll[64], sq_ml[64], sq_of[64];   // literal run, match length, offset (repeat offsets resolved; 0: the bit stream was overrun)
+            uint32_t sq_cl[65], sq_sh[64];              // literals in front of sequence s (in the batch; [n] = all), match bytes in front of it
+        };
+    };
     uint32_t x[8];                   // lane 0 -> wave mailbox
 };
 
@@ -809,55 +817,168 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 }
             }
             if (__shfl((int)ok, 0) == 0) { status = INF_ERR_DATA; break; }
-            for (uint32_t s = 0; s < nseq; s++) {
-                uint32_t llen = 0, mlen = 0, offset = 0;
+            // Up to 64 sequences at a time.  Executed one by one, a sequence costs the wave two dependent trips to memory (its literals, then
+            // its match): ~50 sequences a frame were 16 of a frame's 29 ms.  So lane 0 walks the chain for the whole batch first (into LDS);
+            // then ALL the batch's literals move — one stream of bytes cut at the sequence boundaries, 16 bytes per lane and step, ascending
+            // (parked literals only ever move DOWN, and by less the later they come: every step loads before it stores and later steps read
+            // further up, as in z_wave_move_down); then every lane copies ITS match as soon as the matches that reach into its source are
+            // done (the rule of inflate_par_dev.h's waiting matches: destinations ascend, two binary searches over the lanes give the
+            // range), long ones by the whole wave.
+            for (uint32_t s0 = 0; s0 < nseq && status == INF_OK; s0 += 64) {
+                const uint32_t nb = min(nseq - s0, 64u);
                 if (lane == 0) {
-                    const uint32_t eo = zfse_get(tof, so), em = zfse_get(tml, sm), el = zfse_get(tll, sl);
-                    const uint32_t ofc = eo & 255, mls = T.mlsym[em & 255], lls = T.llsym[el & 255];
-                    br.need(ofc);
-                    const uint32_t ofv = (1u << ofc) + br.get(ofc);
-                    br.need(32);
-                    mlen = (mls >> 8) + br.get(mls & 255);
-                    llen = (lls >> 8) + br.get(lls & 255);
-                    if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
-                    else {
-                        const uint32_t idx = ofv - 1 + (llen == 0);
-                        if (idx == 0) offset = rep0;
+                    for (uint32_t s = 0; s < nb; s++) {
+                        uint32_t llen, mlen, offset;
+                        const uint32_t eo = zfse_get(tof, so), em = zfse_get(tml, sm), el = zfse_get(tll, sl);
+                        const uint32_t ofc = eo & 255, mls = T.mlsym[em & 255], lls = T.llsym[el & 255];
+                        br.need(ofc);
+                        const uint32_t ofv = (1u << ofc) + br.get(ofc);
+                        br.need(32);
+                        mlen = (mls >> 8) + br.get(mls & 255);
+                        llen = (lls >> 8) + br.get(lls & 255);
+                        if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
                         else {
-                            offset = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
-                            if (idx > 1) rep2 = rep1;
-                            rep1 = rep0;
-                            rep0 = offset;
+                            const uint32_t idx = ofv - 1 + (llen == 0);
+                            if (idx == 0) offset = rep0;
+                            else {
+                                offset = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
+                                if (idx > 1) rep2 = rep1;
+                                rep1 = rep0;
+                                rep0 = offset;
+                            }
+                        }
+                        if (s0 + s + 1 < nseq) {
+                            br.need(27);
+                            sl = (el >> 16) + br.get((el >> 8) & 255);
+                            sm = (em >> 16) + br.get((em >> 8) & 255);
+                            so = (eo >> 16) + br.get((eo >> 8) & 255);
+                        }
+                        if (br.overrun()) offset = 0;                  // reported as corrupt below
+                        T.sq_ll[s] = llen; T.sq_ml[s] = mlen; T.sq_of[s] = offset;
+                    }
+                }
+                wave_sync();
+                const bool have = (uint32_t)lane < nb;
+                const uint32_t ll = have ? T.sq_ll[lane] : 0u, ml = have ? T.sq_ml[lane] : 0u, of = have ? T.sq_of[lane] : 1u;
+                const uint32_t cl_in = wave_incl_add(ll), cm_in = wave_incl_add(ml);
+                const uint32_t cl = cl_in - ll, cm = cm_in - ml;
+                const uint32_t LB = (uint32_t)__builtin_amdgcn_readlane((int)cl_in, 63), MB = (uint32_t)__builtin_amdgcn_readlane((int)cm_in, 63);
+                const uint64_t dmat = (uint64_t)o + cl_in + cm;                // where my match goes (my literals end there)
+                {   // the checks of the one-by-one form, for the first sequence that fails one
+                    int bad = 0;
+                    if (have) {
+                        const uint64_t lim = lit_parked ? (uint64_t)E - lsize + li + cl_in : (uint64_t)E;   // not into parked literals still unread, nor past the slot
+                        if ((uint64_t)li + cl_in > lsize || of == 0 || (uint64_t)of > dmat) bad = INF_ERR_DATA;
+                        else if (dmat + ml > lim) bad = fcs_bytes ? INF_ERR_DATA : INF_ERR_OVERFLOW;
+                    }
+                    const uint64_t bm = __ballot(bad != 0);
+                    if (bm) { status = __builtin_amdgcn_readlane(bad, __ffsll((long long)bm) - 1); break; }
+                }
+                T.sq_cl[lane] = cl; T.sq_sh[lane] = cm;
+                if (lane == 0) T.sq_cl[64] = LB;
+                wave_sync();
+#if defined(S5_ZCUT) && S5_ZCUT == 5   // the chains and the bookkeeping without the copies
+                o += LB + MB; li += LB;
+                continue;
+#endif
+                // ---- the batch's literals ----
+                for (uint32_t k0 = 16u * (uint32_t)lane; k0 < LB; k0 += 1024u) {
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(1)));
+                    const uint32_t n = min(16u, LB - k0);
+                    uint64_t vlo = (uint64_t)lit_fill * 0x0101010101010101ull, vhi = vlo;
+                    u4 v = {(uint32_t)vlo, (uint32_t)vlo, (uint32_t)vlo, (uint32_t)vlo};
+                    if (lit) {
+                        if (n == 16) { v = *reinterpret_cast<const u4 *>(lit + li + k0); vlo = (uint64_t)v.x | ((uint64_t)v.y << 32); vhi = (uint64_t)v.z | ((uint64_t)v.w << 32); }
+                        else {
+                            vlo = 0; vhi = 0;
+#pragma unroll
+                            for (uint32_t j = 0; j < 15; j++) if (j < n) { const uint64_t x = lit[li + k0 + j]; if (j < 8) vlo |= x << (8 * j); else vhi |= x << (8 * (j - 8)); }
                         }
                     }
-                    if (s + 1 < nseq) {
-                        br.need(27);
-                        sl = (el >> 16) + br.get((el >> 8) & 255);
-                        sm = (em >> 16) + br.get((em >> 8) & 255);
-                        so = (eo >> 16) + br.get((eo >> 8) & 255);
+                    int lo = 0, hi = (int)nb - 1;                               // the last sequence whose literals start at or before k0
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (lo < hi) { if (T.sq_cl[mid] <= k0) lo = mid; else hi = mid - 1; }
                     }
-                    if (br.overrun()) offset = 0;                  // reported as corrupt below
+                    uint32_t sq = (uint32_t)lo;
+                    uint8_t *dstl = out + (uint64_t)o + k0;
+                    if (n == 16 && k0 + 16 <= T.sq_cl[sq + 1 < nb ? sq + 1 : 64]) {
+                        *reinterpret_cast<u4 *>(dstl + T.sq_sh[sq]) = v;
+                    } else {                                                    // a boundary inside (or the stream's last bytes): byte by byte
+                        uint32_t end = sq + 1 < nb ? T.sq_cl[sq + 1] : LB, sh = T.sq_sh[sq];
+                        for (uint32_t j = 0; j < n; j++) {
+                            while (k0 + j >= end && sq + 1 < nb) { sq++; end = sq + 1 < nb ? T.sq_cl[sq + 1] : LB; sh = T.sq_sh[sq]; }
+                            dstl[j + sh] = (uint8_t)((j < 8 ? vlo : vhi) >> (8 * (j & 7)));
+                        }
+                    }
                 }
-                llen = (uint32_t)__builtin_amdgcn_readfirstlane((int)llen);
-                mlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)mlen);
-                offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)offset);
-                if (li + llen > lsize || offset == 0 || (uint64_t)offset > (uint64_t)o + llen) { status = INF_ERR_DATA; break; }
-                // room: the output may not run into the parked literals still unread, nor past the end of the slot
-                const uint32_t lim = lit_parked ? E - lsize + li + llen : E;
-                if ((uint64_t)o + llen + mlen > lim) { status = fcs_bytes ? INF_ERR_DATA : INF_ERR_OVERFLOW; break; }
-#if defined(S5_ZCUT) && S5_ZCUT == 5   // the chains without the copies
-                o += llen + mlen; li += llen;
-#else
-                if (lit) { if (llen > 64) z_wave_move_down(out + o, lit + li, llen); else if ((uint32_t)lane < llen) out[o + lane] = lit[li + lane]; }
-                else { for (uint32_t k = lane; k < llen; k += 64) out[o + k] = (uint8_t)lit_fill; }
-                o += llen; li += llen;
                 wave_sync();
-                const uint8_t *src = out + (o - offset);
-                if (offset >= mlen) { for (uint32_t k = lane; k < mlen; k += 64) out[o + k] = src[k]; }
-                else { for (uint32_t k = lane; k < mlen; k += 64) out[o + k] = src[k % offset]; }
-                o += mlen;
+                // ---- the batch's matches ----
+                {
+                    // positions relative to the batch's first byte (< 2^25: 64 sequences of at most 128 KiB + 128 KiB); a source may start in front of it
+                    const int mop = (int)(cl_in + cm), mlen = (int)ml;
+                    const int64_t ss64 = (int64_t)mop - (int64_t)of;
+                    const int ss = (int)(ss64 < -1 ? -1 : ss64), se = min((int)(ss64 + mlen < 0 ? 0 : ss64 + mlen), mop);   // source bytes [ss, se) exist before this match starts writing
+                    int lo = 0, hi = lane;
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const int mid = (lo + hi) >> 1;
+                        const int v = __builtin_amdgcn_ds_bpermute(mid << 2, mop);
+                        if (lo < hi) { if (v < se) lo = mid + 1; else hi = mid; }
+                    }
+                    const int cand = lo - 1;                                   // the last match in front of me that starts before se
+                    int lo2 = 0, hi2 = lane;                                   // the first one that ends behind ss
+                    const int e_op = mop + mlen;
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const int mid = (lo2 + hi2) >> 1;
+                        const int v = __builtin_amdgcn_ds_bpermute(mid << 2, e_op);
+                        if (lo2 < hi2) { if (v <= ss) lo2 = mid + 1; else hi2 = mid; }
+                    }
+                    const uint64_t need = cand >= lo2 ? (2ull << cand) - (1ull << lo2) : 0ull;
+                    const bool big = mlen > 128;                               // copied by the whole wave
+                    uint8_t *const ob = out + (uint64_t)o;
+                    uint64_t donem = ~__ballot(have);
+                    while (~donem) {
+                        const bool ready = !((donem >> lane) & 1ull) && !(need & ~donem);
+                        if (ready && !big) {
+                            uint8_t *q = ob + mop;
+                            if (of == 1) {                                     // a run: dwords wherever they start, the last one overlapping
+                                typedef uint32_t u1 __attribute__((aligned(1)));
+                                const uint32_t x4 = (uint32_t)q[-1] * 0x01010101u;
+                                for (int k = 0; k + 4 < mlen; k += 4) *reinterpret_cast<u1 *>(q + k) = x4;
+                                *reinterpret_cast<u1 *>(q + mlen - 4) = x4;    // (mlen >= 3: at worst this rewrites q[-1], which holds x)
+                            } else {
+                                // the bytes in front of q are periodic with period `of`: every step copies as much as is known, then twice as much is
+                                int k = 0;
+                                int64_t d = (int64_t)of;
+                                while (k < mlen) {
+                                    const int n = (int)min((int64_t)(mlen - k), d);
+                                    copy_ends(q + k, q + k - d, n);
+                                    k += n;
+                                    d += d;
+                                }
+                            }
+                        }
+                        uint64_t bigm = __ballot(ready && big);
+                        while (bigm) {
+                            const int l = __ffsll((long long)bigm) - 1;
+                            bigm &= bigm - 1;
+                            const uint32_t bo = (uint32_t)__builtin_amdgcn_readlane(mop, l), bl = (uint32_t)__builtin_amdgcn_readlane(mlen, l);
+                            const uint32_t bf = (uint32_t)__builtin_amdgcn_readlane((int)of, l);
+                            uint8_t *bq = ob + bo;
+                            const uint8_t *src = bq - bf;
+                            if (bf >= bl) { for (uint32_t k = lane; k < bl; k += 64) bq[k] = src[k]; }
+                            else { for (uint32_t k = lane; k < bl; k += 64) bq[k] = src[k % bf]; }
+                        }
+                        wave_sync();
+                        donem |= __ballot(ready);
+                    }
+                }
+                o += LB + MB;
+                li += LB;
                 wave_sync();
-#endif
             }
             if (status != INF_OK) break;
             if (__shfl((int)(br.done() && !br.overrun()), 0) == 0) { status = INF_ERR_DATA; break; }
