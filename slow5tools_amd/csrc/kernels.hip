@@ -2218,3 +2218,12 @@ extern "C" int s5gpu_synth_hdr_dev(uint8_t *hdr, uint64_t n_reads, uint64_t firs
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }
+
+#ifdef S5_ZPROBE   // tools/zstd_phases.py only (variant build): the phase clocks of zstd_dev.h, read and cleared
+extern "C" int s5gpu_zprobe_read(unsigned long long *out16) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(s5::g_zprobe), sizeof z) != hipSuccess) return S5GPU_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(s5::g_zprobe), z, sizeof z) != hipSuccess) return S5GPU_ERR_HIP;
+    return S5GPU_OK;
+}
+#endif

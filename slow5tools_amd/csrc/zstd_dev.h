@@ -56,14 +56,25 @@ constexpr uint32_t ZW_NIB = 128;                 // bytes of nibbles in a record
 constexpr uint32_t ZW_REC = 144;                 // ... then u32 offset of the description in the frame (0: none), u32 weights sent; 16-byte stride
 constexpr int ZW_LANE_DW = 45;                   // LDS dwords per lane (odd: the lanes' tables start in different banks)
 
+// tools/zstd_phases.py (variant build -DS5_ZPROBE): clock ticks a frame's wave spends in each phase, summed over the batch
+#ifdef S5_ZPROBE
+__device__ unsigned long long g_zprobe[16];
+#define ZP_DECL unsigned long long zp_t = __builtin_readcyclecounter(), zp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define ZP(i) { const unsigned long long n_ = __builtin_readcyclecounter(); zp_acc[i] += n_ - zp_t; zp_t = n_; }
+#define ZP_FLUSH { if (lane_id() == 0) { for (int i_ = 0; i_ < 10; i_++) atomicAdd(&g_zprobe[i_], zp_acc[i_]); atomicAdd(&g_zprobe[15], 1ull); } }
+#else
+#define ZP_DECL
+#define ZP(i)
+#define ZP_FLUSH
+#endif
+typedef uint64_t __attribute__((aligned(1))) z_u64u;
+typedef uint32_t __attribute__((aligned(1))) z_u32u;
+
 struct ZFse { uint16_t *e; uint8_t *s; };                       // one FSE decode table
 __device__ __forceinline__ uint32_t zfse_get(const ZFse &t, uint32_t i) {   // symbol | bits << 8 | baseline << 16
     const uint32_t e = t.e[i];
     return (uint32_t)t.s[i] | ((e & 15u) << 8) | ((e >> 4) << 16);
 }
-
-typedef uint64_t __attribute__((aligned(1))) z_u64u;
-typedef uint32_t __attribute__((aligned(1))) z_u32u;
 
 __device__ __forceinline__ int z_highbit(uint32_t v) { return 31 - __clz((int)v); }   // v != 0
 
@@ -100,16 +111,38 @@ struct ZBits {
     __device__ __forceinline__ bool done() const { return ptr == 0 && used == 64; }
 };
 
-// forward bits of an FSE table description (lane 0)
+// forward bits of an FSE table description (one lane).  The description is either read where it lies (five byte loads per peek: the
+// lane-per-frame pass, whose 64 lanes wait together) or out of LDS words the wave staged (z_stage_desc: lane 0 parsing a sequence table
+// waited for memory ~100 times per table — 11 of a libzstd-written frame's 46 ms per 1 M were the three count headers)
 __device__ __forceinline__ uint32_t z_fpeek(const uint8_t *p, uint32_t len, uint32_t pos, int n) {
     uint64_t v = 0;
     const uint32_t b = pos >> 3;
     for (uint32_t i = 0; i < 5; i++) if (b + i < len) v |= (uint64_t)p[b + i] << (8 * i);
     return (uint32_t)(v >> (pos & 7)) & ((1u << n) - 1);
 }
+constexpr uint32_t Z_DESC_STAGE = 256;           // bytes of a description staged (a count header of 53 symbols at table log 9 is < 80)
+__device__ __forceinline__ uint32_t z_fpeek_lds(const uint32_t *w, uint32_t len, uint32_t pos, int n) {   // len <= Z_DESC_STAGE; bytes past len are zero
+    const uint32_t i = pos >> 5;
+    const uint64_t v = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);             // (the stage is followed by as many zero words)
+    return (uint32_t)(v >> (pos & 31)) & ((1u << n) - 1);
+}
+// the first min(len, Z_DESC_STAGE) bytes at p into LDS words, zero behind them (all lanes; a dword per lane where four bytes are there)
+__device__ __forceinline__ void z_stage_desc(uint32_t *w, const uint8_t *p, uint32_t len) {
+    const uint32_t lane = (uint32_t)lane_id(), n = min(len, Z_DESC_STAGE), at = 4u * lane;
+    uint32_t v = 0;
+    if (at + 4 <= n) v = *(const z_u32u *)(p + at);
+    else for (uint32_t k = 0; at + k < n; k++) v |= (uint32_t)p[at + k] << (8 * k);
+    w[lane] = v;
+    w[64 + lane] = 0;                            // (a malformed header may be read a few hundred bits past its end: zeros, as in memory form)
+    wave_sync();
+}
 
 // normalised counts of an FSE table; bytes consumed, 0 on error (oracle/zstd_dec.c fse_read_ncount)
-__device__ __noinline__ uint32_t z_ncount(const uint8_t *p, uint32_t len, int16_t *norm, int *maxsym, int *log, int max_log, int max_sym) {
+template <bool LDS>
+__device__ __noinline__ uint32_t z_ncount_t(const void *src, uint32_t len, int16_t *norm, int *maxsym, int *log, int max_log, int max_sym) {
+    const uint8_t *p = static_cast<const uint8_t *>(src);
+    const uint32_t *w = static_cast<const uint32_t *>(src);
+#define z_fpeek(p_, len_, pos_, n_) (LDS ? z_fpeek_lds(w, len_, pos_, n_) : z_fpeek(p_, len_, pos_, n_))
     uint32_t pos = 4;
     const int al = (int)z_fpeek(p, len, 0, 4) + 5;
     if (al > max_log) return 0;
@@ -148,6 +181,10 @@ __device__ __noinline__ uint32_t z_ncount(const uint8_t *p, uint32_t len, int16_
     *maxsym = sym - 1;
     const uint32_t used = (pos + 7) >> 3;
     return used <= len ? used : 0;
+#undef z_fpeek
+}
+__device__ __forceinline__ uint32_t z_ncount(const uint8_t *p, uint32_t len, int16_t *norm, int *maxsym, int *log, int max_log, int max_sym) {
+    return z_ncount_t<false>(p, len, norm, maxsym, log, max_log, max_sym);
 }
 
 // Decode table of an FSE distribution (oracle/zstd_dec.c fse_build is the serial statement of it).
@@ -223,6 +260,31 @@ __device__ __forceinline__ uint32_t z_ml_sym(uint32_t c) {
     return (c - 36) | (((1u << (c - 36)) + 3) << 8);              // 43: 7 bits, base 131 ... 52: 16 bits, base 65539
 }
 
+// an FSE-compressed sequence table (all lanes): count header by lane 0 out of staged LDS words, the table by the wave.  A function of its
+// own: frames whose tables are predefined never come here, and inlined three times it cost them registers in the loops that matter
+#ifdef S5_Z_SEQTAB_INLINE
+#define S5_Z_SEQTAB_ATTR __forceinline__
+#else
+#define S5_Z_SEQTAB_ATTR __noinline__
+#endif
+__device__ S5_Z_SEQTAB_ATTR int z_seq_table_fse(ZstdShared &T, const uint8_t *p, uint32_t len, uint16_t *te, uint8_t *ts, int *log, int max_log, int max_sym) {
+    const int lane = lane_id();
+    const ZFse t = {te, ts};
+    uint32_t *stage = reinterpret_cast<uint32_t *>(T.slot);        // (the spread slots' storage: the table is built after the header is read)
+    z_stage_desc(stage, p, len);
+    if (lane == 0) {
+        int maxsym = 0, l = 0;
+        const uint32_t h = z_ncount_t<true>(stage, min(len, Z_DESC_STAGE), T.norm, &maxsym, &l, max_log, max_sym);
+        T.x[4] = h; T.x[5] = (uint32_t)maxsym; T.x[6] = (uint32_t)l;
+    }
+    wave_sync();
+    const uint32_t h = T.x[4];
+    if (!h) return -1;
+    if (z_fse_build_wave(T, t, (int)T.x[5], (int)T.x[6])) return -1;
+    *log = (int)T.x[6];
+    return (int)h;
+}
+
 // one of the three sequence tables (all lanes; the count header is read by lane 0): bytes of description consumed, -1 on error
 __device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_t *p, uint32_t len, const ZFse &t, int *log, const uint32_t *def,
                                            int def_log, int max_log, int max_sym) {
@@ -240,51 +302,14 @@ __device__ __forceinline__ int z_seq_table(ZstdShared &T, int mode, const uint8_
         *log = 0;
         return 1;
     }
-    if (mode == 2) {
-        if (lane == 0) {
-            int maxsym = 0, l = 0;
-            const uint32_t h = z_ncount(p, len, T.norm, &maxsym, &l, max_log, max_sym);
-            T.x[4] = h; T.x[5] = (uint32_t)maxsym; T.x[6] = (uint32_t)l;
-        }
-        wave_sync();
-        const uint32_t h = T.x[4];
-        if (!h) return -1;
-        if (z_fse_build_wave(T, t, (int)T.x[5], (int)T.x[6])) return -1;
-        *log = (int)T.x[6];
-        return (int)h;
-    }
+    if (mode == 2) return z_seq_table_fse(T, p, len, t.e, t.s, log, max_log, max_sym);
     return *log < 0 ? -1 : 0;
 }
 
-// Huffman weights of a tree description: bytes consumed (0 on error); T.w[0..*nsym_out)
-// `pre` (or nullptr): what k_zstd_weights left for this frame — if it names the description at frame offset `at`, the weights are there
-__device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *p, uint32_t len, uint32_t *nsym_out, const uint8_t *pre, uint32_t at) {   // all lanes
+// the FSE-compressed form, walked inside the frame's wave (frames of small batches, and every tree of a frame but its first: the weights
+// pass does the rest); a function of its own, so that the frames that never come here do not carry its registers
+__device__ __noinline__ uint32_t z_huf_weights_fse(ZstdShared &T, const uint8_t *p, uint32_t hb, uint32_t *nsym_out) {
     const int lane = lane_id();
-    if (len < 1) return 0;
-    const uint32_t hb = p[0];
-    if (hb >= 128) {                                              // nibbles, two per byte
-        const uint32_t nsym = hb - 127, used = 1 + (nsym + 1) / 2;
-        if (used > len) return 0;
-        for (uint32_t i = lane; i < nsym; i += 64) T.w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
-        wave_sync();
-        *nsym_out = nsym;
-        return used;
-    }
-    // FSE-compressed: count header by lane 0, table by the wave, the two interleaved states walked by lane 0
-    const uint32_t used = 1 + hb;
-    if (used > len || hb < 1) return 0;
-    if (pre) {
-        const uint32_t *m = reinterpret_cast<const uint32_t *>(pre + ZW_NIB);
-        const uint32_t pn = m[1];
-        if (m[0] == at && pn) {                                   // four weights per lane, a nibble each
-            const uint32_t v = reinterpret_cast<const uint16_t *>(pre)[lane];
-#pragma unroll
-            for (int k = 0; k < 4; k++) T.w[4 * lane + k] = (uint8_t)((v >> (4 * k)) & 15u);
-            wave_sync();
-            *nsym_out = pn;
-            return used;
-        }
-    }
     if (lane == 0) {
         int maxsym = 0, log = 0;
         const uint32_t h = z_ncount(p + 1, hb, T.norm, &maxsym, &log, 6, 12);
@@ -337,7 +362,39 @@ __device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *
     wave_sync();
     if (!T.x[4]) return 0;
     *nsym_out = T.x[4];
-    return used;
+    return 1 + hb;
+}
+
+// Huffman weights of a tree description: bytes consumed (0 on error); T.w[0..*nsym_out)
+// `pre` (or nullptr): what k_zstd_weights left for this frame — if it names the description at frame offset `at`, the weights are there
+__device__ __forceinline__ uint32_t z_huf_weights(ZstdShared &T, const uint8_t *p, uint32_t len, uint32_t *nsym_out, const uint8_t *pre, uint32_t at) {   // all lanes
+    const int lane = lane_id();
+    if (len < 1) return 0;
+    const uint32_t hb = p[0];
+    if (hb >= 128) {                                              // nibbles, two per byte
+        const uint32_t nsym = hb - 127, used = 1 + (nsym + 1) / 2;
+        if (used > len) return 0;
+        for (uint32_t i = lane; i < nsym; i += 64) T.w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
+        wave_sync();
+        *nsym_out = nsym;
+        return used;
+    }
+    // FSE-compressed: count header by lane 0, table by the wave, the two interleaved states walked by lane 0
+    const uint32_t used = 1 + hb;
+    if (used > len || hb < 1) return 0;
+    if (pre) {
+        const uint32_t *m = reinterpret_cast<const uint32_t *>(pre + ZW_NIB);
+        const uint32_t pn = m[1];
+        if (m[0] == at && pn) {                                   // four weights per lane, a nibble each
+            const uint32_t v = reinterpret_cast<const uint16_t *>(pre)[lane];
+#pragma unroll
+            for (int k = 0; k < 4; k++) T.w[4 * lane + k] = (uint8_t)((v >> (4 * k)) & 15u);
+            wave_sync();
+            *nsym_out = pn;
+            return used;
+        }
+    }
+    return z_huf_weights_fse(T, p, hb, nsym_out);
 }
 
 // ---- the first Huffman tree description of a frame, one frame per LANE (k_zstd_weights, a pass in front of the decoder) ----
@@ -608,6 +665,9 @@ __device__ __forceinline__ bool z_huf_streams_par(const uint16_t *huf, uint32_t 
         if (j == 0) nst = Bs;
         const bool moved = nst != st;
         st = nst;
+#ifdef S5_ZPROBE
+        if (lane == 0) atomicAdd(&g_zprobe[10], 1ull);               // full passes of the literal streams
+#endif
         if (!__ballot(moved)) break;
     }
     // the group's symbols must be exactly ns and the last one must end at the stream's first bit
@@ -645,6 +705,7 @@ __device__ __forceinline__ void z_wave_move_down(uint8_t *d, const uint8_t *s, u
 __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out, const uint8_t *pre = nullptr) {
     const int lane = lane_id();
     *olen_out = 0;
+    ZP_DECL
     if (len < 6) return INF_ERR_TRUNC;
     if (in[0] != 0x28 || in[1] != 0xB5 || in[2] != 0x2F || in[3] != 0xFD) return INF_ERR_HEADER;
     uint32_t p = 5;
@@ -704,6 +765,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             else { lsize = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; q = 5; streams = 4; }
         }
         if (lsize > 128 * 1024) { status = INF_ERR_DATA; break; }
+        ZP(0)
 #if defined(S5_ZCUT) && S5_ZCUT == 1   // variant builds (tools/zstd_cuts.sh): where a frame's time goes, by leaving early
         break;
 #endif
@@ -745,6 +807,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 }
                 wave_sync();
             } else if (!huf_log) { status = INF_ERR_DATA; break; }
+            ZP(1)
 #if defined(S5_ZCUT) && S5_ZCUT == 2
             break;
 #endif
@@ -774,6 +837,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             lit = park;
             lit_parked = true;
         }
+        ZP(2)
 #if defined(S5_ZCUT) && S5_ZCUT == 3
         break;
 #endif
@@ -800,6 +864,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             wave_sync();
             if (T.x[0]) { status = INF_ERR_DATA; break; }
             q = T.x[1];
+            ZP(3)
 #if defined(S5_ZCUT) && S5_ZCUT == 4
             break;
 #endif
@@ -826,6 +891,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
             // range), long ones by the whole wave.
             for (uint32_t s0 = 0; s0 < nseq && status == INF_OK; s0 += 64) {
                 const uint32_t nb = min(nseq - s0, 64u);
+                ZP(4)
                 if (lane == 0) {
                     for (uint32_t s = 0; s < nb; s++) {
                         uint32_t llen, mlen, offset;
@@ -858,6 +924,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                     }
                 }
                 wave_sync();
+                ZP(5)
                 const bool have = (uint32_t)lane < nb;
                 const uint32_t ll = have ? T.sq_ll[lane] : 0u, ml = have ? T.sq_ml[lane] : 0u, of = have ? T.sq_of[lane] : 1u;
                 const uint32_t cl_in = wave_incl_add(ll), cm_in = wave_incl_add(ml);
@@ -881,6 +948,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 o += LB + MB; li += LB;
                 continue;
 #endif
+                ZP(6)
                 // ---- the batch's literals ----
                 for (uint32_t k0 = 16u * (uint32_t)lane; k0 < LB; k0 += 1024u) {
                     typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(1)));
@@ -914,6 +982,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                     }
                 }
                 wave_sync();
+                ZP(7)
                 // ---- the batch's matches ----
                 {
                     // positions relative to the batch's first byte (< 2^25: 64 sequences of at most 128 KiB + 128 KiB); a source may start in front of it
@@ -979,6 +1048,7 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                 o += LB + MB;
                 li += LB;
                 wave_sync();
+                ZP(8)
             }
             if (status != INF_OK) break;
             if (__shfl((int)(br.done() && !br.overrun()), 0) == 0) { status = INF_ERR_DATA; break; }
@@ -990,6 +1060,8 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
         o += restl;
         wave_sync();
     }
+    ZP(9)
+    ZP_FLUSH
     if (status != INF_OK) return status;
     if (checksum) { if (p + 4 > len) return INF_ERR_TRUNC; p += 4; }
     if (p != len) return INF_ERR_DATA;
