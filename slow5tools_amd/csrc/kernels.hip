@@ -49,8 +49,13 @@ struct EncParams {
     uint32_t pay_cap;      // LDS bytes of the payload buffer (fused) / staging buffer (staged)
     uint32_t dbg;          // tools/ only (env S5GPU_DEBUG_STAGE): 1 = stop after the payload is built
     uint32_t zseq;         // zstd records: runs as sequences (option "zstd_sequences", default 1; 0 = the literals-only frames of round 1)
+    uint32_t tier = 0;     // k_encode_fused: 0 = the only fused launch (a read that does not fit goes on the overflow list); 1 = the first of two (it is
+                           // left alone: out_len[r] stays 0); 2 = the second, with a larger LDS budget (reads the first one did are skipped, a read
+                           // that does not fit this budget either goes on the list)
 };
 
+static uint32_t g_fused_tier2 = 0;      // mixed batches (a caller-named fused budget): LDS budget of a SECOND fused launch (option "fused_tier2"; 0 = one launch, the default:
+                                        // measured on the mixed leg, profiles/r04_mixed_tier2.txt — 16 KiB 393 GB/s, 12 KiB 408, one launch 405)
 static uint32_t g_zstd_sequences = 1;   // zstd encoder: runs as sequences (zstd_enc_dev.h); 0 = literals-only frames (option "zstd_sequences")
 
 __device__ __forceinline__ uint32_t payload_bound_dev(const s5gpu_read_desc_t &d, int sig_method) {
@@ -174,13 +179,14 @@ __device__ __forceinline__ uint32_t build_payload_hbm(const s5gpu_encode_args_t 
 template <typename M, bool EXZD = false>
 __global__ __launch_bounds__(NT, S5_FUSED_WG_PER_CU) void k_encode_fused(EncParams p) {
     const uint32_t r = blockIdx.x;
+    if (p.tier == 2 && p.a.out_len[r] != 0) return;   // (uniform) done by the first launch
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
     const s5gpu_read_desc_t d = p.a.desc[r];
     const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
     if (plen == OVF) {
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && p.tier != 1) {
             const uint32_t at = atomicAdd(&p.a.ovf[0], 1u);
             p.a.ovf[1 + at] = r;
         }
@@ -505,13 +511,14 @@ template <bool EXZD>
 #endif
 __global__ __launch_bounds__(NT, S5_ZF_WG) void k_zstd_fused(EncParams p) {
     const uint32_t r = blockIdx.x;
+    if (p.tier == 2 && p.a.out_len[r] != 0) return;   // (uniform) done by the first launch
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
     const s5gpu_read_desc_t d = p.a.desc[r];
     const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
     if (plen == OVF) {
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && p.tier != 1) {
             const uint32_t at = atomicAdd(&p.a.ovf[0], 1u);
             p.a.ovf[1 + at] = r;
         }
@@ -1742,8 +1749,30 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         // a lane owns ceil(len / 256) bytes: payloads up to 8 KiB need 32-bit position masks only
         const bool xz = a->sig_method == S5GPU_SIG_EX_ZD, zs = a->rec_method == S5GPU_REC_ZSTD;
         if (zs) { if (xz) hipLaunchKernelGGL(k_zstd_fused<true>, dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_zstd_fused<false>, dim3(a->n_reads), dim3(NT), lds, st, p); }
-        else if (cap <= 8192) { if (xz) hipLaunchKernelGGL((k_encode_fused<uint32_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_encode_fused<uint32_t>, dim3(a->n_reads), dim3(NT), lds, st, p); }
-        else { if (xz) hipLaunchKernelGGL((k_encode_fused<uint64_t, true>), dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_encode_fused<uint64_t>, dim3(a->n_reads), dim3(NT), lds, st, p); }
+        else {
+            // A caller that names an LDS budget has a batch of mixed lengths.  Option "fused_tier2" (round 4, off by default) gives it TWO fused
+            // launches — the named budget at eight workgroups per CU for the short reads, then up to one 16 KiB DEFLATE block for the reads in
+            // between, which the staged kernels take through HBM twice; only what fits neither goes on the overflow list.  The first launch leaves
+            // out_len[r] = 0 for a read it does not take, the second skips the ones it took.  Measured (profiles/r04_mixed_tier2.txt): the second
+            // launch runs at four workgroups per CU (36 KiB of LDS) and takes 3.4 ms for the reads the staged kernels did in 3.6 — nothing gained.
+            uint32_t cap2 = a->lds_payload_cap && g_fused_tier2 > cap ? g_fused_tier2 : 0u;
+            if (cap2 > a->max_payload) cap2 = (a->max_payload + 15u) & ~15u;
+            if (cap2 > (uint32_t)DEFL_BLK) cap2 = DEFL_BLK;
+            if (cap2 <= cap) cap2 = 0;
+            if (cap2) { HIP_TRY(hipMemsetAsync(a->out_len, 0, 4ull * a->n_reads, st)); p.tier = 1; }
+            auto fused = [&](uint32_t c, size_t l) {
+                if (c <= 8192) { if (xz) hipLaunchKernelGGL((k_encode_fused<uint32_t, true>), dim3(a->n_reads), dim3(NT), l, st, p); else hipLaunchKernelGGL(k_encode_fused<uint32_t>, dim3(a->n_reads), dim3(NT), l, st, p); }
+                else { if (xz) hipLaunchKernelGGL((k_encode_fused<uint64_t, true>), dim3(a->n_reads), dim3(NT), l, st, p); else hipLaunchKernelGGL(k_encode_fused<uint64_t>, dim3(a->n_reads), dim3(NT), l, st, p); }
+            };
+            fused(cap, lds);
+            if (cap2) {
+                p.tier = 2;
+                p.pay_cap = cap2;
+                p.obuf_words = (cap2 + 64 > B_BYTES ? cap2 + 64 : B_BYTES) / 4;
+                fused(cap2, S_BYTES + 4ull * p.obuf_words + p.pay_cap);
+                p.tier = 0;
+            }
+        }
         // overflow reads (usually none: the two launches below then exit at once)
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
         const uint32_t g = a->n_reads < 8192 ? a->n_reads : 8192;   // persistent loops over the list; enough workgroups for the CUs to balance
@@ -1867,6 +1896,7 @@ static uint32_t g_inflate_simt_min = 24576;   // measured crossover on 4000-samp
 extern "C" int s5gpu_set_option(const char *key, long value) {
     if (key && strcmp(key, "inflate_simt_min") == 0 && value >= 0) { g_inflate_simt_min = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_route") == 0 && (value == 0 || value == 1)) { g_inflate_route = (uint32_t)value; return S5GPU_OK; }
+    if (key && strcmp(key, "fused_tier2") == 0 && value >= 0 && value <= DEFL_BLK) { g_fused_tier2 = (uint32_t)value & ~15u; return S5GPU_OK; }
     if (key && strcmp(key, "zstd_sequences") == 0 && (value == 0 || value == 1)) { g_zstd_sequences = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "unpack_fused") == 0 && (value == 0 || value == 1)) { g_unpack_fused = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_par") == 0 && value >= 0 && value <= 2) { g_inflate_par = (uint32_t)value; return S5GPU_OK; }   // 2 (tools): no fallback pass, declined records keep status 8

@@ -253,12 +253,18 @@ def test_lds_overflow_reads_take_the_staged_path(press, cap):
     sig[40] = rng.integers(-2000, 2000, n, dtype=np.int16)        # ~2 bytes/sample
     sig[41][:] = 0
     hdrs = [_hdr(press, 400 + i) for i in range(n_reads)]
-    b = press.DeviceBatch([n] * n_reads, lds_payload_cap=cap)
-    b.upload(list(sig), hdrs)
-    b.encode()
-    b.compact()
-    recs = b.records()
-    n_ovf = int(b.ovf[0].item())
+    from slow5tools_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.s5gpu_set_option(b"fused_tier2", 0))            # one fused launch: whatever misses the named budget is staged
+    try:
+        b = press.DeviceBatch([n] * n_reads, lds_payload_cap=cap)
+        b.upload(list(sig), hdrs)
+        b.encode()
+        b.compact()
+        recs = b.records()
+        n_ovf = int(b.ovf[0].item())
+    finally:
+        _lib.check(L.s5gpu_set_option(b"fused_tier2", 0))
     if cap == 2048:
         assert n_ovf == n_reads
     elif cap == 0:
@@ -904,3 +910,48 @@ def test_mixed_batch_overflow_list_is_launched_longest_first_and_encodes_the_sam
         rec = stream[int(off[i]):int(off[i + 1])]
         want, _ = _oracle_payload(hdrs[i], sigs[i], b"", 1)
         assert zlib.decompress(rec[8:]) == want, i
+
+
+def test_mixed_batch_second_fused_launch_takes_the_reads_in_between(press):
+    """round 4, option fused_tier2 (off by default: it bought nothing on the mixed leg): a batch with a named LDS budget gets TWO fused launches
+    — the named budget (8 KiB, eight workgroups per CU) and then up to one 16 KiB DEFLATE block for the reads in between; only what fits neither is staged.  Every record must inflate to the
+    oracle's payload whichever launch made it, the overflow list must shrink to the long reads, and the records of reads neither launch
+    touches differently (short ones, long ones) must be byte-identical to the one-launch run"""
+    from slow5tools_amd import _lib
+    import torch
+    rng = np.random.default_rng(91)
+    n_rec = 3000
+    ns = np.clip(np.exp(rng.normal(np.log(6000), 0.9, n_rec)), 1, 120000).astype(np.uint64)
+    ns[:6] = (120000, 1, 6300, 6500, 12400, 12900)               # around both budgets' edges
+    sigs = [(520 + np.cumsum(rng.integers(-9, 10, int(n))) % 300).astype(np.int16) for n in ns]
+    sigs[7] = rng.integers(-32768, 32768, int(ns[7]), dtype=np.int16)   # ~3 bytes per sample: overflows wherever its length would fit
+    hdrs = [_hdr(press, i) for i in range(n_rec)]
+    L = _lib.lib()
+    out = {}
+    for tier2 in (16384, 12288, 0):
+        _lib.check(L.s5gpu_set_option(b"fused_tier2", tier2))
+        try:
+            b = press.DeviceBatch(ns, hdr_len=[len(h) for h in hdrs], lds_payload_cap=8192)
+            b.upload(sigs, hdrs)
+            b.encode()
+            b.compact()
+            stream, off = b.stream_bytes()
+            out[tier2] = (stream, off.copy(), int(b.ovf[0].item()))
+            del b
+            torch.cuda.empty_cache()
+        finally:
+            _lib.check(L.s5gpu_set_option(b"fused_tier2", 0))
+    assert out[16384][2] < out[12288][2] < out[0][2], [out[k][2] for k in out]
+    n_long = int((ns > 13500).sum())
+    assert n_long <= out[16384][2] <= n_long + int(((ns > 9000) & (ns <= 13500)).sum())
+    for tier2 in (16384, 12288):
+        stream, off, _ = out[tier2]
+        for i in range(n_rec):
+            rec = stream[int(off[i]):int(off[i + 1])]
+            one = out[0][0][int(out[0][1][i]):int(out[0][1][i + 1])]
+            if (ns[i] < 5000 or ns[i] > 17000) and i != 7:
+                assert rec == one, i
+            if i < 64 or i % 37 == 0 or rec != one:
+                want, _ = _oracle_payload(hdrs[i], sigs[i], b"", 1)
+                assert zlib.decompress(rec[8:]) == want, (tier2, i)
+        assert len(stream) <= 1.002 * len(out[0][0])
