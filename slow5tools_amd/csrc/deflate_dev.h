@@ -635,6 +635,9 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         for (; j + 4 <= kk; j += 4) {
             int b0, b1, b2, b3;
             const uint32_t w = load4(j, b0, b1, b2, b3);
+#ifdef S5_DEFL_OPAQUE
+            if constexpr (!DW) asm("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));   // (keeps the compares 32 bits wide: narrowed to 16, each byte costs a v_and)
+#endif
             if (b0 != prev) { brk |= (M)1 << j; atomicAdd(&S.freq[b0], 1u); }
             if (b1 != b0) { brk |= (M)2 << j; atomicAdd(&S.freq[b1], 1u); }
             if (b2 != b1) { brk |= (M)4 << j; atomicAdd(&S.freq[b2], 1u); }
@@ -790,8 +793,14 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         }
     }
     if (dbg == 23) { z.bitpos += (uint32_t)tok + (uint32_t)mat + a_sum + b_sum + nmatch + nextra + mc0 + mc1; return; }
-    nmatch = wave_sum(nmatch);
-    nextra = wave_sum(nextra);
+    // (uniform per wave) every position of every lane of this wave is a literal token — the waves that lie in the data area of an svb-zd
+    // payload, nearly always (a run of >= 4 equal data bytes is rare): the bit-count and pack passes then run their full groups of four
+    // positions without token masks (round 4: 7690 -> 7450 VALU instructions per 4000-sample read, 13.68 -> 13.43 ms per 1 M reads)
+    const bool alllit = __ballot(mat != 0 || tok != (kk >= MO::BITS ? (M)~(M)0 : (M)(((M)1 << kk) - 1))) == 0;
+    if (!alllit) {   // (no matches, no extra bits otherwise)
+        nmatch = wave_sum(nmatch);
+        nextra = wave_sum(nextra);
+    }
     a_sum = wave_sum(a_sum);
     b_sum = wave_sum(b_sum % 65521u);
     if (lane_id() == 0) {
@@ -894,6 +903,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     uint32_t clv[2] = {0, 0}, clnb[2] = {0, 0};   // this lane's two code-length-sequence entries (dynamic only)
     if (use_fixed) {
         for (int s = tid; s < 288; s += NT) S.code[s] = fixed_code(s);
+        for (int s = tid; s < 288; s += NT) S.lens[s] = (uint8_t)fixed_len(s);   // (the bit count reads the lengths as bytes)
         if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
         pos0 = z.bitpos + 3;
         dist_bits = 5;
@@ -938,12 +948,20 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         // literal tokens: branch-free over groups of four positions (4 byte loads, then 4 code loads, in flight together)
         M lt = tok & (M)~mat;
         int j = 0;
+        if (alllit) {
+            for (; j + 4 <= kk; j += 4) {
+                int b0, b1, b2, b3;
+                load4(j, b0, b1, b2, b3);
+                mybits += (uint32_t)S.lens[b0] + (uint32_t)S.lens[b1] + (uint32_t)S.lens[b2] + (uint32_t)S.lens[b3];
+            }
+            lt = j >= MO::BITS ? (M)0 : (M)(lt >> j);
+        }
         // the last group may reach up to three bytes past the lane's chunk: those positions carry no token bit and the
         // bytes read there are in-bounds LDS (neighbour chunk / slack), so no separate tail loop is needed
         for (; j < kk; j += 4, lt >>= 4) {
             int b0, b1, b2, b3;
             load4(j, b0, b1, b2, b3);
-            const uint32_t c0 = S.code[b0] >> 16, c1 = S.code[b1] >> 16, c2 = S.code[b2] >> 16, c3 = S.code[b3] >> 16;
+            const uint32_t c0 = S.lens[b0], c1 = S.lens[b1], c2 = S.lens[b2], c3 = S.lens[b3];   // (bytes: no shift; the same lengths as S.code[] >> 16)
             const uint32_t lit = (uint32_t)lt & 15u;
             mybits += (lit & 1 ? c0 : 0) + (lit & 2 ? c1 : 0) + (lit & 4 ? c2 : 0) + (lit & 8 ? c3 : 0);
         }
@@ -1022,6 +1040,18 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         } else {
             M t = tok, mm = mat;
             int j = 0;
+            if (alllit) {
+                for (; j + 4 <= kk; j += 4) {
+                    int b0, b1, b2, b3;
+                    load4(j, b0, b1, b2, b3);
+                    const uint32_t c0 = S.code[b0], c1 = S.code[b1], c2 = S.code[b2], c3 = S.code[b3];
+                    const uint32_t n0 = c0 >> 16, n1 = c1 >> 16, n2 = c2 >> 16, n3 = c3 >> 16;
+                    const uint32_t lo = (c0 & 0xFFFFu) | ((c1 & 0xFFFFu) << n0), nlo = n0 + n1;
+                    const uint32_t hi = (c2 & 0xFFFFu) | ((c3 & 0xFFFFu) << n2), nhi = n2 + n3;
+                    or_bits((uint64_t)lo | ((uint64_t)hi << nlo), nlo + nhi);
+                }
+                t = j >= MO::BITS ? (M)0 : (M)(t >> j);      // (mm is zero)
+            }
             for (; j < kk; j += 4, t >>= 4, mm >>= 4) {   // the last group may overhang the chunk: no token bits there
                 int b0, b1, b2, b3;
                 load4(j, b0, b1, b2, b3);

@@ -17,6 +17,24 @@
 
 namespace s5 {
 
+// tools/inflate_phases.py (variant build -DS5_IPROBE): clock ticks a record's wave spends in each phase of the parallel inflate, summed over the batch
+#ifdef S5_IPROBE
+__device__ unsigned long long g_iprobe[20];
+struct IProbe { unsigned long long t; };
+#define IPP_DECL IProbe ipp_; ipp_.t = __builtin_readcyclecounter(); IProbe *ipp = &ipp_;
+#define IPP(i) { if (ipp) { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane_id() == 0) atomicAdd(&g_iprobe[i], n_ - ipp->t); ipp->t = __builtin_readcyclecounter(); } }
+#define IPP_FLUSH { if (ipp && lane_id() == 0) atomicAdd(&g_iprobe[19], 1ull); }
+#define IPP_ARG , IProbe *ipp = nullptr
+#define IPP_PASS , ipp
+#else
+#define IPP_DECL
+#define IPP(i)
+#define IPP_FLUSH
+#define IPP_ARG
+#define IPP_PASS
+#endif
+
+
 constexpr int INF_LBITS = 10;      // primary lit/len lookup bits
 constexpr int INF_DBITS = 8;       // primary distance lookup bits
 constexpr int INF_IW = 2048;       // input window, bytes
@@ -323,7 +341,7 @@ __device__ __forceinline__ int infl_cl_sequence_wave(TT &T, BitIn &b, int tot) {
 // LITLUT = 0: no lit/len lookup table (the parallel decoder resolves those codes by comparison); PARCL: the code-length sequence by
 // the whole wave (infl_cl_sequence_wave)
 template <class TT, int LITLUT = INF_LBITS, bool PARCL = false, int DBITS = INF_DBITS>
-__device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint32_t total, uint64_t total_bits, BitIn &b, int type, int &nl, int &nd) {
+__device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint32_t total, uint64_t total_bits, BitIn &b, int type, int &nl, int &nd IPP_ARG) {
     const int lane = lane_id();
     // ---- code lengths ----
     if (type == 1) {
@@ -362,8 +380,10 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
             }
         }
         wave_sync();
+        IPP(1)
         // the code-length code reuses the distance tables' storage (built before the real ones)
         if (infl_build(T.lens, 19, T.dcount, T.dsym, T.dlut, 7, 5)) return INF_ERR_DATA;
+        IPP(2)
         int bad = 0;
         if (PARCL) {
             for (int i = lane; i < 320; i += 64) T.lens[32 + i] = 0;
@@ -399,6 +419,7 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
         }
         if (bad) return bad == 2 ? INF_ERR_TRUNC : INF_ERR_DATA;
         wave_sync();
+        IPP(3)
     }
     // tables: dynamic lengths sit at T.lens[32 ..] (lit/len then dist); fixed at [0..288) + [288..)
     const uint8_t *ll = type == 1 ? T.lens : T.lens + 32;
@@ -406,7 +427,9 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
     if (type == 2 && ll[256] == 0) return INF_ERR_DATA;
     if constexpr (LITLUT == 0) { if (infl_build_syms(ll, nl, T.lcount, T.lsym, reinterpret_cast<uint32_t *>(T.llut))) return INF_ERR_DATA; }   // (T.llut: >= 64 bytes of scratch)
     else { if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, LITLUT, 9)) return INF_ERR_DATA; }
+    IPP(4)
     if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, DBITS, 5)) return INF_ERR_DATA;
+    IPP(5)
     return INF_OK;
 }
 

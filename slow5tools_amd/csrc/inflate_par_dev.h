@@ -291,6 +291,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                                                 uint32_t *out_len, uint32_t *dbg = nullptr) {
     const int lane = lane_id();
     *out_len = 0;
+    IPP_DECL
     if (in_len < 6) return INF_ERR_TRUNC;
     {
         const uint32_t cmf = in[0], flg = in[1];
@@ -309,6 +310,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
         b.buf = 0; b.cnt = 0; b.wpos = 0;
         b.wbase = (uint32_t)(pos >> 3) & ~3u;
         ip_load_window(T.win, src, b.wbase, total);                           // the whole round window: the tokens behind the header are in it
+        IPP(0)
         const uint32_t hdr_wb = b.wbase;
         bool win_fresh = true;
         bi_need32_u(b, T.win);
@@ -333,7 +335,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             continue;
         }
         int nl, nd;
-        { const int rc = infl_block_tables<SH, 0, true, IP_DBITS>(T, src, total, total_bits, b, type, nl, nd); if (rc != INF_OK) return rc; }
+        { const int rc = infl_block_tables<SH, 0, true, IP_DBITS>(T, src, total, total_bits, b, type, nl, nd IPP_PASS); if (rc != INF_OK) return rc; }
         pos = bi_consumed_bits(b);
         if (b.wbase != hdr_wb) win_fresh = false;                             // (the header parser slid its window: never, for a window that starts at the header)
         if (dbg && dbg[3] == 1) return INF_OK;       // tools/par_probe.py cut-off: block header and tables only
@@ -372,6 +374,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             L.np = (maxlen - minlen + 1) >> 1;                                // limits of minlen .. maxlen - 1
             wave_sync();
         }
+        IPP(6)
         // ---- the block's tokens, a window at a time ----
         for (;;) {
             if (pos >= total_bits) return INF_ERR_TRUNC;                      // no end-of-block code before the data ran out
@@ -412,6 +415,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                 st = ns;
                 if (!__ballot(moved)) break;
             }
+            IPP(7)
             if (dbg && dbg[3] == 2) return INF_OK;   // cut-off: + window load and synchronisation passes
             // which lanes hold real tokens of this block, and where their bytes go
             const uint64_t eobs = __ballot(sg.eob != 0u && st < seg_end);
@@ -444,7 +448,9 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             wave_sync();
             IpSeg wr;
             wr.nwait = 0; wr.bad = 0; wr.eob = 0; wr.eobpos = 0; wr.cross = st; wr.nout = 0;
+            IPP(8)
             if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, L, st, seg_end, obase, o, dst, wincl - w_act, w_act);
+            IPP(9)
             if (__ballot(wr.bad != 0u)) return INF_ERR_DATA;
             if (__ballot(wr.nwait != w_act)) { if (dbg) dbg[2] = 4; return INF_NEED_FALLBACK; }   // (the two kinds of pass disagree: never seen)
             wave_sync();
@@ -466,6 +472,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             wave_sync();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            IPP(10)
             // ---- waiting matches: 64 at a time, each copied by ITS lane as soon as nothing it reads is still to come.  The list is
             // in stream order, so the destinations — starts and ends — are ascending and disjoint: the entries that reach into my
             // source are a contiguous range of the lanes in front of me, from the first whose end lies behind my source's start to
@@ -521,6 +528,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                 }
                 if (dbg) dbg[2] += 1u;                           // ... batches of 64 in the low half)
             }
+            IPP(11)
             o += round_out;
             // where the round ended: behind the end-of-block code, or at the last emitted lane's last token
             const uint32_t endbit = (uint32_t)__builtin_amdgcn_readlane((int)wr.cross, m - 1);
@@ -555,6 +563,8 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
     }
     const uint8_t *t = in + in_len - 4;
     const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+    IPP(12)
+    IPP_FLUSH
     if (((adB << 16) | adA) != want) return INF_ERR_ADLER;
     return INF_OK;
 }

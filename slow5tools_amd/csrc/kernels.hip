@@ -1053,8 +1053,14 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode
             }
 #endif
             if (status == 0) {
+#ifdef S5_IPROBE
+                const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
                 if (EXZD) status = unpack_exzd_wave(a, d, pay, a.fields[r], olen, *reinterpret_cast<ExzdWaveScratch *>(&T));
                 else status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
+#ifdef S5_IPROBE
+                if (lane_id() == 0) atomicAdd(&g_iprobe[13], (unsigned long long)__builtin_readcyclecounter() - t0_);
+#endif
             }
 #ifdef S5_NP_TRIPWIRE
             if (status == 0) {
@@ -2249,6 +2255,14 @@ extern "C" int s5gpu_synth_hdr_dev(uint8_t *hdr, uint64_t n_reads, uint64_t firs
     return S5GPU_OK;
 }
 
+#ifdef S5_IPROBE   // tools/inflate_phases.py only (variant build): the phase clocks of inflate_par_dev.h, read and cleared
+extern "C" int s5gpu_iprobe_read(unsigned long long *out20) {
+    unsigned long long z[20] = {0};
+    if (hipMemcpyFromSymbol(out20, HIP_SYMBOL(s5::g_iprobe), sizeof z) != hipSuccess) return S5GPU_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(s5::g_iprobe), z, sizeof z) != hipSuccess) return S5GPU_ERR_HIP;
+    return S5GPU_OK;
+}
+#endif
 #ifdef S5_ZPROBE   // tools/zstd_phases.py only (variant build): the phase clocks of zstd_dev.h, read and cleared
 extern "C" int s5gpu_zprobe_read(unsigned long long *out16) {
     unsigned long long z[16] = {0};
