@@ -635,9 +635,6 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         for (; j + 4 <= kk; j += 4) {
             int b0, b1, b2, b3;
             const uint32_t w = load4(j, b0, b1, b2, b3);
-#ifdef S5_DEFL_OPAQUE
-            if constexpr (!DW) asm("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));   // (keeps the compares 32 bits wide: narrowed to 16, each byte costs a v_and)
-#endif
             if (b0 != prev) { brk |= (M)1 << j; atomicAdd(&S.freq[b0], 1u); }
             if (b1 != b0) { brk |= (M)2 << j; atomicAdd(&S.freq[b1], 1u); }
             if (b2 != b1) { brk |= (M)4 << j; atomicAdd(&S.freq[b2], 1u); }
