@@ -555,11 +555,12 @@ __device__ __forceinline__ Tok token_at(const uint8_t *__restrict__ buf, int bas
 
 // Copy completed words obuf -> HBM slot and slide the partial word to obuf[0].
 // final_all: copy everything including the last partial word, no slide.
+template <int TN = NT>   // threads of the calling workgroup
 __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOut &z, bool final_all) {
     const int tid = threadIdx.x;
     const uint32_t full = final_all ? (z.bitpos + 31) >> 5 : z.bitpos >> 5;
     const uint32_t n = full - z.flushed;
-    for (uint32_t i = tid; i < n; i += NT) {
+    for (uint32_t i = tid; i < n; i += TN) {
         const uint32_t w = z.flushed + i;
         if (w >= 2) out32[w] = obuf[i];   // words 0,1 = u64 size prefix, written last by lane 0
     }
@@ -567,7 +568,7 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
     __syncthreads();
     const uint32_t partial = obuf[n];
     __syncthreads();
-    for (uint32_t i = tid; i <= n; i += NT) obuf[i] = i == 0 ? partial : 0u;
+    for (uint32_t i = tid; i <= n; i += TN) obuf[i] = i == 0 ? partial : 0u;
     __syncthreads();
     z.flushed = full;
 }

@@ -401,15 +401,17 @@ __global__ __launch_bounds__(NT, S5_STAGED_WG) void k_deflate_staged(EncParams p
 // record (LzLong only), 1 = this kernel's share of a batch that runs both (LzShort: payloads <= 8 KiB, LzLong: the others).
 constexpr uint32_t LZ_BYTES = (sizeof(LzSharedT<LzLong>) + 15u) & ~15u;
 constexpr uint32_t LZS_BYTES = (sizeof(LzSharedT<LzShort>) + 15u) & ~15u;
+static_assert(S_BYTES + (DEFL_BLK + 64) + LZ_BYTES <= 160u * 1024u - 256u, "the long shape holds a CU's LDS by itself");
 // build = 1 (LzShort, a batch of short raw-signal records only): the payload head | u64 N | int16 samples | aux is put together right here
 // in the window — no k_pack launch, no parked copy of the payload through HBM
 template <class C>
-__global__ __launch_bounds__(NT, C::HIST ? 1 : 4) void k_deflate_lz(EncParams p, int use_list, int which, int build) {
+__global__ __launch_bounds__(C::TN, C::HIST ? 1 : 4) void k_deflate_lz(EncParams p, int use_list, int which, int build) {
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     LzSharedT<C> &X = *reinterpret_cast<LzSharedT<C> *>(smem + S_BYTES + (C::HIST ? 4u * p.obuf_words : 0u));
     uint32_t *obuf = C::HIST ? reinterpret_cast<uint32_t *>(smem + S_BYTES) : X.obuf_alias;
     const uint32_t obuf_words = C::HIST ? p.obuf_words : (uint32_t)(C::BLK + 64) / 4u;
     const int tid = threadIdx.x;
+    constexpr uint32_t TN = (uint32_t)C::TN;   // threads of this shape's workgroup (lz_dev.h)
     const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         const uint32_t r = use_list ? p.a.ovf[1 + it] : it;
@@ -434,13 +436,13 @@ __global__ __launch_bounds__(NT, C::HIST ? 1 : 4) void k_deflate_lz(EncParams p,
             if (build) {
                 uint8_t *w8 = X.win;
                 const uint8_t *hdr = p.a.hdr + d.hdr_off;
-                for (uint32_t i = tid; i < d.hdr_len; i += NT) w8[i] = hdr[i];
+                for (uint32_t i = tid; i < d.hdr_len; i += TN) w8[i] = hdr[i];
                 if (tid < 8) w8[d.hdr_len + tid] = (uint8_t)((uint64_t)d.n_samples >> (8 * tid));
                 // samples: dword loads from the (16-byte aligned) signal, 16-bit stores (the head's 2 + id + 36 + 8 bytes leave the samples 2-byte aligned)
                 const uint32_t *s32 = reinterpret_cast<const uint32_t *>(p.a.sig + d.sig_off);
                 uint8_t *sp = w8 + d.hdr_len + 8;
                 const bool al2 = ((d.hdr_len + 8u) & 1u) == 0;
-                for (uint32_t i = tid; i < (d.n_samples + 1) / 2; i += NT) {
+                for (uint32_t i = tid; i < (d.n_samples + 1) / 2; i += TN) {
                     const uint32_t v = s32[i];
                     if (al2) {
                         reinterpret_cast<uint16_t *>(sp)[2 * i] = (uint16_t)v;
@@ -453,14 +455,14 @@ __global__ __launch_bounds__(NT, C::HIST ? 1 : 4) void k_deflate_lz(EncParams p,
                 if (d.aux_len) {
                     const uint8_t *aux = p.a.aux + d.aux_off;
                     uint8_t *ap = sp + 2 * d.n_samples;
-                    for (uint32_t i = tid; i < d.aux_len; i += NT) ap[i] = aux[i];
+                    for (uint32_t i = tid; i < d.aux_len; i += TN) ap[i] = aux[i];
                 }
                 plen = d.hdr_len + 8u + 2u * d.n_samples + d.aux_len;
             }
         }
         {   // a record starts with an empty table (the output must not depend on what this workgroup encoded before)
             uint4 *t4 = reinterpret_cast<uint4 *>(X.table);
-            for (uint32_t i = tid; i < sizeof(X.table) / 16; i += NT) t4[i] = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = tid; i < sizeof(X.table) / 16; i += TN) t4[i] = make_uint4(0, 0, 0, 0);
         }
         ZOut z;
         z.bitpos = 80;        // u64 size prefix (words 0, 1: written last) + CMF/FLG 78 9c
@@ -474,18 +476,18 @@ __global__ __launch_bounds__(NT, C::HIST ? 1 : 4) void k_deflate_lz(EncParams p,
             if (!build) {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
                 const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
                 uint4 *d4 = reinterpret_cast<uint4 *>(X.win + C::WOFF);
-                for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
+                for (uint32_t i = tid; i < (blen + 15) / 16; i += TN) d4[i] = s4[i];
             }
             __syncthreads();
             deflate_block_lz<C>(S, X, obuf, obuf_words, (int)blen, done ? (uint32_t)C::WOFF : 0u, done, final, z, adA, adB);
             done += blen;
             if (!final) {
                 if constexpr (C::HIST) {
-                    flush_words(obuf, out32, z, false);
+                    flush_words<C::TN>(obuf, out32, z, false);
                     z.carry = obuf[0];
                     const uint4 *c4 = reinterpret_cast<const uint4 *>(X.win + C::WOFF);   // the block becomes the next one's history
                     uint4 *h4 = reinterpret_cast<uint4 *>(X.win);
-                    for (uint32_t i = tid; i < C::BLK / 16; i += NT) h4[i] = c4[i];
+                    for (uint32_t i = tid; i < C::BLK / 16; i += TN) h4[i] = c4[i];
                     __syncthreads();
                 }
             }
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(NT, C::HIST ? 1 : 4) void k_deflate_lz(EncParams p,
         if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
         z.bitpos += 32;
         __syncthreads();
-        flush_words(obuf, out32, z, true);
+        flush_words<C::TN>(obuf, out32, z, true);
         const uint32_t total = z.bitpos >> 3;
         __syncthreads();
         if (tid == 0) {
@@ -1742,7 +1744,7 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         if (all_short) {   // reads whose descriptors belie max_payload (the short shape put them on the overflow list): parked + the long shape; usually none
             const uint32_t g = a->n_reads < 1024 ? a->n_reads : 1024;
             hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2, nullptr);
-            hipLaunchKernelGGL(k_deflate_lz<LzLong>, dim3(g), dim3(NT), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, st, p, 1, 0, 0);
+            hipLaunchKernelGGL(k_deflate_lz<LzLong>, dim3(g), dim3(LzLong::TN), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, st, p, 1, 0, 0);
         }
         HIP_TRY(hipGetLastError());
         return S5GPU_OK;
@@ -1809,7 +1811,7 @@ static void launch_lz(EncParams p, uint32_t n, uint32_t max_payload, hipStream_t
                        build && !any_long ? 1 : 0);
     if (any_long) {
         const uint32_t gl = n < 2048 ? n : 2048;
-        hipLaunchKernelGGL(k_deflate_lz<LzLong>, dim3(gl), dim3(NT), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, st, p, 0, 1, 0);
+        hipLaunchKernelGGL(k_deflate_lz<LzLong>, dim3(gl), dim3(LzLong::TN), S_BYTES + 4ull * p.obuf_words + LZ_BYTES, st, p, 0, 1, 0);
     }
 }
 
@@ -2255,6 +2257,14 @@ extern "C" int s5gpu_synth_hdr_dev(uint8_t *hdr, uint64_t n_reads, uint64_t firs
     return S5GPU_OK;
 }
 
+#ifdef S5_LZPROBE   // tools/lz_phases.py only (variant build): the phase clocks of lz_dev.h, read and cleared
+extern "C" int s5gpu_lzprobe_read(unsigned long long *out16) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(s5::g_lzprobe), sizeof z) != hipSuccess) return S5GPU_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(s5::g_lzprobe), z, sizeof z) != hipSuccess) return S5GPU_ERR_HIP;
+    return S5GPU_OK;
+}
+#endif
 #ifdef S5_IPROBE   // tools/inflate_phases.py only (variant build): the phase clocks of inflate_par_dev.h, read and cleared
 extern "C" int s5gpu_iprobe_read(unsigned long long *out20) {
     unsigned long long z[20] = {0};

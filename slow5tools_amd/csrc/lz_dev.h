@@ -35,10 +35,42 @@ constexpr int LZ_MINLEN = 4, LZ_WAYS = 4;          // (four ways = four waves: w
 // raw-signal record is 8086 bytes) need no history, a quarter of the positions and a table an eighth the size, and the table is dead
 // when the bit buffer comes to life, so the two share storage: 38 KiB, four workgroups per CU — the matcher is a chain of dependent
 // LDS round trips, so what it gains is resident waves (tools/lz_time.py).
-template <int BLK_, int HBITS_, bool HIST_>
-struct LzCfg { static constexpr int BLK = BLK_, HBITS = HBITS_; static constexpr bool HIST = HIST_; static constexpr int WOFF = HIST_ ? BLK_ : 0; };
-using LzLong = LzCfg<LZ_BLK, 13, true>;
+// TN = threads of the workgroup.  LzLong holds a CU by itself (150 KiB of LDS) and every phase of it is a chain of dependent LDS round trips —
+// table lookup -> candidates -> compare; a lane's serial greedy parse; its token loops — so the only thing that hides the latency is more
+// waves ON that one workgroup: round 4 runs it with S5_LZ_TN threads (16 waves at 1024) instead of 256; a lane then owns BLK / TN positions.
+#ifndef S5_LZ_TN
+#define S5_LZ_TN 1024
+#endif
+// tools/lz_phases.py (variant build -DS5_LZPROBE): clock ticks thread 0 of a workgroup spends in each phase of deflate_block_lz, summed over the batch
+#ifdef S5_LZPROBE
+__device__ unsigned long long g_lzprobe[16];
+#define LZP_DECL unsigned long long lzp_t = __builtin_readcyclecounter();
+#define LZP(i) { const unsigned long long n_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_lzprobe[i], n_ - lzp_t); lzp_t = n_; }
+#else
+#define LZP_DECL
+#define LZP(i)
+#endif
+template <int BLK_, int HBITS_, bool HIST_, int TN_ = NT>
+struct LzCfg { static constexpr int BLK = BLK_, HBITS = HBITS_, TN = TN_; static constexpr bool HIST = HIST_; static constexpr int WOFF = HIST_ ? BLK_ : 0; };
+using LzLong = LzCfg<LZ_BLK, 13, true, S5_LZ_TN>;
 using LzShort = LzCfg<8192, 10, false>;
+// workgroup exclusive prefix sum for a workgroup of NWV waves (dev_common.h's block_excl_add is the NW = 4 form)
+template <int NWV>
+__device__ __forceinline__ uint32_t block_excl_add_w(uint32_t v, uint32_t *ws, uint32_t &total) {
+    const uint32_t incl = wave_incl_add(v);
+    if (lane_id() == 63) ws[wave_id()] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; w++) {
+        const uint32_t x = ws[w];
+        if (w < wave_id()) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
 
 template <class C>
 struct LzSharedT {
@@ -48,9 +80,13 @@ struct LzSharedT {
         alignas(16) uint32_t obuf_alias[C::HIST ? 4 : (C::BLK + 64) / 4];   // LzShort: the bit buffer lives where the table was
     };
     alignas(16) uint16_t D[C::BLK + 8];                     // per position: match distance (0 none); after the parse D[p + 1] = length of the match starting at p
-    uint16_t entry[NT + 2];
+    uint16_t entry[C::TN + 2];
     uint32_t blcount_d[16];
     uint32_t bins_d[64];
+    // Rounds of more than 256 positions: the positions of the CURRENT round are not in `table` yet (it is filled behind the round), and with 1024
+    // of them a payload of period 255 would see nothing for its first four periods.  cur[] holds, per 10-bit hash, the EARLIEST position of the
+    // round with that hash (an LDS atomic min, so it does not depend on the waves' timing): one more candidate for every later position of the round.
+    uint32_t cur[C::TN > 256 ? 1024 : 1];   // (0xFFFF - round) << 16 | position in the block; cleared per block
 };
 using LzShared = LzSharedT<LzLong>;
 
@@ -112,47 +148,89 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
     const int tid = threadIdx.x;
     constexpr uint32_t WOFF = (uint32_t)C::WOFF;
     const uint8_t *cur = X.win + WOFF;
-    constexpr int K = C::BLK / NT;   // positions per lane (64 / 32)
+    constexpr int TN = C::TN;
+    static_assert(TN % 256 == 0 && TN / 64 <= 16, "S.ws holds 16 wave sums");
+    constexpr int K = C::BLK / TN;   // positions per lane (64 / 32 at 256 threads, 16 at 1024)
     const int base = tid * K;
     if (len == 0) {   // empty stream: a fixed block holding only end-of-block
-        for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
+        for (uint32_t i = tid; i < obuf_words; i += TN) obuf[i] = 0;
         __syncthreads();
         if (tid == 0) { obuf[0] = z.carry; put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 10); }
         z.bitpos += 10;
         __syncthreads();
         return;
     }
-    for (int i = tid; i < 320; i += NT) S.freq[i] = 0;
+    LZP_DECL
+    for (int i = tid; i < 320; i += TN) S.freq[i] = 0;
     if (tid < 8) S.red[tid] = 0;
     if (tid < 20) S.clfreq[tid] = 0;
-    // ---- match: rounds of NT positions ----
-    const int nround = (len + NT - 1) / NT;
+    // ---- match: rounds of TN positions ----
+    const int nround = (len + TN - 1) / TN;
+    // (wide rounds) a round's positions enter cur[] BEFORE the round: round 0's here, round r + 1's under the last table writes of round r, so
+    // that the barrier that ends those writes also completes cur[] — five barriers per round of 1024 positions instead of six
+    uint32_t w_n = 0, h_n = 0;                               // my position of the coming round: its four bytes and their hash
+    auto enter_cur = [&](int r) {
+        const int i = r * TN + tid;
+        if (i + LZ_MINLEN <= len) {
+            w_n = lds_load32u(X.win + WOFF + (uint32_t)i);
+            h_n = (w_n * 2654435761u) >> (32 - C::HBITS);
+            atomicMin(&X.cur[h_n & 1023u], ((0xFFFFu - (uint32_t)r) << 16) | (uint32_t)i);
+        }
+    };
+    if constexpr (TN > 256) {
+        for (int i = tid; i < 1024; i += TN) X.cur[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        enter_cur(0);
+    }
     for (int r = 0; r < nround; r++) {
-        const int i = r * NT + tid;
+        const int i = r * TN + tid;
         const bool act = i + LZ_MINLEN <= len;
         uint32_t w = 0, h = 0, best_l = 0, best_d = 0;
         const uint32_t p16 = (abs0 + (uint32_t)i) & 0xFFFFu;
+        uint32_t dcur = 0;                                   // distance to the round's earliest position with my hash (0: none in front of me)
+        if constexpr (TN > 256) {
+            const uint32_t rkey = (0xFFFFu - (uint32_t)r) << 16;
+            __syncthreads();                                 // cur[] holds this round; the table holds every round before it
+            if (act) {
+                const uint32_t ce = X.cur[h_n & 1023u];
+                if ((ce & 0xFFFF0000u) == rkey && (ce & 0xFFFFu) < (uint32_t)i) dcur = (uint32_t)i - (ce & 0xFFFFu);
+            }
+        }
         if (act) {
             const uint32_t widx = WOFF + (uint32_t)i;
-            w = lds_load32u(X.win + widx);
-            h = (w * 2654435761u) >> (32 - C::HBITS);
             const uint32_t maxl = min(258u, (uint32_t)(len - i)), avail = (uint32_t)i + hist;
+            // my four bytes, the four in front of them and the four behind them: twelve consecutive bytes = four ALIGNED dwords (neighbouring lanes read
+            // the same ones: no bank conflicts) and three byte-aligns in registers, instead of three unaligned loads of two dwords each.
+            // prev4: the candidates at distances 1..4 come out of (prev4 : w) in registers (round 3: a third of the matcher's LDS reads);
+            // w2: a verified candidate's length is settled by ONE more dword compare in nearly every case (raw signals match over 4 - 5
+            // bytes); only a candidate that agrees over all eight bytes walks on
+            uint32_t prev4, w2;
+            if (WOFF > 0 || widx >= 4u) {
+                const uint32_t a = widx - 4u;
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(X.win + (a & ~3u));
+                const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], sh = (a & 3u) * 8u;
+                prev4 = __builtin_amdgcn_alignbit(q1, q0, sh);
+                w = __builtin_amdgcn_alignbit(q2, q1, sh);
+                w2 = __builtin_amdgcn_alignbit(q3, q2, sh);
+            } else {
+                prev4 = 0u;
+                w = lds_load32u(X.win + widx);
+                w2 = lds_load32u(X.win + widx + 4);
+            }
+            h = (w * 2654435761u) >> (32 - C::HBITS);
             const uint2 e = *reinterpret_cast<const uint2 *>(&X.table[h * LZ_WAYS]);
-            // the four bytes in front of mine: the candidates at distances 1..4 come out of (prev4 : w) in registers (one byte-align each)
-            // instead of four more unaligned LDS loads (round 3: a third of the matcher's LDS reads)
-            const uint32_t prev4 = avail >= 4u ? lds_load32u(X.win + widx - 4) : 0u;
-            // ... and the four bytes behind mine: a verified candidate's length is settled by ONE more dword compare in nearly every case
-            // (raw signals match over 4 - 5 bytes); only a candidate that agrees over all eight bytes walks on
-            const uint32_t w2 = lds_load32u(X.win + widx + 4);
+            constexpr int NC = TN > 256 ? 9 : 8;             // table ways 0..3, distances 1..4, (wide rounds) the round's earliest position
+            // (loading the first dwords of all far candidates side by side, before any is looked at, was measured: 38.1 -> 32.8 GB/s on the long shape,
+            // 64.6 -> 61.4 on the short one — the matcher is bound by LDS throughput now, not by the candidates' round trips)
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < NC; k++) {
                 const uint32_t ent = k == 0 ? e.x & 0xFFFFu : k == 1 ? e.x >> 16 : k == 2 ? e.y & 0xFFFFu : e.y >> 16;
-                const uint32_t d = k < 4 ? (p16 - ent) & 0xFFFFu : (uint32_t)(k - 3);
+                const uint32_t d = k < 4 ? (p16 - ent) & 0xFFFFu : k < 8 ? (uint32_t)(k - 3) : dcur;
                 bool hit;
-                if (k < 4) hit = d >= 1 && d <= avail && d <= 32768u && lds_load32u(X.win + widx - d) == w;
+                if (k < 4 || k == 8) hit = d >= (k == 8 ? 5u : 1u) && d <= avail && d <= 32768u && lds_load32u(X.win + widx - d) == w;
                 else hit = avail >= 4u && __builtin_amdgcn_alignbyte(w, prev4, 4u - d) == w;
                 if (hit) {
-                    const uint32_t x = (k < 4 ? lds_load32u(X.win + widx - d + 4) : __builtin_amdgcn_alignbyte(w2, w, 4u - d)) ^ w2;
+                    const uint32_t x = (k < 4 || k == 8 ? lds_load32u(X.win + widx - d + 4) : __builtin_amdgcn_alignbyte(w2, w, 4u - d)) ^ w2;
                     uint32_t l = x ? 4u + ((uint32_t)__ffs((int)x) - 1u) / 8u : 8u;
                     if (l >= maxl) l = maxl;                                   // (the bytes behind the block's end do not count)
                     else if (!x) l = lz_match_len(X.win, widx, widx - d, maxl, 8u);
@@ -164,15 +242,22 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
         // the passes behind it need not walk the window again for nearly every match (raw signals: matches of 4 - 5 bytes)
         if (i < len) X.D[i] = best_l >= (uint32_t)LZ_MINLEN ? (uint16_t)(best_d | (C::HIST ? 0u : (min(best_l, 11u) - 4u) << 13)) : (uint16_t)0;
         __syncthreads();
-        if (act) X.table[h * LZ_WAYS + wave_id()] = (uint16_t)p16;   // wave k fills way k: see the header note on determinism
-        __syncthreads();
+        // wave k fills way k & 3: see the header note on determinism.  With more than four waves the waves that share a way write in turn
+        // (lower positions first), a barrier between them, so that the survivor of a bucket does not depend on the waves' timing
+#pragma unroll
+        for (int g = 0; g < TN / 256; g++) {
+            if (act && (wave_id() >> 2) == g) X.table[h * LZ_WAYS + (wave_id() & 3)] = (uint16_t)p16;
+            if (TN == 256 || g + 1 < TN / 256) __syncthreads();
+        }
+        if constexpr (TN > 256) { if (r + 1 < nround) enter_cur(r + 1); }   // (the barrier at the top of the next round ends the last group's writes too)
     }
+    LZP(0)
     // ---- parse: lane-local greedy parses, entry offsets handed on until they settle ----
     uint64_t tok = 0, mat = 0;
     {
         uint32_t my_entry = 0;
         const int end = min(base + K, len);
-        for (int guard = 0; guard <= NT + 1; guard++) {
+        for (int guard = 0; guard <= TN + 1; guard++) {
             tok = 0; mat = 0;
             int pos = base + (int)my_entry;
             while (pos < end) {
@@ -189,6 +274,10 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
             const uint32_t ne = tid ? X.entry[tid] : 0u;
             const int changed = ne != my_entry;
             my_entry = ne;
+            LZP(1)
+#ifdef S5_LZPROBE
+            if (threadIdx.x == 0) atomicAdd(&g_lzprobe[9], 1ull);
+#endif
             if (!__syncthreads_or(changed)) break;
         }
         // the settled parse: park every match's length behind its distance (position p + 1 lies inside the match)
@@ -203,6 +292,7 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
         }
     }
     __syncthreads();
+    LZP(2)
     // ---- histograms, Adler-32 partial sums ----
     uint32_t nextra = 0, a_sum = 0, b_sum = 0;
     {
@@ -240,6 +330,7 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
     }
     if (tid == 0) atomicAdd(&S.freq[256], 1u);
     __syncthreads();
+    LZP(3)
     // ---- code lengths and codes: lit/len on wave 0, distances on wave 1; waves 2-3 clear the bit buffer ----
     if (wave_id() == 0) {
         const bool ok = assign_lengths_wave(S.freq, NLIT, S.lens, S.blcount, S.bins);
@@ -250,9 +341,10 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
         if (lane_id() == 0 && !ok) S.red[7] = 1;
         assign_codes_wave(X.blcount_d, S.lens + DOFF, 30, S.code + DOFF);
     } else {
-        for (uint32_t i = tid - 128; i < obuf_words; i += NT - 128) obuf[i] = 0;
+        for (uint32_t i = tid - 128; i < obuf_words; i += TN - 128) obuf[i] = 0;
     }
     __syncthreads();
+    LZP(4)
     if (tid == 0) obuf[0] = z.carry;
     // ---- header (wave 0), block costs (waves 1-3) ----
     if (wave_id() == 0) {
@@ -262,7 +354,7 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
         cl_header_wave(S, hdist);
     } else {
         uint32_t dynb = 0, fixb = 0;
-        for (int s = tid - 64; s < 320; s += NT - 64) {
+        for (int s = tid - 64; s < 320; s += TN - 64) {
             const uint32_t f = S.freq[s];
             if (s < NLIT) { dynb += f * S.lens[s]; fixb += f * fixed_len(s); }
             else if (s >= DOFF && s < DOFF + 30) { dynb += f * S.lens[s]; fixb += f * 5u; }
@@ -272,6 +364,7 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
         if (lane_id() == 0) { atomicAdd(&S.red[4], dynb); atomicAdd(&S.red[5], fixb); }
     }
     __syncthreads();
+    LZP(5)
     const uint32_t extra = S.red[1], hdist = S.icount[0];
     const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
     const uint32_t dyn_total = hdr_dyn + S.red[4] + extra;
@@ -290,7 +383,7 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
             put_bits(obuf, z, bytepos * 8, (uint32_t)len | ((~(uint32_t)len) << 16), 32);
         }
         __syncthreads();
-        for (int i = tid; i < len; i += NT) ob8[4 + i] = cur[i];
+        for (int i = tid; i < len; i += TN) ob8[4 + i] = cur[i];
         z.bitpos = (bytepos + 4 + (uint32_t)len) * 8;
         __syncthreads();
         return;
@@ -300,7 +393,7 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
     uint32_t clv[2] = {0, 0}, clnb[2] = {0, 0};
     if (use_fixed) {
         __syncthreads();   // every lane has read the dynamic code's costs
-        for (int s = tid; s < 288; s += NT) S.code[s] = fixed_code(s);
+        for (int s = tid; s < 288; s += TN) S.code[s] = fixed_code(s);
         if (tid < 30) S.code[DOFF + tid] = (__brev((uint32_t)tid) >> 27) | (5u << 16);
         if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
         pos0 = z.bitpos + 3;
@@ -342,8 +435,9 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
             } else mybits += S.code[cur[pos]] >> 16;
         }
     }
+    LZP(6)
     uint32_t packed_total;
-    const uint32_t packed = block_excl_add((clnb[0] + clnb[1]) | (mybits << 13), S.ws, packed_total);
+    const uint32_t packed = block_excl_add_w<TN / 64>((clnb[0] + clnb[1]) | (mybits << 13), S.ws, packed_total);
     const uint32_t total_bits = packed_total >> 13;
     if (!use_fixed) {
         const uint32_t p = z.bitpos + 17 + 3 * S.hclen + (packed & 0x1FFF);
@@ -388,6 +482,10 @@ __device__ __forceinline__ void deflate_block_lz(DeflShared &S, LzSharedT<C> &X,
     if (tid == 0) put_bits(obuf, z, pos0 + total_bits, eob & 0xFFFF, eob >> 16);
     z.bitpos = pos0 + total_bits + (eob >> 16);
     __syncthreads();
+    LZP(7)
+#ifdef S5_LZPROBE
+    if (tid == 0) atomicAdd(&g_lzprobe[15], 1ull);
+#endif
 }
 
 }  // namespace s5
