@@ -579,16 +579,22 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
 // zlib header written here once B is dead (caller passes z.bitpos = 80, z.flushed = 0, obuf_words = size to zero).
 // MODE 2 (staged, multi-block): B overlays obuf as well; between blocks the only live word of obuf is the partial word
 // obuf[0], which travels in z.carry and is put back after the zeroing.
-template <int MODE, typename M = uint64_t>
+// TN: threads of the calling workgroup (round 4).  The staged kernel is held to four workgroups per CU by its LDS (a 16 KiB block + its bit buffer), and
+// at 256 threads that is half the waves the fused kernel needs to cover its LDS latency: it runs 512 threads per workgroup — a lane owns 32 bytes of a
+// block, 32-bit position masks, byte loads, exactly the shape of the fused kernel on a payload of 8 KiB.
+template <int MODE, typename M = uint64_t, int TN = NT>
 __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words,
                                               const uint8_t *__restrict__ buf, int len, bool final, ZOut &z, uint32_t &adA,
                                               uint32_t &adB, uint32_t dbg = 0, EarlySize es = EarlySize{nullptr, 0}) {
     using MO = MaskOps<M>;
     const int tid = threadIdx.x;
     constexpr bool FUSED = MODE == 1;
+    constexpr int NWV = TN / 64;
+    static_assert(TN % 64 == 0 && NWV >= 4 && NWV <= 8, "S.ws holds two words per wave");
+    static_assert(TN == NT || MODE == 2, "more than 256 threads: the staged form (its per-lane scratch lies in the bit buffer, which is dead then)");
     if (len == 0) {
         if (MODE != 0) {
-            for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
+            for (uint32_t i = tid; i < obuf_words; i += TN) obuf[i] = 0;
             __syncthreads();
             if (tid == 0) { if (FUSED) put_bits(obuf, z, 64, 0x9c78u, 16); else obuf[0] = z.carry; }
         }   // empty stream: fixed block holding only end-of-block
@@ -603,7 +609,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     // dword (buf is 4-byte aligned) — measured +28 % on 100 k-sample reads.  Small blocks (32-bit masks, 8 workgroups per CU)
     // are VALU bound: byte loads arrive zero-extended and save the extraction instructions — measured 3 % faster than dwords.
     constexpr bool DW = sizeof(M) == 8;
-    const int K = DW ? (((len + NT - 1) / NT + 3) & ~3) : (len + NT - 1) / NT;
+    const int K = DW ? (((len + TN - 1) / TN + 3) & ~3) : (len + TN - 1) / TN;
     const int base = tid * K;
     auto load4 = [&](int j, int &b0, int &b1, int &b2, int &b3) -> uint32_t {
         if constexpr (DW) {
@@ -617,7 +623,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     };
     const int kk = max(0, min(K, len - base));
 
-    for (int i = tid; i < 320; i += NT) S.freq[i] = 0;
+    for (int i = tid; i < 320; i += TN) S.freq[i] = 0;
     if (tid < 8) S.red[tid] = 0;
     if (tid < 20) S.clfreq[tid] = 0;
 
@@ -673,19 +679,20 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         const bool has = brk != 0;
         const uint64_t bal = __ballot(has);
         if (lane_id() == 0) { S.ws[2 * wave_id()] = (uint32_t)bal; S.ws[2 * wave_id() + 1] = (uint32_t)(bal >> 32); }
-        if (has) S.code[tid] = (uint32_t)local_first | ((uint32_t)local_last << 16);
+        uint32_t *fl = TN > 320 ? obuf : S.code;   // one word per lane: S.code (not yet in use) has 320, the bit buffer (not yet in use either) has more
+        if (has) fl[tid] = (uint32_t)local_first | ((uint32_t)local_last << 16);
         __syncthreads();
         int up_lane = -1, dn_lane = -1;            // wave-uniform (kept in SGPRs): nearest break-owning lane in a later / earlier wave
         const int wv = __builtin_amdgcn_readfirstlane(wave_id());
 #pragma unroll
-        for (int w = NW - 1; w >= 0; w--) {
+        for (int w = NWV - 1; w >= 0; w--) {
             const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w]);
             const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w + 1]);
             const uint64_t mw = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
             if (w > wv && mw) up_lane = w * 64 + __ffsll((long long)mw) - 1;
         }
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
+        for (int w = 0; w < NWV; w++) {
             const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w]);
             const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w + 1]);
             const uint64_t mw = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
@@ -696,8 +703,8 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         const uint64_t below = bal & ((1ull << lane) - 1);
         const int up = above ? wave_id() * 64 + __ffsll((long long)above) - 1 : up_lane;
         const int dn = below ? wave_id() * 64 + 63 - __clzll((long long)below) : dn_lane;
-        nextb = up >= 0 ? (int)(S.code[up] & 0xFFFFu) : len;
-        lastb = dn >= 0 ? (int)(S.code[dn] >> 16) : -1;
+        nextb = up >= 0 ? (int)(fl[up] & 0xFFFFu) : len;
+        lastb = dn >= 0 ? (int)(fl[dn] >> 16) : -1;
     }   // S.ws / S.code are next written behind later barriers
     if (dbg == 22) { z.bitpos += (uint32_t)brk + a_sum + b_sum + lastb + nextb; return; }
 
@@ -817,7 +824,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     build_lengths(S, B, &B.sort, S.freq, NLIT, 15, S.lens, S.blcount, S.icount);
     if (dbg == 3 || dbg == 31 || dbg == 32) { z.bitpos += S.lens[tid] + B.lf[tid] + B.nf[tid]; return; }
     if (MODE != 0) {   // B is dead from here on: its storage becomes the bit buffer
-        for (uint32_t i = tid; i < obuf_words; i += NT) obuf[i] = 0;
+        for (uint32_t i = tid; i < obuf_words; i += TN) obuf[i] = 0;
         __syncthreads();
     }
 #else
@@ -826,7 +833,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         const bool ok = assign_lengths_wave(S.freq, NLIT, S.lens, S.blcount, S.bins);
         if (lane_id() == 0) S.dbg = ok ? 0u : 1u;
     } else if (MODE != 0) {
-        for (uint32_t i = tid - 64; i < obuf_words; i += NT - 64) obuf[i] = 0;
+        for (uint32_t i = tid - 64; i < obuf_words; i += TN - 64) obuf[i] = 0;
     }
     __syncthreads();
     if (dbg == 3) { z.bitpos += S.lens[tid]; return; }
@@ -852,7 +859,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         assign_codes_wave(S.blcount, S.lens, NLIT, S.code);   // canonical lit/len codes, concurrently with wave 0
     } else {
         uint32_t dynb = 0, fixb = 0;
-        for (int s = tid - 128; s < NLIT; s += NT - 128) {
+        for (int s = tid - 128; s < NLIT; s += TN - 128) {
             const uint32_t f = S.freq[s];
             dynb += f * S.lens[s];
             fixb += f * fixed_len(s);
@@ -885,7 +892,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
             put_bits(obuf, z, bytepos * 8, (uint32_t)len | ((~(uint32_t)len) << 16), 32);
         }
         __syncthreads();
-        for (int i = tid; i < len; i += NT) ob8[4 + i] = buf[i];
+        for (int i = tid; i < len; i += TN) ob8[4 + i] = buf[i];
         z.bitpos = (bytepos + 4 + (uint32_t)len) * 8;
         __syncthreads();
         return;
@@ -900,8 +907,8 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     uint32_t dist_bits, dist_code = 0;
     uint32_t clv[2] = {0, 0}, clnb[2] = {0, 0};   // this lane's two code-length-sequence entries (dynamic only)
     if (use_fixed) {
-        for (int s = tid; s < 288; s += NT) S.code[s] = fixed_code(s);
-        for (int s = tid; s < 288; s += NT) S.lens[s] = (uint8_t)fixed_len(s);   // (the bit count reads the lengths as bytes)
+        for (int s = tid; s < 288; s += TN) S.code[s] = fixed_code(s);
+        for (int s = tid; s < 288; s += TN) S.lens[s] = (uint8_t)fixed_len(s);   // (the bit count reads the lengths as bytes)
         if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
         pos0 = z.bitpos + 3;
         dist_bits = 5;
@@ -975,7 +982,7 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
         }
     }
     uint32_t packed_total;
-    const uint32_t packed = block_excl_add((clnb[0] + clnb[1]) | (mybits << 13), S.ws, packed_total);
+    const uint32_t packed = block_excl_add_w<NWV>((clnb[0] + clnb[1]) | (mybits << 13), S.ws, packed_total);
     const uint32_t total_bits = packed_total >> 13;
     const uint32_t start = pos0 + (packed >> 13);
     publish_size(es, pos0 + total_bits + (S.code[256] >> 16));

@@ -121,6 +121,23 @@ __device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *ws, uin
     total = tot;
     return base + incl - v;
 }
+// workgroup exclusive prefix sum for a workgroup of NWV waves (block_excl_add above is the NW = 4 form)
+template <int NWV>
+__device__ __forceinline__ uint32_t block_excl_add_w(uint32_t v, uint32_t *ws, uint32_t &total) {
+    const uint32_t incl = wave_incl_add(v);
+    if (lane_id() == 63) ws[wave_id()] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; w++) {
+        const uint32_t x = ws[w];
+        if (w < wave_id()) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
 // exclusive prefix max (identity `ident`)
 __device__ __forceinline__ int block_excl_max(int v, int ident, uint32_t *ws) {
     int incl = wave_incl_max(v);

@@ -9,6 +9,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/slow5gpu.h"
@@ -331,6 +332,14 @@ __global__ __launch_bounds__(NT, S5_PACK_WG) void k_pack(EncParams p, int mode, 
 
 // Staged path, step 2: DEFLATE a parked payload, 16 KiB block at a time through LDS, in place in the read's slot.  Returns the record's
 // length (u64 prefix included; uniform); the prefix and out_len[r] are written here.
+// Threads of the staged kernel's workgroup.  Its LDS — a 16 KiB block, the block's bit buffer, the tables — allows four workgroups per CU, 16 waves at
+// 256 threads where the same code in the fused kernel needs 32; round 4 made deflate_block a template on the thread count and measured 512 (a lane owns
+// 32 bytes: 32-bit masks, byte loads, the fused kernel's shape): 64 VGPRs with 51 of them spilled (the block loop's state on top of the fused kernel's),
+// and the long-read leg takes 26.9 ms per step against 21.5 (80 VGPRs / 24 waves: 27.7) — profiles/r04_staged_threads.txt.  256 stays.
+#ifndef S5_STAGED_TN
+#define S5_STAGED_TN 256
+#endif
+using StagedMask = std::conditional<S5_STAGED_TN >= 512, uint32_t, uint64_t>::type;
 __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, uint32_t r, const s5gpu_read_desc_t &d, uint32_t plen, DeflShared &S, uint32_t *obuf, BuildScratch &B, uint8_t *stage) {
     const int tid = threadIdx.x;
     uint8_t *out = p.a.slots + d.out_off;
@@ -348,13 +357,13 @@ __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, ui
         {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
             const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
             uint4 *d4 = reinterpret_cast<uint4 *>(stage);
-            for (uint32_t i = tid; i < (blen + 15) / 16; i += NT) d4[i] = s4[i];
+            for (uint32_t i = tid; i < (blen + 15) / 16; i += S5_STAGED_TN) d4[i] = s4[i];
         }
         __syncthreads();
-        deflate_block<2, uint64_t>(S, B, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
+        deflate_block<2, StagedMask, S5_STAGED_TN>(S, B, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
         done += blen;
         if (!final) {
-            flush_words(obuf, out32, z, false);
+            flush_words<S5_STAGED_TN>(obuf, out32, z, false);
             z.carry = obuf[0];      // uniform: every lane reads the same word (flush_words ends on a barrier)
             __syncthreads();        // ... before the next block's scratch overwrites it
         }
@@ -363,7 +372,7 @@ __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, ui
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
     z.bitpos += 32;
     __syncthreads();
-    flush_words(obuf, out32, z, true);
+    flush_words<S5_STAGED_TN>(obuf, out32, z, true);
     const uint32_t total = z.bitpos >> 3;
     __syncthreads();
     if (tid == 0) {
@@ -373,9 +382,9 @@ __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, ui
     return total;
 }
 #ifndef S5_STAGED_WG
-#define S5_STAGED_WG 4
+#define S5_STAGED_WG (S5_STAGED_TN >= 512 ? 8 : 4)   // (the second launch bound counts WAVES PER SIMD: four workgroups of 512 threads per CU are eight)
 #endif
-__global__ __launch_bounds__(NT, S5_STAGED_WG) void k_deflate_staged(EncParams p, int use_list, const uint32_t *ord) {
+__global__ __launch_bounds__(S5_STAGED_TN, S5_STAGED_WG) void k_deflate_staged(EncParams p, int use_list, const uint32_t *ord) {
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     BuildScratch &B = *reinterpret_cast<BuildScratch *>(obuf);   // dead whenever the bit buffer is live (deflate_block MODE 2)
@@ -1790,12 +1799,12 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
         if (a->lds_payload_cap) { const int rc2 = launch_eorder(a, st, &eord, hold); if (rc2) return rc2; }
         hipLaunchKernelGGL(k_pack, dim3(g), dim3(NT), 0, st, p, 2, eord);
         if (zs) hipLaunchKernelGGL(k_zstd_staged, dim3(g), dim3(NT), st_lds, st, p, 1);
-        else hipLaunchKernelGGL(k_deflate_staged, dim3(g), dim3(NT), st_lds, st, p, 1, eord);
+        else hipLaunchKernelGGL(k_deflate_staged, dim3(g), dim3(S5_STAGED_TN), st_lds, st, p, 1, eord);
     } else {
         p.obuf_words = st_obuf; p.pay_cap = DEFL_BLK;
         hipLaunchKernelGGL(k_pack, dim3(a->n_reads), dim3(NT), 0, st, p, 0, nullptr);
         if (a->rec_method == S5GPU_REC_ZSTD) hipLaunchKernelGGL(k_zstd_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0);
-        else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), st_lds, st, p, 0, nullptr);
+        else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(S5_STAGED_TN), st_lds, st, p, 0, nullptr);
     }
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
@@ -1890,7 +1899,7 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
     if (a->rec_method == S5GPU_REC_ZSTD) hipLaunchKernelGGL(k_zstd_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0);
     else if (a->sig_method == S5GPU_SIG_NONE)   // byte ranges of unknown kind (the solo zlib press): the LZ77 matcher
         launch_lz(p, a->n_reads, a->max_payload, (hipStream_t)stream_);
-    else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(NT), lds, (hipStream_t)stream_, p, 0, nullptr);
+    else hipLaunchKernelGGL(k_deflate_staged, dim3(a->n_reads), dim3(S5_STAGED_TN), lds, (hipStream_t)stream_, p, 0, nullptr);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }

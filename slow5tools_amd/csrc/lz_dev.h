@@ -54,23 +54,7 @@ template <int BLK_, int HBITS_, bool HIST_, int TN_ = NT>
 struct LzCfg { static constexpr int BLK = BLK_, HBITS = HBITS_, TN = TN_; static constexpr bool HIST = HIST_; static constexpr int WOFF = HIST_ ? BLK_ : 0; };
 using LzLong = LzCfg<LZ_BLK, 13, true, S5_LZ_TN>;
 using LzShort = LzCfg<8192, 10, false>;
-// workgroup exclusive prefix sum for a workgroup of NWV waves (dev_common.h's block_excl_add is the NW = 4 form)
-template <int NWV>
-__device__ __forceinline__ uint32_t block_excl_add_w(uint32_t v, uint32_t *ws, uint32_t &total) {
-    const uint32_t incl = wave_incl_add(v);
-    if (lane_id() == 63) ws[wave_id()] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NWV; w++) {
-        const uint32_t x = ws[w];
-        if (w < wave_id()) base += x;
-        tot += x;
-    }
-    __syncthreads();
-    total = tot;
-    return base + incl - v;
-}
+
 
 template <class C>
 struct LzSharedT {
