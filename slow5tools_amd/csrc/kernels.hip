@@ -177,8 +177,8 @@ __device__ __forceinline__ uint32_t build_payload_hbm(const s5gpu_encode_args_t 
 #ifndef S5_FUSED_WG_PER_CU
 #define S5_FUSED_WG_PER_CU 8
 #endif
-template <typename M, bool EXZD = false>
-__global__ __launch_bounds__(NT, S5_FUSED_WG_PER_CU) void k_encode_fused(EncParams p) {
+template <typename M, bool EXZD = false, int WPS = S5_FUSED_WG_PER_CU>   // WPS: waves per SIMD the registers are budgeted for (the second fused launch of a
+__global__ __launch_bounds__(NT, WPS) void k_encode_fused(EncParams p) {     // mixed batch holds 36 KiB of LDS: four workgroups per CU, so 128 VGPRs)
     const uint32_t r = blockIdx.x;
     if (p.tier == 2 && p.a.out_len[r] != 0) return;   // (uniform) done by the first launch
     DeflShared &S = *reinterpret_cast<DeflShared *>(smem);
@@ -1684,6 +1684,7 @@ static int set_lds_attrs() {
     if (g_attr_devs.load(std::memory_order_relaxed) & bit) return S5GPU_OK;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint64_t, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_stream<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -1786,7 +1787,9 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
                 p.tier = 2;
                 p.pay_cap = cap2;
                 p.obuf_words = (cap2 + 64 > B_BYTES ? cap2 + 64 : B_BYTES) / 4;
-                fused(cap2, S_BYTES + 4ull * p.obuf_words + p.pay_cap);
+                const size_t l2 = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
+                if (cap2 > 8192 && !xz) hipLaunchKernelGGL((k_encode_fused<uint64_t, false, 4>), dim3(a->n_reads), dim3(NT), l2, st, p);   // registers for the four workgroups per CU its LDS allows
+                else fused(cap2, l2);
                 p.tier = 0;
             }
         }
