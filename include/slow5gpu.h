@@ -168,7 +168,10 @@ int s5gpu_device_count(void);
  * "unpack_fused" (0/1, default 1): s5gpu_decode_dev on zlib / zstd + svb-zd records lets the wave that decompressed a record parse it and decode
  * its signal as well (fields.reserved is scratch on the way and 0 at the end); 0 = always the separate unpack kernel.
  * "zstd_sequences" (0/1, default 1): the zstd encoder sends runs of >= 5 equal bytes as one literal + one match at the repeat
- * offset (predefined FSE tables); 0 = literals-only frames cut at the record's seams (round 1; ~2 % larger records). */
+ * offset (predefined FSE tables); 0 = literals-only frames cut at the record's seams (round 1; ~2 % larger records).
+ * "fused_tier2" (bytes, 0 .. 16384, default 0 = off): batches of mixed lengths (s5gpu_encode_args.lds_payload_cap named) get a SECOND
+ * one-workgroup-per-read launch with this LDS budget for the reads between the named budget and one 16 KiB DEFLATE block, before
+ * the HBM-staged kernels take the rest; measured on real-run read lengths it gains nothing (profiles/r04_mixed_tier2.txt). */
 int s5gpu_set_option(const char *key, long value);
 
 /* ---- device-resident entry points (asynchronous on `hip_stream`, a hipStream_t; NULL = default) ---- */
