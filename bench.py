@@ -431,6 +431,8 @@ def svb_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, K, W):
     kern_s = float(np.mean(enc)) / 1e3
     kname = "k_svbzd_stream" if one_pass else "k_svbzd_encode"
     traffic, traffic_src = pmc_traffic(kname, n, n_reads)
+    # which form is the faster one changed in round 4 (k_compact with 16-byte copies: the two launches 4.7 ms, the one-launch kernel 4.8): the leg's value
+    # is the form the timed region ran (one launch unless --two-pass); the other form's figure stands beside it (`two_pass`)
     return {
         "workload": "BASELINE configs[1]: svb-zd zig-zag-delta encode only, %d reads x %d int16 samples per GPU, bit-exact vs the CPU svb" % (n_reads, n),
         "value": round(2 * n * n_reads * world * K / dt / 1e9, 3), "unit": "GB/s", "reads_per_s": round(n_reads * world * K / dt, 1),

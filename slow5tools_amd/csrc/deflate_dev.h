@@ -560,9 +560,21 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
     const int tid = threadIdx.x;
     const uint32_t full = final_all ? (z.bitpos + 31) >> 5 : z.bitpos >> 5;
     const uint32_t n = full - z.flushed;
-    for (uint32_t i = tid; i < n; i += TN) {
-        const uint32_t w = z.flushed + i;
-        if (w >= 2) out32[w] = obuf[i];   // words 0,1 = u64 size prefix, written last by lane 0
+    {   // four words per lane: an aligned 16-byte LDS read, a 16-byte store wherever the stream stands (z.flushed is any word count)
+        typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+        typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+        const u4a *s16 = reinterpret_cast<const u4a *>(obuf);
+        const uint32_t nv = n >> 2;
+        for (uint32_t j = tid; j < nv; j += TN) {
+            const uint32_t w = z.flushed + 4u * j;
+            const u4a v = s16[j];
+            if (w >= 2) *reinterpret_cast<u4u *>(out32 + w) = v;
+            else { out32[w + 2] = v.z; out32[w + 3] = v.w; }   // (w = 0) words 0,1 = u64 size prefix, written last by lane 0
+        }
+        for (uint32_t i = 4u * nv + tid; i < n; i += TN) {
+            const uint32_t w = z.flushed + i;
+            if (w >= 2) out32[w] = obuf[i];
+        }
     }
     if (final_all) return;
     __syncthreads();
@@ -1187,19 +1199,18 @@ __device__ __forceinline__ uint64_t lookback_offset(unsigned long long *st, uint
     return excl;
 }
 // copy `total` bytes of the LDS record image (word-aligned at obuf) to a byte-aligned HBM destination
+// `total` bytes from LDS (obuf: 16-byte aligned) to dst (any alignment: BLOW5 framing has no padding).  Round 4: a lane moves 16 bytes — one aligned
+// ds_read_b128, one UNALIGNED 16-byte global store (the memory system takes it: a wave still writes one contiguous kilobyte) — instead of a dword put
+// together from two LDS dwords by a funnel shift; the last total % 16 bytes go one per lane
 __device__ __forceinline__ void copy_record_out(const uint32_t *obuf, uint32_t total, uint8_t *dst) {
     const int tid = threadIdx.x;
+    typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(1)));
+    typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+    const u4a *s16 = reinterpret_cast<const u4a *>(obuf);
+    const uint32_t nv = total >> 4;
+    for (uint32_t i = tid; i < nv; i += NT) *reinterpret_cast<u4u *>(dst + 16u * i) = s16[i];
+    const uint32_t tail0 = 16u * nv;
     const uint8_t *ob8 = reinterpret_cast<const uint8_t *>(obuf);
-    const uint32_t head = min(total, (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3));
-    if ((uint32_t)tid < head) dst[tid] = ob8[tid];
-    const uint32_t nw = (total - head) >> 2;
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
-    const uint32_t sh = head * 8;
-    for (uint32_t i = tid; i < nw; i += NT) {
-        const uint32_t lo = obuf[i], hi = obuf[i + 1];
-        d32[i] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
-    }
-    const uint32_t tail0 = head + 4 * nw;
     if ((uint32_t)tid < total - tail0) dst[tail0 + tid] = ob8[tail0 + tid];
 }
 

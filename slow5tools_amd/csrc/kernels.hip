@@ -310,8 +310,8 @@ __device__ __forceinline__ uint32_t ovf_at(const uint32_t *ovf, const uint32_t *
 #endif
 __global__ __launch_bounds__(NT, S5_PACK_WG) void k_pack(EncParams p, int mode, const uint32_t *ord) {
     __shared__ uint32_t ws[16];
-    __shared__ uint32_t tile_keys[SVB_TILE / 16 + 4];       // one tile's key bytes (4096 / 4) ...
-    __shared__ uint32_t tile_data[3 * SVB_TILE / 4 + 4];    // ... and data bytes (at most 3 per int16 sample), + the copy's look-ahead word
+    __shared__ __attribute__((aligned(16))) uint32_t tile_keys[SVB_TILE / 16 + 4];       // one tile's key bytes (4096 / 4) ...
+    __shared__ __attribute__((aligned(16))) uint32_t tile_data[3 * SVB_TILE / 4 + 4];    // ... and data bytes (at most 3 per int16 sample), + the copy's slack
     const uint32_t count = mode == 2 ? p.a.ovf[0] : p.a.n_reads;
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         const uint32_t r = mode == 2 ? ovf_at(p.a.ovf, ord, it) : it;
