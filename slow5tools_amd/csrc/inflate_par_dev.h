@@ -69,7 +69,7 @@ constexpr int IP_WAIT_SVB = S5_IP_WAIT_SVB;       // ... in the instantiation fo
 template <int WAIT>
 struct InflParSharedT {                 // per wave: 6.6 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
                                        // LDS per wave = + 33 % time), so nothing here is larger than it has to be
-    uint32_t win[IP_SPAN / 4 + 8];     // window; the header parser uses its first INF_IW bytes
+    alignas(16) uint32_t win[IP_SPAN / 4 + 8];     // window (16-byte aligned: filled 16 bytes per lane); the header parser uses its first INF_IW bytes
     union {
         uint16_t wq[WAIT];             // waiting match: position in the round's output (< 64 Ki); its length and distance wait in the
                                        // first three of the bytes it will produce — a match is at least three bytes long
@@ -111,11 +111,24 @@ __device__ __forceinline__ uint32_t ip_peek(const uint32_t *win, uint32_t p) {
 // window byte 0 = deflate byte `from` (a multiple of 4 keeps the copy aligned when src is); bytes at or past `total` read as zero
 __device__ __forceinline__ void ip_load_window(uint32_t *win, const uint8_t *src, uint32_t from, uint32_t total) {
     const int lane = lane_id();
+    const uint32_t avail = from < total ? total - from : 0;
+#ifndef S5_IP_WIN4   // (round 4; -DS5_IP_WIN4: the dword form — 28.41 ms per 1 M own records against 28.05, K = 4096 batches 0.2376 ms against 0.2350)
+    // sixteen bytes per lane and step: an UNALIGNED 16-byte global load (the record lies wherever the file put it) into an aligned 16-byte LDS store, for
+    // every vector that lies inside the record; the dwords around the record's end (cut, masked, zero) the old way
+    typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(1)));
+    typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+    constexpr uint32_t NV = (IP_SPAN / 4 + 8) / 4;                       // 258 vectors
+    static_assert((IP_SPAN / 4 + 8) % 4 == 0, "");
+    const uint32_t nfull = min(avail >> 4, NV);
+    for (uint32_t j = lane; j < nfull; j += 64) reinterpret_cast<u4a *>(win)[j] = *reinterpret_cast<const u4u *>(src + from + 16u * j);
+    const uint32_t i0 = 4u * nfull;
+#else
+    const uint32_t i0 = 0;
+#endif
     const uintptr_t addr = reinterpret_cast<uintptr_t>(src) + from;
     const uint32_t *g = reinterpret_cast<const uint32_t *>(addr & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(addr & 3) * 8;
-    const uint32_t avail = from < total ? total - from : 0;
-    for (uint32_t i = lane; i < IP_SPAN / 4 + 8; i += 64) {
+    for (uint32_t i = i0 + lane; i < IP_SPAN / 4 + 8; i += 64) {
         uint32_t w = 0;
         if (4 * i < avail) {
             const uint32_t lo = g[i];
@@ -548,7 +561,24 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             const uint32_t *w32 = reinterpret_cast<const uint32_t *>(out + from);
             uint32_t sa = 0;
             uint64_t sb = 0;
+#ifndef S5_IP_ADLER4   // four dwords per lane and step (the slot is 16-byte aligned, `from` a multiple of 2^20); round 4: with the 16-byte window load
+                       // 28.41 -> 27.74 ms per 1 M own records (35.2 -> 36.1 M reads/s), K = 4096 batches 0.2376 -> 0.2322 ms (-DS5_IP_ADLER4: the dword form)
+            const uint4 *w128 = reinterpret_cast<const uint4 *>(w32);
+            const uint32_t nvec = n / 16;
+            for (uint32_t i = lane; i < nvec; i += 64) {
+                const uint4 v = w128[i];
+                const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t s4 = __builtin_amdgcn_udot4(ww[k], 0x01010101u, 0u, false);
+                    sa += s4;
+                    sb += (uint64_t)((n - 16 * i - 4 * k) * s4 - __builtin_amdgcn_udot4(ww[k], 0x03020100u, 0u, false));
+                }
+            }
+            for (uint32_t i = 4 * nvec + lane; i < n / 4; i += 64) {
+#else
             for (uint32_t i = lane; i < n / 4; i += 64) {
+#endif
                 const uint32_t w = w32[i];
                 const uint32_t s4 = __builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
                 sa += s4;

@@ -204,9 +204,14 @@ __device__ __forceinline__ uint32_t svb_decode_tile_wave(const uint8_t *keys, co
     const int valid = i0 >= n ? 0 : (int)min(16u, n - i0);
     const int nk = (valid + 3) >> 2;
     uint32_t key = 0;
+    if (valid == 16) {   // a full lane's four key bytes as one (unaligned) dword
+        typedef uint32_t u1 __attribute__((aligned(1)));
+        key = *reinterpret_cast<const u1 *>(keys + 4 * lane);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (q < nk) key |= (uint32_t)keys[4 * lane + q] << (8 * q);
+        for (int q = 0; q < 4; q++)
+            if (q < nk) key |= (uint32_t)keys[4 * lane + q] << (8 * q);
+    }
     // bytes of my values: one each + the sum of the 2-bit codes (bits of values past `valid` are masked out)
     uint32_t nbytes;
     {
