@@ -244,6 +244,20 @@ int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec
                            int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
                            int32_t *status);
 
+/* The ARENA form of the two calls above (round 5).  One malloc per record is what slow5_rec_to_mem promises (src/view.c:49,298), and at
+ * a million records per call it is what bounds the call: a million fresh buffers the process has never touched, page-faulted in one by
+ * one.  Here out[i] point INTO a few pinned buffers the device-to-host copies landed in — no copy, no allocation per record — and the
+ * caller gives the whole batch back with ONE s5gpu_arena_release(*arena) once its ordered write loop is through (the free() of
+ * src/view.c:298 goes).  The buffers return to a process-wide pool (up to 6 GB kept; drained by s5gpu_shutdown), so a loop of
+ * similar batches neither allocates nor faults after its first ones.  *arena is NULL when the call fails.  Never free() an out[i]. */
+int s5gpu_encode_batch_arena(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                             const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                             int sig_method, void **out, size_t *out_len, void **arena);
+int s5gpu_recompress_batch_arena(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                 int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                                 int32_t *status, void **arena);
+void s5gpu_arena_release(void *arena);   /* NULL is fine */
+
 /* The same worker on a CHUNK of a BLOW5 file (what bounds `view` end to end is the read and write phases around
  * work_db, /root/reference/src/view.c:265-278,296-299, not the compute).  The n records sit framed — [u64 size][bytes] — in one
  * host buffer `chunk` exactly as read from disk: rec_pos[i] = offset of record i's bytes (behind its size prefix), rec_len[i]

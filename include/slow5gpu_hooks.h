@@ -54,6 +54,15 @@ int slow5_gpu_hook_recompress(int64_t n, char **mem, size_t *bytes, int from_rec
                               int to_record_method, int to_signal_method, const uint32_t *new_read_group, int drop_aux,
                               void **out, size_t *out_len);
 
+/* The same worker with ONE release per batch instead of one free per record (round 5): out[i] point into pinned buffers the library
+ * owns (no malloc, no memcpy, no page fault per record — what holds the malloc form to 5 GB/s at a million records per call), and
+ * the ordered write loop ends with slow5_gpu_hook_release(batch) where it had free(db.read_record[i].buffer) per record
+ * (/root/reference/src/view.c:296-299; INTEGRATION.md shows the three changed lines).  *batch is NULL on failure. */
+int slow5_gpu_hook_recompress_arena(int64_t n, char **mem, size_t *bytes, int from_record_method, int from_signal_method,
+                                    int to_record_method, int to_signal_method, const uint32_t *new_read_group, int drop_aux,
+                                    void **out, size_t *out_len, void **batch);
+void slow5_gpu_hook_release(void *batch);
+
 /* The same worker on a CHUNK of a BLOW5 file, for a loop that reads the file in large pieces instead of one record at a time
  * (examples/s5view.c; 17 GB/s of raw signal end to end against 2.9 with one fread + malloc per record): the n records sit framed
  * — [u64 size][bytes] — in `chunk` exactly as read from disk, rec_pos[i] / rec_len[i] = offset and length of record i's bytes
@@ -90,6 +99,9 @@ int slow5_gpu_hook_depress_parse(int64_t n, char **mem, size_t *bytes, int from_
 /* encode n in-memory reads (f2s-style producers, src/read_fast5.c:176-181): out[i] = [u64 size][record] */
 int slow5_gpu_hook_rec_to_mem(int64_t n, const slow5_gpu_read_t *reads, int drop_aux, int to_record_method, int to_signal_method,
                               void **out, size_t *out_len);
+/* ... into an arena (slow5_gpu_hook_release(batch) instead of n free()s) */
+int slow5_gpu_hook_rec_to_mem_arena(int64_t n, const slow5_gpu_read_t *reads, int drop_aux, int to_record_method, int to_signal_method,
+                                    void **out, size_t *out_len, void **batch);
 
 #ifdef __cplusplus
 }

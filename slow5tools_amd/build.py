@@ -12,7 +12,7 @@ S5VIEW = os.path.join(HERE, "s5view")
 
 HIP_SOURCES = ["kernels.hip", "host_api.hip", "ascii_kernels.hip", "ascii_api.hip"]
 C_SOURCES = ["slow5_compat.c", "blow5_file.c"]
-DEPS = ["dev_common.h", "deflate_dev.h", "lz_dev.h", "inflate_dev.h", "inflate_simt_dev.h", "inflate_par_dev.h", "svb_dev.h", "exzd_dev.h", "zstd_dev.h", "zstd_enc_dev.h", "host_ctx.h",
+DEPS = ["dev_common.h", "deflate_dev.h", "deflate2_dev.h", "lz_dev.h", "inflate_dev.h", "inflate_simt_dev.h", "inflate_par_dev.h", "svb_dev.h", "exzd_dev.h", "zstd_dev.h", "zstd_enc_dev.h", "host_ctx.h",
         os.path.join(ROOT, "include", "slow5gpu.h"), os.path.join(ROOT, "include", "slow5_compat.h"), os.path.join(ROOT, "include", "slow5gpu_hooks.h")]
 
 

@@ -1,0 +1,473 @@
+// deflate2_dev.h — the DEFLATE block encoder of round 5: slabs of 256 positions per wave step instead of a contiguous chunk per lane.
+//
+// Same contract as deflate_block (deflate_dev.h): one block of <= 16 KiB of payload that sits in LDS -> run-length tokens
+// (literal | length 3..258 at distance 1) -> dynamic / fixed / stored DEFLATE block in the LDS bit buffer; stock zlib inflates the
+// stream to the payload (/root/reference/src/view.c:49, zlib behind slow5_rec_to_mem).  What changed is who owns which byte:
+//
+//   round 1-4  lane t owns K = ceil(len / 256) CONTIGUOUS bytes.  The bit offset of a lane's first token needs the bit total of every
+//              lane in front of it: one pass over all bytes only to count bits (851 of 7331 VALU instructions per 4000-sample read),
+//              and the lanes of the svb key area (long zero runs, a handful of tokens) walk their tokens one by one while the lanes
+//              of the data area (every byte a literal) run groups of four — the first wave executes both loops with most lanes off
+//              (profiles/r04_encode_stages.txt: the emit stage 1534 VALU at 32 active lanes of 64).
+//   round 5    a wave walks its region in SLABS of 256 positions, lane t taking four consecutive positions of each slab: every LDS
+//              access of the two passes is one aligned dword per lane, the bit offset inside a slab is one wave prefix scan on the
+//              DPP path, and the offset of a wave's region comes from PER-WAVE HISTOGRAMS (sum of frequency x code length) —
+//              no bit-count pass.  A slab is classified with byte-parallel mask arithmetic on the dword: E = "equal to the
+//              previous byte" per position; a position is a literal unless it lies in a sequence of >= 3 E-positions (a run of
+//              >= 4 equal bytes), and such a sequence is sent by its LAST position as length-258 matches + one shorter match (or
+//              one / two literals), so every decision looks at most two positions ahead — inside the lane's own dword, because the
+//              lane's four positions are taken two to the left of it ("centred frame": positions 256 k + 4 t - 2 .. + 1 from the
+//              dwords at 256 k + 4 t - 4 and 256 k + 4 t).  Slabs without such a sequence (nearly all of the data area) run
+//              without masks and without branches: 4 histogram adds in the first pass; 4 code loads, one 64-bit OR value, one scan
+//              in the second.  Only a sequence that started in front of the slab needs its start: a wave prefix-max over the
+//              last break of every lane, and behind that a backward search (rare).
+//
+// The token sequence is the one deflate_block produces (same literals, same matches), so sizes and the "<= zlib level 6" property of
+// tests/test_full_size.py carry over; code lengths, code-length header and block choice are the same functions.
+#pragma once
+// (included by deflate_dev.h in front of its zlib framing functions: everything above that point is in scope)
+
+namespace s5 {
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+// 0x80 in every byte of x that is zero (exact: no carries between bytes)
+__device__ __forceinline__ uint32_t zbytes(uint32_t x) {
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;   // bit 7: the low seven bits are not all zero
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+// spread mask (bit 8q + 7 for slot q) of the slots of a four-position frame starting at a0 that lie in [first, len)
+__device__ __forceinline__ uint32_t frame_mask(int a0, int first, int len) {
+    const int lo = min(4, max(0, first - a0)), hi = min(4, max(0, len - a0));
+    const uint32_t mh = hi >= 4 ? 0xFFFFFFFFu : (1u << (8 * hi)) - 1u;
+    const uint32_t ml = lo >= 4 ? 0xFFFFFFFFu : (1u << (8 * lo)) - 1u;
+    return mh & ~ml & 0x80808080u;
+}
+__device__ __forceinline__ int top_slot(uint32_t m) { return (31 - __clz((int)m)) >> 3; }   // m != 0, bits at 8q + 7
+
+// length symbol of a match of L bytes (3..258): symbol, extra bits, extra value
+__device__ __forceinline__ void length_symbol(int L, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+    const int l = L - 3;
+    eb = 0; ev = 0;
+    if (L == 258) sym = 285;
+    else if (l < 8) sym = 257 + l;
+    else {
+        const int nb = 29 - __clz(l);
+        sym = 261 + 4 * nb + ((l >> nb) & 3);
+        eb = nb;
+        ev = l & ((1 << nb) - 1);
+    }
+}
+
+// last position p < pos with a break (p == 0 or buf[p] != buf[p - 1]); pos >= 1.  All 64 lanes, uniform result.
+__device__ __forceinline__ int find_break_before(const uint8_t *__restrict__ buf, int pos) {
+    const int lane = lane_id();
+    for (int hi = pos - 1;; hi -= 64) {
+        const int p = hi - lane;
+        const bool brk = p >= 0 && (p == 0 || buf[p] != buf[p - 1]);
+        const uint64_t m = __ballot(brk);
+        if (m) return hi - (__ffsll((long long)m) - 1);
+    }
+}
+
+// What a lane knows of its four positions of a slab (centred frame: positions p0 .. p0 + 3, p0 = 256 k + 4 lane - 2).
+struct SlabCls {
+    uint32_t bytes;     // the four bytes
+    uint32_t C;         // E (equal to the previous byte, valid positions only) per slot
+    uint32_t Cp1;       // E of the position after each slot
+    uint32_t member;    // slots inside a sequence of >= 3 E-positions
+    uint32_t V;         // valid slots (0 <= p < len)
+};
+// carryE: E of the aligned frame of lane 63 of the previous slab (uniform); updated.
+template <bool EDGE>
+__device__ __forceinline__ SlabCls classify_slab(const uint32_t *__restrict__ buf32, int k, int len, uint32_t &carryE) {
+    const int lane = lane_id();
+    const int di = 64 * k + lane;
+    uint32_t w, wp;
+    if (EDGE) {
+        const int ndw = (len + 3) >> 2;
+        w = di < ndw ? buf32[di] : 0u;
+        wp = di - 1 < ndw ? buf32[di - 1] : 0u;      // (di = 0: the word in front of the buffer — LDS of this workgroup, masked out below)
+    } else {
+        w = buf32[di];
+        wp = buf32[di - 1];
+    }
+    uint32_t E = zbytes(w ^ alignbit(w, wp, 24));    // aligned frame: positions 4 di .. 4 di + 3 (bits 8q + 7 only)
+    if (EDGE) E &= frame_mask(4 * di, 1, len);
+    const uint32_t Ep = dpp_u32<DPP_WAVE_SHR1>(carryE, E);
+    carryE = (uint32_t)__builtin_amdgcn_readlane((int)E, 63);
+    SlabCls c;
+    c.bytes = alignbit(w, wp, 16);
+    c.C = alignbit(E, Ep, 16);
+    const uint32_t Cm1 = alignbit(E, Ep, 8);
+    c.Cp1 = alignbit(E, Ep, 24);
+    // E at p - 2 is Ep, at p + 2 is E.  A slot is a member if it is E and one of the three windows of three around it is all E.
+    c.member = c.C & ((c.Cp1 & (E | Cm1)) | (Ep & Cm1));
+    c.V = EDGE ? frame_mask(256 * k + 4 * lane - 2, 0, len) : 0x80808080u;
+    return c;
+}
+
+// The tail a lane sends for the sequence of >= 3 E-positions that ENDS at one of its slots: body = positions of the sequence.
+struct SlabTail {
+    uint32_t ql;        // slot of the sequence's last position (4: none)
+    uint32_t nfull;     // matches of 258
+    uint32_t rem;       // then: >= 3 one match of rem, 1 / 2 literals of the run byte, 0 nothing
+    uint32_t runbyte;
+};
+struct WaveCarry {      // per wave, uniform
+    int lastb;          // last break position in front of the current slab, when known
+    bool ok;
+};
+// Uniform call (all lanes) for a slab that holds members.  k: slab, c: its classification.
+__device__ __forceinline__ SlabTail slab_tail(const uint8_t *__restrict__ buf, int k, const SlabCls &c, WaveCarry &wc) {
+    const int lane = lane_id();
+    const int p0 = 256 * k + 4 * lane - 2;
+    const uint32_t lastmem = c.member & ~c.Cp1;                   // at most one slot per lane: two sequences are >= 4 positions apart
+    const uint32_t Bm = c.V & ~c.C;                                // breaks
+    const int lb = Bm ? p0 + top_slot(Bm) : -1;
+    const int Lincl = wave_incl_max(lb);
+    const int Lprev = (int)wave_prev((uint32_t)Lincl, 0xFFFFFFFFu);
+    const int slab_last = __builtin_amdgcn_readlane(Lincl, 63);
+    SlabTail t;
+    t.ql = 4; t.nfull = 0; t.rem = 0; t.runbyte = 0;
+    int s = 0;
+    const bool has = lastmem != 0u;
+    if (has) {
+        t.ql = (uint32_t)top_slot(lastmem);
+        const uint32_t below = Bm & ((1u << (8 * t.ql)) - 1u);
+        s = below ? p0 + top_slot(below) : Lprev;
+    }
+    if (__ballot(has && s < 0)) {                                  // (uniform) a sequence that started in front of this slab
+        if (!wc.ok) { wc.lastb = find_break_before(buf, 256 * k - 2); wc.ok = true; }
+        if (has && s < 0) s = wc.lastb;
+    }
+    if (slab_last >= 0) { wc.lastb = slab_last; wc.ok = true; }
+    if (has) {
+        const int body = p0 + (int)t.ql - s;                       // >= 3
+        t.nfull = (uint32_t)((body * 16257) >> 22);                // body / 258 for body < 70000
+        t.rem = (uint32_t)body - 258u * t.nfull;
+        t.runbyte = (c.bytes >> (8 * t.ql)) & 255u;
+    }
+    return t;
+}
+
+template <int MODE, int TN = NT>
+__device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, uint32_t obuf_words, const uint8_t *__restrict__ buf, int len,
+                                               bool final, ZOut &z, uint32_t &adA, uint32_t &adB, uint32_t dbg = 0,
+                                               EarlySize es = EarlySize{nullptr, 0}) {
+    static_assert(MODE == 1 || MODE == 2, "fused single block (1) or staged multi-block (2): the bit buffer is this function's to clear");
+    constexpr bool FUSED = MODE == 1;
+    constexpr int NWV = TN / 64;
+    static_assert(TN % 64 == 0 && NWV >= 4 && NWV <= 8, "S.freq[0 .. 32) holds four words per wave");
+    const int tid = threadIdx.x, lane = lane_id();
+    const int wv = __builtin_amdgcn_readfirstlane(wave_id());
+    if (len == 0) {   // empty stream: a fixed block holding only end-of-block
+        for (uint32_t i = tid; i < obuf_words; i += TN) obuf[i] = 0;
+        __syncthreads();
+        if (tid == 0) { if (FUSED) put_bits(obuf, z, 64, 0x9c78u, 16); else obuf[0] = z.carry; }
+        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 10);
+        z.bitpos += 10;
+        publish_size(es, z.bitpos);
+        __syncthreads();
+        return;
+    }
+    // one histogram of the 286 lit/len symbols per wave, in the tail of the bit buffer (dead until the tokens are packed)
+    const uint32_t wf_at = obuf_words - (uint32_t)(NWV * 288);
+    uint32_t *wfa = obuf + wf_at;
+    uint32_t *wf = wfa + wv * 288;
+    for (int i = tid; i < NWV * 288; i += TN) wfa[i] = 0;
+    if (tid < 32) S.freq[tid] = 0;      // [0, 8) dynamic body bits per wave, [8, 16) fixed, [16, 24) extra bits, [24, 32) matches
+    if (tid < 8) S.red[tid] = 0;
+    if (tid < 20) S.clfreq[tid] = 0;
+    __syncthreads();
+
+    const uint32_t *buf32 = reinterpret_cast<const uint32_t *>(buf);
+    const int nsl = (len + 2 + 255) >> 8;                   // slabs: centred frames cover positions [-2, 256 nsl - 2)
+    const int SW = (nsl + NWV - 1) / NWV;
+    const int k0 = wv * SW, k1 = min(k0 + SW, nsl);
+    // E of the aligned dword in front of the region (lane 0's left neighbour in the region's first slab)
+    uint32_t carryE0 = 0;
+    if (k0 > 0 && k0 < k1) {
+        const int di = 64 * k0 - 1;                         // (uniform address) positions 256 k0 - 4 .. - 1
+        const uint32_t w = buf32[di], wp = buf32[di - 1];
+        carryE0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(zbytes(w ^ alignbit(w, wp, 24)) & frame_mask(4 * di, 1, len)));
+    }
+
+    // ---- pass 1: histogram, Adler-32 partial sums, match / extra-bit counts ----
+    {
+        uint32_t a_acc = 0, b_acc = 0, d_acc = 0, nmatch = 0, nextra = 0;
+        uint32_t carryE = carryE0;
+        WaveCarry wc{-1, k0 == 0};
+        for (int k = k0; k < k1; k++) {
+            const bool full = k > 0 && 256 * k + 256 <= len;     // every slot of every lane is a valid position >= 1
+            const uint32_t wgt = (uint32_t)(len - (256 * k + 4 * lane - 2));   // Adler: weight of slot 0
+            SlabCls c;
+            if (full) c = classify_slab<false>(buf32, k, len, carryE);
+            else c = classify_slab<true>(buf32, k, len, carryE);
+            const bool anymem = __ballot(c.member != 0u) != 0ull;
+            if (full && !anymem) {
+                atomicAdd(&wf[c.bytes & 255u], 1u);
+                atomicAdd(&wf[(c.bytes >> 8) & 255u], 1u);
+                atomicAdd(&wf[(c.bytes >> 16) & 255u], 1u);
+                atomicAdd(&wf[c.bytes >> 24], 1u);
+                const uint32_t s4 = __builtin_amdgcn_udot4(c.bytes, 0x01010101u, 0u, false);
+                a_acc += s4;
+                b_acc += wgt * s4;
+                d_acc = __builtin_amdgcn_udot4(c.bytes, 0x03020100u, d_acc, false);
+                wc.ok = false;
+                continue;
+            }
+            const uint32_t lit = c.V & ~c.member;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (lit & (0x80u << (8 * q))) atomicAdd(&wf[(c.bytes >> (8 * q)) & 255u], 1u);
+            {
+                const uint32_t vb = c.V >> 7, bytes = c.bytes & ((vb << 8) - vb);   // bytes of invalid slots count as zero
+                const uint32_t s4 = __builtin_amdgcn_udot4(bytes, 0x01010101u, 0u, false);
+                a_acc += s4;
+                b_acc += wgt * s4;
+                d_acc = __builtin_amdgcn_udot4(bytes, 0x03020100u, d_acc, false);
+            }
+            if (!anymem) { wc.ok = false; continue; }
+            const SlabTail t = slab_tail(buf, k, c, wc);
+            if (t.ql < 4) {
+                if (t.nfull) atomicAdd(&wf[285], t.nfull);
+                nmatch += t.nfull;
+                if (t.rem >= 3) {
+                    uint32_t sym, eb, ev;
+                    length_symbol((int)t.rem, sym, eb, ev);
+                    atomicAdd(&wf[sym], 1u);
+                    nmatch += 1;
+                    nextra += eb;
+                } else if (t.rem) atomicAdd(&wf[t.runbyte], t.rem);
+            }
+        }
+        // Adler: sum of (len - p) x_p = sum over slabs of wgt * (x0 + x1 + x2 + x3) - (0 x0 + 1 x1 + 2 x2 + 3 x3)
+        const uint32_t a_w = wave_sum(a_acc);
+        const uint32_t b_w = wave_sum((b_acc - d_acc) % 65521u);
+        nmatch = wave_sum(nmatch);
+        nextra = wave_sum(nextra);
+        if (lane == 0) {
+            atomicAdd(&S.red[2], a_w);
+            atomicAdd(&S.red[3], b_w);
+            atomicAdd(&S.red[0], nmatch);
+            atomicAdd(&S.red[1], nextra);
+            S.freq[16 + wv] = nextra;
+            S.freq[24 + wv] = nmatch;
+        }
+    }
+    __syncthreads();
+    if (dbg == 2) { z.bitpos += wfa[tid] + S.red[0]; return; }   // tools/stage_time.py cut-off
+
+    // ---- code lengths (wave 0, no tree: assign_lengths_wave over the sum of the histograms); the other waves clear the bit buffer ----
+    if (wv == 0) {
+        const bool ok = assign_lengths_wave<15, NWV, true>(wfa, NLIT, S.lens, S.blcount, S.bins);
+        if (lane == 0) S.dbg = ok ? 0u : 1u;
+    } else {
+        for (uint32_t i = tid - 64; i < wf_at; i += TN - 64) obuf[i] = 0;
+    }
+    __syncthreads();
+    if (dbg == 3) { z.bitpos += S.lens[tid]; return; }
+    if (tid == 0) {
+        if (FUSED) put_bits(obuf, z, 64, 0x9c78u, 16);   // CMF/FLG 78 9c (deflate, 32K window, default level)
+        else obuf[0] = z.carry;                          // the stream's pending partial word
+    }
+    // ---- wave 0: code-length header; wave 1: canonical codes; waves 2..: body bits of every wave's region under the dynamic / fixed code ----
+    if (wv == 0) {
+        if (lane == 0) {   // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
+            S.lens[DOFF] = 1; S.lens[DOFF + 1] = 1;
+            S.code[DOFF] = 0u | (1u << 16); S.code[DOFF + 1] = 1u | (1u << 16);
+        }
+        cl_header_wave(S, 2);
+    } else if (wv == 1) {
+        assign_codes_wave(S.blcount, S.lens, NLIT, S.code);
+    } else {
+        for (int h = wv - 2; h < NWV; h += NWV - 2) {
+            uint32_t dynb = 0, fixb = 0;
+            for (int s = lane; s < NLIT; s += 64) {
+                const uint32_t f = wfa[h * 288 + s];
+                dynb += f * S.lens[s];
+                fixb += f * (uint32_t)fixed_len(s);
+            }
+            dynb = wave_sum(dynb);
+            fixb = wave_sum(fixb);
+            if (lane == 0) { S.freq[h] = dynb; S.freq[8 + h] = fixb; }
+        }
+    }
+    __syncthreads();
+    if (dbg == 4 || dbg == 41) { z.bitpos += S.freq[tid & 31] + S.red[6] + S.code[tid]; return; }
+    // the histograms are dead: their words become bit buffer (ordered before the first OR by the barrier of the header's scan below)
+    for (int i = tid; i < NWV * 288; i += TN) wfa[i] = 0;
+
+    const uint32_t matches = S.red[0], extra = S.red[1];
+    uint32_t dynbody = 0, fixbody = 0;
+#pragma unroll
+    for (int h = 0; h < NWV; h++) { dynbody += S.freq[h]; fixbody += S.freq[8 + h]; }
+    const uint32_t eob_dyn = S.lens[256];
+    const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
+    const uint32_t dyn_total = hdr_dyn + dynbody + eob_dyn + extra + matches * 1;
+    const uint32_t fix_total = 3 + fixbody + 7 + extra + matches * 5;
+    const uint32_t sto_total = 3 + ((0u - (z.bitpos + 3)) & 7) + 32 + 8u * (uint32_t)len;
+    {   // Adler-32 running update (RFC 1950): B' = B + len * A + sum (len - i) x_i
+        const uint32_t nb = (uint32_t)(((uint64_t)adB + (uint64_t)len * adA + S.red[3]) % 65521u);
+        adA = (adA + S.red[2]) % 65521u;
+        adB = nb;
+    }
+    if (sto_total <= dyn_total && sto_total <= fix_total) {
+        // ---- stored block ----
+        const uint32_t bytepos = (z.bitpos + 3 + 7) >> 3;
+        publish_size(es, (bytepos + 4 + (uint32_t)len) * 8);
+        uint8_t *ob8 = reinterpret_cast<uint8_t *>(obuf) + (bytepos - z.flushed * 4);
+        __syncthreads();                                   // the histogram words are zero
+        if (tid == 0) {
+            put_bits(obuf, z, z.bitpos, final ? 1u : 0u, 3);
+            put_bits(obuf, z, bytepos * 8, (uint32_t)len | ((~(uint32_t)len) << 16), 32);
+        }
+        __syncthreads();
+        for (int i = tid; i < len; i += TN) ob8[4 + i] = buf[i];
+        z.bitpos = (bytepos + 4 + (uint32_t)len) * 8;
+        __syncthreads();
+        return;
+    }
+    const bool use_fixed = fix_total < dyn_total || S.dbg != 0;   // S.dbg: the length assignment gave up (never seen)
+    uint32_t pos0, dist_bits;
+    uint32_t clv[2] = {0, 0}, clnb[2] = {0, 0};
+    if (use_fixed) {
+        __syncthreads();                                   // everyone has read S.lens / S.freq under the dynamic code
+        for (int s = tid; s < 288; s += TN) S.code[s] = fixed_code(s);
+        pos0 = z.bitpos + 3;
+        dist_bits = 5;
+        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
+    } else {
+        const int ncl = S.ncl;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {   // code-length sequence: lane t owns entries 2t, 2t + 1
+            const int e = 2 * tid + q;
+            if (e < ncl) {
+                const uint32_t ent = S.clseq[e];
+                const uint32_t sym = ent & 31, cc = S.clcode[sym], cl = cc >> 16;
+                const uint32_t eb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+                clv[q] = (cc & 0xFFFF) | ((ent >> 5) << cl);
+                clnb[q] = cl + eb;
+            }
+        }
+        pos0 = z.bitpos + hdr_dyn;
+        dist_bits = 1;
+    }
+    // bit offset of every wave's region
+    uint32_t wbase = pos0, total_bits = 0;
+#pragma unroll
+    for (int h = 0; h < NWV; h++) {
+        const uint32_t t = (use_fixed ? S.freq[8 + h] : S.freq[h]) + S.freq[16 + h] + S.freq[24 + h] * dist_bits;
+        if (h < wv) wbase += t;
+        total_bits += t;
+    }
+    const uint32_t eob = use_fixed ? fixed_code(256) : S.code[256];
+    publish_size(es, pos0 + total_bits + (eob >> 16));
+    {
+        uint32_t hdr_total;
+        const uint32_t hoff = block_excl_add_w<NWV>(clnb[0] + clnb[1], S.ws, hdr_total);   // (its barriers also order the zeroing above / the fixed codes)
+        if (!use_fixed) {
+            const uint32_t hclen = S.hclen;
+            if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (2u << 1) | ((S.hlit - 257) << 3) | (1u << 8) | ((hclen - 4) << 13), 17);
+            if (tid < (int)hclen) {
+                const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                put_bits(obuf, z, z.bitpos + 17 + 3 * tid, S.cllens[order[tid]], 3);
+            }
+            const uint32_t p = z.bitpos + 17 + 3 * hclen + hoff;
+            if (clnb[0]) put_bits(obuf, z, p, clv[0], clnb[0]);
+            if (clnb[1]) put_bits(obuf, z, p + clnb[0], clv[1], clnb[1]);
+        }
+    }
+    if (dbg == 5) { z.bitpos += wbase; return; }
+
+    // ---- pass 2: the tokens, slab by slab: one scan gives every lane its bit offset ----
+    {
+        auto or_bits = [&](uint32_t pos, uint64_t v, uint32_t nb) {          // nb <= 60
+            const uint32_t w = (pos >> 5) - z.flushed, sh = pos & 31;
+            const uint64_t lo = v << sh;
+            atomicOr(&obuf[w], (uint32_t)lo);
+            atomicOr(&obuf[w + 1], (uint32_t)(lo >> 32));
+            if (sh + nb > 64) atomicOr(&obuf[w + 2], (uint32_t)(v >> (64 - sh)));   // rare: four long codes
+        };
+        uint32_t carryE = carryE0;
+        WaveCarry wc{-1, k0 == 0};
+        for (int k = k0; k < k1; k++) {
+            const bool full = k > 0 && 256 * k + 256 <= len;
+            SlabCls c;
+            if (full) c = classify_slab<false>(buf32, k, len, carryE);
+            else c = classify_slab<true>(buf32, k, len, carryE);
+            const bool anymem = __ballot(c.member != 0u) != 0ull;
+            const uint32_t c0 = S.code[c.bytes & 255u], c1 = S.code[(c.bytes >> 8) & 255u], c2 = S.code[(c.bytes >> 16) & 255u], c3 = S.code[c.bytes >> 24];
+            if (full && !anymem) {
+                const uint32_t n0 = c0 >> 16, n1 = c1 >> 16, n2 = c2 >> 16, n3 = c3 >> 16;
+                const uint32_t lo = (c0 & 0xFFFFu) | ((c1 & 0xFFFFu) << n0), nlo = n0 + n1;
+                const uint32_t hi = (c2 & 0xFFFFu) | ((c3 & 0xFFFFu) << n2), nhi = n2 + n3;
+                const uint32_t nb = nlo + nhi;
+                const uint32_t incl = wave_incl_add(nb);
+                or_bits(wbase + incl - nb, (uint64_t)lo | ((uint64_t)hi << nlo), nb);
+                wbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                wc.ok = false;
+                continue;
+            }
+            const uint32_t lit = c.V & ~c.member;
+            SlabTail t;
+            t.ql = 4; t.nfull = 0; t.rem = 0; t.runbyte = 0;
+            if (anymem) t = slab_tail(buf, k, c, wc);
+            else wc.ok = false;
+            // literals in front of the tail's slot (all of them without a tail), the tail, the literals behind it
+            const uint32_t mA = t.ql >= 4 ? 0xFFFFFFFFu : (1u << (8 * t.ql)) - 1u;
+            const uint32_t litA = lit & mA, litB = lit & ~mA;
+            const uint32_t cc[4] = {c0, c1, c2, c3};
+            uint64_t vA = 0, vB = 0;
+            uint32_t nA = 0, nB = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t n = cc[q] >> 16, v = cc[q] & 0xFFFFu;
+                if (litA & (0x80u << (8 * q))) { vA |= (uint64_t)v << nA; nA += n; }
+                if (litB & (0x80u << (8 * q))) { vB |= (uint64_t)v << nB; nB += n; }
+            }
+            uint32_t nT = 0, tv = 0, tn = 0;      // tv / tn: the tail's last token (a match of rem bytes, or nothing)
+            uint32_t c285 = 0, crun = 0;
+            if (t.ql < 4) {
+                c285 = S.code[285];
+                crun = S.code[t.runbyte];
+                nT = t.nfull * ((c285 >> 16) + dist_bits);
+                if (t.rem >= 3) {
+                    uint32_t sym, eb, ev;
+                    length_symbol((int)t.rem, sym, eb, ev);
+                    const uint32_t cs = S.code[sym];
+                    tn = cs >> 16;
+                    tv = (cs & 0xFFFFu) | (ev << tn);
+                    tn += eb + dist_bits;                         // (the distance code is all zeros)
+                    nT += tn;
+                } else nT += t.rem * (crun >> 16);
+            }
+            const uint32_t nb = nA + nT + nB;
+            const uint32_t incl = wave_incl_add(nb);
+            uint32_t pos = wbase + incl - nb;
+            wbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            or_bits(pos, vA, nA);
+            pos += nA;
+            if (t.ql < 4) {
+                const uint32_t n285 = (c285 >> 16) + dist_bits;
+                for (uint32_t i = 0; i < t.nfull; i++) { or_bits(pos, (uint64_t)(c285 & 0xFFFFu), n285); pos += n285; }
+                if (t.rem >= 3) { or_bits(pos, (uint64_t)tv, tn); pos += tn; }
+                else for (uint32_t i = 0; i < t.rem; i++) { or_bits(pos, (uint64_t)(crun & 0xFFFFu), crun >> 16); pos += crun >> 16; }
+                or_bits(pos, vB, nB);
+            }
+        }
+#ifdef S5_DEFL2_CHECK   // tests: every wave must end exactly where the next one starts
+        {
+            uint32_t want = pos0;
+            for (int h = 0; h <= wv; h++) want += (use_fixed ? S.freq[8 + h] : S.freq[h]) + S.freq[16 + h] + S.freq[24 + h] * dist_bits;
+            if (lane == 0 && wbase != want) atomicOr(&S.red[7], 1u);
+        }
+#endif
+        if (dbg == 6) { z.bitpos += wbase; return; }
+    }
+    if (tid == 0) put_bits(obuf, z, pos0 + total_bits, eob & 0xFFFF, eob >> 16);
+    z.bitpos = pos0 + total_bits + (eob >> 16);
+    __syncthreads();
+}
+
+}  // namespace s5

@@ -286,7 +286,9 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
 // Returns false (uniform) if the pass limit was hit — never seen; the caller then sends the block with the fixed code.
 // MAXL: longest code allowed (15 DEFLATE, 11 zstd literals).  A Shannon length above MAXL is clamped; if the clamped lengths
 // over-subscribe the code space the function returns false as well (the caller then uses the exact construction).
-template <int MAXL = 15>
+// NH: the frequencies are the sum of NH histograms that lie 288 words apart (deflate2_dev.h keeps one per wave); EOB1: symbol 256 (end of
+// block) is not in the histograms and counts once.
+template <int MAXL = 15, int NH = 1, bool EOB1 = false>
 __device__ __forceinline__ bool assign_lengths_wave(const uint32_t *freq, int n, uint8_t *lens, uint32_t *blcount, uint32_t *bins) {
     const int lane = lane_id();
     constexpr uint32_t HUGE_C = 0x80000000u;   // "cannot be shortened": no symbol / already 1 bit
@@ -297,13 +299,16 @@ __device__ __forceinline__ bool assign_lengths_wave(const uint32_t *freq, int n,
     for (int q = 0; q < 5; q++) {
         const int s = 5 * lane + q;
         f[q] = s < n ? freq[s] : 0u;
+#pragma unroll
+        for (int h = 1; h < NH; h++) f[q] += s < n ? freq[288 * h + s] : 0u;
+        if (EOB1 && s == 256) f[q] += 1u;
         fsum += f[q];
         used += f[q] != 0u;
     }
     if (lane < 16) blcount[lane] = 0;
     const uint32_t N = wave_sum(fsum), m = wave_sum(used);
     if (m <= 1) {   // degenerate: keep the code complete with two 1-bit codes
-        const int other = freq[0] ? 1 : 0;   // the second 1-bit code goes to a symbol that is not in use
+        const int other = __builtin_amdgcn_readfirstlane((int)f[0]) ? 1 : 0;   // (lane 0 holds symbol 0) the second 1-bit code goes to a symbol that is not in use
 #pragma unroll
         for (int q = 0; q < 5; q++) { const int s = 5 * lane + q; if (s < n) lens[s] = (f[q] || s == other || (m == 0 && s == 1)) ? 1 : 0; }
         if (lane == 0) blcount[1] = 2;
@@ -1109,6 +1114,10 @@ __device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, ui
     __syncthreads();
 }
 
+}  // namespace s5
+#include "deflate2_dev.h"   // round 5: the slab form of the block encoder (deflate_block2), the default; -DS5_DEFL_V1 keeps deflate_block above
+namespace s5 {
+
 // Fused path: zlib-frame a payload of at most DEFL_BLK bytes that sits in LDS (`pay`) as ONE DEFLATE block.
 // Leaves the whole record in the LDS bit buffer, bytes [8, total): 78 9c | block | adler32 BE (bytes [0, 8) are
 // reserved for the u64 size prefix) and returns total.  obuf_words >= max(plen + 64, sizeof(BuildScratch)) / 4.
@@ -1119,7 +1128,11 @@ __device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *ob
     z.bitpos = 80;   // 64 bits of size prefix + 16 bits of zlib header, both written later
     z.flushed = 0;
     uint32_t adA = 1, adB = 0;
+#ifdef S5_DEFL_V1
     deflate_block<1, M>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es);
+#else
+    deflate_block2<1, NT>(S, obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es);
+#endif
     if (dbg) return 16;
     z.bitpos = (z.bitpos + 7) & ~7u;
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);

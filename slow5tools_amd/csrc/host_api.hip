@@ -208,6 +208,7 @@ extern "C" void s5gpu_shutdown(void) {
     g_ndev = 0;
     s5kern_release_aux();
     s5kern_release_order();
+    s5host::arena_pool_drain();
     s5host_generation++;
 }
 
@@ -296,13 +297,76 @@ int s5host::encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_r
     return s5gpu_compact_dev(n, a.desc, (const uint8_t *)c->d_slots.p, (const uint32_t *)c->d_len.p, d_off, (uint8_t *)c->d_stream.p, d_tmp, c->st);
 }
 
-// ... then bring back only what was produced and hand out one malloc per record.
+// ---- pool of pinned buffers behind the arena form of the batch calls ----
+namespace {
+struct PoolBuf { void *p; size_t cap; };
+std::mutex g_pool_mu;
+std::vector<PoolBuf> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_KEEP_BYTES = 6ull << 30;   // what the pool holds on to between calls (a 1 M-read batch gives back ~3.6 GB)
+}  // namespace
+void *s5host::arena_pool_take(size_t bytes, size_t *cap) {
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool.size(); i++)   // smallest buffer that fits and is not wastefully large
+            if (g_pool[i].cap >= bytes && g_pool[i].cap <= 2 * bytes + (8u << 20) && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
+        if (best >= 0) {
+            const PoolBuf b = g_pool[best];
+            g_pool.erase(g_pool.begin() + best);
+            g_pool_bytes -= b.cap;
+            *cap = b.cap;
+            return b.p;
+        }
+    }
+    const size_t want = (size_t)up(bytes + bytes / 8 + 4096, 1u << 20);
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, want, hipHostMallocPortable);
+    if (e != hipSuccess) { s5gpu_set_error("arena allocation of %zu pinned bytes failed: %s", want, hipGetErrorString(e)); return nullptr; }
+    *cap = want;
+    return p;
+}
+void s5host::arena_pool_give(void *p, size_t cap) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        if (g_pool_bytes + cap <= POOL_KEEP_BYTES && g_pool.size() < 64) { g_pool.push_back({p, cap}); g_pool_bytes += cap; return; }
+    }
+    (void)hipHostFree(p);
+}
+void s5host::arena_pool_drain() {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    for (const PoolBuf &b : g_pool) (void)hipHostFree(b.p);
+    g_pool.clear();
+    g_pool_bytes = 0;
+}
+extern "C" void s5gpu_arena_release(void *arena) {
+    s5host::Arena *ar = (s5host::Arena *)arena;
+    if (!ar) return;
+    for (auto &b : ar->bufs) {
+        if (ar->generation == s5host_generation) s5host::arena_pool_give(b.first, b.second);
+        else (void)hipHostFree(b.first);           // the library was shut down (and its pool drained) while the caller still held the batch
+    }
+    delete ar;
+}
+
+// ... then bring back only what was produced and hand out one malloc per record — or, with an arena, pointers into the buffer the D2H filled.
 int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
-                              void **out, size_t *out_len) {
+                              void **out, size_t *out_len, Arena *ar) {
     std::vector<uint64_t> off;
     int rc = s5host::encode_stream_resident(c, n, desc, a, slots_bytes, off);
     if (rc) return rc;
     const uint64_t produced = off[n];
+    if (ar) {
+        size_t cap = 0;
+        uint8_t *buf = (uint8_t *)arena_pool_take(produced + 64, &cap);
+        if (!buf) return S5GPU_ERR_NOMEM;
+        ar->add(buf, cap);                                  // (from here on the arena owns it, whatever happens)
+        HIP_TRY(hipMemcpyAsync(buf, c->d_stream.p, produced, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        for (uint32_t i = 0; i < n; i++) { out[i] = buf + off[i]; out_len[i] = (size_t)(off[i + 1] - off[i]); }
+        return S5GPU_OK;
+    }
     if ((rc = c->h_out.reserve(produced + 64))) return rc;
     uint8_t *ho_stream = (uint8_t *)c->h_out.p;
     HIP_TRY(hipMemcpyAsync(ho_stream, c->d_stream.p, produced, hipMemcpyDeviceToHost, c->st));
@@ -326,19 +390,19 @@ int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_
 // record (the ownership contract of slow5_rec_to_mem: caller frees each buffer, src/view.c:298).
 static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
                             const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
-                            int sig_method, void **out, size_t *out_len);
+                            int sig_method, void **out, size_t *out_len, s5host::Arena *ar);
 
 // one device's share of a batch
 static int encode_batch_dev(int slot, uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
                             const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
-                            int sig_method, void **out, size_t *out_len) {
+                            int sig_method, void **out, size_t *out_len, s5host::Arena *ar) {
     // A big batch is cut in pieces that run on two contexts at once: one piece's H2D overlaps the other's kernels and D2H (PCIe is
     // full duplex, and the host-side packing of one piece hides behind the copies of the other).  Two halves up to 131072 reads; beyond that
     // pieces of about 65536 reads, two host threads taking them in turn — the pinned staging stays at a few hundred MB whatever the batch
     // (round 4: 1 M reads in one call went through two 4 GB halves at 4.1 GB/s; 65536-read pieces run at 20+).
     const char *e = getenv("S5GPU_SPLIT");
     const bool split = n >= 16384 && (!e || atoi(e) != 0);
-    if (!split) return encode_batch_one(slot, n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
+    if (!split) return encode_batch_one(slot, n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len, ar);
     const char *pe = getenv("S5GPU_PIECE");
     const uint32_t piece = pe && atoi(pe) >= 1024 ? (uint32_t)atoi(pe) : 65536u;
     const uint32_t P = n <= 2 * piece ? 2u : (n + piece - 1) / piece;
@@ -351,7 +415,7 @@ static int encode_batch_dev(int slot, uint32_t n, const int16_t *const *sig, con
             if (k >= P || rcs[0].load() || rcs[1].load()) return;
             const uint32_t lo = (uint32_t)((uint64_t)n * k / P), hi = (uint32_t)((uint64_t)n * (k + 1) / P);
             const int rc = encode_batch_one(slot, hi - lo, sig + lo, n_samples + lo, hdr + lo, hdr_len + lo, aux ? aux + lo : nullptr, aux_len ? aux_len + lo : nullptr,
-                                            rec_method, sig_method, out + lo, out_len + lo);
+                                            rec_method, sig_method, out + lo, out_len + lo, ar);
             if (rc) { snprintf(errs[w], sizeof errs[w], "%s", s5gpu_last_error()); rcs[w].store(rc); return; }   // the message lives in that thread
         }
     };
@@ -366,25 +430,48 @@ static int encode_batch_dev(int slot, uint32_t n, const int16_t *const *sig, con
     return S5GPU_OK;
 }
 
-extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
-                                  const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
-                                  int sig_method, void **out, size_t *out_len) {
+static int encode_batch_any(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                            const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                            int sig_method, void **out, size_t *out_len, void **arena) {
+    if (arena) *arena = NULL;
     if (n == 0) return S5GPU_OK;
     if (!sig || !n_samples || !hdr || !hdr_len || !out || !out_len) { s5gpu_set_error("s5gpu_encode_batch: NULL argument"); return S5GPU_ERR_ARG; }
     for (uint32_t i = 0; i < n; i++) out[i] = NULL;
+    s5host::Arena *ar = nullptr;
+    if (arena) {
+        if (s5host::n_devices() == 0) return S5GPU_ERR_NODEV;   // (initialises the library: the arena remembers its generation)
+        ar = new s5host::Arena;
+        ar->generation = s5host_generation;
+    }
     // contiguous index range per device (src/thread.c:76-90 does the same per thread); every record's result lands in the
     // caller's out[i], so the ordered fwrite loop of src/view.c:296-299 is untouched
     const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) {
         return encode_batch_dev(slot, hi - lo, sig + lo, n_samples + lo, hdr + lo, hdr_len + lo, aux ? aux + lo : nullptr,
-                                aux_len ? aux_len + lo : nullptr, rec_method, sig_method, out + lo, out_len + lo);
+                                aux_len ? aux_len + lo : nullptr, rec_method, sig_method, out + lo, out_len + lo, ar);
     });
-    if (rc) for (uint32_t i = 0; i < n; i++) { free(out[i]); out[i] = NULL; }
+    if (rc) {
+        for (uint32_t i = 0; i < n; i++) { if (!ar) free(out[i]); out[i] = NULL; }
+        if (ar) s5gpu_arena_release(ar);
+        return rc;
+    }
+    if (arena) *arena = ar;
     return rc;
+}
+extern "C" int s5gpu_encode_batch(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                                  const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                                  int sig_method, void **out, size_t *out_len) {
+    return encode_batch_any(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len, nullptr);
+}
+extern "C" int s5gpu_encode_batch_arena(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                                        const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                                        int sig_method, void **out, size_t *out_len, void **arena) {
+    if (!arena) { s5gpu_set_error("s5gpu_encode_batch_arena: NULL arena"); return S5GPU_ERR_ARG; }
+    return encode_batch_any(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len, arena);
 }
 
 static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
                             const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
-                            int sig_method, void **out, size_t *out_len) {
+                            int sig_method, void **out, size_t *out_len, s5host::Arena *ar) {
     s5host::CtxHold hold;
     int rc = hold.acquire(slot);
     if (rc) return rc;
@@ -435,7 +522,7 @@ static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, con
     a.desc = (const s5gpu_read_desc_t *)c->d_desc.p;
     a.sig = (const int16_t *)c->d_sig.p; a.hdr = (const uint8_t *)c->d_hdr.p; a.aux = (const uint8_t *)c->d_aux.p;
     a.max_payload = max_payload;
-    return encode_and_collect(c, n, desc, a, oo, out, out_len);
+    return encode_and_collect(c, n, desc, a, oo, out, out_len, ar);
 }
 
 // first guess at a record's uncompressed size: a zstd frame says it in its header, zlib does not
@@ -808,27 +895,50 @@ static int decode_resident_impl(Ctx *c, uint32_t n, const void *const *rec, cons
 
 // ---- view / merge worker for a whole batch, device-resident between decode and encode ----
 static int recompress_batch_dev(int slot, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
-                                int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, int32_t *status);
+                                int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, int32_t *status, s5host::Arena *ar);
 
-extern "C" int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
-                                      int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
-                                      int32_t *status) {
+static int recompress_batch_any(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                                int32_t *status, void **arena) {
+    if (arena) *arena = NULL;
     if (n == 0) return S5GPU_OK;
     if (!rec || !rec_len || !out || !out_len) { s5gpu_set_error("s5gpu_recompress_batch: NULL argument"); return S5GPU_ERR_ARG; }
     for (uint32_t i = 0; i < n; i++) { out[i] = NULL; out_len[i] = 0; if (status) status[i] = 0; }
+    s5host::Arena *ar = nullptr;
+    if (arena) {
+        if (s5host::n_devices() == 0) return S5GPU_ERR_NODEV;
+        ar = new s5host::Arena;
+        ar->generation = s5host_generation;
+    }
     const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) {
         return recompress_batch_dev(slot, hi - lo, rec + lo, rec_len + lo, from_rec, from_sig, to_rec, to_sig,
-                                    new_read_group ? new_read_group + lo : nullptr, drop_aux, out + lo, out_len + lo, status ? status + lo : nullptr);
+                                    new_read_group ? new_read_group + lo : nullptr, drop_aux, out + lo, out_len + lo, status ? status + lo : nullptr, ar);
     });
-    if (rc) for (uint32_t i = 0; i < n; i++) { free(out[i]); out[i] = NULL; }
+    if (rc) {
+        for (uint32_t i = 0; i < n; i++) { if (!ar) free(out[i]); out[i] = NULL; }
+        if (ar) s5gpu_arena_release(ar);
+        return rc;
+    }
+    if (arena) *arena = ar;
     return rc;
+}
+extern "C" int s5gpu_recompress_batch(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                      int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                                      int32_t *status) {
+    return recompress_batch_any(n, rec, rec_len, from_rec, from_sig, to_rec, to_sig, new_read_group, drop_aux, out, out_len, status, nullptr);
+}
+extern "C" int s5gpu_recompress_batch_arena(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                            int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                                            int32_t *status, void **arena) {
+    if (!arena) { s5gpu_set_error("s5gpu_recompress_batch_arena: NULL arena"); return S5GPU_ERR_ARG; }
+    return recompress_batch_any(n, rec, rec_len, from_rec, from_sig, to_rec, to_sig, new_read_group, drop_aux, out, out_len, status, arena);
 }
 
 static int recompress_encode_half(Ctx *c, uint32_t n, const std::vector<s5gpu_rec_desc_t> &rd, const std::vector<s5gpu_rec_fields_t> &ff, int to_rec, int to_sig,
-                                  const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, std::vector<uint64_t> *stream_off);
+                                  const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, std::vector<uint64_t> *stream_off, s5host::Arena *ar = nullptr);
 
 static int recompress_batch_dev(int slot, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
-                                int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, int32_t *status) {
+                                int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, int32_t *status, s5host::Arena *ar) {
     s5host::CtxHold hold;
     int rc = hold.acquire(slot);
     if (rc) return rc;
@@ -836,12 +946,12 @@ static int recompress_batch_dev(int slot, uint32_t n, const void *const *rec, co
     std::vector<s5gpu_rec_desc_t> rd;
     std::vector<s5gpu_rec_fields_t> ff;
     if ((rc = s5host::decode_resident(c, n, rec, rec_len, from_rec, from_sig, rd, ff, status))) return rc;
-    return recompress_encode_half(c, n, rd, ff, to_rec, to_sig, new_read_group, drop_aux, out, out_len, nullptr);
+    return recompress_encode_half(c, n, rd, ff, to_rec, to_sig, new_read_group, drop_aux, out, out_len, nullptr, ar);
 }
 
 // second half of the worker: encode descriptors straight from the decoded fields (payloads in c->d_pay, signals in c->d_sig2)
 static int recompress_encode_half(Ctx *c, uint32_t n, const std::vector<s5gpu_rec_desc_t> &rd, const std::vector<s5gpu_rec_fields_t> &ff, int to_rec, int to_sig,
-                                  const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, std::vector<uint64_t> *stream_off) {
+                                  const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, std::vector<uint64_t> *stream_off, s5host::Arena *ar) {
     int rc;
     // encode descriptors straight from the decoded fields: heads and aux tails are read out of the decoded payloads
     std::vector<s5gpu_read_desc_t> ed(n);
@@ -884,7 +994,7 @@ static int recompress_encode_half(Ctx *c, uint32_t n, const std::vector<s5gpu_re
     a.sig = (const int16_t *)c->d_sig2.p; a.hdr = (const uint8_t *)c->d_pay.p; a.aux = (const uint8_t *)c->d_pay.p;
     a.max_payload = max_payload;
     if (stream_off) return s5host::encode_stream_resident(c, n, ed, a, oo, *stream_off);   // the caller fetches c->d_stream itself
-    return encode_and_collect(c, n, ed, a, oo, out, out_len);
+    return encode_and_collect(c, n, ed, a, oo, out, out_len, ar);
 }
 
 // ---- the decode half alone on a chunk of framed records: `get --benchmark` (/root/reference/src/get.c:52: slow5_get per id, nothing

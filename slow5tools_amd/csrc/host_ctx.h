@@ -72,9 +72,22 @@ int n_devices();
 // per-record slots, so the order is the caller's.  fn(slot, lo, hi) -> S5GPU_* code.  Batches of fewer than
 // multi_min_per_device * G records stay on device 0.
 int for_each_device_range(uint32_t n, const std::function<int(int, uint32_t, uint32_t)> &fn);
-// encode descriptors already on the device -> one malloc per record on the host (host_api.hip)
+// The batch calls' ARENA form (round 5): the records of a call are not handed out as one malloc each but as pointers into a few
+// pinned host buffers — the D2H lands in them directly — that the caller gives back with ONE s5gpu_arena_release.  The buffers come
+// from a process-wide pool and return to it: a steady caller (view's loop: batch after batch of similar size) neither allocates nor
+// page-faults after its first batches.  A call's shares (devices, pieces) each add the buffers they filled.
+struct Arena {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> bufs;
+    uint32_t generation = 0;
+    void add(void *p, size_t cap) { std::lock_guard<std::mutex> g(mu); bufs.emplace_back(p, cap); }
+};
+void *arena_pool_take(size_t bytes, size_t *cap);   // pinned; NULL + error message when the allocation fails
+void arena_pool_give(void *p, size_t cap);
+void arena_pool_drain();                            // s5gpu_shutdown
+// encode descriptors already on the device -> one malloc per record on the host, or (ar != nullptr) pointers into arena buffers (host_api.hip)
 int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
-                       void **out, size_t *out_len);
+                       void **out, size_t *out_len, Arena *ar = nullptr);
 // decode host records, results resident in c->d_pay / c->d_sig2 (host_api.hip)
 int decode_resident(Ctx *c, uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig,
                     std::vector<s5gpu_rec_desc_t> &rd, std::vector<s5gpu_rec_fields_t> &ff, int32_t *status);

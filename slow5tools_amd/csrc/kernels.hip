@@ -360,7 +360,11 @@ __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, ui
             for (uint32_t i = tid; i < (blen + 15) / 16; i += S5_STAGED_TN) d4[i] = s4[i];
         }
         __syncthreads();
+#ifdef S5_DEFL_V1
         deflate_block<2, StagedMask, S5_STAGED_TN>(S, B, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
+#else
+        deflate_block2<2, S5_STAGED_TN>(S, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
+#endif
         done += blen;
         if (!final) {
             flush_words<S5_STAGED_TN>(obuf, out32, z, false);

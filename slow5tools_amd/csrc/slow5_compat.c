@@ -151,9 +151,14 @@ static uint8_t *pack_head(const struct slow5_rec *r, uint32_t *len) {
     return h;
 }
 
+static int rec_to_mem_batch_any(int64_t n, struct slow5_rec **reads, int drop_aux, slow5_press_method_t to, void **out, size_t *out_len, void **arena);
 int slow5_gpu_rec_to_mem_batch(int64_t n, struct slow5_rec **reads, int drop_aux, slow5_press_method_t to, void **out,
                                size_t *out_len) {
+    return rec_to_mem_batch_any(n, reads, drop_aux, to, out, out_len, NULL);
+}
+static int rec_to_mem_batch_any(int64_t n, struct slow5_rec **reads, int drop_aux, slow5_press_method_t to, void **out, size_t *out_len, void **arena) {
     const int rc_m = rec_code(to.record_method), sg_m = sig_code(to.signal_method);
+    if (arena) *arena = NULL;
     if (n < 0 || rc_m < 0 || sg_m < 0) { slow5_errno = SLOW5_ERR_PRESS; return -1; }
     if (n == 0) return 0;
     const int16_t **sig = (const int16_t **)malloc(sizeof(void *) * n);
@@ -173,7 +178,8 @@ int slow5_gpu_rec_to_mem_batch(int64_t n, struct slow5_rec **reads, int drop_aux
         aux[i] = drop_aux ? NULL : r->aux_blob;
         al[i] = drop_aux ? 0u : (uint32_t)r->aux_len;
     }
-    if (s5gpu_encode_batch((uint32_t)n, sig, ns, hdr, hl, aux, al, rc_m, sg_m, out, out_len) != S5GPU_OK) { slow5_errno = SLOW5_ERR_PRESS; goto done; }
+    if ((arena ? s5gpu_encode_batch_arena((uint32_t)n, sig, ns, hdr, hl, aux, al, rc_m, sg_m, out, out_len, arena)
+               : s5gpu_encode_batch((uint32_t)n, sig, ns, hdr, hl, aux, al, rc_m, sg_m, out, out_len)) != S5GPU_OK) { slow5_errno = SLOW5_ERR_PRESS; goto done; }
     ret = 0;
 done:
     if (hdr) for (int64_t i = 0; i < n; i++) free((void *)hdr[i]);
@@ -356,6 +362,26 @@ int slow5_gpu_hook_recompress(int64_t n, char **mem, size_t *bytes, int from_rec
     return slow5_gpu_recompress_batch(n, mem, bytes, from, to, new_read_group, drop_aux, out, out_len);
 }
 
+int slow5_gpu_hook_recompress_arena(int64_t n, char **mem, size_t *bytes, int from_record_method, int from_signal_method, int to_record_method,
+                                    int to_signal_method, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, void **batch) {
+    if (!batch) { slow5_errno = SLOW5_ERR_ARG; return -1; }
+    *batch = NULL;
+    if (n < 0 || n > 0xFFFFFFFFll || !hook_method_ok(from_record_method, from_signal_method) || !hook_method_ok(to_record_method, to_signal_method)) {
+        slow5_errno = SLOW5_ERR_PRESS;
+        return -1;
+    }
+    if (n == 0) return 0;
+    if (s5gpu_recompress_batch_arena((uint32_t)n, (const void *const *)mem, bytes, rec_code((enum slow5_press_method)from_record_method),
+                                     sig_code((enum slow5_press_method)from_signal_method), rec_code((enum slow5_press_method)to_record_method),
+                                     sig_code((enum slow5_press_method)to_signal_method), new_read_group, drop_aux, out, out_len, NULL, batch) != S5GPU_OK) {
+        slow5_errno = SLOW5_ERR_RECPARSE;
+        return -1;
+    }
+    for (int64_t i = 0; i < n; i++) { free(mem[i]); mem[i] = NULL; }   /* the reference's worker frees the input record (src/view.c:41) */
+    return 0;
+}
+void slow5_gpu_hook_release(void *batch) { s5gpu_arena_release(batch); }
+
 void *slow5_gpu_hook_alloc(size_t bytes) { return s5gpu_host_alloc(bytes); }
 void slow5_gpu_hook_free(void *p) { s5gpu_host_free(p); }
 int slow5_gpu_hook_recompress_chunk(int64_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len,
@@ -422,8 +448,20 @@ done:
     return ret;
 }
 
+static int hook_rec_to_mem_any(int64_t n, const slow5_gpu_read_t *reads, int drop_aux, int to_record_method, int to_signal_method, void **out,
+                               size_t *out_len, void **arena);
 int slow5_gpu_hook_rec_to_mem(int64_t n, const slow5_gpu_read_t *reads, int drop_aux, int to_record_method, int to_signal_method, void **out,
                               size_t *out_len) {
+    return hook_rec_to_mem_any(n, reads, drop_aux, to_record_method, to_signal_method, out, out_len, NULL);
+}
+int slow5_gpu_hook_rec_to_mem_arena(int64_t n, const slow5_gpu_read_t *reads, int drop_aux, int to_record_method, int to_signal_method, void **out,
+                                    size_t *out_len, void **batch) {
+    if (!batch) { slow5_errno = SLOW5_ERR_ARG; return -1; }
+    return hook_rec_to_mem_any(n, reads, drop_aux, to_record_method, to_signal_method, out, out_len, batch);
+}
+static int hook_rec_to_mem_any(int64_t n, const slow5_gpu_read_t *reads, int drop_aux, int to_record_method, int to_signal_method, void **out,
+                               size_t *out_len, void **arena) {
+    if (arena) *arena = NULL;
     if (n < 0 || !hook_method_ok(to_record_method, to_signal_method)) { slow5_errno = SLOW5_ERR_PRESS; return -1; }
     if (n == 0) return 0;
     struct slow5_rec *recs = (struct slow5_rec *)calloc((size_t)n, sizeof *recs);
@@ -440,7 +478,7 @@ int slow5_gpu_hook_rec_to_mem(int64_t n, const slow5_gpu_read_t *reads, int drop
     }
     {
         slow5_press_method_t to = {(enum slow5_press_method)to_record_method, (enum slow5_press_method)to_signal_method};
-        ret = slow5_gpu_rec_to_mem_batch(n, ptrs, drop_aux, to, out, out_len);
+        ret = rec_to_mem_batch_any(n, ptrs, drop_aux, to, out, out_len, arena);
     }
 done:
     free(recs); free(ptrs);

@@ -182,3 +182,79 @@ def test_merge_batch_rewrites_read_group(L):
         idl = struct.unpack_from("<H", ref, 0)[0]
         want = ref[: 2 + idl] + struct.pack("<I", 10 + i) + ref[2 + idl + 4:]
         assert pl == want
+
+
+def test_arena_form_of_the_view_hook_hands_out_the_same_bytes_with_one_release(L):
+    """slow5_gpu_hook_recompress_arena / slow5_gpu_hook_release (include/slow5gpu_hooks.h): the view worker of src/view.c:292 with the
+    free loop of src/view.c:296-299 replaced by ONE release — records identical to the malloc form's, the pointers lie inside a few
+    library-owned buffers, a second batch reuses them, and a failing call leaves no batch behind"""
+    L.slow5_gpu_hook_recompress.argtypes = [C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.slow5_gpu_hook_recompress_arena.argtypes = L.slow5_gpu_hook_recompress.argtypes + [C.POINTER(C.c_void_p)]
+    L.slow5_gpu_hook_release.argtypes = [C.c_void_p]
+    src = Blow5(golden("merged_expected_zlib_svb.blow5"))
+    recs = src.records * 40                     # 240 records, 15 k .. 243 k samples
+    n = len(recs)
+
+    def batch():
+        return (C.c_void_p * n)(*[_malloc_copy(r) for r in recs]), (C.c_size_t * n)(*[len(r) for r in recs])
+
+    mem, nb = batch()
+    out = (C.c_void_p * n)()
+    ol = (C.c_size_t * n)()
+    assert L.slow5_gpu_hook_recompress(n, mem, nb, ZLIB, SVB, ZLIB, SVB, None, 0, out, ol) == 0
+    want = [C.string_at(out[i], ol[i]) for i in range(n)]
+    for i in range(n):
+        libc.free(out[i])
+    seen = []
+    for rep in range(3):
+        mem, nb = batch()
+        h = C.c_void_p()
+        assert L.slow5_gpu_hook_recompress_arena(n, mem, nb, ZLIB, SVB, ZLIB, SVB, None, 0, out, ol, C.byref(h)) == 0
+        assert h.value and all(mem[i] is None for i in range(n))          # inputs freed like the reference's worker does
+        assert [C.string_at(out[i], ol[i]) for i in range(n)] == want
+        addr = sorted(out[i] for i in range(n))
+        assert addr[-1] - addr[0] < 2 * sum(ol) + (16 << 20)               # one arena buffer, not n allocations
+        seen.append(addr[0])
+        L.slow5_gpu_hook_release(h)
+    assert seen[1] == seen[2]                                              # the pool hands the same buffer out again
+    for i, r in enumerate(want[:6]):
+        assert zlib.decompress(r[8:]) == zlib.decompress(src.records[i])
+    # a corrupt record fails the whole call, *batch stays NULL, nothing to release
+    mem, nb = batch()
+    bad = bytearray(recs[3]); bad[len(bad) // 2] ^= 0x55
+    libc.free(mem[3]); mem[3] = _malloc_copy(bytes(bad))
+    h = C.c_void_p(1)
+    assert L.slow5_gpu_hook_recompress_arena(n, mem, nb, ZLIB, SVB, ZLIB, SVB, None, 0, out, ol, C.byref(h)) == -1
+    assert h.value is None
+    for i in range(n):
+        if mem[i]:
+            libc.free(mem[i])
+    L.slow5_gpu_hook_release(None)
+
+
+def test_arena_form_of_encode_batch_at_the_reference_batch_sizes(L):
+    """s5gpu_encode_batch_arena at K = 4096 (/root/reference/src/cmd.h:8) and K = 10 000 (test/test_view_integrity.sh:62-66): the records
+    of the malloc form, byte for byte"""
+    from slow5tools_amd import press
+
+    L.s5gpu_encode_batch_arena.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.s5gpu_arena_release.argtypes = [C.c_void_p]
+    for n in (4096, 10000):
+        ns_ = [1000 + (i * 37) % 5000 for i in range(n)]
+        sig = [ob.synth_read(0x5105, i % 64, ns_[i]) for i in range(n)]
+        hdrs = [press.pack_hdr(ob.synth_read_id(i), 0, 8192.0, 23.0, 1467.61, 4000.0) for i in range(n)]
+        want = press.encode_records(sig, hdrs)
+        vp = C.c_void_p
+        sig_p = (vp * n)(*[s.ctypes.data for s in sig])
+        nsa = (C.c_uint64 * n)(*ns_)
+        hb = [C.create_string_buffer(h, len(h)) for h in hdrs]
+        hdr_p = (vp * n)(*[C.addressof(b) for b in hb])
+        hl = (C.c_uint32 * n)(*[len(h) for h in hdrs])
+        out = (vp * n)()
+        ol = (C.c_size_t * n)()
+        h = vp()
+        assert L.s5gpu_encode_batch_arena(n, sig_p, nsa, hdr_p, hl, None, None, 1, 1, out, ol, C.byref(h)) == 0
+        assert [C.string_at(out[i], ol[i]) for i in range(n)] == want
+        L.s5gpu_arena_release(h)

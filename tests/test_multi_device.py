@@ -88,8 +88,27 @@ assert rc == -5, (rc, msg)                               # S5GPU_ERR_DATA
 assert st[bad_i] != 0 and sum(1 for x in st if x) == 1, list(st)[-6:]
 ndev = L.s5gpu_devices_in_use()
 assert ndev == 1 or (b"device slot %%d" %% (ndev - 1)) in msg, msg
+# the arena form of the worker (round 5): the same records, pointers into pinned buffers (one or more per device share), one release;
+# a batch still held across s5gpu_shutdown is released without touching the drained pool
+def recompress_arena(rs, f, t):
+    m = len(rs)
+    bufs = [C.create_string_buffer(r, len(r)) for r in rs]
+    ptr = (vp * m)(*[C.addressof(b) for b in bufs]); ln = (C.c_size_t * m)(*[len(r) for r in rs])
+    out = (vp * m)(); ol = (C.c_size_t * m)(); st = (C.c_int32 * m)(); h = vp()
+    L.s5gpu_recompress_batch_arena.argtypes = [C.c_uint32, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.POINTER(vp)]
+    _lib.check(L.s5gpu_recompress_batch_arena(m, ptr, ln, f[0], f[1], t[0], t[1], None, 0, out, ol, st, C.byref(h)), "recompress_arena")
+    return [C.string_at(out[i], ol[i]) for i in range(m)], h
+L.s5gpu_arena_release.argtypes = [vp]
+again, h = recompress_arena([p[8:] for p in plain], (0, 0), (1, 1))
+for i, r in enumerate(again):
+    rec, keep = ob.make_rec(ob.synth_read_id(i), 7, 8192.0, 23.0, 1467.61, 4000.0, sigs[i])
+    assert zlib.decompress(r[8:]) == ob.rec_pack(rec, ob.SIG_SVB_ZD), i
+L.s5gpu_arena_release(h)
+again2, h2 = recompress_arena([p[8:] for p in plain], (0, 0), (1, 1))
+assert again2 == again
 L.s5gpu_shutdown()
 assert L.s5gpu_devices_in_use() == 0
+L.s5gpu_arena_release(h2)
 print("multi ok", len(b"".join(recs)))
 """
 
