@@ -150,6 +150,25 @@ __device__ __forceinline__ SlabTail slab_tail(const uint8_t *__restrict__ buf, i
     return t;
 }
 
+// extra bits of a length symbol
+__device__ __forceinline__ uint32_t length_extra_bits(uint32_t sym) { return sym >= 265u && sym < 285u ? (sym - 261u) >> 2 : 0u; }
+// E of the aligned dword in front of slab k (lane 0's left neighbour there): uniform addresses, uniform result
+__device__ __forceinline__ uint32_t carry_e_before(const uint32_t *__restrict__ buf32, int k, int len) {
+    const int di = 64 * k - 1;                              // positions 256 k - 4 .. 256 k - 1
+    const uint32_t w = buf32[di], wp = buf32[di - 1];
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(zbytes(w ^ alignbit(w, wp, 24)) & frame_mask(4 * di, 1, len)));
+}
+
+// Token list (round 5, second step).  A "general" slab — one that holds a sequence of >= 3 E-positions, or touches an end of the block —
+// costs three to four times a plain one in either pass (masks, the tail analysis with its wave prefix-max, per-slot predicates), and
+// on an svb-zd payload the key area is made of such slabs: a fifth of the bytes, half of the two passes' instructions.  So pass 1
+// does the analysis ONCE and leaves the slab's tokens — few: a key slab of 256 positions holds ~40 — as 16-bit words
+// (symbol | extra value << 9) in a list that lives in S.freq (not otherwise used here); the histogram is counted from the list, and
+// pass 2 sends a listed slab 64 tokens per step: one load, one code lookup, one scan, one OR per lane.  DEFL2_LIST_CAP tokens for
+// the whole workgroup, handed out by one LDS counter; a slab that finds the list full is redone from the bytes in pass 2.
+constexpr uint32_t DEFL2_LIST_CAP = 640;
+constexpr uint32_t SEG_FAST = 0xFFFFFFFFu, SEG_REDO = 0xFFFFFFFEu, SEG_MASK = 0xFFFFFFFDu;
+
 template <int MODE, int TN = NT>
 __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, uint32_t obuf_words, const uint8_t *__restrict__ buf, int len,
                                                bool final, ZOut &z, uint32_t &adA, uint32_t &adB, uint32_t dbg = 0,
@@ -157,9 +176,10 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     static_assert(MODE == 1 || MODE == 2, "fused single block (1) or staged multi-block (2): the bit buffer is this function's to clear");
     constexpr bool FUSED = MODE == 1;
     constexpr int NWV = TN / 64;
-    static_assert(TN % 64 == 0 && NWV >= 4 && NWV <= 8, "S.freq[0 .. 32) holds four words per wave");
+    static_assert(TN % 64 == 0 && NWV >= 4 && NWV <= 8, "S.wtot holds four words per wave");
     const int tid = threadIdx.x, lane = lane_id();
-    const int wv = __builtin_amdgcn_readfirstlane(wave_id());
+    const int wv = __builtin_amdgcn_readfirstlane(wave_id());   // (rotating the roles with the workgroup number was measured: by its low bits no change,
+                                                                // by a hash of it 3 % slower — the hardware already spreads the waves of successive workgroups)
     if (len == 0) {   // empty stream: a fixed block holding only end-of-block
         for (uint32_t i = tid; i < obuf_words; i += TN) obuf[i] = 0;
         __syncthreads();
@@ -174,28 +194,28 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     const uint32_t wf_at = obuf_words - (uint32_t)(NWV * 288);
     uint32_t *wfa = obuf + wf_at;
     uint32_t *wf = wfa + wv * 288;
-    for (int i = tid; i < NWV * 288; i += TN) wfa[i] = 0;
-    if (tid < 32) S.freq[tid] = 0;      // [0, 8) dynamic body bits per wave, [8, 16) fixed, [16, 24) extra bits, [24, 32) matches
+    {
+        typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+        u4a *w16 = reinterpret_cast<u4a *>(wfa);            // (obuf is 16-byte aligned, obuf_words and 288 are multiples of four)
+        for (int i = tid; i < NWV * 72; i += TN) w16[i] = u4a{0u, 0u, 0u, 0u};
+    }
+    if (tid < 32) S.wtot[tid] = 0;
     if (tid < 8) S.red[tid] = 0;
     if (tid < 20) S.clfreq[tid] = 0;
+    if (tid == 0) S.lalloc = 0;
     __syncthreads();
 
     const uint32_t *buf32 = reinterpret_cast<const uint32_t *>(buf);
+    uint16_t *tl = reinterpret_cast<uint16_t *>(S.freq);   // the token list
     const int nsl = (len + 2 + 255) >> 8;                   // slabs: centred frames cover positions [-2, 256 nsl - 2)
     const int SW = (nsl + NWV - 1) / NWV;
     const int k0 = wv * SW, k1 = min(k0 + SW, nsl);
-    // E of the aligned dword in front of the region (lane 0's left neighbour in the region's first slab)
-    uint32_t carryE0 = 0;
-    if (k0 > 0 && k0 < k1) {
-        const int di = 64 * k0 - 1;                         // (uniform address) positions 256 k0 - 4 .. - 1
-        const uint32_t w = buf32[di], wp = buf32[di - 1];
-        carryE0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(zbytes(w ^ alignbit(w, wp, 24)) & frame_mask(4 * di, 1, len)));
-    }
+    uint32_t segs = SEG_FAST;                               // lane j: what pass 2 does with slab k0 + j (start | count << 16 of its tokens)
 
-    // ---- pass 1: histogram, Adler-32 partial sums, match / extra-bit counts ----
+    // ---- pass 1: histogram, Adler-32 partial sums, match / extra-bit counts; token lists of the general slabs ----
     {
         uint32_t a_acc = 0, b_acc = 0, d_acc = 0, nmatch = 0, nextra = 0;
-        uint32_t carryE = carryE0;
+        uint32_t carryE = k0 > 0 && k0 < k1 ? carry_e_before(buf32, k0, len) : 0u;
         WaveCarry wc{-1, k0 == 0};
         for (int k = k0; k < k1; k++) {
             const bool full = k > 0 && 256 * k + 256 <= len;     // every slot of every lane is a valid position >= 1
@@ -211,35 +231,71 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
                 atomicAdd(&wf[c.bytes >> 24], 1u);
                 const uint32_t s4 = __builtin_amdgcn_udot4(c.bytes, 0x01010101u, 0u, false);
                 a_acc += s4;
-                b_acc += wgt * s4;
+                b_acc = __umul24(wgt, s4) + b_acc;
                 d_acc = __builtin_amdgcn_udot4(c.bytes, 0x03020100u, d_acc, false);
                 wc.ok = false;
                 continue;
             }
-            const uint32_t lit = c.V & ~c.member;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (lit & (0x80u << (8 * q))) atomicAdd(&wf[(c.bytes >> (8 * q)) & 255u], 1u);
-            {
-                const uint32_t vb = c.V >> 7, bytes = c.bytes & ((vb << 8) - vb);   // bytes of invalid slots count as zero
+            {   // Adler: bytes of invalid slots count as zero
+                uint32_t bytes = c.bytes;
+                if (!full) { const uint32_t vb = c.V >> 7; bytes &= (vb << 8) - vb; }
                 const uint32_t s4 = __builtin_amdgcn_udot4(bytes, 0x01010101u, 0u, false);
                 a_acc += s4;
-                b_acc += wgt * s4;
+                b_acc = __umul24(wgt, s4) + b_acc;
                 d_acc = __builtin_amdgcn_udot4(bytes, 0x03020100u, d_acc, false);
             }
-            if (!anymem) { wc.ok = false; continue; }
-            const SlabTail t = slab_tail(buf, k, c, wc);
-            if (t.ql < 4) {
-                if (t.nfull) atomicAdd(&wf[285], t.nfull);
-                nmatch += t.nfull;
-                if (t.rem >= 3) {
-                    uint32_t sym, eb, ev;
-                    length_symbol((int)t.rem, sym, eb, ev);
-                    atomicAdd(&wf[sym], 1u);
-                    nmatch += 1;
-                    nextra += eb;
-                } else if (t.rem) atomicAdd(&wf[t.runbyte], t.rem);
+            const uint32_t lit = c.V & ~c.member;
+            if (!anymem) {
+                // an end slab without a run: plain literals under a validity mask in both passes, no list
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (lit & (0x80u << (8 * q))) atomicAdd(&wf[(c.bytes >> (8 * q)) & 255u], 1u);
+                if (lane == k - k0) segs = SEG_MASK;
+                wc.ok = false;
+                continue;
             }
+            const SlabTail t = slab_tail(buf, k, c, wc);
+            uint32_t tsym = 0, teb = 0, tev = 0;           // the tail's match of rem bytes
+            if (t.ql < 4 && t.rem >= 3) length_symbol((int)t.rem, tsym, teb, tev);
+            const uint32_t ntail = t.ql < 4 ? t.nfull + (t.rem >= 3 ? 1u : t.rem) : 0u;
+            // literal slots below each slot (token index inside the lane, before the tail is spliced in)
+            const uint32_t i1 = (lit >> 7) & 1u, i2 = i1 + ((lit >> 15) & 1u), i3 = i2 + ((lit >> 23) & 1u);
+            const uint32_t cnt = i3 + (lit >> 31) + ntail;
+            const uint32_t incl = wave_incl_add(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t st = 0;
+            if (lane == 0) st = atomicAdd(&S.lalloc, total);
+            st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
+            const bool listed = st + total <= DEFL2_LIST_CAP;
+            // tokens in position order: a literal slot in front of the tail's slot (only slot 0 under a tail at slot 3 can be one), the tail,
+            // the literal slots behind it.  The histogram is counted on the way.
+            const uint32_t base = st + incl - cnt;
+            const uint32_t idx[4] = {0u, i1, i2, i3};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (lit & (0x80u << (8 * q))) {
+                    const uint32_t b = (c.bytes >> (8 * q)) & 255u;
+                    atomicAdd(&wf[b], 1u);
+                    if (listed) tl[base + idx[q] + ((uint32_t)q > t.ql ? ntail : 0u)] = (uint16_t)b;
+                }
+            if (t.ql < 4) {
+                uint32_t at = base + (t.ql == 3 ? (lit >> 7) & 1u : 0u);   // (slots ql - 1, ql - 2 are members: only slot 0 under ql = 3 can be a literal)
+                if (t.nfull) {
+                    atomicAdd(&wf[285], t.nfull);
+                    nmatch += t.nfull;
+                    if (listed) for (uint32_t i = 0; i < t.nfull; i++) tl[at++] = (uint16_t)285;
+                }
+                if (t.rem >= 3) {
+                    atomicAdd(&wf[tsym], 1u);
+                    nmatch += 1;
+                    nextra += teb;
+                    if (listed) tl[at] = (uint16_t)(tsym | (tev << 9));
+                } else if (t.rem) {
+                    atomicAdd(&wf[t.runbyte], t.rem);
+                    if (listed) for (uint32_t i = 0; i < t.rem; i++) tl[at++] = (uint16_t)t.runbyte;
+                }
+            }
+            if (lane == k - k0) segs = listed ? st | (total << 16) : SEG_REDO;
         }
         // Adler: sum of (len - p) x_p = sum over slabs of wgt * (x0 + x1 + x2 + x3) - (0 x0 + 1 x1 + 2 x2 + 3 x3)
         const uint32_t a_w = wave_sum(a_acc);
@@ -249,21 +305,21 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
         if (lane == 0) {
             atomicAdd(&S.red[2], a_w);
             atomicAdd(&S.red[3], b_w);
-            atomicAdd(&S.red[0], nmatch);
-            atomicAdd(&S.red[1], nextra);
-            S.freq[16 + wv] = nextra;
-            S.freq[24 + wv] = nmatch;
+            S.wtot[16 + wv] = nextra;
+            S.wtot[24 + wv] = nmatch;
         }
     }
     __syncthreads();
-    if (dbg == 2) { z.bitpos += wfa[tid] + S.red[0]; return; }   // tools/stage_time.py cut-off
+    if (dbg == 2) { z.bitpos += wfa[tid] + S.red[2]; return; }   // tools/stage_time.py cut-off
 
     // ---- code lengths (wave 0, no tree: assign_lengths_wave over the sum of the histograms); the other waves clear the bit buffer ----
     if (wv == 0) {
         const bool ok = assign_lengths_wave<15, NWV, true>(wfa, NLIT, S.lens, S.blcount, S.bins);
         if (lane == 0) S.dbg = ok ? 0u : 1u;
     } else {
-        for (uint32_t i = tid - 64; i < wf_at; i += TN - 64) obuf[i] = 0;
+        typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+        u4a *o16 = reinterpret_cast<u4a *>(obuf);
+        for (uint32_t i = (uint32_t)(wv * 64 + lane) - 64u; i < wf_at / 4; i += TN - 64) o16[i] = u4a{0u, 0u, 0u, 0u};   // (logical waves 1 ..)
     }
     __syncthreads();
     if (dbg == 3) { z.bitpos += S.lens[tid]; return; }
@@ -281,31 +337,32 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     } else if (wv == 1) {
         assign_codes_wave(S.blcount, S.lens, NLIT, S.code);
     } else {
+        // fixed code: 8 bits for every symbol, 9 for 144..255, 7 for 256..279 -> 8 * count + count(144..255) - count(256..279)
         for (int h = wv - 2; h < NWV; h += NWV - 2) {
-            uint32_t dynb = 0, fixb = 0;
-            for (int s = lane; s < NLIT; s += 64) {
-                const uint32_t f = wfa[h * 288 + s];
-                dynb += f * S.lens[s];
-                fixb += f * (uint32_t)fixed_len(s);
-            }
+            const uint32_t *fh = wfa + h * 288;
+            const uint32_t f0 = fh[lane], f1 = fh[64 + lane], f2 = fh[128 + lane], f3 = fh[192 + lane], f4 = lane < NLIT - 256 ? fh[256 + lane] : 0u;
+            uint32_t dynb = f0 * S.lens[lane] + f1 * S.lens[64 + lane] + f2 * S.lens[128 + lane] + f3 * S.lens[192 + lane] + f4 * S.lens[256 + lane];
+            uint32_t fixb = 8u * (f0 + f1 + f2 + f3 + f4) + (lane >= 16 ? f2 : 0u) + f3 - (lane < 24 ? f4 : 0u);
             dynb = wave_sum(dynb);
             fixb = wave_sum(fixb);
-            if (lane == 0) { S.freq[h] = dynb; S.freq[8 + h] = fixb; }
+            if (lane == 0) { S.wtot[h] = dynb; S.wtot[8 + h] = fixb; }
         }
     }
     __syncthreads();
-    if (dbg == 4 || dbg == 41) { z.bitpos += S.freq[tid & 31] + S.red[6] + S.code[tid]; return; }
-    // the histograms are dead: their words become bit buffer (ordered before the first OR by the barrier of the header's scan below)
-    for (int i = tid; i < NWV * 288; i += TN) wfa[i] = 0;
-
-    const uint32_t matches = S.red[0], extra = S.red[1];
-    uint32_t dynbody = 0, fixbody = 0;
-#pragma unroll
-    for (int h = 0; h < NWV; h++) { dynbody += S.freq[h]; fixbody += S.freq[8 + h]; }
+    if (dbg == 4 || dbg == 41) { z.bitpos += S.wtot[tid & 31] + S.red[6] + S.code[tid]; return; }
+    {   // the histograms are dead: their words become bit buffer
+        typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+        u4a *w16 = reinterpret_cast<u4a *>(wfa);
+        for (int i = tid; i < NWV * 72; i += TN) w16[i] = u4a{0u, 0u, 0u, 0u};
+    }
+    // per-wave totals: lane h of every wave holds wave h's numbers
+    uint32_t my_dyn = 0, my_fix = 0, my_x = 0, my_m = 0;
+    if (lane < NWV) { my_dyn = S.wtot[lane]; my_fix = S.wtot[8 + lane]; my_x = S.wtot[16 + lane]; my_m = S.wtot[24 + lane]; }
+    const uint32_t dyn_body_all = wave_sum(my_dyn + my_x + my_m), fix_body_all = wave_sum(my_fix + my_x + 5u * my_m);   // tokens incl. extra and distance bits
     const uint32_t eob_dyn = S.lens[256];
     const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
-    const uint32_t dyn_total = hdr_dyn + dynbody + eob_dyn + extra + matches * 1;
-    const uint32_t fix_total = 3 + fixbody + 7 + extra + matches * 5;
+    const uint32_t dyn_total = hdr_dyn + dyn_body_all + eob_dyn;
+    const uint32_t fix_total = 3 + fix_body_all + 7;
     const uint32_t sto_total = 3 + ((0u - (z.bitpos + 3)) & 7) + 32 + 8u * (uint32_t)len;
     {   // Adler-32 running update (RFC 1950): B' = B + len * A + sum (len - i) x_i
         const uint32_t nb = (uint32_t)(((uint64_t)adB + (uint64_t)len * adA + S.red[3]) % 65521u);
@@ -329,53 +386,54 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
         return;
     }
     const bool use_fixed = fix_total < dyn_total || S.dbg != 0;   // S.dbg: the length assignment gave up (never seen)
-    uint32_t pos0, dist_bits;
-    uint32_t clv[2] = {0, 0}, clnb[2] = {0, 0};
-    if (use_fixed) {
-        __syncthreads();                                   // everyone has read S.lens / S.freq under the dynamic code
-        for (int s = tid; s < 288; s += TN) S.code[s] = fixed_code(s);
-        pos0 = z.bitpos + 3;
-        dist_bits = 5;
-        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
-    } else {
-        const int ncl = S.ncl;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {   // code-length sequence: lane t owns entries 2t, 2t + 1
-            const int e = 2 * tid + q;
-            if (e < ncl) {
-                const uint32_t ent = S.clseq[e];
-                const uint32_t sym = ent & 31, cc = S.clcode[sym], cl = cc >> 16;
-                const uint32_t eb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
-                clv[q] = (cc & 0xFFFF) | ((ent >> 5) << cl);
-                clnb[q] = cl + eb;
-            }
-        }
-        pos0 = z.bitpos + hdr_dyn;
-        dist_bits = 1;
-    }
-    // bit offset of every wave's region
-    uint32_t wbase = pos0, total_bits = 0;
-#pragma unroll
-    for (int h = 0; h < NWV; h++) {
-        const uint32_t t = (use_fixed ? S.freq[8 + h] : S.freq[h]) + S.freq[16 + h] + S.freq[24 + h] * dist_bits;
-        if (h < wv) wbase += t;
-        total_bits += t;
-    }
+    const uint32_t dist_bits = use_fixed ? 5u : 1u;
+    const uint32_t pos0 = z.bitpos + (use_fixed ? 3u : hdr_dyn);
+    // bit offset of every wave's region: an exclusive scan over lanes 0 .. NWV - 1
+    const uint32_t my_t = (use_fixed ? my_fix : my_dyn) + my_x + my_m * dist_bits;
+    const uint32_t t_incl = wave_incl_add(my_t);
+    const uint32_t total_bits = (uint32_t)__builtin_amdgcn_readlane((int)t_incl, NWV - 1);
+    uint32_t wbase = pos0 + (wv ? (uint32_t)__builtin_amdgcn_readlane((int)t_incl, wv - 1) : 0u);
     const uint32_t eob = use_fixed ? fixed_code(256) : S.code[256];
     publish_size(es, pos0 + total_bits + (eob >> 16));
-    {
-        uint32_t hdr_total;
-        const uint32_t hoff = block_excl_add_w<NWV>(clnb[0] + clnb[1], S.ws, hdr_total);   // (its barriers also order the zeroing above / the fixed codes)
-        if (!use_fixed) {
+    if (use_fixed) {
+        __syncthreads();                                   // everyone has read the dynamic code's numbers
+        for (int s = tid; s < 288; s += TN) { S.code[s] = fixed_code(s); S.lens[s] = (uint8_t)fixed_len(s); }
+    }
+    __syncthreads();                                       // the histogram words are zero (and the fixed codes in place)
+    if (wv == 0) {
+        // block header on one wave, beside the other waves' tokens (disjoint bits, atomic ORs)
+        if (use_fixed) {
+            if (lane == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
+        } else {
+            // BFINAL, BTYPE = 10, HLIT, HDIST (2 codes), HCLEN in one 17-bit field; the HCLEN 3-bit code-length-code lengths one per lane;
+            // the code-length sequence five entries per lane
             const uint32_t hclen = S.hclen;
-            if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (2u << 1) | ((S.hlit - 257) << 3) | (1u << 8) | ((hclen - 4) << 13), 17);
-            if (tid < (int)hclen) {
+            if (lane == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (2u << 1) | ((S.hlit - 257) << 3) | (1u << 8) | ((hclen - 4) << 13), 17);
+            if (lane < (int)hclen) {
                 const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                put_bits(obuf, z, z.bitpos + 17 + 3 * tid, S.cllens[order[tid]], 3);
+                put_bits(obuf, z, z.bitpos + 17 + 3 * lane, S.cllens[order[lane]], 3);
             }
-            const uint32_t p = z.bitpos + 17 + 3 * hclen + hoff;
-            if (clnb[0]) put_bits(obuf, z, p, clv[0], clnb[0]);
-            if (clnb[1]) put_bits(obuf, z, p + clnb[0], clv[1], clnb[1]);
+            const int ncl = S.ncl;
+            uint32_t cv[5], cn[5], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int e = 5 * lane + q;
+                cv[q] = 0; cn[q] = 0;
+                if (e < ncl) {
+                    const uint32_t ent = S.clseq[e];
+                    const uint32_t sym = ent & 31, cc = S.clcode[sym], cl = cc >> 16;
+                    const uint32_t eb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+                    cv[q] = (cc & 0xFFFF) | ((ent >> 5) << cl);
+                    cn[q] = cl + eb;
+                }
+                sum += cn[q];
+            }
+            uint32_t p = z.bitpos + 17 + 3 * hclen + wave_incl_add(sum) - sum;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                if (cn[q]) put_bits(obuf, z, p, cv[q], cn[q]);
+                p += cn[q];
+            }
         }
     }
     if (dbg == 5) { z.bitpos += wbase; return; }
@@ -389,31 +447,71 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
             atomicOr(&obuf[w + 1], (uint32_t)(lo >> 32));
             if (sh + nb > 64) atomicOr(&obuf[w + 2], (uint32_t)(v >> (64 - sh)));   // rare: four long codes
         };
-        uint32_t carryE = carryE0;
-        WaveCarry wc{-1, k0 == 0};
+        const uint16_t *code16 = reinterpret_cast<const uint16_t *>(S.code);   // S.code[s] = code | length << 16: the low half alone is the code
         for (int k = k0; k < k1; k++) {
+            const uint32_t seg = (uint32_t)__builtin_amdgcn_readlane((int)segs, k - k0);
+            if (seg == SEG_FAST || seg == SEG_MASK) {
+                // every (valid) position a literal: the four bytes of the centred frame, no classification.  The code comes as the low half of
+                // its table word and the length from the byte table: two loads per slot, but no shift and no mask on the vector unit.
+                const int di = 64 * k + lane;
+                uint32_t w = 0, wp = 0;
+                if (seg == SEG_FAST) { w = buf32[di]; wp = buf32[di - 1]; }
+                else { const int ndw = (len + 3) >> 2; if (di < ndw) w = buf32[di]; if (di - 1 < ndw) wp = buf32[di - 1]; }
+                const uint32_t bytes = alignbit(w, wp, 16);
+                const uint32_t b0 = bytes & 255u, b1 = (bytes >> 8) & 255u, b2 = (bytes >> 16) & 255u, b3 = bytes >> 24;
+                uint32_t v0 = code16[2 * b0], v1 = code16[2 * b1], v2 = code16[2 * b2], v3 = code16[2 * b3];
+                uint32_t n0 = S.lens[b0], n1 = S.lens[b1], n2 = S.lens[b2], n3 = S.lens[b3];
+                if (seg == SEG_MASK) {
+                    const uint32_t V = frame_mask(256 * k + 4 * lane - 2, 0, len);
+                    if (!(V & 0x80u)) { v0 = 0; n0 = 0; }
+                    if (!(V & 0x8000u)) { v1 = 0; n1 = 0; }
+                    if (!(V & 0x800000u)) { v2 = 0; n2 = 0; }
+                    if (!(V & 0x80000000u)) { v3 = 0; n3 = 0; }
+                }
+                const uint32_t lo = v0 | (v1 << n0), nlo = n0 + n1;
+                const uint32_t hi = v2 | (v3 << n2), nhi = n2 + n3;
+                const uint32_t nb = nlo + nhi;
+                const uint32_t incl = wave_incl_add(nb);
+                or_bits(wbase + incl - nb, (uint64_t)lo | ((uint64_t)hi << nlo), nb);
+                wbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                continue;
+            }
+            if (seg != SEG_REDO) {
+                // listed: 64 tokens per step
+                const uint32_t st = seg & 0xFFFFu, total = seg >> 16;
+                for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                    const uint32_t idx = i0 + (uint32_t)lane;
+                    uint32_t v = 0, nb = 0;
+                    if (idx < total) {
+                        const uint32_t tok = tl[st + idx];
+                        const uint32_t sym = tok & 0x1FFu, cc = S.code[sym];
+                        nb = cc >> 16;
+                        v = (cc & 0xFFFFu) | ((tok >> 9) << nb);
+                        nb += length_extra_bits(sym) + (sym > 256u ? dist_bits : 0u);   // (the distance code is all zeros)
+                    }
+                    const uint32_t incl = wave_incl_add(nb);
+                    const uint32_t pos = wbase + incl - nb;
+                    const uint32_t w = (pos >> 5) - z.flushed, sh = pos & 31;            // nb <= 25: two words
+                    const uint64_t lo = (uint64_t)v << sh;
+                    atomicOr(&obuf[w], (uint32_t)lo);
+                    atomicOr(&obuf[w + 1], (uint32_t)(lo >> 32));
+                    wbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+                continue;
+            }
+            // the list was full in pass 1: the slab's analysis again (rare)
             const bool full = k > 0 && 256 * k + 256 <= len;
+            uint32_t carryE = k > 0 ? carry_e_before(buf32, k, len) : 0u;
+            WaveCarry wc{-1, k == 0};
             SlabCls c;
             if (full) c = classify_slab<false>(buf32, k, len, carryE);
             else c = classify_slab<true>(buf32, k, len, carryE);
             const bool anymem = __ballot(c.member != 0u) != 0ull;
             const uint32_t c0 = S.code[c.bytes & 255u], c1 = S.code[(c.bytes >> 8) & 255u], c2 = S.code[(c.bytes >> 16) & 255u], c3 = S.code[c.bytes >> 24];
-            if (full && !anymem) {
-                const uint32_t n0 = c0 >> 16, n1 = c1 >> 16, n2 = c2 >> 16, n3 = c3 >> 16;
-                const uint32_t lo = (c0 & 0xFFFFu) | ((c1 & 0xFFFFu) << n0), nlo = n0 + n1;
-                const uint32_t hi = (c2 & 0xFFFFu) | ((c3 & 0xFFFFu) << n2), nhi = n2 + n3;
-                const uint32_t nb = nlo + nhi;
-                const uint32_t incl = wave_incl_add(nb);
-                or_bits(wbase + incl - nb, (uint64_t)lo | ((uint64_t)hi << nlo), nb);
-                wbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                wc.ok = false;
-                continue;
-            }
             const uint32_t lit = c.V & ~c.member;
             SlabTail t;
             t.ql = 4; t.nfull = 0; t.rem = 0; t.runbyte = 0;
             if (anymem) t = slab_tail(buf, k, c, wc);
-            else wc.ok = false;
             // literals in front of the tail's slot (all of them without a tail), the tail, the literals behind it
             const uint32_t mA = t.ql >= 4 ? 0xFFFFFFFFu : (1u << (8 * t.ql)) - 1u;
             const uint32_t litA = lit & mA, litB = lit & ~mA;
@@ -458,8 +556,7 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
         }
 #ifdef S5_DEFL2_CHECK   // tests: every wave must end exactly where the next one starts
         {
-            uint32_t want = pos0;
-            for (int h = 0; h <= wv; h++) want += (use_fixed ? S.freq[8 + h] : S.freq[h]) + S.freq[16 + h] + S.freq[24 + h] * dist_bits;
+            const uint32_t want = pos0 + (uint32_t)__builtin_amdgcn_readlane((int)t_incl, wv);
             if (lane == 0 && wbase != want) atomicOr(&S.red[7], 1u);
         }
 #endif

@@ -57,6 +57,8 @@ struct DeflShared {
     uint32_t bins[64];       // assign_lengths_wave: Kraft cost per priority bin
     uint32_t red[8];         // 0 matches, 1 extra bits, 2 adler A part, 3 adler B part, 4 dyn bits, 5 fixed bits, 6 cl bits
     uint32_t ncl, hlit, hclen, dbg;
+    uint32_t wtot[32];       // deflate_block2: per wave [0, 8) dynamic body bits, [8, 16) fixed, [16, 24) extra bits, [24, 32) matches
+    uint32_t lalloc, lpad[3];   // deflate_block2: tokens handed out of the token list (which lives in freq[])
 };
 
 // Ordered single-pass output: as soon as a single-block record's final size is known (right after the bit-offset

@@ -41,7 +41,12 @@ extern uint32_t s5host_generation;                    // host_api.hip: bumped by
 extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
 constexpr uint32_t S_BYTES = (sizeof(DeflShared) + 15u) & ~15u;
-constexpr uint32_t B_BYTES = (sizeof(BuildScratch) + 15u) & ~15u;
+constexpr uint32_t BZ_BYTES = (sizeof(BuildScratch) + 15u) & ~15u;   // deflate_block (round 1-4) and the zstd encoder overlay their build scratch on the bit buffer
+#ifdef S5_DEFL_V1
+constexpr uint32_t B_BYTES = BZ_BYTES;
+#else
+constexpr uint32_t B_BYTES = NW * 288u * 4u + 64u;                   // deflate_block2 keeps one histogram per wave in the bit buffer's tail
+#endif
 constexpr uint32_t OVF = 0xFFFFFFFFu;
 
 struct EncParams {
@@ -1766,10 +1771,10 @@ extern "C" int s5gpu_encode_dev(const s5gpu_encode_args_t *a, void *stream_) {
     if (!all_staged) {
         HIP_TRY(hipMemsetAsync(a->ovf, 0, 4, st));
         p.pay_cap = cap;
-        p.obuf_words = (cap + 64 > B_BYTES ? cap + 64 : B_BYTES) / 4;
-        const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
-        // a lane owns ceil(len / 256) bytes: payloads up to 8 KiB need 32-bit position masks only
         const bool xz = a->sig_method == S5GPU_SIG_EX_ZD, zs = a->rec_method == S5GPU_REC_ZSTD;
+        const uint32_t floor_b = zs ? BZ_BYTES : B_BYTES;
+        p.obuf_words = (cap + 64 > floor_b ? cap + 64 : floor_b) / 4;
+        const size_t lds = S_BYTES + 4ull * p.obuf_words + p.pay_cap;
         if (zs) { if (xz) hipLaunchKernelGGL(k_zstd_fused<true>, dim3(a->n_reads), dim3(NT), lds, st, p); else hipLaunchKernelGGL(k_zstd_fused<false>, dim3(a->n_reads), dim3(NT), lds, st, p); }
         else {
             // A caller that names an LDS budget has a batch of mixed lengths.  Option "fused_tier2" (round 4, off by default) gives it TWO fused
