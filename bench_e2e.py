@@ -234,21 +234,25 @@ def _same_file(a, b, block=1 << 24):
 
 def pcie_inclusive(L, _lib, press, n_reads, n, reps=2):
     """s5gpu_encode_batch on host buffers: what a patched view.c sees per batch (host int16 signals in, one malloc'd record per read out: the
-    ownership contract of slow5_rec_to_mem, /root/reference/src/view.c:49,298) — at 65536 reads per call (sixteen of the reference's default
-    batches) and at the full 1 M.  The first call of a size also allocates the library's pinned and device workspaces; best and first are
-    both reported.  The 1 M call hands out 3.5 GB in a million malloc'd buffers the process has never touched: page faults, not PCIe, bound it —
-    the chunk calls (s5gpu_recompress_stream ...) exist for that reason."""
-    out = {"call": "s5gpu_encode_batch (host int16 signals in, one malloc'd record per read out)", "note": "PCIe-inclusive: never `value`"}
-    for m in (65536, n_reads):
+    ownership contract of slow5_rec_to_mem, /root/reference/src/view.c:49,298) — at the reference's own batch sizes (K = 4096, /root/reference/src/cmd.h:8;
+    K = 10 000, test/test_view_integrity.sh:62-66: one synchronous call per batch, as view.c:292 would issue it), at 65536 reads per call and at the
+    full 1 M.  The first call of a size also allocates the library's pinned and device workspaces; best and first are both reported.  The 1 M call of
+    the malloc form hands out 3.5 GB in a million buffers the process has never touched: page faults, not PCIe, bound it.  `arena` = the same call
+    through s5gpu_encode_batch_arena (round 5): records are pointers into pooled pinned buffers, one release per batch."""
+    out = {"call": "s5gpu_encode_batch (host int16 signals in, one malloc'd record per read out) and its arena form (pointers into pooled pinned buffers, one release)",
+           "note": "PCIe-inclusive: never `value`"}
+    for m in (4096, 10000, 65536, n_reads):
         if m > n_reads:
             continue
-        out["batch_%d" % m] = _pcie_one(L, _lib, press, m, n, 6 if m <= 65536 else reps)      # (the allocator needs a few calls to settle: 1.4 / 5.4 / 21.5 GB/s on calls 1 / 2 / 3)
+        r = 8 if m <= 10000 else 6 if m <= 65536 else reps      # (the allocator needs a few calls to settle: 1.4 / 5.4 / 21.5 GB/s on calls 1 / 2 / 3 of 65536)
+        out["batch_%d" % m] = _pcie_one(L, _lib, press, m, n, r, arena=False)
+        out["batch_%d" % m]["arena"] = _pcie_one(L, _lib, press, m, n, r + 1, arena=True)
     big = out["batch_%d" % n_reads]
-    out.update({"reads": n_reads, "samples_per_read": n, "GB_per_s": big["GB_per_s"], "reads_per_s": big["reads_per_s"]})
+    out.update({"reads": n_reads, "samples_per_read": n, "GB_per_s": big["GB_per_s"], "reads_per_s": big["reads_per_s"], "arena_GB_per_s": big["arena"]["GB_per_s"]})
     return out
 
 
-def _pcie_one(L, _lib, press, n_reads, n, reps):
+def _pcie_one(L, _lib, press, n_reads, n, reps, arena=False):
     rng = np.random.default_rng(0)
     base = (500 + 30 * rng.standard_normal((1024, n))).astype(np.int16)
     sig = np.ascontiguousarray(np.tile(base, (n_reads // 1024 + 1, 1))[:n_reads])
@@ -263,16 +267,29 @@ def _pcie_one(L, _lib, press, n_reads, n, reps):
     ol = (C.c_size_t * n_reads)()
     libc = C.CDLL(None)
     libc.free.argtypes = [vp]
+    L.s5gpu_encode_batch_arena.argtypes = [C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
+    L.s5gpu_arena_release.argtypes = [vp]
     times = []
     tot = 0
     for it in range(reps):
-        t0 = time.perf_counter()
-        _lib.check(L.s5gpu_encode_batch(n_reads, sig_p, ns, hdr_p, hl, None, None, 1, 1, out, ol))
-        times.append(time.perf_counter() - t0)
+        if arena:
+            h = vp()
+            t0 = time.perf_counter()
+            _lib.check(L.s5gpu_encode_batch_arena(n_reads, sig_p, ns, hdr_p, hl, None, None, 1, 1, out, ol, C.byref(h)))
+            times.append(time.perf_counter() - t0)
+        else:
+            t0 = time.perf_counter()
+            _lib.check(L.s5gpu_encode_batch(n_reads, sig_p, ns, hdr_p, hl, None, None, 1, 1, out, ol))
+            times.append(time.perf_counter() - t0)
         lens = np.frombuffer(ol, dtype=np.uint64 if C.sizeof(C.c_size_t) == 8 else np.uint32)
         tot = int(lens.sum())
-        for p in np.frombuffer(out, dtype=np.uint64).tolist():
-            libc.free(p)
+        if arena:
+            t1 = time.perf_counter()
+            L.s5gpu_arena_release(h)
+            times[-1] += time.perf_counter() - t1          # the release belongs to the call's cost, as the free loop does to the malloc form's user
+        else:
+            for p in np.frombuffer(out, dtype=np.uint64).tolist():
+                libc.free(p)
     best = min(times)
-    return {"reads": n_reads, "seconds": [round(t, 3) for t in times], "GB_per_s": round(n_reads * n * 2 / best / 1e9, 3), "reads_per_s": round(n_reads / best, 1),
+    return {"reads": n_reads, "seconds": [round(t, 4) for t in times], "GB_per_s": round(n_reads * n * 2 / best / 1e9, 3), "reads_per_s": round(n_reads / best, 1),
             "first_call_GB_per_s": round(n_reads * n * 2 / times[0] / 1e9, 3), "bytes_per_sample": round(tot / (n_reads * n), 4)}
