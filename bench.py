@@ -1011,6 +1011,27 @@ def main():
         "e2e": e2e_obj,
         "pcie_inclusive": pcie_obj,
     }
+    # the other legs' headline numbers in ONE small object inside `roofline` (the driver's record keeps roofline / cpu_baseline / config whole and
+    # only the NAMES of further top-level keys): every figure below is measured in this run, its full object is the top-level key of the same name
+    def pick(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    line["roofline"]["legs"] = {
+        "mixed_GB_per_s": pick(leg_mixed, "value"), "mixed_frac": pick(leg_mixed, "roofline", "frac"),
+        "configs3_GB_per_s": pick(leg3, "value"), "configs3_frac": pick(leg3, "roofline", "frac"),
+        "configs4_k4096_batch_latency_ms": pick(leg4, "batch_latency_ms"), "configs4_k4096_reads_per_s": pick(leg4, "reads_per_s"),
+        "configs4_k4096_frac": pick(leg4, "roofline", "frac"),
+        "bulk_decode_one_call": {k: pick(leg4, "bulk_decode_one_call", k) for k in ("reads", "ms", "reads_per_s")},
+        "bulk_decode_frac": pick(leg4, "bulk_decode_one_call", "roofline", "frac"),
+        "stock_zlib_records_reads_per_s": pick(leg4, "bulk_decode_one_call", "stock_zlib_records", "reads_per_s"),
+        "pcie_inclusive_GB_per_s": {k: {"malloc": pick(pcie_obj, k, "GB_per_s"), "arena": pick(pcie_obj, k, "arena", "GB_per_s")}
+                                    for k in ("batch_4096", "batch_10000", "batch_65536", "batch_%d" % n_reads)} if isinstance(pcie_obj, dict) else None,
+        "e2e_whole_process_s": {k: pick(e2e_obj, k, "gpu", "whole_process_s") for k in ("slow5_to_blow5", "blow5_to_blow5")} if isinstance(e2e_obj, dict) else None,
+        "e2e_get_100k_whole_process_s": pick(e2e_obj, "get_100k", "gpu", "benchmark", "whole_process_s"),
+    }
     finish(line)
 
 

@@ -447,29 +447,62 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
             atomicOr(&obuf[w + 1], (uint32_t)(lo >> 32));
             if (sh + nb > 64) atomicOr(&obuf[w + 2], (uint32_t)(v >> (64 - sh)));   // rare: four long codes
         };
-        const uint16_t *code16 = reinterpret_cast<const uint16_t *>(S.code);   // S.code[s] = code | length << 16: the low half alone is the code
+        // the codes of four literal bytes as one value of <= 60 bits
+        auto lit4 = [&](uint32_t bytes, uint64_t &v, uint32_t &nb) {
+            const uint32_t c0 = S.code[bytes & 255u], c1 = S.code[(bytes >> 8) & 255u], c2 = S.code[(bytes >> 16) & 255u], c3 = S.code[bytes >> 24];
+            const uint32_t n0 = c0 >> 16, n1 = c1 >> 16, n2 = c2 >> 16, n3 = c3 >> 16;
+            const uint32_t lo = (c0 & 0xFFFFu) | ((c1 & 0xFFFFu) << n0), nlo = n0 + n1;
+            const uint32_t hi = (c2 & 0xFFFFu) | ((c3 & 0xFFFFu) << n2), nhi = n2 + n3;
+            v = (uint64_t)lo | ((uint64_t)hi << nlo);
+            nb = nlo + nhi;
+        };
         for (int k = k0; k < k1; k++) {
             const uint32_t seg = (uint32_t)__builtin_amdgcn_readlane((int)segs, k - k0);
-            if (seg == SEG_FAST || seg == SEG_MASK) {
-                // every (valid) position a literal: the four bytes of the centred frame, no classification.  The code comes as the low half of
-                // its table word and the length from the byte table: two loads per slot, but no shift and no mask on the vector unit.
+            if (seg == SEG_FAST && k + 1 < k1 && (uint32_t)__builtin_amdgcn_readlane((int)segs, k + 1 - k0) == SEG_FAST) {
+                // TWO plain slabs in one step, eight consecutive positions per lane.  With four positions a lane's codes span ~33 bits, so
+                // neighbouring lanes often OR into the same word in the same instruction — same-address LDS atomics serialise, and pass 2
+                // was bound by the LDS pipe (91 % busy, two thirds of it conflict cycles: profiles/r05_encode_stages.txt).  With eight a
+                // lane spans >= 32 bits: the word indices of one instruction rise strictly from lane to lane.  Half the scans, too.
+                const int d0 = 64 * k + 2 * lane;
+                const uint32_t wp = buf32[d0 - 1], w0 = buf32[d0], w1 = buf32[d0 + 1];
+                uint64_t vA, vB;
+                uint32_t nA, nB;
+                lit4(alignbit(w0, wp, 16), vA, nA);
+                lit4(alignbit(w1, w0, 16), vB, nB);
+                const uint32_t nb = nA + nB;
+                const uint32_t incl = wave_incl_add(nb);
+                const uint32_t pos = wbase + incl - nb;
+                or_bits(pos, vA, nA);
+                or_bits(pos + nA, vB, nB);
+                wbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                k++;
+                continue;
+            }
+            if (seg == SEG_FAST) {
                 const int di = 64 * k + lane;
+                uint64_t v;
+                uint32_t nb;
+                lit4(alignbit(buf32[di], buf32[di - 1], 16), v, nb);
+                const uint32_t incl = wave_incl_add(nb);
+                or_bits(wbase + incl - nb, v, nb);
+                wbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                continue;
+            }
+            if (seg == SEG_MASK) {
+                // an end slab without a run: the literals of the valid positions
+                const int di = 64 * k + lane, ndw = (len + 3) >> 2;
                 uint32_t w = 0, wp = 0;
-                if (seg == SEG_FAST) { w = buf32[di]; wp = buf32[di - 1]; }
-                else { const int ndw = (len + 3) >> 2; if (di < ndw) w = buf32[di]; if (di - 1 < ndw) wp = buf32[di - 1]; }
+                if (di < ndw) w = buf32[di];
+                if (di - 1 < ndw) wp = buf32[di - 1];
                 const uint32_t bytes = alignbit(w, wp, 16);
-                const uint32_t b0 = bytes & 255u, b1 = (bytes >> 8) & 255u, b2 = (bytes >> 16) & 255u, b3 = bytes >> 24;
-                uint32_t v0 = code16[2 * b0], v1 = code16[2 * b1], v2 = code16[2 * b2], v3 = code16[2 * b3];
-                uint32_t n0 = S.lens[b0], n1 = S.lens[b1], n2 = S.lens[b2], n3 = S.lens[b3];
-                if (seg == SEG_MASK) {
-                    const uint32_t V = frame_mask(256 * k + 4 * lane - 2, 0, len);
-                    if (!(V & 0x80u)) { v0 = 0; n0 = 0; }
-                    if (!(V & 0x8000u)) { v1 = 0; n1 = 0; }
-                    if (!(V & 0x800000u)) { v2 = 0; n2 = 0; }
-                    if (!(V & 0x80000000u)) { v3 = 0; n3 = 0; }
-                }
-                const uint32_t lo = v0 | (v1 << n0), nlo = n0 + n1;
-                const uint32_t hi = v2 | (v3 << n2), nhi = n2 + n3;
+                const uint32_t V = frame_mask(256 * k + 4 * lane - 2, 0, len);
+                uint32_t cc[4] = {S.code[bytes & 255u], S.code[(bytes >> 8) & 255u], S.code[(bytes >> 16) & 255u], S.code[bytes >> 24]};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (!(V & (0x80u << (8 * q)))) cc[q] = 0;
+                const uint32_t n0 = cc[0] >> 16, n1 = cc[1] >> 16, n2 = cc[2] >> 16, n3 = cc[3] >> 16;
+                const uint32_t lo = (cc[0] & 0xFFFFu) | ((cc[1] & 0xFFFFu) << n0), nlo = n0 + n1;
+                const uint32_t hi = (cc[2] & 0xFFFFu) | ((cc[3] & 0xFFFFu) << n2), nhi = n2 + n3;
                 const uint32_t nb = nlo + nhi;
                 const uint32_t incl = wave_incl_add(nb);
                 or_bits(wbase + incl - nb, (uint64_t)lo | ((uint64_t)hi << nlo), nb);
