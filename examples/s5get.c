@@ -218,7 +218,7 @@ static void *early_init_main(void *arg) {
 /* The work is done and every file is closed: leave without the HIP runtime's static destructors (code objects, memory pools: ~0.1 s of a
  * one-second job).  S5_FULL_EXIT=1 takes the ordinary way out (leak checkers). */
 static int leave(void) {
-    fflush(stdout);
+    if (fflush(stdout) != 0) { fprintf(stderr, "%s: writing the standard output failed\n", "s5get"); fflush(stderr); _exit(EXIT_FAILURE); }
     fflush(stderr);
     const char *e = getenv("S5_FULL_EXIT");
     if (e && atoi(e)) { s5gpu_shutdown(); return EXIT_SUCCESS; }
@@ -263,7 +263,7 @@ int main(int argc, char **argv) {
     /* the HIP runtime and the device context come up (~0.15 s) while the index is loaded (~0.13 s per million reads) and the ids are read */
     pthread_t init_th;
     const int early_init = !(getenv("S5VIEW_DEV_MASK") && strtoull(getenv("S5VIEW_DEV_MASK"), NULL, 0));     /* (a device mask has initialised the library already) */
-    if (early_init) pthread_create(&init_th, NULL, early_init_main, NULL);
+    const int early_init_started = early_init && pthread_create(&init_th, NULL, early_init_main, NULL) == 0;   /* (no thread: the first GPU call initialises) */
     P.in = slow5_open(av[1], "r");
     if (!P.in || P.in->format != SLOW5_FORMAT_BINARY) return die("cannot open input (an indexed BLOW5 file)");
     const double t_idx0 = now_s();
@@ -271,7 +271,7 @@ int main(int argc, char **argv) {
     const double t_idx = now_s() - t_idx0;
     P.ids = read_ids(av[2], &P.n_ids);
     if (!P.ids) return die("cannot read the id list");
-    if (early_init) pthread_join(init_th, NULL);
+    if (early_init_started) pthread_join(init_th, NULL);
     P.from.record_method = P.in->compress->record_press->method; P.from.signal_method = P.in->compress->signal_press->method;
     P.to.record_method = SLOW5_COMPRESS_ZLIB; P.to.signal_method = SLOW5_COMPRESS_SVB_ZD;
     int argk = benchmark ? 3 : 6;
@@ -335,7 +335,7 @@ int main(int argc, char **argv) {
     if (P.failed) { fprintf(stderr, "s5get: %s\n", P.why); return EXIT_FAILURE; }
     if (out) {
         if (fseek(out, 0, SEEK_END) != 0 || slow5_eof_fwrite(out) < 0) return die("eof write failed");
-        fclose(out);
+        if (fclose(out) != 0) return die("closing the output failed (its last bytes may not be on disk)");
     }
     int64_t nl = P.n_batches;
     if (nl > 1 && (uint64_t)P.K * (uint64_t)nl != P.n_ids) nl--;       /* the last batch is a short one */

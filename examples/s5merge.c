@@ -145,7 +145,7 @@ static char *remap_line(const char *line, size_t len, const long *map, size_t n_
 /* The work is done and every file is closed: leave without the HIP runtime's static destructors (code objects, memory pools: ~0.1 s of a
  * one-second job).  S5_FULL_EXIT=1 takes the ordinary way out (leak checkers). */
 static int leave(void) {
-    fflush(stdout);
+    if (fflush(stdout) != 0) { fprintf(stderr, "%s: writing the standard output failed\n", "s5merge"); fflush(stderr); _exit(EXIT_FAILURE); }
     fflush(stderr);
     const char *e = getenv("S5_FULL_EXIT");
     if (e && atoi(e)) { s5gpu_shutdown(); return EXIT_SUCCESS; }
@@ -358,7 +358,7 @@ int main(int argc, char **argv) {
         slow5_close(s);
     }
     if (slow5_eof_fwrite(fo) < 0) return die("eof write failed", NULL);
-    fclose(fo);
+    if (fclose(fo) != 0) return die("closing the output failed (its last bytes may not be on disk)", NULL);
     fprintf(stderr, "s5merge: %llu records of %zu files into %zu read groups, %zu aux fields (%llu records through the text detour)\n",
             (unsigned long long)total, nf, out.n_rg, lossy ? (size_t)0 : out.n_aux, (unsigned long long)detour);
     return leave();

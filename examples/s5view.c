@@ -485,8 +485,9 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     const double t0 = now_s();
     pthread_t rd, wk[8], al;
     const int W = workers > 8 ? 8 : workers;
-    pthread_create(&al, NULL, fslot_alloc_rest, &P);
-    pthread_create(&rd, NULL, freader_main, &P);
+    const int al_started = pthread_create(&al, NULL, fslot_alloc_rest, &P) == 0;
+    if (!al_started) fslot_alloc_rest(&P);                              /* no helper thread: pin the other slots here */
+    if (pthread_create(&rd, NULL, freader_main, &P) != 0) { fprintf(stderr, "s5view: cannot start the reader thread\n"); return -1; }
     for (int i = 0; i < W; i++) pthread_create(&wk[i], NULL, fworker_main, &P);
     uint64_t out_bytes = 0;
     off_t out_pos = lseek(P.fd_out, 0, SEEK_CUR);                    /* (the header is flushed: the records start here) */
@@ -517,7 +518,7 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     }
     pthread_join(rd, NULL);
     for (int i = 0; i < W; i++) pthread_join(wk[i], NULL);
-    pthread_join(al, NULL);
+    if (al_started) pthread_join(al, NULL);
     if (out_pos >= 0 && lseek(P.fd_out, out_pos, SEEK_SET) < 0) fpipe_fail(&P, "seek failed");   /* the end marker follows the last record */
     const double t1 = now_s();
     stamp("last write");
@@ -534,7 +535,7 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
 /* The work is done and every file is closed: leave without the HIP runtime's static destructors (code objects, memory pools: ~0.1 s of a
  * one-second job).  S5_FULL_EXIT=1 takes the ordinary way out (leak checkers). */
 static int leave(void) {
-    fflush(stdout);
+    if (fflush(stdout) != 0) { fprintf(stderr, "%s: writing the standard output failed\n", "s5view"); fflush(stderr); _exit(EXIT_FAILURE); }
     fflush(stderr);
     const char *e = getenv("S5_FULL_EXIT");
     if (e && atoi(e)) { s5gpu_shutdown(); return EXIT_SUCCESS; }
@@ -585,7 +586,7 @@ int main(int argc, char **argv) {
     /* the HIP runtime and the device context come up (~0.15 s) while the input's header is read and the output is created */
     pthread_t init_th;
     const int early_init = !(getenv("S5VIEW_DEV_MASK") && strtoull(getenv("S5VIEW_DEV_MASK"), NULL, 0));
-    if (early_init) pthread_create(&init_th, NULL, early_init_main, NULL);
+    int early_init_started = early_init && pthread_create(&init_th, NULL, early_init_main, NULL) == 0;   /* (no thread: the first GPU call initialises) */
     slow5_file_t *in = slow5_open(argv[1], "r");
     if (!in) return die("cannot open input");
     stamp("input opened, header read");
@@ -598,7 +599,7 @@ int main(int argc, char **argv) {
 
     const int workers = argc > 6 ? atoi(argv[6]) : 1;
     uint64_t total = 0;
-    if (early_init) pthread_join(init_th, NULL);
+    if (early_init_started) pthread_join(init_th, NULL);
     stamp("device ready");
     const char *nofast = getenv("S5VIEW_PER_RECORD");
     /* chunked pipeline: BLOW5 -> BLOW5, SLOW5 -> BLOW5 (the conversion BASELINE configs[0] names) and BLOW5 -> SLOW5; text to text takes the per-record one */
@@ -678,7 +679,7 @@ int main(int argc, char **argv) {
         free(mem); free(bytes); free(bufs); free(lens);
     }
     if (fmt_out == SLOW5_FORMAT_BINARY && slow5_eof_fwrite(out) < 0) return die("eof write failed");   /* src/view.c:311-313 */
-    fclose(out);
+    if (fclose(out) != 0) return die("closing the output failed (its last bytes may not be on disk)");
     slow5_close(in);
     fprintf(stderr, "s5view: %llu records\n", (unsigned long long)total);
     stamp("output closed");

@@ -30,7 +30,7 @@ extern "C" {
 /* on-disk method codes, identical to slow5lib's enum slow5_press_method values used by
  * /root/reference/src/misc.c:253-263 (SLOW5_COMPRESS_NONE/ZLIB, SLOW5_COMPRESS_NONE/SVB_ZD) */
 enum { S5GPU_REC_NONE = 0, S5GPU_REC_ZLIB = 1, S5GPU_REC_ZSTD = 2 };   /* zstd: any frame libzstd writes is decoded (an optional content
-                                                                         * checksum is skipped, not verified); encoded frames are literals-only
+                                                                         * checksum is verified: status 4 on a mismatch); encoded frames are literals-only
                                                                          *  */
 enum { S5GPU_SIG_NONE = 0, S5GPU_SIG_SVB_ZD = 1, S5GPU_SIG_EX_ZD = 2 };
 
@@ -151,7 +151,9 @@ int s5gpu_init_mask(uint64_t dev_mask);
 int s5gpu_devices_in_use(void);          /* devices the batch calls run on (0 before initialisation) */
 /* Brings up, on the first device in use, what the first batch call would otherwise pay for: the HIP runtime and context, the kernels'
  * code objects (loaded on first launch) and one set of streams.  A tool calls it from a helper thread at start-up, under its own file
- * opening / index loading (examples/s5view.c, s5get.c: the first GPU call of a 100 k-id `get` was 175 ms of a 230 ms job).  Optional. */
+ * opening / index loading (examples/s5view.c, s5get.c: the first GPU call of a 100 k-id `get` was 175 ms of a 230 ms job).  Optional.
+ * If the library is not initialised yet it initialises it as s5gpu_init(0) does — a caller that wants other devices calls
+ * s5gpu_init_mask FIRST (afterwards it reports "already initialised"). */
 int s5gpu_warmup(void);
 void s5gpu_shutdown(void);
 const char *s5gpu_last_error(void);
@@ -171,7 +173,13 @@ int s5gpu_device_count(void);
  * offset (predefined FSE tables); 0 = literals-only frames cut at the record's seams (round 1; ~2 % larger records).
  * "fused_tier2" (bytes, 0 .. 16384, default 0 = off): batches of mixed lengths (s5gpu_encode_args.lds_payload_cap named) get a SECOND
  * one-workgroup-per-read launch with this LDS budget for the reads between the named budget and one 16 KiB DEFLATE block, before
- * the HBM-staged kernels take the rest; measured on real-run read lengths it gains nothing (profiles/r04_mixed_tier2.txt). */
+ * the HBM-staged kernels take the rest; measured on real-run read lengths it gains nothing (profiles/r04_mixed_tier2.txt).
+ * "order_min" (default 8192; 0 = never): batches of at least this many zlib / zstd records are DECODED longest record first (a counting sort
+ * by compressed length on the device builds the launch order), and the overflow list of a mixed ENCODE batch (the reads the staged kernels
+ * redo) is taken longest read first.  Costs 4 bytes per record of scratch per (device, stream), kept until s5gpu_shutdown.
+ * "zstd_pre_min" (default 256; 0 = never): zstd batches of at least this many frames run a first pass that reads every frame's first tree
+ * description, a frame per lane, in front of the decoder.  Costs 144 bytes per record in the same per-(device, stream) scratch
+ * (144 MB for a million frames); a process that decodes on many short-lived streams should reuse streams or set this to 0. */
 int s5gpu_set_option(const char *key, long value);
 
 /* ---- device-resident entry points (asynchronous on `hip_stream`, a hipStream_t; NULL = default) ---- */
@@ -274,7 +282,9 @@ int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chunk_bytes, c
 /* The decode half alone on a chunk of framed records (`get --benchmark`, /root/reference/src/get.c:52, and any consumer of signals): the
  * decoded signals come back as ONE contiguous int16 block — sig_off[i] = first sample of record i, sig_off[n] = total — and the parsed
  * fields in fields[i]; no malloc per record.  sig_cap in samples; too little: S5GPU_ERR_NOMEM and sig_off[0] = samples needed.  A corrupt
- * record fails the call with S5GPU_ERR_DATA (fields[i].status says which). */
+ * record fails the call with S5GPU_ERR_DATA (fields[i].status says which; with several devices, records of a share that gave up because
+ * another share failed read S5GPU_STATUS_NOT_DECODED, never 0). */
+#define S5GPU_STATUS_NOT_DECODED 15
 int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int rec_method,
                         int sig_method, int16_t *sig_out, size_t sig_cap, uint64_t *sig_off, s5gpu_rec_fields_t *fields);
 

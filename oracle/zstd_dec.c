@@ -10,7 +10,7 @@
  *
  * Supported: single / multi block frames, raw / RLE / compressed blocks, all four literal modes (1 and 4 streams, direct and
  * FSE-compressed Huffman weights, treeless), all sequence modes (predefined / RLE / FSE / repeat), repeat offsets, optional
- * content checksum (skipped, not verified), skippable frames are rejected, dictionaries are rejected.
+ * content checksum (XXH64: verified when the frame carries one), skippable frames are rejected, dictionaries are rejected.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -255,6 +255,29 @@ int s5o_zstd_seq_dtable(int which, uint32_t *cells) {
     return 1 << log;
 }
 
+/* XXH64, seed 0 (the published algorithm: four accumulators over 32-byte stripes, merge, tail, avalanche) */
+static uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t xxh64(const uint8_t *p, size_t n) {
+    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull, P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+    uint64_t h;
+    size_t i = 0;
+    if (n >= 32) {
+        uint64_t v[4] = {P1 + P2, P2, 0, 0 - P1};
+        for (; i + 32 <= n; i += 32)
+            for (int k = 0; k < 4; k++) v[k] = rotl64(v[k] + rd64(p + i + 8 * k) * P2, 31) * P1;
+        h = rotl64(v[0], 1) + rotl64(v[1], 7) + rotl64(v[2], 12) + rotl64(v[3], 18);
+        for (int k = 0; k < 4; k++) h = (h ^ (rotl64(v[k] * P2, 31) * P1)) * P1 + P4;
+    } else h = P5;
+    h += n;
+    for (; i + 8 <= n; i += 8) h = rotl64(h ^ (rotl64(rd64(p + i) * P2, 31) * P1), 27) * P1 + P4;
+    if (i + 4 <= n) { h = rotl64(h ^ ((uint64_t)rd32(p + i) * P1), 23) * P2 + P3; i += 4; }
+    for (; i < n; i++) h = rotl64(h ^ ((uint64_t)p[i] * P5), 11) * P1;
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
 size_t s5o_zstd_restated_decompress(const uint8_t *in, size_t len, uint8_t *out, size_t cap) {
     const size_t ERR = (size_t)-1;
     if (len < 6 || in[0] != 0x28 || in[1] != 0xB5 || in[2] != 0x2F || in[3] != 0xFD) return ERR;
@@ -394,7 +417,14 @@ size_t s5o_zstd_restated_decompress(const uint8_t *in, size_t len, uint8_t *out,
         if (o + (lsize - li) > cap) { bad = 1; break; }
         memcpy(out + o, lit + li, lsize - li); o += lsize - li;
     }
-    if (!bad && checksum) { if (p + 4 > len) bad = 1; else p += 4; }
+    if (!bad && checksum) {   /* the low 32 bits of XXH64(content, seed 0), little-endian (RFC 8878 3.1.1) */
+        if (p + 4 > len) bad = 1;
+        else {
+            const uint32_t want = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
+            if ((uint32_t)xxh64(out, o) != want) bad = 1;
+            p += 4;
+        }
+    }
     if (!bad && p != len) bad = 1;
     if (!bad && fcs_bytes && fcs != o) bad = 1;
     free(z); free(lit);

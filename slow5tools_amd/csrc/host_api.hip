@@ -170,6 +170,7 @@ int s5host::for_each_device_range(uint32_t n, const std::function<int(int, uint3
     std::vector<std::thread> th;
     auto body = [&](int g) {
         const uint32_t lo = (uint32_t)((uint64_t)n * g / G), hi = (uint32_t)((uint64_t)n * (g + 1) / G);
+        s5gpu_set_error("%s", "");                  // a share that gives up with a bare code must not report an older call's message of this thread
         rcs[g] = lo < hi ? fn(g, lo, hi) : S5GPU_OK;
         if (rcs[g]) errs[g] = s5gpu_last_error();   // the message lives in the thread that failed
     };
@@ -1010,6 +1011,8 @@ extern "C" int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_b
         if (rec_pos[i] > chunk_bytes || rec_len[i] > chunk_bytes - rec_pos[i]) { s5gpu_set_error("record %u lies outside the chunk", i); return S5GPU_ERR_ARG; }
     const int G = s5host::n_devices();
     if (G == 0) return S5GPU_ERR_NODEV;
+    // a share that waits behind a failing one gives up before it has looked at its records: their statuses must not read as "ok"
+    for (uint32_t i = 0; i < n; i++) { memset(&fields[i], 0, sizeof fields[i]); fields[i].status = S5GPU_STATUS_NOT_DECODED; }
     s5host::ShareGather sg(G);
     auto share = [&](int slot, uint32_t lo, uint32_t hi) -> int {
         s5host::CtxHold hold;

@@ -1574,17 +1574,25 @@ static uint32_t g_order_min = 8192;            // batches of at least this many 
 // when the next call on that stream is enqueued — grown on demand, released by s5gpu_shutdown.  One pool and one lock PER DEVICE: the
 // multi-device batch calls run one host thread per device, and those must not serialise on each other's list builds.  A buffer that is
 // outgrown is retired, not freed (hipFree waits for the device — and an earlier launch on the stream may still read the old list): the
-// retired ones go with the pool at shutdown; growth is geometric, so they add up to less than the live buffer.
+// retired ones are freed once an event recorded on their stream at that moment has completed (round 5; before: at shutdown), and a device keeps
+// entries for at most ORD_MAX_STREAMS streams, the least recently used one making room.
 struct OrderBuf {
     uint32_t *p = nullptr;
     size_t words = 0;
     hipStream_t st = nullptr;
+    uint64_t used = 0;             // the pool's use counter when this stream last asked: the least recently used entry goes first
+};
+struct RetiredBuf {
+    uint32_t *p;
+    hipEvent_t ev;                 // recorded on the buffer's stream when it was outgrown: once it has completed nobody reads the buffer any more
 };
 constexpr int ORD_MAX_DEV = 64;
+constexpr size_t ORD_MAX_STREAMS = 32;   // entries kept per device; a process that makes streams by the thousand does not keep a buffer for each
 struct OrderPool {
     std::mutex mu;
     std::vector<OrderBuf> live;
-    std::vector<uint32_t *> retired;
+    std::vector<RetiredBuf> retired;
+    uint64_t tick = 0;
 };
 static OrderPool g_ord[ORD_MAX_DEV];
 void s5kern_release_order() {                 // s5gpu_shutdown
@@ -1596,7 +1604,7 @@ void s5kern_release_order() {                 // s5gpu_shutdown
         if (P.live.empty() && P.retired.empty()) continue;
         (void)hipSetDevice(dev);
         for (OrderBuf &b : P.live) if (b.p) (void)hipFree(b.p);
-        for (uint32_t *q : P.retired) (void)hipFree(q);
+        for (RetiredBuf &q : P.retired) { (void)hipFree(q.p); if (q.ev) (void)hipEventDestroy(q.ev); }
         P.live.clear();
         P.retired.clear();
     }
@@ -1610,14 +1618,41 @@ static int order_scratch(hipStream_t st, size_t need, uint32_t **out, std::uniqu
     if (dev < 0 || dev >= ORD_MAX_DEV) return S5GPU_OK;          // (file order is always correct)
     OrderPool &P = g_ord[dev];
     hold = std::unique_lock<std::mutex>(P.mu);
+    // retired buffers whose last reader has finished go back to the device (round 5: they used to wait for s5gpu_shutdown)
+    for (size_t i = 0; i < P.retired.size();) {
+        if (!P.retired[i].ev || hipEventQuery(P.retired[i].ev) == hipSuccess) {
+            if (P.retired[i].ev) { (void)hipFree(P.retired[i].p); (void)hipEventDestroy(P.retired[i].ev); P.retired[i] = P.retired.back(); P.retired.pop_back(); continue; }
+        }
+        i++;
+    }
     OrderBuf *hit = nullptr;
     for (OrderBuf &b : P.live) if (b.st == st) { hit = &b; break; }
-    if (!hit) { P.live.emplace_back(); hit = &P.live.back(); hit->st = st; }
+    if (!hit) {
+        if (P.live.size() >= ORD_MAX_STREAMS) {
+            // the stream not seen for the longest time gives up its entry.  Its handle may be gone (the caller destroyed it), so no event can be
+            // recorded on it: hipFree waits for the device, which is correct whatever became of the stream — and rare (the 33rd stream)
+            size_t lru = 0;
+            for (size_t i = 1; i < P.live.size(); i++) if (P.live[i].used < P.live[lru].used) lru = i;
+            if (P.live[lru].p) (void)hipFree(P.live[lru].p);
+            P.live[lru] = P.live.back();
+            P.live.pop_back();
+        }
+        P.live.emplace_back();
+        hit = &P.live.back();
+        hit->st = st;
+    }
+    hit->used = ++P.tick;
     if (hit->words < need) {
         const size_t w = need + need / 2;
         uint32_t *q = nullptr;
         if (hipMalloc((void **)&q, w * sizeof(uint32_t)) != hipSuccess) { hold.unlock(); s5gpu_set_error("no device memory for the launch-order list"); return S5GPU_ERR_NOMEM; }
-        if (hit->p) P.retired.push_back(hit->p);
+        if (hit->p) {
+            RetiredBuf r{hit->p, nullptr};
+            if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.ev, st) != hipSuccess) {
+                if (r.ev) { (void)hipEventDestroy(r.ev); r.ev = nullptr; }      // no event: the buffer waits for s5gpu_shutdown, as before
+            }
+            P.retired.push_back(r);
+        }
         hit->p = q;
         hit->words = w;
     }

@@ -15,7 +15,7 @@
 //     out[o+k] = out[o-d + k mod d], sources precede o);
 //   - table descriptions (normalised counts, weights) are tiny and decoded by lane 0.
 // The CPU twin of this file is oracle/zstd_dec.c (same structure, checked against libzstd itself).
-// Not verified: the optional content checksum (XXH64; slow5lib's one-shot ZSTD_compress never writes it).
+// The optional content checksum (XXH64; slow5lib's one-shot ZSTD_compress never writes it) is verified when a frame carries one (round 5).
 // Rejected: dictionaries, skippable frames, reserved bits.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -700,7 +700,41 @@ __device__ __forceinline__ void z_wave_move_down(uint8_t *d, const uint8_t *s, u
     if (lane < n - body) d[body + lane] = b;
 }
 
-// One frame -> out (olen bytes).  INF_OK, or INF_ERR_HEADER / DATA / TRUNC / OVERFLOW (olen = bytes needed when the frame says).
+// XXH64 (seed 0) of n bytes: the content checksum of a frame that carries one is its low 32 bits (RFC 8878 3.1.1).  slow5lib's one-shot
+// ZSTD_compress never sets the flag, so this is off the hot path: the four accumulators of the 32-byte stripes on lanes 0-3, the merge and
+// the tail on lane 0.  Uniform result.
+__device__ __forceinline__ uint64_t z_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t z_xxh64_wave(const uint8_t *p, uint64_t n) {
+    constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull, P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+    typedef uint64_t u64u __attribute__((aligned(1)));
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    const int lane = lane_id();
+    auto round = [&](uint64_t acc, uint64_t in) { return z_rotl64(acc + in * P2, 31) * P1; };
+    uint64_t h;
+    uint64_t i = 0;
+    if (n >= 32) {
+        uint64_t v = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0ull : 0ull - P1;
+        for (; i + 32 <= n; i += 32)
+            if (lane < 4) v = round(v, *reinterpret_cast<const u64u *>(p + i + 8 * lane));
+        const uint64_t v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
+        h = z_rotl64(v1, 1) + z_rotl64(v2, 7) + z_rotl64(v3, 12) + z_rotl64(v4, 18);
+        h = (h ^ round(0, v1)) * P1 + P4;
+        h = (h ^ round(0, v2)) * P1 + P4;
+        h = (h ^ round(0, v3)) * P1 + P4;
+        h = (h ^ round(0, v4)) * P1 + P4;
+    } else h = P5;
+    h += n;
+    if (lane == 0) {
+        for (; i + 8 <= n; i += 8) h = z_rotl64(h ^ round(0, *reinterpret_cast<const u64u *>(p + i)), 27) * P1 + P4;
+        if (i + 4 <= n) { h = z_rotl64(h ^ ((uint64_t)*reinterpret_cast<const u32u *>(p + i) * P1), 23) * P2 + P3; i += 4; }
+        for (; i < n; i++) h = z_rotl64(h ^ ((uint64_t)p[i] * P5), 11) * P1;
+        h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    }
+    return __shfl(h, 0);
+}
+
+// One frame -> out (olen bytes).  INF_OK, or INF_ERR_HEADER / DATA / TRUNC / OVERFLOW (olen = bytes needed when the frame says);
+// INF_ERR_ADLER when the frame carries a content checksum and the decoded bytes do not hash to it.
 // `pre`: this frame's record of the weights scratch (k_zstd_weights ran over the batch), or nullptr
 __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t cap, uint32_t *olen_out, const uint8_t *pre = nullptr) {
     const int lane = lane_id();
@@ -963,6 +997,11 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                             for (uint32_t j = 0; j < 15; j++) if (j < n) { const uint64_t x = lit[li + k0 + j]; if (j < 8) vlo |= x << (8 * j); else vhi |= x << (8 * (j - 8)); }
                         }
                     }
+                    // every lane of the wave has LOADED its 16 bytes before any lane stores (parked literals move down inside `out`: one lane's
+                    // destination can be another lane's source); the barrier is a convergence point, so the two load shapes above cannot be
+                    // merged with the two store shapes below into load-store / load-store
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
                     int lo = 0, hi = (int)nb - 1;                               // the last sequence whose literals start at or before k0
 #pragma unroll
                     for (int it = 0; it < 6; it++) {
@@ -1041,7 +1080,11 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
                             if (bf >= bl) { for (uint32_t k = lane; k < bl; k += 64) bq[k] = src[k]; }
                             else { for (uint32_t k = lane; k < bl; k += 64) bq[k] = src[k % bf]; }
                         }
-                        wave_sync();
+                        // a match copied in this step may be the source of one in the next: the same release / acquire pair as the
+                        // waiting matches of inflate_par_dev.h (the bytes travel through global memory between lanes of the wave)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         donem |= __ballot(ready);
                     }
                 }
@@ -1063,9 +1106,16 @@ __device__ __forceinline__ int zstd_decode_wave(ZstdShared &T, const uint8_t *in
     ZP(9)
     ZP_FLUSH
     if (status != INF_OK) return status;
-    if (checksum) { if (p + 4 > len) return INF_ERR_TRUNC; p += 4; }
+    uint32_t want_sum = 0;
+    if (checksum) { if (p + 4 > len) return INF_ERR_TRUNC; want_sum = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24); p += 4; }
     if (p != len) return INF_ERR_DATA;
     if (fcs_bytes && fcs != o) return INF_ERR_DATA;
+    if (checksum) {                                               // libzstd rejects a frame whose content does not hash to its checksum: so do we
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if ((uint32_t)z_xxh64_wave(out, o) != want_sum) return INF_ERR_ADLER;
+    }
     *olen_out = o;
     return INF_OK;
 }
