@@ -26,6 +26,9 @@
 #include "slow5gpu.h"
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static int g_timing;                 /* S5VIEW_TIMING=1: a timeline of the process on stderr (as s5view's) */
+static double g_t_main;
+static void stamp(const char *what) { if (g_timing) fprintf(stderr, "s5get[t] %8.3f  %s\n", now_s() - g_t_main, what); }
 static int die(const char *what) {
     fprintf(stderr, "s5get: %s (slow5_errno %d; %s)\n", what, slow5_errno, s5gpu_last_error());
     return EXIT_FAILURE;
@@ -52,6 +55,7 @@ typedef struct {
     pthread_mutex_t mu;
     pthread_cond_t cv;
     gslot_t slot[GSLOT];
+    int nslot;                       /* slots in use (<= GSLOT): a short job pins fewer buffers — pinning costs 0.23 ms per MB */
     slow5_file_t *in;
     int fd;
     char **ids;
@@ -76,7 +80,7 @@ static void gfail(gpipe_t *P, const char *what, const char *arg) {
 static int gslot_alloc(gpipe_t *P, gslot_t *b) {
     b->in_cap = (size_t)P->K * 4096 + 65536;
     b->in = (uint8_t *)s5gpu_host_alloc(b->in_cap);
-    b->out_cap = (size_t)P->K * (P->benchmark ? 16384 : 6144) + 65536;     /* decoded samples / re-encoded records; a batch that outgrows it is redone */
+    b->out_cap = (size_t)P->K * (P->benchmark ? 10240 : 6144) + 65536;     /* decoded samples / re-encoded records; a batch that outgrows it is redone */
     b->out = (uint8_t *)s5gpu_host_alloc(b->out_cap);
     b->rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)P->K);
     b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)P->K);
@@ -96,8 +100,8 @@ static void *greader_main(void *arg) {
         const int64_t s = P->next_fill;
         if (P->failed || s >= P->n_batches) { pthread_mutex_unlock(&P->mu); return NULL; }
         P->next_fill = s + 1;
-        gslot_t *b = &P->slot[s % GSLOT];
-        while (!P->failed && !(b->state == ST_EMPTY && b->seq == s - GSLOT)) pthread_cond_wait(&P->cv, &P->mu);   /* the slot's previous batch has been written */
+        gslot_t *b = &P->slot[s % P->nslot];
+        while (!P->failed && !(b->state == ST_EMPTY && b->seq == s - P->nslot)) pthread_cond_wait(&P->cv, &P->mu);   /* the slot's previous batch has been written */
         const int stop = P->failed;
         pthread_mutex_unlock(&P->mu);
         if (stop) return NULL;
@@ -151,7 +155,7 @@ static void *gworker_main(void *arg) {
         int64_t s;
         for (;;) {
             s = P->next_work;
-            b = &P->slot[s % GSLOT];
+            b = &P->slot[s % P->nslot];
             if (P->failed || s >= P->n_batches) { pthread_mutex_unlock(&P->mu); return NULL; }
             if (b->state == ST_FILLED && b->seq == s) break;
             pthread_cond_wait(&P->cv, &P->mu);
@@ -210,9 +214,15 @@ static char **read_ids(const char *path, uint64_t *n_out) {
     return ids;
 }
 
+static int gslot_alloc(gpipe_t *P, gslot_t *b);
 static void *early_init_main(void *arg) {
-    (void)arg;
-    if (s5gpu_warmup() == S5GPU_OK) s5gpu_host_free(s5gpu_host_alloc(4096));
+    gpipe_t *P = (gpipe_t *)arg;
+    if (s5gpu_warmup() != S5GPU_OK) return NULL;
+    /* Round 5: the batch slots are pinned HERE, under the index load of the main thread.  Pinned by the reader threads at their first
+     * batch they cost 0.23 ms per MB in the middle of the job, and they hold the runtime's lock while the first GPU call allocates its
+     * workspaces (that call: 130 ms of a 190 ms job).  A slot that could not be pinned here is pinned by its first reader as before. */
+    for (int i = 0; i < P->nslot; i++)
+        if (!P->slot[i].in && gslot_alloc(P, &P->slot[i]) != 0) break;
     return NULL;
 }
 /* The work is done and every file is closed: leave without the HIP runtime's static destructors (code objects, memory pools: ~0.1 s of a
@@ -243,6 +253,8 @@ int main(int argc, char **argv) {
         slow5_close(s);
         return EXIT_SUCCESS;
     }
+    g_t_main = now_s();
+    { const char *e = getenv("S5VIEW_TIMING"); g_timing = e && atoi(e); }
     const int benchmark = argc >= 2 && strcmp(argv[1], "--benchmark") == 0;
     char **av = argv + (benchmark ? 1 : 0);
     const int ac = argc - (benchmark ? 1 : 0);
@@ -260,18 +272,31 @@ int main(int argc, char **argv) {
     pthread_mutex_init(&P.mu, NULL);
     pthread_cond_init(&P.cv, NULL);
     P.benchmark = benchmark;
-    /* the HIP runtime and the device context come up (~0.15 s) while the index is loaded (~0.13 s per million reads) and the ids are read */
+    /* the id list first (milliseconds): the number of batches, and with it the number of slots, is known before anything is pinned */
+    P.ids = read_ids(av[2], &P.n_ids);
+    if (!P.ids) return die("cannot read the id list");
+    stamp("id list read");
+    {
+        const int argk0 = benchmark ? 3 : 6;
+        P.K = ac > argk0 ? atoll(av[argk0]) : 4096;
+        if (P.K < 1) P.K = 1;
+        P.n_batches = (int64_t)((P.n_ids + (uint64_t)P.K - 1) / (uint64_t)P.K);
+        /* Round 5: eight slots of K x (4 KiB in + 16 KiB out) are 670 MB of pinned memory — 150 ms of page pinning for a job whose 24 batches
+         * take 35 ms of GPU time.  A job gets one slot per six batches (2 .. 8), and no more reader threads than slots. */
+        P.nslot = P.n_batches / 6 < 2 ? 2 : P.n_batches / 6 > GSLOT ? GSLOT : (int)(P.n_batches / 6);
+    }
+    /* the HIP runtime and the device context come up (~0.15 s), and the batch slots are pinned, while the index is loaded (~0.13 s per million reads) */
     pthread_t init_th;
     const int early_init = !(getenv("S5VIEW_DEV_MASK") && strtoull(getenv("S5VIEW_DEV_MASK"), NULL, 0));     /* (a device mask has initialised the library already) */
-    const int early_init_started = early_init && pthread_create(&init_th, NULL, early_init_main, NULL) == 0;   /* (no thread: the first GPU call initialises) */
+    const int early_init_started = early_init && pthread_create(&init_th, NULL, early_init_main, &P) == 0;   /* (no thread: the first GPU call initialises) */
     P.in = slow5_open(av[1], "r");
     if (!P.in || P.in->format != SLOW5_FORMAT_BINARY) return die("cannot open input (an indexed BLOW5 file)");
     const double t_idx0 = now_s();
     if (slow5_idx_load(P.in) != 0) return die("cannot load index");
     const double t_idx = now_s() - t_idx0;
-    P.ids = read_ids(av[2], &P.n_ids);
-    if (!P.ids) return die("cannot read the id list");
+    stamp("index loaded");
     if (early_init_started) pthread_join(init_th, NULL);
+    stamp("library warm, slots pinned (early-init thread joined)");
     P.from.record_method = P.in->compress->record_press->method; P.from.signal_method = P.in->compress->signal_press->method;
     P.to.record_method = SLOW5_COMPRESS_ZLIB; P.to.signal_method = SLOW5_COMPRESS_SVB_ZD;
     int argk = benchmark ? 3 : 6;
@@ -284,23 +309,21 @@ int main(int argc, char **argv) {
         if (slow5_hdr_fwrite(out, P.in->header, SLOW5_FORMAT_BINARY, P.to) < 0) return die("header write failed");
         fflush(out);
     }
-    P.K = ac > argk ? atoll(av[argk]) : 4096;
-    if (P.K < 1) P.K = 1;
     const int readers = ac > argk + 1 ? atoi(av[argk + 1]) : 8;
     { const char *e = getenv("S5GET_SKIP"); P.skip = e && atoi(e); }
     P.fd = fileno(P.in->fp);
-    P.n_batches = (int64_t)((P.n_ids + (uint64_t)P.K - 1) / (uint64_t)P.K);
-    for (int i = 0; i < GSLOT; i++) P.slot[i].seq = (int64_t)i - GSLOT;     /* (a slot's buffers are pinned by the reader that first fills it: gslot_alloc) */
+    for (int i = 0; i < P.nslot; i++) P.slot[i].seq = (int64_t)i - P.nslot;     /* (a slot's buffers are pinned by the reader that first fills it: gslot_alloc) */
     double *lat = (double *)malloc(sizeof(double) * (size_t)(P.n_batches ? P.n_batches : 1));
     const double t0 = now_s();
     pthread_t rd[32], wk[4];
-    const int R = readers < 1 ? 1 : readers > 32 ? 32 : readers;
+    const int R0 = readers < 1 ? 1 : readers > 32 ? 32 : readers;
+    const int R = R0 > P.nslot ? P.nslot : R0;
     const int W = 2;
     for (int i = 0; i < R; i++) pthread_create(&rd[i], NULL, greader_main, &P);
     for (int i = 0; i < W; i++) pthread_create(&wk[i], NULL, gworker_main, &P);
     uint64_t total = 0, samples = 0, out_bytes = 0, checksum = 0;
     for (int64_t s = 0; s < P.n_batches; s++) {                          /* ordered write phase (get.c:373-384): one write per batch */
-        gslot_t *b = &P.slot[s % GSLOT];
+        gslot_t *b = &P.slot[s % P.nslot];
         pthread_mutex_lock(&P.mu);
         while (!P.failed && !(b->state == ST_DONE && b->seq == s)) pthread_cond_wait(&P.cv, &P.mu);
         const int stop = P.failed;
@@ -332,6 +355,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < R; i++) pthread_join(rd[i], NULL);
     for (int i = 0; i < W; i++) pthread_join(wk[i], NULL);
     const double dt = now_s() - t0;
+    stamp("last batch done");
     if (P.failed) { fprintf(stderr, "s5get: %s\n", P.why); return EXIT_FAILURE; }
     if (out) {
         if (fseek(out, 0, SEEK_END) != 0 || slow5_eof_fwrite(out) < 0) return die("eof write failed");
@@ -345,7 +369,14 @@ int main(int argc, char **argv) {
             (long long)P.K, R, W, t_idx, (unsigned long long)P.missing);
     if (nl > 0) fprintf(stderr, "s5get: GPU call per batch: p50 %.3f ms, p99 %.3f ms over %lld batches\n", 1e3 * lat[nl / 2], 1e3 * lat[(nl * 99) / 100], (long long)nl);
     if (benchmark) printf("%llu\t%llu\t%016llx\n", (unsigned long long)total, (unsigned long long)samples, (unsigned long long)checksum);
-    for (int i = 0; i < GSLOT; i++) { gslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->off); free(b->fields); }
-    slow5_close(P.in);
+    /* The process is about to _exit (leave()): un-pinning ~200 MB of slot buffers costs 90-130 ms and freeing a million index entries 50 — a
+     * quarter of a 100 k-id job — for memory the kernel takes back anyway.  S5_FULL_EXIT=1 (leak checkers) releases everything. */
+    { const char *fe = getenv("S5_FULL_EXIT");
+      if (fe && atoi(fe)) {
+          for (int i = 0; i < GSLOT; i++) { gslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->off); free(b->fields); }
+          stamp("slot buffers released");
+          slow5_close(P.in);
+          stamp("input closed (index freed)");
+      } }
     return leave();
 }

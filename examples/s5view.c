@@ -522,7 +522,10 @@ static int fast_view(slow5_file_t *in, FILE *out, slow5_press_method_t from, slo
     if (out_pos >= 0 && lseek(P.fd_out, out_pos, SEEK_SET) < 0) fpipe_fail(&P, "seek failed");   /* the end marker follows the last record */
     const double t1 = now_s();
     stamp("last write");
-    for (int i = 0; i < P.nslot; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); free(b->nl); }
+    /* (the process leaves through _exit right after this: un-pinning the chunk buffers — 0.12 ms per MB — is skipped unless S5_FULL_EXIT=1) */
+    { const char *fe = getenv("S5_FULL_EXIT");
+      if (fe && atoi(fe))
+          for (int i = 0; i < P.nslot; i++) { fslot_t *b = &P.slot[i]; s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->out_off); free(b->nl); } }
     if (g_timing) fprintf(stderr, "s5view[t] stages (seconds, summed): reader pread %.3f + framing %.3f + waiting for a free slot %.3f | GPU calls %.3f over %d worker(s) | writer write %.3f + waiting for a chunk %.3f | %d slots\n",
                           P.t_read, P.t_frame, P.t_rwait, P.t_gpu, W, P.t_write, P.t_wwait, P.nslot);
     if (P.failed && P.oversize) return -2;

@@ -160,6 +160,12 @@ int s5host::CtxHold::acquire(int want_slot) {
     return S5GPU_OK;
 }
 
+// s5gpu_warmup: the first device's contexts (streams) exist before the first batch call
+int s5host_warm_contexts() {
+    s5host::CtxHold hold;
+    return hold.acquire(0);
+}
+
 int s5host::for_each_device_range(uint32_t n, const std::function<int(int, uint32_t, uint32_t)> &fn) {
     int G = s5host::n_devices();
     if (G == 0) return S5GPU_ERR_NODEV;
@@ -863,6 +869,7 @@ static int decode_resident_impl(Ctx *c, uint32_t n, const void *const *rec, cons
             (rc = c->d_desc2.reserve(sizeof(s5gpu_rec_desc_t) * n)) || (rc = c->d_pay.reserve(po + 64)) ||
             (rc = c->d_sig2.reserve(so * 2 + 64)) || (rc = c->d_fields.reserve(sizeof(s5gpu_rec_fields_t) * n)))
             return rc;
+        s5_trace("decode_resident: workspaces reserved");
         uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + (framed ? 0 : up(io + 64, 64));
         if (!framed)
             parallel_for(n, io, [&](uint32_t lo, uint32_t hi_) {
@@ -879,9 +886,12 @@ static int decode_resident_impl(Ctx *c, uint32_t n, const void *const *rec, cons
         da.desc = (const s5gpu_rec_desc_t *)c->d_desc2.p; da.in = (const uint8_t *)c->d_in.p;
         da.payload = (uint8_t *)c->d_pay.p; da.sig_out = (int16_t *)c->d_sig2.p; da.fields = (s5gpu_rec_fields_t *)c->d_fields.p;
         for (uint32_t i = 0; i < n; i++) if (rd[i].pay_cap > da.max_pay_cap) da.max_pay_cap = rd[i].pay_cap;
+        s5_trace("decode_resident: uploads enqueued");
         if ((rc = s5gpu_decode_dev(&da, c->st))) return rc;
+        s5_trace("decode_resident: kernels enqueued");
         HIP_TRY(hipMemcpyAsync(ff.data(), c->d_fields.p, sizeof(s5gpu_rec_fields_t) * n, hipMemcpyDeviceToHost, c->st));
         HIP_TRY(hipStreamSynchronize(c->st));
+        s5_trace("decode_resident: fields back");
         bool retry = false, bad = false;
         for (uint32_t i = 0; i < n; i++) {
             if (ff[i].status == 5 && attempt < 2) { pcap[i] = ff[i].payload_len ? ff[i].payload_len : (pcap[i] < 0x10000000u ? 8 * pcap[i] + 65536 : 0xFFFFFF00u); if (scap[i] < pcap[i]) scap[i] = pcap[i]; retry = true; }
@@ -1015,9 +1025,11 @@ extern "C" int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_b
     for (uint32_t i = 0; i < n; i++) { memset(&fields[i], 0, sizeof fields[i]); fields[i].status = S5GPU_STATUS_NOT_DECODED; }
     s5host::ShareGather sg(G);
     auto share = [&](int slot, uint32_t lo, uint32_t hi) -> int {
+        s5_trace("decode_stream: share starts");
         s5host::CtxHold hold;
         int r = hold.acquire(slot);
         if (r) return sg.fail(r, slot);
+        s5_trace("decode_stream: context held");
         Ctx *c = hold.c;
         const uint32_t m = hi - lo;
         uint64_t b0 = UINT64_MAX, e1 = 0;
@@ -1051,6 +1063,7 @@ extern "C" int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_b
         bool copy = false;
         if ((r = sg.place(slot, off[m], sig_cap, &base, &copy))) return r;
         if (!copy) return S5GPU_OK;
+        s5_trace("decode_stream: placed");
         const size_t b8 = up(8ull * m, 64);
         if ((r = c->d_gather.reserve(2 * off[m] + 64)) || (r = c->d_patch.reserve(2 * b8 + 4ull * m + 64)) || (r = c->h_in.reserve(2 * b8 + 4ull * m + 64))) return r;
         uint8_t *h = (uint8_t *)c->h_in.p, *dv = (uint8_t *)c->d_patch.p;
@@ -1063,6 +1076,7 @@ extern "C" int s5gpu_decode_stream(uint32_t n, const void *chunk, size_t chunk_b
         for (uint32_t i = 0; i < m; i++) sig_off[lo + i] = base + off[i];
         if (hi == n) sig_off[n] = base + off[m];
         HIP_TRY(hipStreamSynchronize(c->st));
+        s5_trace("decode_stream: signals back");
         return S5GPU_OK;
     };
     // any way a share gives up releases the shares waiting behind it (ShareGather::place)

@@ -2283,6 +2283,7 @@ extern "C" int s5gpu_patch_u32_dev(uint8_t *base, const uint64_t *off, const uin
 // ---- s5gpu_warmup: the code objects of this file and of ascii_kernels.hip are loaded by their first launch ----
 __global__ void k_noop(uint32_t *p) { if (p) p[0] = 0; }
 int s5ascii_warm(hipStream_t st);              // ascii_kernels.hip
+int s5host_warm_contexts();   // host_api.hip
 extern "C" int s5gpu_warmup(void) {
     int rc;
     if (s5gpu_devices_in_use() == 0 && (rc = s5gpu_init(0))) return rc;
@@ -2290,6 +2291,7 @@ extern "C" int s5gpu_warmup(void) {
     hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, nullptr, (uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     if ((rc = s5ascii_warm(nullptr))) return rc;
+    if ((rc = s5host_warm_contexts())) return rc;   // the batch calls' streams (round 5: 2 x 21 ms that the first batch call of a `get` used to pay)
     HIP_TRY(hipStreamSynchronize(nullptr));
     return S5GPU_OK;
 }
