@@ -2284,15 +2284,33 @@ extern "C" int s5gpu_patch_u32_dev(uint8_t *base, const uint64_t *off, const uin
 __global__ void k_noop(uint32_t *p) { if (p) p[0] = 0; }
 int s5ascii_warm(hipStream_t st);              // ascii_kernels.hip
 int s5host_warm_contexts();   // host_api.hip
+#include <time.h>
+static void s5_trace(const char *what) {   // S5GPU_TRACE=1 (tools): milliseconds since this thread's previous trace point (as host_ctx.h's)
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("S5GPU_TRACE"); on = e && atoi(e) ? 1 : 0; }
+    if (!on) return;
+    static thread_local double last = 0;
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    const double now = (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+    fprintf(stderr, "s5gpu[trace] %p +%8.3f ms  %s\n", (void *)&last, last ? 1e3 * (now - last) : 0.0, what);
+    last = now;
+}
 extern "C" int s5gpu_warmup(void) {
     int rc;
+    s5_trace("warmup: start");
     if (s5gpu_devices_in_use() == 0 && (rc = s5gpu_init(0))) return rc;
+    s5_trace("warmup: runtime + device up");
     if ((rc = set_lds_attrs())) return rc;     // (the function attributes need the functions: this loads the code object)
+    s5_trace("warmup: function attributes set (code object loaded)");
     hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, nullptr, (uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     if ((rc = s5ascii_warm(nullptr))) return rc;
+    s5_trace("warmup: first launches enqueued");
     if ((rc = s5host_warm_contexts())) return rc;   // the batch calls' streams (round 5: 2 x 21 ms that the first batch call of a `get` used to pay)
+    s5_trace("warmup: contexts (streams) created");
     HIP_TRY(hipStreamSynchronize(nullptr));
+    s5_trace("warmup: done");
     return S5GPU_OK;
 }
 
