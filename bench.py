@@ -921,6 +921,16 @@ def main():
     if rank != 0:
         return finish(None)
 
+    # ---- N > 1: the HOST-FED curve beside the device-resident one (round 5): one process, one batch call, all N devices ----
+    host_fed = None
+    if default_shape and world > 1 and not args.no_e2e:
+        import bench_e2e
+        # (every rank has left its legs — each ends on a barrier — and the other ranks are on their way out: rank 0 goes on alone)
+        try:
+            host_fed = bench_e2e.host_fed_multi(world, n_reads, n, bool(os.environ.get("S5BENCH_ALIAS_DEVICES")))
+        except Exception as e:
+            host_fed = {"error": repr(e)}
+
     # ---- end to end through files + the host-buffer (PCIe-inclusive) batch call: N = 1 figures, like the CPU baseline ----
     e2e_obj = pcie_obj = None
     if default_shape and world == 1 and not args.no_e2e:
@@ -1010,6 +1020,7 @@ def main():
         "mixed": leg_mixed,
         "e2e": e2e_obj,
         "pcie_inclusive": pcie_obj,
+        "host_fed": host_fed,
     }
     # the other legs' headline numbers in ONE small object inside `roofline` (the driver's record keeps roofline / cpu_baseline / config whole and
     # only the NAMES of further top-level keys): every figure below is measured in this run, its full object is the top-level key of the same name
@@ -1031,6 +1042,7 @@ def main():
                                     for k in ("batch_4096", "batch_10000", "batch_65536", "batch_%d" % n_reads)} if isinstance(pcie_obj, dict) else None,
         "e2e_whole_process_s": {k: pick(e2e_obj, k, "gpu", "whole_process_s") for k in ("slow5_to_blow5", "blow5_to_blow5")} if isinstance(e2e_obj, dict) else None,
         "e2e_get_100k_whole_process_s": pick(e2e_obj, "get_100k", "gpu", "benchmark", "whole_process_s"),
+        "host_fed_all_devices_GB_per_s": {k: pick(host_fed, k, "arena", "GB_per_s") for k in ("batch_65536", "batch_%d" % n_reads)} if isinstance(host_fed, dict) else None,
     }
     finish(line)
 

@@ -293,3 +293,39 @@ def _pcie_one(L, _lib, press, n_reads, n, reps, arena=False):
     best = min(times)
     return {"reads": n_reads, "seconds": [round(t, 4) for t in times], "GB_per_s": round(n_reads * n * 2 / best / 1e9, 3), "reads_per_s": round(n_reads / best, 1),
             "first_call_GB_per_s": round(n_reads * n * 2 / times[0] / 1e9, 3), "bytes_per_sample": round(tot / (n_reads * n), 4)}
+
+
+HOST_FED_CODE = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import bench_e2e
+from slow5tools_amd import _lib, press
+L = _lib.lib()
+mask = %(mask)d
+_lib.check(L.s5gpu_init_mask(mask), "s5gpu_init_mask")
+out = {"devices": L.s5gpu_devices_in_use(), "dev_mask": mask, "call": "s5gpu_encode_batch_arena / s5gpu_encode_batch: ONE host batch call cut into one contiguous index range per device (SURVEY 8e), host int16 signals in, records out"}
+for m in %(sizes)r:
+    out["batch_%%d" %% m] = {"arena": bench_e2e._pcie_one(L, _lib, press, m, %(n)d, 4, arena=True), "malloc": bench_e2e._pcie_one(L, _lib, press, m, %(n)d, 2, arena=False) if m <= 65536 else None}
+print("HOSTFED " + json.dumps(out))
+"""
+
+
+def host_fed_multi(n_gpus, n_reads, n, alias):
+    """The host-buffer path over ALL the node's GPUs from one process (what a patched slow5tools does after slow5_gpu_hook_init(mask)): a fresh
+    process — the bench's own ranks each hold one device — initialises the library on devices 0 .. n_gpus - 1 and times the arena batch call at
+    65536 reads and at n_reads per call.  With S5BENCH_ALIAS_DEVICES (one-GPU rehearsal) the devices are aliases of device 0."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if alias:
+        env["S5GPU_ALIAS_DEVICES"] = "1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    sizes = [m for m in (65536, n_reads) if m <= n_reads] or [n_reads]
+    code = HOST_FED_CODE % dict(root=ROOT, mask=(1 << n_gpus) - 1, sizes=sorted(set(sizes)), n=n)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    for line in r.stdout.splitlines():
+        if line.startswith("HOSTFED "):
+            import json
+            return json.loads(line[8:])
+    return {"error": (r.stdout + r.stderr)[-600:]}

@@ -222,3 +222,9 @@ def test_bench_two_ranks_preflight_on_one_gpu(tmp_path):
     assert j["cpu_baseline"] is None                       # an N = 1 figure
     assert j["mixed"]["parity_spot_check"] is True and j["mixed"]["scaling"] == "weak"
     assert j["e2e"] is None and j["pcie_inclusive"] is None                   # file-to-file and host-buffer figures are N = 1 figures too
+    # ... but the HOST-FED curve comes out of the same command (round 5): one fresh process, s5gpu_init_mask over the N devices (aliases of
+    # device 0 here), the arena batch call at 20000 reads per call — what a patched slow5tools would do on the node
+    hf = j["host_fed"]
+    assert hf["devices"] == 2 and hf["dev_mask"] == 3, hf
+    assert hf["batch_20000"]["arena"]["GB_per_s"] > 0 and hf["batch_20000"]["arena"]["bytes_per_sample"] < 1.1
+    assert j["roofline"]["legs"]["host_fed_all_devices_GB_per_s"]["batch_20000"] == hf["batch_20000"]["arena"]["GB_per_s"]
