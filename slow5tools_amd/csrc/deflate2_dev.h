@@ -167,6 +167,12 @@ __device__ __forceinline__ uint32_t carry_e_before(const uint32_t *__restrict__ 
 // pass 2 sends a listed slab 64 tokens per step: one load, one code lookup, one scan, one OR per lane.  DEFL2_LIST_CAP tokens for
 // the whole workgroup, handed out by one LDS counter; a slab that finds the list full is redone from the bytes in pass 2.
 constexpr uint32_t DEFL2_LIST_CAP = 640;
+// Staged (multi-block) form: a 16 KiB block of the key area of a long read holds ~2700 tokens in 64 general slabs — four times what S.freq
+// takes, and the slabs that found the list full were redone at ~220 instructions each in pass 2.  Such a block's OUTPUT is small (that is what
+// makes its slabs general), so the list's overflow lives in the bit buffer itself, growing DOWN from the histograms (word wf_at) while the
+// block's bits grow up from word 0: K bytes of keys make ~K / 6 tokens (K / 3 bytes of list) and shrink the output by ~0.5 K bytes, so the two
+// do not meet.  Pass 2 checks that they did not; otherwise the list's words are cleared and those slabs are redone from the bytes.
+constexpr uint32_t DEFL2_LISTB_MIN = 64;    // the list never reaches below this word
 constexpr uint32_t SEG_FAST = 0xFFFFFFFFu, SEG_REDO = 0xFFFFFFFEu, SEG_MASK = 0xFFFFFFFDu;
 
 template <int MODE, int TN = NT>
@@ -206,7 +212,12 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     __syncthreads();
 
     const uint32_t *buf32 = reinterpret_cast<const uint32_t *>(buf);
-    uint16_t *tl = reinterpret_cast<uint16_t *>(S.freq);   // the token list
+    constexpr bool POOLB = MODE == 2;                       // the token list: S.freq, then (staged) the bit buffer below the histograms
+    const bool poolb_ok = POOLB && wf_at >= DEFL2_LISTB_MIN + 64u;
+    // token index t: t < DEFL2_LIST_CAP lies in S.freq, the ones above in the bit buffer (staged only); a slab's tokens never straddle the two
+    uint16_t *tla = reinterpret_cast<uint16_t *>(S.freq);
+    uint16_t *tlb_top = reinterpret_cast<uint16_t *>(obuf + wf_at);    // a slab's tokens [st, st + total) of the second pool end (st - CAP) tokens below this
+    const uint32_t list_cap = DEFL2_LIST_CAP + (poolb_ok ? (wf_at - DEFL2_LISTB_MIN) * 2u : 0u);
     const int nsl = (len + 2 + 255) >> 8;                   // slabs: centred frames cover positions [-2, 256 nsl - 2)
     const int SW = (nsl + NWV - 1) / NWV;
     const int k0 = wv * SW, k1 = min(k0 + SW, nsl);
@@ -264,9 +275,14 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
             const uint32_t incl = wave_incl_add(cnt);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             uint32_t st = 0;
-            if (lane == 0) st = atomicAdd(&S.lalloc, total);
+            if (lane == 0) {
+                st = atomicAdd(&S.lalloc, total);
+                if (st < DEFL2_LIST_CAP && st + total > DEFL2_LIST_CAP) st = atomicAdd(&S.lalloc, total + (DEFL2_LIST_CAP - st));   // would straddle: take it from the second pool
+                if (st < DEFL2_LIST_CAP && st + total > DEFL2_LIST_CAP) st = list_cap;                                                // (another wave got in between: no list)
+            }
             st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
-            const bool listed = st + total <= DEFL2_LIST_CAP;
+            const bool listed = st + total <= list_cap && st + total < 65536u;
+            uint16_t *tl = st < DEFL2_LIST_CAP ? tla : tlb_top - (st - DEFL2_LIST_CAP) - total - st;     // (indexed by st + ...)
             // tokens in position order: a literal slot in front of the tail's slot (only slot 0 under a tail at slot 3 can be one), the tail,
             // the literal slots behind it.  The histogram is counted on the way.
             const uint32_t base = st + incl - cnt;
@@ -312,6 +328,10 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     __syncthreads();
     if (dbg == 2) { z.bitpos += wfa[tid] + S.red[2]; return; }   // tools/stage_time.py cut-off
 
+    // (uniform) words of the bit buffer, below the histograms, that hold tokens
+    const uint32_t la = S.lalloc;
+    const uint32_t listb_words = poolb_ok && la > DEFL2_LIST_CAP ? (((la < list_cap ? la : list_cap) - DEFL2_LIST_CAP + 7u) >> 3) << 2 : 0u;
+    const bool poolb_used = listb_words != 0u;
     // ---- code lengths (wave 0, no tree: assign_lengths_wave over the sum of the histograms); the other waves clear the bit buffer ----
     if (wv == 0) {
         const bool ok = assign_lengths_wave<15, NWV, true>(wfa, NLIT, S.lens, S.blcount, S.bins);
@@ -319,7 +339,8 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     } else {
         typedef uint32_t u4a __attribute__((ext_vector_type(4)));
         u4a *o16 = reinterpret_cast<u4a *>(obuf);
-        for (uint32_t i = (uint32_t)(wv * 64 + lane) - 64u; i < wf_at / 4; i += TN - 64) o16[i] = u4a{0u, 0u, 0u, 0u};   // (logical waves 1 ..)
+        const uint32_t zend = (wf_at - listb_words) / 4;   // (staged: the words above hold the block's token list, if it needed them)
+        for (uint32_t i = (uint32_t)(wv * 64 + lane) - 64u; i < zend; i += TN - 64) o16[i] = u4a{0u, 0u, 0u, 0u};   // (waves 1 ..)
     }
     __syncthreads();
     if (dbg == 3) { z.bitpos += S.lens[tid]; return; }
@@ -398,6 +419,13 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     if (use_fixed) {
         __syncthreads();                                   // everyone has read the dynamic code's numbers
         for (int s = tid; s < 288; s += TN) { S.code[s] = fixed_code(s); S.lens[s] = (uint8_t)fixed_len(s); }
+    }
+    // staged: the token list in the bit buffer is good for pass 2 only if the block's bits stay below it
+    const bool list_ok = !poolb_used || ((pos0 + total_bits + 15u + 31u) >> 5) - z.flushed + 4u <= wf_at - listb_words;
+    if (!list_ok) {
+        typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+        u4a *l16 = reinterpret_cast<u4a *>(obuf + (wf_at - listb_words));
+        for (uint32_t i = tid; i < listb_words / 4; i += TN) l16[i] = u4a{0u, 0u, 0u, 0u};
     }
     __syncthreads();                                       // the histogram words are zero (and the fixed codes in place)
     if (wv == 0) {
@@ -509,9 +537,10 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
                 wbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 continue;
             }
-            if (seg != SEG_REDO) {
+            if (seg != SEG_REDO && (list_ok || (seg & 0xFFFFu) < DEFL2_LIST_CAP)) {
                 // listed: 64 tokens per step
                 const uint32_t st = seg & 0xFFFFu, total = seg >> 16;
+                const uint16_t *tl = st < DEFL2_LIST_CAP ? tla : tlb_top - (st - DEFL2_LIST_CAP) - total - st;
                 for (uint32_t i0 = 0; i0 < total; i0 += 64) {
                     const uint32_t idx = i0 + (uint32_t)lane;
                     uint32_t v = 0, nb = 0;
