@@ -178,7 +178,7 @@ constexpr uint32_t SEG_FAST = 0xFFFFFFFFu, SEG_REDO = 0xFFFFFFFEu, SEG_MASK = 0x
 template <int MODE, int TN = NT>
 __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, uint32_t obuf_words, const uint8_t *__restrict__ buf, int len,
                                                bool final, ZOut &z, uint32_t &adA, uint32_t &adB, uint32_t dbg = 0,
-                                               EarlySize es = EarlySize{nullptr, 0}) {
+                                               EarlySize es = EarlySize{nullptr, 0}, uint32_t gen_hint = 0) {
     static_assert(MODE == 1 || MODE == 2, "fused single block (1) or staged multi-block (2): the bit buffer is this function's to clear");
     constexpr bool FUSED = MODE == 1;
     constexpr int NWV = TN / 64;
@@ -219,8 +219,21 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     uint16_t *tlb_top = reinterpret_cast<uint16_t *>(obuf + wf_at);    // a slab's tokens [st, st + total) of the second pool end (st - CAP) tokens below this
     const uint32_t list_cap = DEFL2_LIST_CAP + (poolb_ok ? (wf_at - DEFL2_LISTB_MIN) * 2u : 0u);
     const int nsl = (len + 2 + 255) >> 8;                   // slabs: centred frames cover positions [-2, 256 nsl - 2)
-    const int SW = (nsl + NWV - 1) / NWV;
-    const int k0 = wv * SW, k1 = min(k0 + SW, nsl);
+    // Which slabs a wave takes: contiguous regions of about equal COST.  gen_hint = bytes at the front of the block that the caller expects
+    // to be run-heavy (an svb-zd payload's head and key area): their slabs are general ones, about four times the work of a plain slab, and in
+    // equal-sized regions the first wave would do most of pass 1 alone.  Only a hint: any split is correct.
+#ifndef S5_DEFL2_GEN_W
+#define S5_DEFL2_GEN_W 4
+#endif
+    constexpr int GW = S5_DEFL2_GEN_W;                        // weight of a general slab (a plain one: 1)
+    const int gs = min(nsl, gen_hint ? (int)((gen_hint + 2u + 255u) >> 8) : 0);
+    const int cost_all = (GW - 1) * gs + nsl;
+    auto bound = [&](int w) -> int {
+        if (w >= NWV) return nsl;
+        const int T = (cost_all * w + NWV / 2) / NWV;         // cost in front of wave w's first slab
+        return T <= GW * gs ? (T + GW / 2) / GW : gs + (T - GW * gs);
+    };
+    const int k0 = bound(wv), k1 = bound(wv + 1);
     uint32_t segs = SEG_FAST;                               // lane j: what pass 2 does with slab k0 + j (start | count << 16 of its tokens)
 
     // ---- pass 1: histogram, Adler-32 partial sums, match / extra-bit counts; token lists of the general slabs ----

@@ -1125,7 +1125,7 @@ namespace s5 {
 // reserved for the u64 size prefix) and returns total.  obuf_words >= max(plen + 64, sizeof(BuildScratch)) / 4.
 template <typename M>
 __device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words, const uint8_t *pay,
-                                                     uint32_t plen, ZOut &z, uint32_t dbg = 0, EarlySize es = EarlySize{nullptr, 0}) {
+                                                     uint32_t plen, ZOut &z, uint32_t dbg = 0, EarlySize es = EarlySize{nullptr, 0}, uint32_t gen_hint = 0) {
     const int tid = threadIdx.x;
     z.bitpos = 80;   // 64 bits of size prefix + 16 bits of zlib header, both written later
     z.flushed = 0;
@@ -1146,9 +1146,9 @@ __device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *ob
 // ... then into a 16-B aligned HBM slot: [u64 size][record]
 template <typename M>
 __device__ __forceinline__ uint32_t zlib_compress_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words,
-                                                        const uint8_t *pay, uint32_t plen, uint8_t *out, uint32_t dbg = 0) {
+                                                        const uint8_t *pay, uint32_t plen, uint8_t *out, uint32_t dbg = 0, uint32_t gen_hint = 0) {
     ZOut z;
-    const uint32_t total = zlib_frame_fused<M>(S, obuf, obuf_words, pay, plen, z, dbg);
+    const uint32_t total = zlib_frame_fused<M>(S, obuf, obuf_words, pay, plen, z, dbg, EarlySize{nullptr, 0}, gen_hint);
     if (dbg) {
         if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(out) = z.bitpos;
         if (dbg == 41 && threadIdx.x < 20) reinterpret_cast<uint32_t *>(out)[4 + threadIdx.x] = threadIdx.x < 19 ? S.clfreq[threadIdx.x] : S.red[6];   // tools/clfreq_dump.py

@@ -176,6 +176,18 @@ __device__ __forceinline__ uint32_t build_payload_hbm(const s5gpu_encode_args_t 
     return d.hdr_len + 8 + (uint32_t)L + d.aux_len;
 }
 
+// bytes at the front of a read's payload that are run-heavy (head + svb key area: mostly zero bytes): the block encoder's hint for how to
+// cut a block among its waves (deflate2_dev.h)
+__device__ __forceinline__ uint32_t run_heavy_front(const s5gpu_encode_args_t &a, const s5gpu_read_desc_t &d) {
+    return a.sig_method == S5GPU_SIG_SVB_ZD ? d.hdr_len + 12u + ((d.n_samples + 3u) >> 2) : 0u;
+}
+
+// The fused kernels (eight workgroups per CU: other workgroups fill a wave's idle time) do not gain from the hint — measured 13.42 ms per 1 M
+// 4000-sample reads with it against 13.30 without —, the staged kernel (four per CU) does: mixed lengths 456 -> 491 GB/s.
+#ifndef S5_FUSED_HINT
+#define S5_FUSED_HINT(a, d) 0u
+#endif
+
 // K1+K5+K3+K6 fused: svb-zd -> pack -> one DEFLATE block -> zlib frame.  One read per workgroup, every
 // intermediate in LDS.  A read whose payload does not fit the LDS budget (p.pay_cap: long read, or an
 // unusually incompressible signal) is appended to the overflow list and redone by the staged kernels.
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(NT, WPS) void k_encode_fused(EncParams p) {     // 
         return;
     }
     uint8_t *out = p.a.slots + d.out_off;
-    const uint32_t total = zlib_compress_fused<M>(S, obuf, p.obuf_words, pay, plen, out, p.dbg);
+    const uint32_t total = zlib_compress_fused<M>(S, obuf, p.obuf_words, pay, plen, out, p.dbg, S5_FUSED_HINT(p.a, d));
     if (threadIdx.x == 0) p.a.out_len[r] = total;
 }
 
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(NT, S5_FUSED_WG_PER_CU) void k_encode_stream(EncPar
     } else {
         __syncthreads();
         ZOut z;
-        total = zlib_frame_fused<M>(S, obuf, p.obuf_words, pay, plen, z, 0, EarlySize{sp.state, r});
+        total = zlib_frame_fused<M>(S, obuf, p.obuf_words, pay, plen, z, 0, EarlySize{sp.state, r}, S5_FUSED_HINT(p.a, d));
         if (threadIdx.x == 0) { obuf[0] = total - 8; obuf[1] = 0; }   // u64 size prefix
     }
     if (wave_id() == 0) {
@@ -345,7 +357,21 @@ __global__ __launch_bounds__(NT, S5_PACK_WG) void k_pack(EncParams p, int mode, 
 #define S5_STAGED_TN 256
 #endif
 using StagedMask = std::conditional<S5_STAGED_TN >= 512, uint32_t, uint64_t>::type;
-__device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, uint32_t r, const s5gpu_read_desc_t &d, uint32_t plen, DeflShared &S, uint32_t *obuf, BuildScratch &B, uint8_t *stage) {
+// the next 16 KiB block of a parked payload on its way HBM -> registers (64 bytes per lane at 256 threads)
+struct StagedPf { uint4 v[DEFL_BLK / 16 / S5_STAGED_TN]; };
+__device__ __forceinline__ void staged_fetch(StagedPf &pf, const uint8_t *src, uint32_t at, uint32_t plen) {
+    const uint32_t bl = min(plen - at, (uint32_t)DEFL_BLK);
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src + at);
+#pragma unroll
+    for (int j = 0; j < DEFL_BLK / 16 / S5_STAGED_TN; j++) {
+        const uint32_t i = threadIdx.x + j * S5_STAGED_TN;
+        pf.v[j] = i < (bl + 15) / 16 ? s4[i] : uint4{0u, 0u, 0u, 0u};
+    }
+}
+// pf: this record's first block, already on its way; next_src / next_plen: the record this workgroup takes next (nullptr: none) — its first
+// block is fetched under this record's last one
+__device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, uint32_t r, const s5gpu_read_desc_t &d, uint32_t plen, DeflShared &S, uint32_t *obuf, BuildScratch &B, uint8_t *stage,
+                                                          StagedPf &pf, const uint8_t *next_src, uint32_t next_plen) {
     const int tid = threadIdx.x;
     uint8_t *out = p.a.slots + d.out_off;
     const uint8_t *src = out + park_offset(d, p.a.sig_method);
@@ -356,19 +382,27 @@ __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, ui
     z.carry = 0x9c78u;
     uint32_t adA = 1, adB = 0, done = 0;
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    // Round 5: the NEXT block travels HBM -> registers while this one is encoded (16 KiB = 64 bytes per lane), and goes to LDS when the block
+    // buffer is free again: at four workgroups per CU nothing else hides the load.  (Reading ahead is safe in place: the stream only ever
+    // overwrites payload that is already in LDS or in these registers.)
+    constexpr int NPF = DEFL_BLK / 16 / S5_STAGED_TN;
     do {
         const uint32_t blen = min(plen - done, (uint32_t)DEFL_BLK);
         const bool final = done + blen == plen;
-        {   // HBM -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + done);
+        {   // registers -> LDS, 16 B per lane (park offset and block offsets are 16-B aligned)
             uint4 *d4 = reinterpret_cast<uint4 *>(stage);
-            for (uint32_t i = tid; i < (blen + 15) / 16; i += S5_STAGED_TN) d4[i] = s4[i];
+#pragma unroll
+            for (int j = 0; j < NPF; j++) { const uint32_t i = tid + j * S5_STAGED_TN; if (i < (blen + 15) / 16) d4[i] = pf.v[j]; }
         }
+        if (!final) staged_fetch(pf, src, done + blen, plen);
+        else if (next_src) staged_fetch(pf, next_src, 0, next_plen);
         __syncthreads();
 #ifdef S5_DEFL_V1
         deflate_block<2, StagedMask, S5_STAGED_TN>(S, B, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
 #else
-        deflate_block2<2, S5_STAGED_TN>(S, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
+        const uint32_t front = run_heavy_front(p.a, d);
+        deflate_block2<2, S5_STAGED_TN>(S, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB, 0, EarlySize{nullptr, 0},
+                                        front > done ? min(front - done, blen) : 0u);
 #endif
         done += blen;
         if (!final) {
@@ -399,9 +433,15 @@ __global__ __launch_bounds__(S5_STAGED_TN, S5_STAGED_WG) void k_deflate_staged(E
     BuildScratch &B = *reinterpret_cast<BuildScratch *>(obuf);   // dead whenever the bit buffer is live (deflate_block MODE 2)
     uint8_t *stage = smem + S_BYTES + 4u * p.obuf_words;
     const uint32_t count = use_list ? p.a.ovf[0] : p.a.n_reads;
+    // (Fetching the NEXT record's first block under this record's last one was measured too: the second descriptor's registers push the kernel
+    // into scratch — 6 VGPRs and 100 SGPRs spilled — and the mixed leg falls from 500 to 485 GB/s.)
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         const uint32_t r = use_list ? ovf_at(p.a.ovf, ord, it) : it;
-        deflate_staged_record(p, r, p.a.desc[r], p.a.out_len[r], S, obuf, B, stage);
+        const s5gpu_read_desc_t d = p.a.desc[r];
+        const uint32_t plen = p.a.out_len[r];
+        StagedPf pf;
+        staged_fetch(pf, p.a.slots + d.out_off + park_offset(d, p.a.sig_method), 0, plen);
+        deflate_staged_record(p, r, d, plen, S, obuf, B, stage, pf, nullptr, 0);
     }
 }
 // (Round 3 tried steps 1 + 2 in ONE workgroup — park the read's payload, barrier, deflate it from there — so that the streaming of one read
