@@ -563,10 +563,10 @@ __device__ __forceinline__ Tok token_at(const uint8_t *__restrict__ buf, int bas
 // Copy completed words obuf -> HBM slot and slide the partial word to obuf[0].
 // final_all: copy everything including the last partial word, no slide.
 template <int TN = NT>   // threads of the calling workgroup
-__device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOut &z, bool final_all) {
+__device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOut &z, bool final_all, uint32_t n_words = 0xFFFFFFFFu) {
     const int tid = threadIdx.x;
     const uint32_t full = final_all ? (z.bitpos + 31) >> 5 : z.bitpos >> 5;
-    const uint32_t n = full - z.flushed;
+    const uint32_t n = n_words != 0xFFFFFFFFu ? n_words : full - z.flushed;   // (n_words: copy exactly that many words, nothing else)
     {   // four words per lane: an aligned 16-byte LDS read, a 16-byte store wherever the stream stands (z.flushed is any word count)
         typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
         typedef uint32_t u4a __attribute__((ext_vector_type(4)));

@@ -406,9 +406,19 @@ __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, ui
 #endif
         done += blen;
         if (!final) {
+#ifdef S5_DEFL_V1
             flush_words<S5_STAGED_TN>(obuf, out32, z, false);
             z.carry = obuf[0];      // uniform: every lane reads the same word (flush_words ends on a barrier)
             __syncthreads();        // ... before the next block's scratch overwrites it
+#else
+            // deflate_block2 clears the bit buffer itself and takes the pending partial word from z.carry: the completed words go out,
+            // the partial one is read where it stands — one barrier instead of four and no slide
+            const uint32_t full = z.bitpos >> 5;
+            flush_words<S5_STAGED_TN>(obuf, out32, z, true, full - z.flushed);
+            z.carry = obuf[full - z.flushed];      // uniform
+            z.flushed = full;
+            __syncthreads();        // ... before the next block's histograms overwrite the buffer's tail
+#endif
         }
     } while (done < plen);
     z.bitpos = (z.bitpos + 7) & ~7u;
