@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 sigs = []
 for i in range(n_rec):
     kind = i % 6
-    n = int(np.exp(rng.uniform(np.log(1), np.log(40000))))
+    n = int(np.exp(rng.uniform(np.log(1), np.log(int(os.environ.get('S5_SOAK_MAXLEN', 40000))))))
     if kind == 0: sig = ob.synth_read(0x5105, 9000 + i, n)
     elif kind == 1: sig = (500 + np.cumsum(rng.integers(-12, 13, n)) % 400).astype(np.int16)
     elif kind == 2: sig = rng.integers(-32768, 32768, n).astype(np.int16)
