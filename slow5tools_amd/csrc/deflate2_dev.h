@@ -347,7 +347,10 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     const bool poolb_used = listb_words != 0u;
     // ---- code lengths (wave 0, no tree: assign_lengths_wave over the sum of the histograms); the other waves clear the bit buffer ----
     if (wv == 0) {
-        const bool ok = assign_lengths_wave<15, NWV, true>(wfa, NLIT, S.lens, S.blcount, S.bins);
+#ifndef S5_DEFL2_ABSORB
+#define S5_DEFL2_ABSORB 2
+#endif
+        const bool ok = assign_lengths_wave<15, NWV, true, S5_DEFL2_ABSORB>(wfa, NLIT, S.lens, S.blcount, S.bins);
         if (lane == 0) S.dbg = ok ? 0u : 1u;
     } else {
         typedef uint32_t u4a __attribute__((ext_vector_type(4)));

@@ -290,7 +290,13 @@ __device__ __forceinline__ void build_lengths(DeflShared &S, BuildScratchT<CAP> 
 // over-subscribe the code space the function returns false as well (the caller then uses the exact construction).
 // NH: the frequencies are the sum of NH histograms that lie 288 words apart (deflate2_dev.h keeps one per wave); EOB1: symbol 256 (end of
 // block) is not in the histograms and counts once.
-template <int MAXL = 15, int NH = 1, bool EOB1 = false>
+// ABSORB (round 5; 0 = off): after that many passes whatever slack is left goes to UNUSED symbols — one per set bit of the slack, the lowest
+// unused symbols first (holes among the literals in use, so the code-length header's zero runs are not cut) — instead of more passes over the
+// used ones.  A code for a symbol that never occurs costs only its header entry (~8 bits); the body loses the bits the slack would still have
+// bought: measured on every 16 KiB block of the fixture records and on the bench reads (tools/len_assign_probe.py's model), 2 passes + absorb
+// = +0.02 .. +0.10 % bits (+0.06 % on the bench reads), 3 passes +0.01 .. +0.05 %.  The passes are ~100 dependent instructions each on ONE
+// wave while the workgroup's other waves wait: the loop runs 4-6 of them.  Falls back to the loop when too few symbols are unused.
+template <int MAXL = 15, int NH = 1, bool EOB1 = false, int ABSORB = 0>
 __device__ __forceinline__ bool assign_lengths_wave(const uint32_t *freq, int n, uint8_t *lens, uint32_t *blcount, uint32_t *bins) {
     const int lane = lane_id();
     constexpr uint32_t HUGE_C = 0x80000000u;   // "cannot be shortened": no symbol / already 1 bit
@@ -337,6 +343,26 @@ __device__ __forceinline__ bool assign_lengths_wave(const uint32_t *freq, int n,
     uint32_t R = (1u << MAXL) - used_c;
     int guard = 0;
     while (R) {   // uniform
+        if (ABSORB > 0 && guard == ABSORB) {
+            uint32_t nun = 0;
+#pragma unroll
+            for (int q = 0; q < 5; q++) nun += (5 * lane + q < n && f[q] == 0u) ? 1u : 0u;
+            const uint32_t incl = wave_incl_add(nun);
+            if ((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) >= (uint32_t)__popc(R)) {   // (uniform)
+                uint32_t r = R;                                    // my first unused symbol takes the (incl - nun)-th set bit of R from the bottom
+                const uint32_t skip = incl - nun;
+#pragma unroll
+                for (uint32_t i = 0; i < (uint32_t)MAXL; i++) if (i < skip) r &= r - 1u;
+#pragma unroll
+                for (int q = 0; q < 5; q++)
+                    if (5 * lane + q < n && f[q] == 0u && r) {
+                        l[q] = MAXL - (__ffs((int)r) - 1);         // slack unit 2^j = a code of MAXL - j bits
+                        r &= r - 1u;
+                    }
+                R = 0;
+                break;
+            }
+        }
         if (++guard > 40) return false;
         bins[lane] = 0;
         wave_sync();
