@@ -383,15 +383,15 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
             dynb = wave_sum(dynb);
             fixb = wave_sum(fixb);
             if (lane == 0) { S.wtot[h] = dynb; S.wtot[8 + h] = fixb; }
+            // this wave was the histogram's last reader: its words become bit buffer right here (words 286, 287 were never counted into), so the
+            // barrier below is the only one between the codes and the tokens
+            uint32_t *fz = wfa + h * 288;
+            fz[lane] = 0u; fz[64 + lane] = 0u; fz[128 + lane] = 0u; fz[192 + lane] = 0u;
+            if (lane < NLIT - 256) fz[256 + lane] = 0u;
         }
     }
     __syncthreads();
     if (dbg == 4 || dbg == 41) { z.bitpos += S.wtot[tid & 31] + S.red[6] + S.code[tid]; return; }
-    {   // the histograms are dead: their words become bit buffer
-        typedef uint32_t u4a __attribute__((ext_vector_type(4)));
-        u4a *w16 = reinterpret_cast<u4a *>(wfa);
-        for (int i = tid; i < NWV * 72; i += TN) w16[i] = u4a{0u, 0u, 0u, 0u};
-    }
     // per-wave totals: lane h of every wave holds wave h's numbers
     uint32_t my_dyn = 0, my_fix = 0, my_x = 0, my_m = 0;
     if (lane < NWV) { my_dyn = S.wtot[lane]; my_fix = S.wtot[8 + lane]; my_x = S.wtot[16 + lane]; my_m = S.wtot[24 + lane]; }
@@ -401,7 +401,8 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     const uint32_t dyn_total = hdr_dyn + dyn_body_all + eob_dyn;
     const uint32_t fix_total = 3 + fix_body_all + 7;
     const uint32_t sto_total = 3 + ((0u - (z.bitpos + 3)) & 7) + 32 + 8u * (uint32_t)len;
-    {   // Adler-32 running update (RFC 1950): B' = B + len * A + sum (len - i) x_i
+    if (!FUSED) {   // Adler-32 running update (RFC 1950): B' = B + len * A + sum (len - i) x_i.  (Fused: one block — the frame's writer takes
+                    // S.red[2], S.red[3] itself, on one lane, instead of a 64-bit modulo on every lane of the workgroup.)
         const uint32_t nb = (uint32_t)(((uint64_t)adB + (uint64_t)len * adA + S.red[3]) % 65521u);
         adA = (adA + S.red[2]) % 65521u;
         adB = nb;
@@ -443,7 +444,7 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
         u4a *l16 = reinterpret_cast<u4a *>(obuf + (wf_at - listb_words));
         for (uint32_t i = tid; i < listb_words / 4; i += TN) l16[i] = u4a{0u, 0u, 0u, 0u};
     }
-    __syncthreads();                                       // the histogram words are zero (and the fixed codes in place)
+    if (use_fixed || !list_ok) __syncthreads();            // (uniform, rare) the fixed codes / the cleared list words are in place
     if (wv == 0) {
         // block header on one wave, beside the other waves' tokens (disjoint bits, atomic ORs)
         if (use_fixed) {

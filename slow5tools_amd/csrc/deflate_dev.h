@@ -1159,10 +1159,16 @@ __device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *ob
 #ifdef S5_DEFL_V1
     deflate_block<1, M>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es);
 #else
-    deflate_block2<1, NT>(S, obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es);
+    deflate_block2<1, NT>(S, obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es, gen_hint);
 #endif
     if (dbg) return 16;
     z.bitpos = (z.bitpos + 7) & ~7u;
+#ifndef S5_DEFL_V1
+    if (tid == 0 && plen) {   // deflate_block2<1> leaves the block's Adler sums in S.red: A = 1 + sum x_i, B = len + sum (len - i) x_i
+        adB = (uint32_t)(((uint64_t)plen + S.red[3]) % 65521u);
+        adA = (1u + S.red[2]) % 65521u;
+    }
+#endif
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
     z.bitpos += 32;
     __syncthreads();
