@@ -175,10 +175,21 @@ constexpr uint32_t DEFL2_LIST_CAP = 640;
 constexpr uint32_t DEFL2_LISTB_MIN = 64;    // the list never reaches below this word
 constexpr uint32_t SEG_FAST = 0xFFFFFFFFu, SEG_REDO = 0xFFFFFFFEu, SEG_MASK = 0xFFFFFFFDu;
 
+// What has to be zero before pass 1 of a block: the per-wave histograms and the token list's counter.  (Everything else the block
+// leaves in S is written before it is read.)  No barrier in here: the caller orders it.
+template <int TN = NT>
+__device__ __forceinline__ void deflate2_prepare(DeflShared &S, uint32_t *obuf, uint32_t obuf_words) {
+    constexpr int NWV = TN / 64;
+    typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+    u4a *w16 = reinterpret_cast<u4a *>(obuf + (obuf_words - (uint32_t)(NWV * 288)));   // (obuf is 16-byte aligned, obuf_words and 288 are multiples of four)
+    for (int i = threadIdx.x; i < NWV * 72; i += TN) w16[i] = u4a{0u, 0u, 0u, 0u};
+    if (threadIdx.x == 0) { S.lalloc = 0; S.red[7] = 0; }
+}
+
 template <int MODE, int TN = NT>
 __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, uint32_t obuf_words, const uint8_t *__restrict__ buf, int len,
                                                bool final, ZOut &z, uint32_t &adA, uint32_t &adB, uint32_t dbg = 0,
-                                               EarlySize es = EarlySize{nullptr, 0}, uint32_t gen_hint = 0) {
+                                               EarlySize es = EarlySize{nullptr, 0}, uint32_t gen_hint = 0, bool prepared = false) {
     static_assert(MODE == 1 || MODE == 2, "fused single block (1) or staged multi-block (2): the bit buffer is this function's to clear");
     constexpr bool FUSED = MODE == 1;
     constexpr int NWV = TN / 64;
@@ -200,16 +211,10 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     const uint32_t wf_at = obuf_words - (uint32_t)(NWV * 288);
     uint32_t *wfa = obuf + wf_at;
     uint32_t *wf = wfa + wv * 288;
-    {
-        typedef uint32_t u4a __attribute__((ext_vector_type(4)));
-        u4a *w16 = reinterpret_cast<u4a *>(wfa);            // (obuf is 16-byte aligned, obuf_words and 288 are multiples of four)
-        for (int i = tid; i < NWV * 72; i += TN) w16[i] = u4a{0u, 0u, 0u, 0u};
+    if (!prepared) {      // (uniform; the fused kernels clear these under their signal loads: deflate2_prepare)
+        deflate2_prepare<TN>(S, obuf, obuf_words);
+        __syncthreads();
     }
-    if (tid < 32) S.wtot[tid] = 0;
-    if (tid < 8) S.red[tid] = 0;
-    if (tid < 20) S.clfreq[tid] = 0;
-    if (tid == 0) S.lalloc = 0;
-    __syncthreads();
 
     const uint32_t *buf32 = reinterpret_cast<const uint32_t *>(buf);
     constexpr bool POOLB = MODE == 2;                       // the token list: S.freq, then (staged) the bit buffer below the histograms
@@ -332,14 +337,14 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
         nmatch = wave_sum(nmatch);
         nextra = wave_sum(nextra);
         if (lane == 0) {
-            atomicAdd(&S.red[2], a_w);
-            atomicAdd(&S.red[3], b_w);
+            S.wad[wv] = a_w;
+            S.wad[8 + wv] = b_w;
             S.wtot[16 + wv] = nextra;
             S.wtot[24 + wv] = nmatch;
         }
     }
     __syncthreads();
-    if (dbg == 2) { z.bitpos += wfa[tid] + S.red[2]; return; }   // tools/stage_time.py cut-off
+    if (dbg == 2) { z.bitpos += wfa[tid] + S.wad[tid & 15]; return; }   // tools/stage_time.py cut-off
 
     // (uniform) words of the bit buffer, below the histograms, that hold tokens
     const uint32_t la = S.lalloc;
@@ -402,9 +407,12 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     const uint32_t fix_total = 3 + fix_body_all + 7;
     const uint32_t sto_total = 3 + ((0u - (z.bitpos + 3)) & 7) + 32 + 8u * (uint32_t)len;
     if (!FUSED) {   // Adler-32 running update (RFC 1950): B' = B + len * A + sum (len - i) x_i.  (Fused: one block — the frame's writer takes
-                    // S.red[2], S.red[3] itself, on one lane, instead of a 64-bit modulo on every lane of the workgroup.)
-        const uint32_t nb = (uint32_t)(((uint64_t)adB + (uint64_t)len * adA + S.red[3]) % 65521u);
-        adA = (adA + S.red[2]) % 65521u;
+                    // the per-wave sums (S.wad) itself, on one lane, instead of a 64-bit modulo on every lane of the workgroup.)
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; w++) { a += S.wad[w]; b += S.wad[8 + w]; }
+        const uint32_t nb = (uint32_t)(((uint64_t)adB + (uint64_t)len * adA + b) % 65521u);
+        adA = (adA + a) % 65521u;
         adB = nb;
     }
     if (sto_total <= dyn_total && sto_total <= fix_total) {

@@ -59,6 +59,7 @@ struct DeflShared {
     uint32_t ncl, hlit, hclen, dbg;
     uint32_t wtot[32];       // deflate_block2: per wave [0, 8) dynamic body bits, [8, 16) fixed, [16, 24) extra bits, [24, 32) matches
     uint32_t lalloc, lpad[3];   // deflate_block2: tokens handed out of the token list (which lives in freq[])
+    uint32_t wad[16];        // deflate_block2: Adler-32 partial sums per wave ([0, 8) sum of bytes, [8, 16) weighted sum mod 65521)
 };
 
 // Ordered single-pass output: as soon as a single-block record's final size is known (right after the bit-offset
@@ -452,6 +453,7 @@ __device__ __forceinline__ uint32_t fixed_code(int s) {
 // (S.lens[0 .. hlit) then S.lens[DOFF .. DOFF + hdist)), choice of the code-length code, header cost in S.red[6] ----
 __device__ __forceinline__ void cl_header_wave(DeflShared &S, int hdist) {
     const int lane = lane_id();
+    if (lane < 20) S.clfreq[lane] = 0;   // (this wave is the counters' only user: cleared here, ordered by the wave-scope syncs below)
     int hl = lane < 29 && S.lens[257 + lane] ? 258 + lane : 257;
     const int hlit = __builtin_amdgcn_readlane(wave_incl_max(hl), 63), n = hlit + hdist;
     if (lane == 0) S.hlit = (uint32_t)hlit;
@@ -1151,7 +1153,8 @@ namespace s5 {
 // reserved for the u64 size prefix) and returns total.  obuf_words >= max(plen + 64, sizeof(BuildScratch)) / 4.
 template <typename M>
 __device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words, const uint8_t *pay,
-                                                     uint32_t plen, ZOut &z, uint32_t dbg = 0, EarlySize es = EarlySize{nullptr, 0}, uint32_t gen_hint = 0) {
+                                                     uint32_t plen, ZOut &z, uint32_t dbg = 0, EarlySize es = EarlySize{nullptr, 0}, uint32_t gen_hint = 0,
+                                                     bool prepared = false) {
     const int tid = threadIdx.x;
     z.bitpos = 80;   // 64 bits of size prefix + 16 bits of zlib header, both written later
     z.flushed = 0;
@@ -1159,14 +1162,16 @@ __device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *ob
 #ifdef S5_DEFL_V1
     deflate_block<1, M>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es);
 #else
-    deflate_block2<1, NT>(S, obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es, gen_hint);
+    deflate_block2<1, NT>(S, obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es, gen_hint, prepared);
 #endif
     if (dbg) return 16;
     z.bitpos = (z.bitpos + 7) & ~7u;
 #ifndef S5_DEFL_V1
-    if (tid == 0 && plen) {   // deflate_block2<1> leaves the block's Adler sums in S.red: A = 1 + sum x_i, B = len + sum (len - i) x_i
-        adB = (uint32_t)(((uint64_t)plen + S.red[3]) % 65521u);
-        adA = (1u + S.red[2]) % 65521u;
+    if (tid == 0 && plen) {   // deflate_block2<1> leaves the block's Adler sums per wave: A = 1 + sum x_i, B = len + sum (len - i) x_i
+        uint32_t a = 0, b = 0;
+        for (int w = 0; w < NW; w++) { a += S.wad[w]; b += S.wad[8 + w]; }
+        adB = (uint32_t)(((uint64_t)plen + b) % 65521u);
+        adA = (1u + a) % 65521u;
     }
 #endif
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
@@ -1178,9 +1183,9 @@ __device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *ob
 // ... then into a 16-B aligned HBM slot: [u64 size][record]
 template <typename M>
 __device__ __forceinline__ uint32_t zlib_compress_fused(DeflShared &S, uint32_t *obuf, uint32_t obuf_words,
-                                                        const uint8_t *pay, uint32_t plen, uint8_t *out, uint32_t dbg = 0, uint32_t gen_hint = 0) {
+                                                        const uint8_t *pay, uint32_t plen, uint8_t *out, uint32_t dbg = 0, uint32_t gen_hint = 0, bool prepared = false) {
     ZOut z;
-    const uint32_t total = zlib_frame_fused<M>(S, obuf, obuf_words, pay, plen, z, dbg, EarlySize{nullptr, 0}, gen_hint);
+    const uint32_t total = zlib_frame_fused<M>(S, obuf, obuf_words, pay, plen, z, dbg, EarlySize{nullptr, 0}, gen_hint, prepared);
     if (dbg) {
         if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(out) = z.bitpos;
         if (dbg == 41 && threadIdx.x < 20) reinterpret_cast<uint32_t *>(out)[4 + threadIdx.x] = threadIdx.x < 19 ? S.clfreq[threadIdx.x] : S.red[6];   // tools/clfreq_dump.py

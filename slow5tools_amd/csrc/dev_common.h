@@ -121,6 +121,24 @@ __device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *ws, uin
     total = tot;
     return base + incl - v;
 }
+// The same for a loop that scans once per round: round i uses the half ws[8 * (i & 1) ..] of a 16-word scratch, so ONE barrier per round
+// is enough — a wave can only overwrite the half of round i in round i + 2, behind round i + 1's barrier, which no wave passes before all
+// have read round i's words.  (NW <= 8.)
+__device__ __forceinline__ uint32_t block_excl_add_alt(uint32_t v, uint32_t *ws, uint32_t &total, uint32_t round) {
+    uint32_t *w8 = ws + 8u * (round & 1u);
+    const uint32_t incl = wave_incl_add(v);
+    if (lane_id() == 63) w8[wave_id()] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t x = w8[w];
+        if (w < wave_id()) base += x;
+        tot += x;
+    }
+    total = tot;
+    return base + incl - v;
+}
 // workgroup exclusive prefix sum for a workgroup of NWV waves (block_excl_add above is the NW = 4 form)
 template <int NWV>
 __device__ __forceinline__ uint32_t block_excl_add_w(uint32_t v, uint32_t *ws, uint32_t &total) {

@@ -125,6 +125,18 @@ int s5host::n_devices() {
     return 1;
 }
 
+static std::mutex g_pin_mu;
+hipError_t s5_pinned_alloc(void **p, size_t bytes, size_t *got) {
+    if (bytes < S5_PIN_MIN) bytes = S5_PIN_MIN;
+    if (got) *got = bytes;
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    return hipHostMalloc(p, bytes, hipHostMallocPortable);
+}
+hipError_t s5_pinned_free(void *p) {
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    return hipHostFree(p);
+}
+
 int s5host::CtxHold::acquire(int want_slot) {
     if (s5host::n_devices() == 0) return S5GPU_ERR_NODEV;
     DevState *D;
@@ -267,7 +279,11 @@ int s5host::encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_r
         if (ctl[0] == 0 && ctl[2] == 0) {
             memcpy(off.data(), h, 8ull * (n + 1));
             for (uint32_t i = 0; i < n; i++)
-                if (off[i + 1] < off[i] + 8 || off[i + 1] - off[i] > desc[i].slot_cap) { s5gpu_set_error("read %u: device produced an impossible record extent", i); return S5GPU_ERR_HIP; }
+                if (off[i + 1] < off[i] + 8 || off[i + 1] - off[i] > desc[i].slot_cap) {
+                    s5gpu_set_error("read %u of %u: device produced an impossible record extent (offsets %llu .. %llu, slot %u; next %llu)", i, n, (unsigned long long)off[i],
+                                    (unsigned long long)off[i + 1], desc[i].slot_cap, (unsigned long long)(i + 2 <= n ? off[i + 2 <= n ? i + 2 : n] : 0));
+                    return S5GPU_ERR_HIP;
+                }
             return S5GPU_OK;
         }
     }
@@ -326,9 +342,9 @@ void *s5host::arena_pool_take(size_t bytes, size_t *cap) {
             return b.p;
         }
     }
-    const size_t want = (size_t)up(bytes + bytes / 8 + 4096, 1u << 20);
+    size_t want = (size_t)up(bytes + bytes / 8 + 4096, 1u << 20);
     void *p = nullptr;
-    const hipError_t e = hipHostMalloc(&p, want, hipHostMallocPortable);
+    const hipError_t e = s5_pinned_alloc(&p, want, &want);
     if (e != hipSuccess) { s5gpu_set_error("arena allocation of %zu pinned bytes failed: %s", want, hipGetErrorString(e)); return nullptr; }
     *cap = want;
     return p;
@@ -339,11 +355,11 @@ void s5host::arena_pool_give(void *p, size_t cap) {
         std::lock_guard<std::mutex> g(g_pool_mu);
         if (g_pool_bytes + cap <= POOL_KEEP_BYTES && g_pool.size() < 64) { g_pool.push_back({p, cap}); g_pool_bytes += cap; return; }
     }
-    (void)hipHostFree(p);
+    (void)s5_pinned_free(p);
 }
 void s5host::arena_pool_drain() {
     std::lock_guard<std::mutex> g(g_pool_mu);
-    for (const PoolBuf &b : g_pool) (void)hipHostFree(b.p);
+    for (const PoolBuf &b : g_pool) (void)s5_pinned_free(b.p);
     g_pool.clear();
     g_pool_bytes = 0;
 }
@@ -352,7 +368,7 @@ extern "C" void s5gpu_arena_release(void *arena) {
     if (!ar) return;
     for (auto &b : ar->bufs) {
         if (ar->generation == s5host_generation) s5host::arena_pool_give(b.first, b.second);
-        else (void)hipHostFree(b.first);           // the library was shut down (and its pool drained) while the caller still held the batch
+        else (void)s5_pinned_free(b.first);           // the library was shut down (and its pool drained) while the caller still held the batch
     }
     delete ar;
 }
@@ -1176,10 +1192,10 @@ extern "C" int s5gpu_record_ids_stream(uint32_t n, const void *chunk, size_t chu
 extern "C" void *s5gpu_host_alloc(size_t bytes) {
     if (s5host::n_devices() == 0) return NULL;
     void *p = NULL;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { s5gpu_set_error("pinned allocation of %zu bytes failed", bytes); return NULL; }
+    if (s5_pinned_alloc(&p, bytes ? bytes : 1, nullptr) != hipSuccess) { s5gpu_set_error("pinned allocation of %zu bytes failed", bytes); return NULL; }
     return p;
 }
-extern "C" void s5gpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" void s5gpu_host_free(void *p) { if (p) (void)s5_pinned_free(p); }
 
 // The view / merge worker on a CHUNK of a BLOW5 file: the records sit framed ([u64 size][bytes]) in one host buffer, exactly as
 // read from disk, and the re-encoded records come back as one contiguous stream, exactly as the ordered write loop would emit

@@ -28,6 +28,19 @@ extern "C" const char *s5gpu_last_error(void);
         }                                                                                            \
     } while (0)
 
+// Pinned host memory: never less than S5_PIN_MIN bytes at a time, one host thread inside the allocator at a time (host_api.hip).
+// Round 5: a SMALL pinned buffer (4.9 KB: the stream encoder's offsets) that a worker thread allocated while another worker was in its
+// own first batch came back, one process in a hundred, as a buffer the stream's D2H copies never reached — hipMemcpyAsync + 
+// hipStreamSynchronize succeed, a synchronous hipMemcpy into the same buffer lands, the stream's copies do not, however often they are
+// repeated (tools/view_flake.sh: 8-12 of 900 runs of `s5view` with two workers; none with one worker, none with one context).  Buffers
+// of 2 MiB and more — past the runtime's sub-allocator for small host allocations — do not show it: 0 of 900, and 0 of 600 with the
+// small buffers allocated before the workers start.  Serialising the allocator calls alone did not help (9 of 900).
+#ifndef S5_PIN_MIN
+#define S5_PIN_MIN ((size_t)2 << 20)
+#endif
+hipError_t s5_pinned_alloc(void **p, size_t bytes, size_t *got);   // at least S5_PIN_MIN bytes; *got (may be NULL) = what was allocated
+hipError_t s5_pinned_free(void *p);
+
 // ---- grow-only device / pinned workspaces for the host-buffer batch calls ----
 struct Buf {
     void *p = nullptr;
@@ -35,14 +48,14 @@ struct Buf {
     bool pinned = false;
     int reserve(size_t n) {
         if (n <= cap) return S5GPU_OK;
-        if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
+        if (p) { if (pinned) (void)s5_pinned_free(p); else (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = n + n / 4 + 4096;
-        hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocPortable) : hipMalloc(&p, want);
+        hipError_t e = pinned ? s5_pinned_alloc(&p, want, &want) : hipMalloc(&p, want);
         if (e != hipSuccess) { s5gpu_set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); p = nullptr; return S5GPU_ERR_NOMEM; }
         cap = want;
         return S5GPU_OK;
     }
-    void release() { if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
+    void release() { if (p) { if (pinned) (void)s5_pinned_free(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
 };
 struct Ctx {
     Buf d_sig, d_hdr, d_aux, d_desc, d_slots, d_len, d_ovf, d_in, d_pay, d_fields, d_stream, d_scan, d_sig2, d_desc2, d_patch;

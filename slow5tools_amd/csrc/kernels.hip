@@ -116,7 +116,7 @@ __device__ __forceinline__ uint32_t build_payload(const s5gpu_encode_args_t &a, 
         uint32_t total = 0;
         const uint32_t room = cap - fixed;
         for (uint32_t t0 = 0; t0 < n; t0 += SVB_TILE) {
-            const uint32_t t = svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws, room - total);
+            const uint32_t t = svb_encode_tile(sig, n, t0, keys + (t0 >> 2), data + total, ws, room - total, true);   // (one read per workgroup: ws is fresh)
             if (t > room - total) return OVF;
             total += t;
         }
@@ -202,6 +202,9 @@ __global__ __launch_bounds__(NT, WPS) void k_encode_fused(EncParams p) {     // 
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
     const s5gpu_read_desc_t d = p.a.desc[r];
+#ifndef S5_DEFL_V1
+    deflate2_prepare<NT>(S, obuf, p.obuf_words);     // (cleared under the signal loads; ordered by the barriers of the payload's scans)
+#endif
     const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
     if (plen == OVF) {
         if (threadIdx.x == 0 && p.tier != 1) {
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(NT, WPS) void k_encode_fused(EncParams p) {     // 
         return;
     }
     uint8_t *out = p.a.slots + d.out_off;
-    const uint32_t total = zlib_compress_fused<M>(S, obuf, p.obuf_words, pay, plen, out, p.dbg, S5_FUSED_HINT(p.a, d));
+    const uint32_t total = zlib_compress_fused<M>(S, obuf, p.obuf_words, pay, plen, out, p.dbg, S5_FUSED_HINT(p.a, d), true);
     if (threadIdx.x == 0) p.a.out_len[r] = total;
 }
 
@@ -249,6 +252,9 @@ __global__ __launch_bounds__(NT, S5_FUSED_WG_PER_CU) void k_encode_stream(EncPar
     const uint32_t r = s_r;
 #endif
     const s5gpu_read_desc_t d = p.a.desc[r];
+#ifndef S5_DEFL_V1
+    deflate2_prepare<NT>(S, obuf, p.obuf_words);     // (cleared under the signal loads; ordered by the barriers of the payload's scans)
+#endif
     const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
     uint32_t total = 0;
     if (plen == OVF) {
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(NT, S5_FUSED_WG_PER_CU) void k_encode_stream(EncPar
     } else {
         __syncthreads();
         ZOut z;
-        total = zlib_frame_fused<M>(S, obuf, p.obuf_words, pay, plen, z, 0, EarlySize{sp.state, r}, S5_FUSED_HINT(p.a, d));
+        total = zlib_frame_fused<M>(S, obuf, p.obuf_words, pay, plen, z, 0, EarlySize{sp.state, r}, S5_FUSED_HINT(p.a, d), true);
         if (threadIdx.x == 0) { obuf[0] = total - 8; obuf[1] = 0; }   // u64 size prefix
     }
     if (wave_id() == 0) {

@@ -104,12 +104,15 @@ __device__ __forceinline__ void svb_tile_write(const SvbTileLane &T, uint8_t *ke
     for (int q = 0; q < 4; q++)
         if (q < nk) keys[4 * tid + q] = (uint8_t)(T.key >> (8 * q));
 }
+// ws: 16 words of scratch.  ws_fresh: nobody has used ws since the workgroup's last barrier (the fused kernels: one read per workgroup) —
+// otherwise a read's first tile waits for the readers of the previous read's last scan.
 __device__ __forceinline__ uint32_t svb_encode_tile(const int16_t *__restrict__ sig, uint32_t n, uint32_t t0,
-                                                    uint8_t *keys, uint8_t *data, uint32_t *ws, uint32_t room) {
+                                                    uint8_t *keys, uint8_t *data, uint32_t *ws, uint32_t room, bool ws_fresh = false) {
     SvbTileLane T;
     svb_tile_classify(sig, n, t0, T);
+    if (t0 == 0 && !ws_fresh) __syncthreads();
     uint32_t total;
-    const uint32_t off = block_excl_add(T.nbytes, ws, total);
+    const uint32_t off = block_excl_add_alt(T.nbytes, ws, total, t0 / (uint32_t)SVB_TILE);   // (ws: 16 words; one barrier per tile)
     if (total > room) return total;
     svb_tile_write(T, keys, data + off);
     return total;
