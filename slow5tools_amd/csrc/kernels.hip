@@ -182,10 +182,11 @@ __device__ __forceinline__ uint32_t run_heavy_front(const s5gpu_encode_args_t &a
     return a.sig_method == S5GPU_SIG_SVB_ZD ? d.hdr_len + 12u + ((d.n_samples + 3u) >> 2) : 0u;
 }
 
-// The fused kernels (eight workgroups per CU: other workgroups fill a wave's idle time) do not gain from the hint — measured 13.42 ms per 1 M
-// 4000-sample reads with it against 13.30 without —, the staged kernel (four per CU) does: mixed lengths 456 -> 491 GB/s.
+// The fused kernels take the hint as the staged one does.  (History: with the round-4 barrier count it cost them 1 % — 13.42 ms per 1 M
+// 4000-sample reads against 13.30, eight workgroups per CU filling a wave's idle time —; after this round's barrier cuts the waves' balance
+// is what is left: 12.71 -> 11.94 ms.  Weight of a general slab 2 / 3 / 4 / 5 / 6 / 8: 12.24 / 11.91 / 11.94 / 12.01 / 12.05 / 12.49.)
 #ifndef S5_FUSED_HINT
-#define S5_FUSED_HINT(a, d) 0u
+#define S5_FUSED_HINT(a, d) run_heavy_front(a, d)
 #endif
 
 // K1+K5+K3+K6 fused: svb-zd -> pack -> one DEFLATE block -> zlib frame.  One read per workgroup, every
