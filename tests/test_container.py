@@ -537,3 +537,35 @@ def test_concurrent_host_batches_from_threads():
     for k in range(4):
         dec = press.decode_records([r[8:] for r in got[k]])
         assert all(d["status"] == 0 and np.array_equal(d["signal"], s) for d, s in zip(dec, jobs[k][0]))
+
+
+@pytest.mark.gpu
+def test_two_workers_first_batches_repeat(tmp_path):
+    """Round 5: twenty fresh processes with two workers each write the same bytes.  (A small pinned buffer allocated by one worker
+    during the other's first batch was, one process in a hundred, a buffer the stream's D2H copies never reached — `read 0 of 64: device
+    produced an impossible record extent`; pinned allocations are 2 MiB or more since: slow5tools_amd/csrc/host_ctx.h, tools/view_flake.sh.)"""
+    import struct
+
+    from slow5tools_amd import press
+
+    rng = np.random.default_rng(33)
+    n = 300
+    sigs = [(480 + 35 * rng.standard_normal(int(k))).astype(np.int16) for k in rng.integers(50, 9000, n)]
+    hdrs = [press.pack_hdr(b"r%06d" % i, 0, 8192.0, 23.0, 1467.61, 4000.0) for i in range(n)]
+    recs = press.encode_records(sigs, hdrs, None, press.REC_NONE, press.SIG_NONE)
+    text = b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
+    head = bytearray(64)
+    head[:6] = b"BLOW5\x01"; head[6:9] = bytes([0, 2, 0]); head[9] = 0; head[10:14] = struct.pack("<I", 1); head[14] = 0
+    src = tmp_path / "in.blow5"
+    src.write_bytes(bytes(head) + struct.pack("<I", len(text)) + text + b"".join(recs) + b"5WOLB")
+    first = None
+    for k in range(20):
+        out = tmp_path / ("o%d.blow5" % k)
+        r = subprocess.run([S5VIEW, str(src), str(out), "zlib", "svb-zd", "64", "2"], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, S5VIEW_PER_RECORD="1"))
+        assert r.returncode == 0, "run %d: %s" % (k, r.stderr)
+        b = out.read_bytes()
+        if first is None:
+            first = b
+        assert b == first, "run %d wrote other bytes" % k
+        out.unlink()
