@@ -272,7 +272,9 @@ void s5gpu_arena_release(void *arena);   /* NULL is fine */
  * their length.  The re-encoded records come back as ONE contiguous stream in out_buf, exactly the bytes the ordered write loop
  * emits: out_off[i] = offset of record i (its u64 prefix), out_off[n] = total.  No per-record malloc or memcpy on either side.
  * chunk / out_buf from s5gpu_host_alloc (pinned) move at PCIe speed; any host memory works.  If out_cap is too small the call
- * fails with S5GPU_ERR_NOMEM and out_off[0] = the capacity needed. */
+ * fails with S5GPU_ERR_NOMEM and out_off[0] = the capacity needed.
+ * s5gpu_host_alloc never pins less than 2 MiB at a time (meant for chunk-sized buffers, not for small objects): round 5 met small pinned
+ * buffers, allocated by one host thread while another was inside its first batch, that device copies did not reach. */
 void *s5gpu_host_alloc(size_t bytes);
 void s5gpu_host_free(void *p);
 int s5gpu_recompress_stream(uint32_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len, int from_rec,
