@@ -26,5 +26,6 @@ for _ in range(5):
     e1.record()
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / 10)
-print("%s: k_encode_stream %d x %d: %s ms  (min %.3f = %.1f GB/s raw)  ok %s"
-      % (os.path.basename(os.environ.get("S5GPU_LIB", "default")), n_reads, n, " ".join("%.3f" % t for t in ts), min(ts), 2 * n * n_reads / min(ts) / 1e6, b.stream_ok()))
+print("%s: k_encode_stream %d x %d: %s ms  (min %.3f = %.1f GB/s raw)  ok %s  %.5f B/sample"
+      % (os.path.basename(os.environ.get("S5GPU_LIB", "default")), n_reads, n, " ".join("%.3f" % t for t in ts), min(ts), 2 * n * n_reads / min(ts) / 1e6, b.stream_ok(),
+         int(b.rec_off[n_reads].item()) / (n * n_reads)))

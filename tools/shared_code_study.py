@@ -1,5 +1,5 @@
 import sys, os, glob, struct, zlib, heapq
-sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle_bind as ob
 
@@ -71,7 +71,7 @@ def payload(sig, rid=b"read_0000001"):
 
 def real_records():
     out = []
-    for path in sorted(glob.glob("/root/repo/tests/golden/ref/**/*.blow5", recursive=True)):
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/ref/**/*.blow5"), recursive=True)):
         b = open(path, "rb").read()
         if b[:6] != b"BLOW5\x01": continue
         rm, sm = b[9], b[14]
@@ -83,7 +83,7 @@ def real_records():
                 body = b[off + 8:off + 8 + sz]
                 pl = zlib.decompress(body) if rm == 1 else (ob.zstd_decompress(body) if rm == 2 else body)
                 d = ob.rec_parse(pl, sm)
-                out.append((os.path.relpath(path, "/root/repo/tests/golden/ref"), d["read_id"], d["signal"]))
+                out.append((os.path.basename(os.path.dirname(path)) + "/" + os.path.basename(path), d["read_id"], d["signal"]))
                 off += 8 + sz
         except Exception as e:
             pass
@@ -102,4 +102,4 @@ if __name__ == "__main__":
         h, nm, xb = tokens_hist(payload(sig, bytes(rid)[:40])); H.append(h); tag.append("real:" + path.split("/")[0])
     H = np.array(H); tag = np.array(tag)
     print("records:", len(H), "synth", (tag == "synth").sum(), "real", (tag != "synth").sum())
-    np.save("/tmp/sc/H.npy", H); np.save("/tmp/sc/tag.npy", tag)
+    np.save("/tmp/H.npy", H); np.save("/tmp/tag.npy", tag)
