@@ -26,10 +26,56 @@ struct SvbTileLane {
     uint32_t key, nbytes;
     int valid;
 };
+#ifndef S5_SVB_PACKED
+#define S5_SVB_PACKED 1
+#endif
 __device__ __forceinline__ void svb_tile_classify(const int16_t *__restrict__ sig, uint32_t n, uint32_t t0, SvbTileLane &T) {
     const int tid = threadIdx.x;
     const uint32_t i0 = t0 + 16u * tid;
     const int valid = i0 >= n ? 0 : (int)min(16u, n - i0);
+#if S5_SVB_PACKED
+    // Round 5: two samples per instruction.  A nanopore signal lives in a few thousand ADC levels; when every sample a wave holds of this tile
+    // (and the one in front of each lane) lies in [-16384, 16384), every delta fits 16 bits and so does its zig-zag value: the packed 16-bit
+    // forms of subtract / shift / min do two samples each, the key bits come out of two accumulators, the byte count is a population count (a
+    // value takes one byte or two).  Lanes without samples ride along on zeros.  Anything else — a sample outside that range, a lane with 1 .. 15
+    // samples — sends the whole wave down the general path below: same results, bit for bit (tests/test_gpu_parity.py, tests/test_full_size.py).
+    {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        typedef short ss2 __attribute__((ext_vector_type(2)));
+        auto U = [](uint32_t v) { return __builtin_bit_cast(us2, v); };
+        auto W = [](us2 v) { return __builtin_bit_cast(uint32_t, v); };
+        uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, pw = 0u;
+        bool ok = valid == 0;
+        if (valid == 16) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(sig + i0);
+            const uint4 b = *reinterpret_cast<const uint4 *>(sig + i0 + 8);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+            if (i0 > 0) pw = *reinterpret_cast<const uint32_t *>(sig + i0 - 2);   // (i0 is a multiple of 16: aligned; its high half is the sample in front)
+            uint32_t rng = W(U(pw) + us2{0x4000, 0x4000});
+#pragma unroll
+            for (int j = 0; j < 8; j++) rng |= W(U(w[j]) + us2{0x4000, 0x4000});
+            ok = (rng & 0x80008000u) == 0u;
+        }
+        if (__ballot(!ok) == 0ull) {                       // (uniform)
+            uint32_t A = 0, B = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t xp = __builtin_amdgcn_alignbit(w[j], j ? w[j - 1] : pw, 16);       // the samples in front of the pair's two
+                const ss2 d = __builtin_bit_cast(ss2, w[j]) - __builtin_bit_cast(ss2, xp);
+                const us2 z = __builtin_bit_cast(us2, d) << us2{1, 1} ^ __builtin_bit_cast(us2, d >> ss2{15, 15});
+                const us2 c = __builtin_elementwise_min(z >> us2{8, 8}, us2{1, 1});               // 0: one byte, 1: two
+                T.z[2 * j] = (uint32_t)z.x;
+                T.z[2 * j + 1] = (uint32_t)z.y;
+                if (j < 4) A |= W(c) << (4 * j); else B |= W(c) << (4 * (j - 4));              // bit 4 j: sample 2 j, bit 16 + 4 j: sample 2 j + 1
+            }
+            const uint32_t key = ((A | (A >> 14)) & 0xFFFFu) | ((B | (B >> 14)) << 16);
+            T.key = key;
+            T.nbytes = valid == 16 ? 16u + (uint32_t)__popc(key) : 0u;
+            T.valid = valid;
+            return;
+        }
+    }
+#endif
     int x[16];
     int prev = 0;
     if (valid == 16) {

@@ -96,6 +96,32 @@ def test_svbzd_encode_adversarial(press):
         assert blob == ob.svbzd_encode(s)
 
 
+def test_svbzd_encode_packed_path_and_its_edges(press):
+    """Round 5: svb_tile_classify does two samples per instruction when every sample a wave holds lies in [-16384, 16384): the largest
+    deltas that path can meet, its limits on either side, one sample outside it at the seams (first / last of a lane, of a wave, of a tile,
+    the sample in front of a tile), and through the fused record encoder as well — all against the oracle, bit for bit."""
+    rng = np.random.default_rng(55)
+    n = 9000
+    base = rng.integers(-16384, 16384, n).astype(np.int16)
+    sigs = [base,
+            np.tile(np.array([16383, -16384], np.int16), n // 2),          # deltas of +-32767: two-byte values throughout
+            np.tile(np.array([-16384, -16384, 16383, 16383], np.int16), n // 4),
+            np.full(n, 16383, np.int16), np.full(n, -16384, np.int16),
+            (rng.normal(500, 40, n)).astype(np.int16)]
+    for pos in (0, 1, 15, 16, 17, 1023, 1024, 4095, 4096, 4097, 8191, 8192, 8999):
+        for v in (16384, -16385, 32767, -32768):
+            t = base.copy(); t[pos] = v
+            sigs.append(t)
+    b = press.DeviceBatch([len(x) for x in sigs], with_stream_out=False)
+    b.upload(sigs, [_hdr(press, i) for i in range(len(sigs))])
+    b.svbzd_encode()
+    for x, blob in zip(sigs, b.records()):
+        assert blob == ob.svbzd_encode(x)
+    hdrs = [_hdr(press, i) for i in range(len(sigs))]
+    for x, h, rec in zip(sigs, hdrs, press.encode_records(sigs, hdrs, None, press.REC_ZLIB, press.SIG_SVB_ZD)):
+        assert zlib.decompress(rec[8:]) == _oracle_payload(h, x, b"", press.SIG_SVB_ZD)[0]
+
+
 def test_svbzd_stream_one_pass_equals_slots_plus_compaction(press):
     """s5gpu_svbzd_encode_stream_dev: the blob stream and the offsets of svbzd_encode + compact, in one launch; ragged lengths,
     empty reads and a read past the LDS budget (ctl[0] tells the caller to take the two-pass route)"""
