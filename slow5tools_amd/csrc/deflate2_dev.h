@@ -230,7 +230,12 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
 #ifndef S5_DEFL2_GEN_W
 #define S5_DEFL2_GEN_W 4
 #endif
-    constexpr int GW = S5_DEFL2_GEN_W;                        // weight of a general slab (a plain one: 1)
+#ifndef S5_DEFL2_GEN_W_FUSED
+#define S5_DEFL2_GEN_W_FUSED 5
+#endif
+    // weight of a general slab (a plain one: 1).  Measured with pass 1's plain slabs taken in pairs: fused 4 / 5 / 6 = 11.68 / 11.62 / 11.63 ms per
+    // 1 M reads; staged (mixed | long reads) 4 / 5 / 6 = 536 | 743, 526 | 726, 528 | 729 GB/s
+    constexpr int GW = FUSED ? S5_DEFL2_GEN_W_FUSED : S5_DEFL2_GEN_W;
     const int gs = min(nsl, gen_hint ? (int)((gen_hint + 2u + 255u) >> 8) : 0);
     const int cost_all = (GW - 1) * gs + nsl;
     auto bound = [&](int w) -> int {
@@ -247,6 +252,42 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
         uint32_t carryE = k0 > 0 && k0 < k1 ? carry_e_before(buf32, k0, len) : 0u;
         WaveCarry wc{-1, k0 == 0};
         for (int k = k0; k < k1; k++) {
+#ifndef S5_DEFL2_NO_PAIRS
+            // TWO plain slabs in one step (as pass 2 does), eight consecutive positions per lane: three loads instead of four, one DPP instead of
+            // two, one membership test, one trip — 58 instructions for what two single steps do in 84.  Tried behind the hinted run-heavy front only
+            // (there every attempt would fail); a pair that holds a sequence after all is done slab by slab below.
+            if (k >= gs && k > 0 && k + 1 < k1 && 256 * k + 512 <= len) {
+                const int d0 = 64 * k + 2 * lane;
+                const uint32_t wp = buf32[d0 - 1], w0 = buf32[d0], w1 = buf32[d0 + 1];
+                const uint32_t E0 = zbytes(w0 ^ alignbit(w0, wp, 24)), E1 = zbytes(w1 ^ alignbit(w1, w0, 24));
+                const uint32_t EpA = dpp_u32<DPP_WAVE_SHR1>(carryE, E1);
+                auto member_of = [](uint32_t E, uint32_t Ep) {           // (classify_slab's rule)
+                    const uint32_t C = alignbit(E, Ep, 16), Cm1 = alignbit(E, Ep, 8), Cp1 = alignbit(E, Ep, 24);
+                    return C & ((Cp1 & (E | Cm1)) | (Ep & Cm1));
+                };
+                if (__ballot((member_of(E0, EpA) | member_of(E1, E0)) != 0u) == 0ull) {
+                    carryE = (uint32_t)__builtin_amdgcn_readlane((int)E1, 63);
+                    const uint32_t bA = alignbit(w0, wp, 16), bB = alignbit(w1, w0, 16);
+                    atomicAdd(&wf[bA & 255u], 1u);
+                    atomicAdd(&wf[(bA >> 8) & 255u], 1u);
+                    atomicAdd(&wf[(bA >> 16) & 255u], 1u);
+                    atomicAdd(&wf[bA >> 24], 1u);
+                    atomicAdd(&wf[bB & 255u], 1u);
+                    atomicAdd(&wf[(bB >> 8) & 255u], 1u);
+                    atomicAdd(&wf[(bB >> 16) & 255u], 1u);
+                    atomicAdd(&wf[bB >> 24], 1u);
+                    const uint32_t wA = (uint32_t)(len - (256 * k + 8 * lane - 2));     // Adler: weight of the lane's first position
+                    const uint32_t sA = __builtin_amdgcn_udot4(bA, 0x01010101u, 0u, false), sB = __builtin_amdgcn_udot4(bB, 0x01010101u, 0u, false);
+                    a_acc += sA + sB;
+                    b_acc = __umul24(wA, sA) + __umul24(wA - 4u, sB) + b_acc;
+                    d_acc = __builtin_amdgcn_udot4(bA, 0x03020100u, d_acc, false);
+                    d_acc = __builtin_amdgcn_udot4(bB, 0x03020100u, d_acc, false);
+                    wc.ok = false;
+                    k++;
+                    continue;
+                }
+            }
+#endif
             const bool full = k > 0 && 256 * k + 256 <= len;     // every slot of every lane is a valid position >= 1
             const uint32_t wgt = (uint32_t)(len - (256 * k + 4 * lane - 2));   // Adler: weight of slot 0
             SlabCls c;
