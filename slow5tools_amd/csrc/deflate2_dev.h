@@ -375,13 +375,12 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
         // Adler: sum of (len - p) x_p = sum over slabs of wgt * (x0 + x1 + x2 + x3) - (0 x0 + 1 x1 + 2 x2 + 3 x3)
         const uint32_t a_w = wave_sum(a_acc);
         const uint32_t b_w = wave_sum((b_acc - d_acc) % 65521u);
-        nmatch = wave_sum(nmatch);
-        nextra = wave_sum(nextra);
+        const uint32_t mx = wave_sum(nmatch | (nextra << 16));     // (a block of <= 16 KiB: < 5462 matches, < 27310 extra bits — one sum for both)
         if (lane == 0) {
             S.wad[wv] = a_w;
             S.wad[8 + wv] = b_w;
-            S.wtot[16 + wv] = nextra;
-            S.wtot[24 + wv] = nmatch;
+            S.wtot[16 + wv] = mx >> 16;
+            S.wtot[24 + wv] = mx & 0xFFFFu;
         }
     }
     __syncthreads();
@@ -441,7 +440,15 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     // per-wave totals: lane h of every wave holds wave h's numbers
     uint32_t my_dyn = 0, my_fix = 0, my_x = 0, my_m = 0;
     if (lane < NWV) { my_dyn = S.wtot[lane]; my_fix = S.wtot[8 + lane]; my_x = S.wtot[16 + lane]; my_m = S.wtot[24 + lane]; }
-    const uint32_t dyn_body_all = wave_sum(my_dyn + my_x + my_m), fix_body_all = wave_sum(my_fix + my_x + 5u * my_m);   // tokens incl. extra and distance bits
+    // (the numbers live in lanes 0 .. NWV - 1 <= 7 of one row: an inclusive scan is two or three row shifts, not the wave's six steps)
+    auto row8_incl = [](uint32_t v) {
+        v += dpp_u32<DPP_ROW_SHR1>(0, v);
+        v += dpp_u32<DPP_ROW_SHR2>(0, v);
+        if (NWV > 4) v += dpp_u32<DPP_ROW_SHR4>(0, v);
+        return v;
+    };
+    const uint32_t dyn_body_all = (uint32_t)__builtin_amdgcn_readlane((int)row8_incl(my_dyn + my_x + my_m), NWV - 1);          // tokens incl. extra and distance bits
+    const uint32_t fix_body_all = (uint32_t)__builtin_amdgcn_readlane((int)row8_incl(my_fix + my_x + 5u * my_m), NWV - 1);
     const uint32_t eob_dyn = S.lens[256];
     const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
     const uint32_t dyn_total = hdr_dyn + dyn_body_all + eob_dyn;
@@ -477,7 +484,7 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
     const uint32_t pos0 = z.bitpos + (use_fixed ? 3u : hdr_dyn);
     // bit offset of every wave's region: an exclusive scan over lanes 0 .. NWV - 1
     const uint32_t my_t = (use_fixed ? my_fix : my_dyn) + my_x + my_m * dist_bits;
-    const uint32_t t_incl = wave_incl_add(my_t);
+    const uint32_t t_incl = row8_incl(my_t);
     const uint32_t total_bits = (uint32_t)__builtin_amdgcn_readlane((int)t_incl, NWV - 1);
     uint32_t wbase = pos0 + (wv ? (uint32_t)__builtin_amdgcn_readlane((int)t_incl, wv - 1) : 0u);
     const uint32_t eob = use_fixed ? fixed_code(256) : S.code[256];
