@@ -752,6 +752,20 @@ def main():
     ap.add_argument("--min-leg-steps-long", type=int, default=40, help="configs[3] leg: steps (28 ms each on 65536 reads)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): make the N ranks here — the same module the driver
+    # uses (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), this file and these
+    # arguments again — so that `--gpus 8` can never quietly be eight copies' worth of one rank (`n_gpus: 1`).  Rank 0 prints the line.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import numpy as np
     import torch
 

@@ -468,6 +468,14 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
         const uint32_t bytepos = (z.bitpos + 3 + 7) >> 3;
         publish_size(es, (bytepos + 4 + (uint32_t)len) * 8);
         uint8_t *ob8 = reinterpret_cast<uint8_t *>(obuf) + (bytepos - z.flushed * 4);
+        if (poolb_used) {
+            // (staged, uniform) the token list of this block's general slabs stands in the bit buffer below the histograms, and waves 1.. cleared
+            // only the words below it: a stored block's bytes are plain stores that may END inside those words, and the stream's next bits — the
+            // Adler-32 trailer, the next block's carry — are ORed into whatever the rest of that word and the next one hold.  Clear them first.
+            typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+            u4a *l16 = reinterpret_cast<u4a *>(obuf + (wf_at - listb_words));
+            for (uint32_t i = tid; i < listb_words / 4; i += TN) l16[i] = u4a{0u, 0u, 0u, 0u};
+        }
         __syncthreads();                                   // the histogram words are zero
         if (tid == 0) {
             put_bits(obuf, z, z.bitpos, final ? 1u : 0u, 3);

@@ -42,7 +42,7 @@ constexpr int IP_SPAN = 4096;          // compressed bytes per round
 #define S5_IP_WAIT 768
 #endif
 #ifndef S5_IP_FILL
-#define S5_IP_FILL 96
+#define S5_IP_FILL 64
 #endif
 constexpr int IP_WAIT = S5_IP_WAIT;    // waiting matches per round (the whole wave's, in stream order)
 constexpr int IP_FILL = S5_IP_FILL;    // runs (distance-1 matches) per round that the whole wave fills afterwards
@@ -61,23 +61,44 @@ constexpr int INF_NEED_FALLBACK = 8;
 #endif
 constexpr int IP_DBITS = S5_IP_DBITS;  // primary distance lookup bits (>= 7: the code-length code's 7-bit table is built in the same storage)
 static_assert(IP_DBITS >= 7 && IP_DBITS <= INF_DBITS, "");
+#ifndef S5_IP_DBITS_SVB
+#define S5_IP_DBITS_SVB 7
+#endif
+constexpr int IP_DBITS_SVB = S5_IP_DBITS_SVB;     // ... in the instantiation for svb-zd records: their distance codes are a handful of short ones
+static_assert(IP_DBITS_SVB >= 7 && IP_DBITS_SVB <= INF_DBITS, "");
 
 #ifndef S5_IP_WAIT_SVB
 #define S5_IP_WAIT_SVB 256
 #endif
 constexpr int IP_WAIT_SVB = S5_IP_WAIT_SVB;       // ... in the instantiation for svb-zd records (below)
-template <int WAIT>
-struct InflParSharedT {                 // per wave: 6.6 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
+// Lit/len lookup table (round 6): 9 root bits + second-level tables for longer codes, 16-bit entries
+//   literal   0x0000 | byte << 4 | len          length   0x4000 | (symbol - 257) << 4 | len
+//   stop      0x8000 | len (end of block)       invalid  0x8010 | 15
+//   sublink   0xC000 | first entry << 4 | bits of the second-level index
+// 512 + 340 entries hold any code of <= 286 symbols and <= 15 bits (zlib's ENOUGH_LENS for a 9-bit root: a second-level table is
+// sized by the longest code under its 9-bit prefix).
+constexpr int IP_LROOT = 9;
+constexpr int IP_LSUB = 340;
+template <int WAIT, int DB>
+struct InflParSharedT {                 // per wave: 6.9 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
                                        // LDS per wave = + 33 % time), so nothing here is larger than it has to be
     alignas(16) uint32_t win[IP_SPAN / 4 + 8];     // window (16-byte aligned: filled 16 bytes per lane); the header parser uses its first INF_IW bytes
     union {
         uint16_t wq[WAIT];             // waiting match: position in the round's output (< 64 Ki); its length and distance wait in the
                                        // first three of the bytes it will produce — a match is at least three bytes long
-        uint16_t llut[32];             // (64 bytes of scratch for the header parser's symbol sort; no lit/len lookup table here)
+        struct {
+            uint16_t llut[32];         // (64 bytes of scratch for the header parser's symbol sort; no lit/len lookup table there)
+            uint16_t ladj[16];         // while the table is built: index of a length's first symbol in lsym - its first code
+        };
     };
-    uint16_t dlut[1 << IP_DBITS];
-    uint16_t ladj[16];                 // lit/len: index of a length's first symbol in lsym - its first code
-    uint16_t lsym[288];
+    uint16_t dlut[1 << DB];
+    union {
+        uint16_t ltab[(1 << IP_LROOT) + IP_LSUB];
+        struct {
+            uint16_t ltab_root_[1 << IP_LROOT];
+            uint16_t lsym[IP_LSUB];    // while the table is built: the symbols in canonical order (288 at most), where the second level will stand
+        };
+    };
     uint16_t dsym[32];
     uint16_t lcount[16], dcount[16];
     union {
@@ -85,22 +106,24 @@ struct InflParSharedT {                 // per wave: 6.6 KiB — the kernel's sp
         struct {
             uint32_t fill_a[IP_FILL];  // ... run: position in the round's output | length << 20
             uint8_t fill_x[IP_FILL];   //     its byte
+            uint32_t nfill;
         };
     };
-    uint32_t nfill;
 #ifdef S5_IP_PAD
     uint8_t pad[S5_IP_PAD];            // tools only: how the kernel's time follows the number of resident waves
 #endif
     static constexpr int N_WAIT = WAIT;
+    static constexpr int DBITS = DB;
 };
+static_assert(IP_LSUB >= 288, "the canonical-order symbols are sorted where the second-level tables will stand");
 // Two sizes of the waiting list (round 3).  The kernel's speed follows the number of resident waves, and at 80 VGPRs the register file
 // holds 24 per CU: 7.4 KiB of LDS per wave allow 21, 6.4 KiB all 24 (measured on 1 M own records: 30.9 -> 28.6 ms).  What the list has to
 // hold depends on what was compressed: stock zlib leaves ~110 waiting matches in a 4000-sample svb-zd record (a list of 256 takes a record
 // per round; long reads take a few more rounds in their key bytes), but several hundred per window in a RAW-SIGNAL record (four tokens
 // out of five are far matches: 768 entries, 15.8 ms per 8192 fixture records against 25 with 512).  The caller of s5gpu_decode_dev names
 // the signal press, so svb-zd records get the small list; inflate-only calls and raw-signal records keep the large one.
-using InflParShared = InflParSharedT<IP_WAIT>;
-using InflParSharedSvb = InflParSharedT<IP_WAIT_SVB>;
+using InflParShared = InflParSharedT<IP_WAIT, IP_DBITS>;
+using InflParSharedSvb = InflParSharedT<IP_WAIT_SVB, IP_DBITS_SVB>;
 static_assert(INF_IW <= IP_SPAN, "the header parser's window is the head of the round window");
 
 // 32 bits of the window starting at bit p (two aligned dwords + one alignbit)
@@ -160,7 +183,7 @@ typedef unsigned short ip_u2 __attribute__((ext_vector_type(2)));
 // limit of length l = (first code of length l + codes of length l) << (15 - l), left-justified in 15 bits; kept minus one, two
 // per word (lengths 2k+1 | 2k+2): eight packed 16-bit subtractions compare all fifteen, and no compare ever goes through VCC
 // (on gfx950 a VALU write of VCC needs wait states before a VALU read of it: the cmp / addc form paid a nop per limit)
-struct IpLimits { ip_s2 m1[8]; uint32_t base; int np; uint32_t lenmask; };   // pairs from the shortest length in use on (lengths below it always count, the
+struct IpLimits { ip_s2 m1[8]; uint32_t base; int np; uint32_t end; };   // end: the code space in use, of 32768 (less: an incomplete code)   // pairs from the shortest length in use on (lengths below it always count, the
                                                            // longest one's limit is the end of the code space and never does): np pairs matter
 // (carrying the index adjustment of the code's length along in the same compare chain — a conditional move per limit instead of
 // the T.ladj read — was measured: 9 % slower; the wave is short of issue slots, not of LDS latency)
@@ -174,54 +197,156 @@ struct IpLimits { ip_s2 m1[8]; uint32_t base; int np; uint32_t lenmask; };   // 
 // The loop is wave-uniform (it runs while any lane has tokens left) and the length / distance part is entered only in steps in
 // which some lane stands at a length code: a lane that is done, or at a literal, rides along predicated instead of parking
 // behind nested exec masks.
+// length of the code that starts the 15 bits v (first bit on top): the number of limits not above it, plus one; 16: behind the last code
+// of an incomplete code.  Only the table construction resolves codes this way now (round 6).
+__device__ __forceinline__ uint32_t ip_code_len(const IpLimits &L, uint32_t v) {
+    const ip_s2 vv = {(short)v, (short)v};
+    ip_u2 acc = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;   // sign bit: v >= limit
+    if (L.np > 4) {   // (uniform: a lit/len code whose lengths span more than nine values; svb-zd records usually stay below)
+#pragma unroll
+        for (int k = 4; k < 6; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;
+        if (L.np > 6) {
+#pragma unroll
+            for (int k = 6; k < 8; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;
+        }
+    }
+    // (only the limits of the lengths in use are compared, and the longest one's never: what lies behind the last code of an incomplete
+    // code is found by its own compare)
+    return v >= L.end ? 16u : L.base + acc.x + acc.y;
+}
+// table entry of the code that starts the 15 bits v (its length: len <= 15, or 16: no such code)
+template <class SH>
+__device__ __forceinline__ uint32_t ip_entry_of(const SH &T, uint32_t v, uint32_t len) {
+    if (len > 15u) return 0x801Fu;
+    uint32_t idx = (uint32_t)((int)(short)T.ladj[len] + (int)(v >> (15u - len)));
+    idx = min(idx, 287u);
+    const uint32_t sym = (uint32_t)T.lsym[idx];
+    return sym < 256u ? (sym << 4) | len : sym == 256u ? 0x8000u | len : 0x4000u | ((sym - 257u) << 4) | len;
+}
+// Lookup table of the lit/len code (layout: InflParSharedT).  Built by DECODING: entry i of the root is the code that starts the nine
+// bits i — resolved once per entry with the packed compare chain against the canonical limits (ip_code_len: the decoder of rounds 2-5
+// ran that chain for every token of every pass) — and a 9-bit prefix under which codes longer than nine bits stand links to a
+// second-level table sized by the longest code under it.  Canonical codes grow with their length, so those prefixes form one ZONE per
+// length 10..15, in that order: zs[k] = first prefix whose longest code has 10 + k bits, zb[k] = table index of that prefix's second
+// level; both follow from the counts alone.  The symbols in canonical order stand where the second level goes: its entries are computed
+// first (six per lane at most) and stored behind a barrier.  Returns 1 if the second level would not fit (never, for <= 286 symbols).
+template <class SH>
+__device__ __forceinline__ int ip_build_ltab(SH &T, const IpLimits &L) {
+    const int lane = lane_id();
+    uint32_t zs[7], zb[7];
+    {
+        uint32_t first = 0;
+#pragma unroll
+        for (int l = 1; l <= 15; l++) {
+            const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)T.lcount[l]);
+            if (l >= 10) zs[l - 10] = (first << (15 - l)) >> 6;
+            if (l == 15) zs[6] = (first + c + 63u) >> 6;               // behind the last prefix that holds a code
+            first = (first + c) << 1;
+        }
+        zb[0] = 1u << IP_LROOT;
+#pragma unroll
+        for (int k = 0; k < 6; k++) zb[k + 1] = zb[k] + ((zs[k + 1] - zs[k]) << (k + 1));
+        if (zb[6] > (uint32_t)((1 << IP_LROOT) + IP_LSUB)) return 1;
+    }
+    // root: nine stream bits i = nine code bits, first bit on top
+#pragma unroll 2
+    for (int it = 0; it < (1 << IP_LROOT) / 64; it++) {
+        const uint32_t i = (uint32_t)(it * 64 + lane);
+        const uint32_t pfx = __brev(i) >> (32 - IP_LROOT), v = pfx << (15 - IP_LROOT);
+        const uint32_t len = ip_code_len(L, v);
+        uint32_t e = ip_entry_of(T, v, len);
+        if (len > (uint32_t)IP_LROOT && len <= 15u) {
+            uint32_t k = 0;
+#pragma unroll
+            for (int q = 1; q < 6; q++) k += pfx >= zs[q] ? 1u : 0u;
+            uint32_t zsk = zs[0], zbk = zb[0];
+#pragma unroll
+            for (int q = 1; q < 6; q++) if (k == (uint32_t)q) { zsk = zs[q]; zbk = zb[q]; }
+            e = 0xC000u | ((zbk + ((pfx - zsk) << (k + 1u))) << 4) | (k + 1u);
+        }
+        T.ltab[i] = (uint16_t)e;
+    }
+    // second level: entry j of zone k stands for prefix zs[k] + (j >> (k + 1)) followed by the k + 1 stream bits j & mask
+    const uint32_t nsub = zb[6] - (1u << IP_LROOT);
+    uint32_t sub[(IP_LSUB + 63) / 64];
+#pragma unroll
+    for (int it = 0; it < (IP_LSUB + 63) / 64; it++) {
+        const uint32_t j = (uint32_t)(it * 64 + lane) + (1u << IP_LROOT);
+        uint32_t k = 0;
+#pragma unroll
+        for (int q = 1; q < 6; q++) k += j >= zb[q] ? 1u : 0u;
+        uint32_t zsk = zs[0], zbk = zb[0];
+#pragma unroll
+        for (int q = 1; q < 6; q++) if (k == (uint32_t)q) { zsk = zs[q]; zbk = zb[q]; }
+        const uint32_t rel = j - zbk, sb = k + 1u;
+        const uint32_t pfx = zsk + (rel >> sb), tail = __brev(rel & ((1u << sb) - 1u)) >> (32u - sb);     // the tail's first stream bit on top
+        const uint32_t v = (pfx << (15 - IP_LROOT)) | (tail << (15u - IP_LROOT - sb));
+        sub[it] = it * 64 < (int)nsub ? ip_entry_of(T, v, ip_code_len(L, v)) : 0u;
+    }
+    wave_sync();
+#pragma unroll
+    for (int it = 0; it < (IP_LSUB + 63) / 64; it++) {
+        const uint32_t j = (uint32_t)(it * 64 + lane);
+        if (j < nsub) T.ltab[(1 << IP_LROOT) + j] = (uint16_t)sub[it];
+    }
+    wave_sync();
+    return 0;
+}
+
+// Decode the tokens that start in [st, end) of the window.  WRITE: also produce the bytes, at dst + obase (dst = the record's
+// output at the round's first byte, o_abs0 bytes into the record; positions are relative to the round), and stop at the
+// end-of-block code.  The bytes go straight to HBM: a lane writes its own run of positions, and L2 collects the lines.
+// Without WRITE (the synchronisation passes) the walk goes on behind an end-of-block code: whatever follows is another
+// block's header, garbage to this decoder, but walking on keeps the lane's end position self-synchronised — a lane that
+// stopped there would cut the chain, and every lane behind it would have to be revived one pass at a time.
+// The loop is wave-uniform (it runs while any lane has tokens left) and the length / distance part is entered only in steps in
+// which some lane stands at a length code: a lane that is done, or at a literal, rides along predicated instead of parking
+// behind nested exec masks.
 template <bool WRITE, class SH>
-__device__ __forceinline__ IpSeg ip_decode_segment(SH &T, const IpLimits &L, uint32_t st, uint32_t end, uint32_t obase, uint32_t o_abs0,
+__device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint32_t st, uint32_t end, uint32_t obase, uint32_t o_abs0,
                                                    uint8_t *dst, uint32_t wbase = 0, uint32_t wmax = 0) {
     IpSeg r;
     r.cross = st; r.nout = 0; r.eob = 0; r.eobpos = 0; r.bad = 0; r.nwait = 0;
     uint32_t p = st, o = obase;
+    uint32_t lim = end;            // the lane walks while p < lim (a stop clears it)
     uint32_t wait_end = obase;     // output position behind this lane's last waiting match / pending run: nothing in front of it is in memory yet
     uint32_t lastb = 0x100u;       // the byte this lane produced last (0x100: not known — nothing yet, or a waiting match); a synchronisation
                                    // pass only keeps track of whether it is known (0 / 0x100): which matches will have to wait is counted there,
                                    // so that the output pass can put every lane's waiting matches at their place in ONE list in stream order
-    bool act = p < end;
-    uint32_t step = 0;
-    while (__ballot(act)) {
-        const uint32_t pp = act ? p : 0u;
-        uint32_t bits = ip_peek(T.win, pp);
-        const uint32_t v = __brev(bits) >> 17;
-        const ip_s2 vv = {(short)v, (short)v};
-        ip_u2 acc = {0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;   // sign bit: v >= limit
-        if (L.np > 4) {   // (uniform: a lit/len code whose lengths span more than nine values; svb-zd records usually stay below)
-#pragma unroll
-            for (int k = 4; k < 6; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;
-            if (L.np > 6) {
-#pragma unroll
-                for (int k = 6; k < 8; k++) acc += __builtin_bit_cast(ip_u2, (ip_s2)(L.m1[k] - vv)) >> (unsigned short)15;
+    // Steps come in GROUPS of lenmask + 1 (round 6): inside a group a lane takes literals — two table reads, the same two for every lane
+    // and every code (rounds 2-5: fifteen packed compares + two reads) — and a lane that meets anything else holds its position; no vote
+    // is taken inside a group (a vote on a condition that is not a plain compare costs two vector instructions on this compiler).  The
+    // length / distance part behind the group costs several literal steps and runs with the few lanes that stand at such a code.
+    const uint32_t group = lenmask + 1u;
+    // (every trip moves every live lane by a bit at least; the trip count is bounded all the same — a scalar counter — so that no table
+    // content whatsoever can hang the wave: what is left over then counts as bad data)
+    for (uint32_t trips = 0; __ballot(p < lim); trips++) {
+        if (trips > 8u * IP_SPAN) { if (p < lim) r.bad = 1; break; }
+        uint32_t bits = 0, e = 0;
+        bool held = false;
+        for (uint32_t g = 0; g < group; g++) {
+            bits = ip_peek(T.win, p);                                       // (a lane that is done stands at most a token behind its limit: inside the window)
+            e = T.ltab[bits & ((1u << IP_LROOT) - 1u)];
+            if (e >= 0xC000u) e = T.ltab[((e >> 4) & 1023u) + __builtin_amdgcn_ubfe(bits, IP_LROOT, e & 15u)];
+            const bool act = p < lim;
+            const bool lit = act && e < 0x4000u;
+            held = act && !(e < 0x4000u);
+            if (lit) {
+                if (WRITE) dst[o] = (uint8_t)(e >> 4);
+                lastb = WRITE ? e >> 4 : 0u;
+                p += e & 15u;
+                o += 1u;
             }
         }
-        const uint32_t len = L.base + acc.x + acc.y;
-        // len = 16: v lies behind the last code of an incomplete code.  The output pass reports it; a synchronisation pass
-        // just walks on (16 bits: T.ladj[16] is T.lsym[0], any value will do) — three instructions less per step
-        const bool badlen = WRITE && len > 15u;
-        const uint32_t lc = badlen ? 15u : len;
-        uint32_t idx = (uint32_t)((int)(short)T.ladj[lc] + (int)(v >> ((15u - lc) & 31u)));
-        idx = min(idx, 287u);                                   // (a walk from a wrong start may compute anything)
-        const uint32_t sym = badlen ? 0x3FFu : (uint32_t)T.lsym[idx];
-        const bool lit = sym < 256u;
-        uint32_t adv = len, nby = 1;
-        bool stop = false;
-        // The length / distance part below costs as much as the literal part above and runs with the few lanes that stand at such
-        // a code: it is entered only every IP_LENSTEP-th step (or when no lane has a literal to go on with); in between those
-        // lanes hold their position.  They lose a step or two per match, the wave saves the part in most steps.
-        const bool lenstep = (step & L.lenmask) == L.lenmask || !__ballot(act && lit);
-        step++;
-        if (act && !lit && !lenstep) { adv = 0; nby = 0; }
-        if (lenstep && __ballot(act && !lit)) {
-            if (act && !lit) {
-                nby = 0;
+        if (__ballot(held)) {
+            const uint32_t len = e & 15u;
+            uint32_t adv = len, nby = 0;
+            bool stop = false;
+            if (held) {
+                // an invalid code (behind the last code of an incomplete code) is a stop like a bad length symbol: sym 0x3FF
+                const uint32_t sym = e < 0x8000u ? 257u + ((e >> 4) & 31u) : (e & 0x10u) ? 0x3FFu : 256u;
                 if (sym == 256u) {
                     if (!r.eob) { r.eob = 1; r.eobpos = p + len; r.nout = o - obase; }
                     if (WRITE) stop = true;
@@ -235,7 +360,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, const IpLimits &L, uin
                     const uint32_t mlen = (ls == 28u ? 258u : ls < 8u ? 3u + ls : 3u + ((4u + (ls & 3u)) << le)) + (b2 & ((1u << le) - 1u));
                     adv += le;
                     b2 = ip_peek(T.win, p + adv);
-                    const uint32_t de = T.dlut[b2 & ((1u << IP_DBITS) - 1)];
+                    const uint32_t de = T.dlut[b2 & ((1u << SH::DBITS) - 1)];
                     uint32_t ds, dlen = de >> 5;
                     if (dlen) ds = de & 31u;
                     else {   // a distance code longer than the lookup table: canonical walk (rare)
@@ -287,11 +412,11 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, const IpLimits &L, uin
                         }
                     }
                 }
+                p += adv;
+                o += nby;
+                if (stop) lim = 0u;
             }
         }
-        if (act && lit) { if (WRITE) dst[o] = (uint8_t)sym; lastb = sym; }
-        if (act) { p += adv; o += nby; }
-        act = act && !stop && p < end;
     }
     r.cross = p;
     if (!r.eob) r.nout = o - obase;
@@ -348,13 +473,14 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             continue;
         }
         int nl, nd;
-        { const int rc = infl_block_tables<SH, 0, true, IP_DBITS>(T, src, total, total_bits, b, type, nl, nd IPP_PASS); if (rc != INF_OK) return rc; }
+        { const int rc = infl_block_tables<SH, 0, true, SH::DBITS>(T, src, total, total_bits, b, type, nl, nd IPP_PASS); if (rc != INF_OK) return rc; }
         pos = bi_consumed_bits(b);
         if (b.wbase != hdr_wb) win_fresh = false;                             // (the header parser slid its window: never, for a window that starts at the header)
         if (dbg && dbg[3] == 1) return INF_OK;       // tools/par_probe.py cut-off: block header and tables only
-        IpLimits L;
+        uint32_t lenmask;
         {   // canonical limits and index adjustments of the lit/len code (uniform).  The limits go through LDS (the code lengths'
             // bytes are dead by now) so that the pairs can start at the shortest length in use
+            IpLimits L;
             uint32_t first = 0, offs = 0;
             int minlen = 16, maxlen = 0;
             // how often the token loop enters its length / distance part: the code lengths tell how common such tokens are (the
@@ -364,7 +490,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                 const uint8_t *ll = type == 1 ? T.lens : T.lens + 32;
                 const uint32_t l = lane < 29 && 257 + lane < nl ? (uint32_t)ll[257 + lane] : 0u;
                 const uint32_t mass = wave_sum(l ? 1u << (15u - l) : 0u);     // of 32768
-                L.lenmask = mass >= 8192u ? 0u : mass >= 3072u ? 1u : IP_LENSTEP - 1u;
+                lenmask = mass >= 8192u ? 0u : mass >= 3072u ? 1u : IP_LENSTEP - 1u;
             }
             wave_sync();
             int16_t *lim = reinterpret_cast<int16_t *>(T.lens);               // lim[l], l = 1 .. 32
@@ -384,8 +510,10 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                 L.m1[k].y = (short)__builtin_amdgcn_readfirstlane((int)lim[minlen + 2 * k + 1]);
             }
             L.base = (uint32_t)minlen;
+            L.end = first >> 1;                                               // (first: twice the left-justified end of the 15-bit codes)
             L.np = (maxlen - minlen + 1) >> 1;                                // limits of minlen .. maxlen - 1
             wave_sync();
+            if (ip_build_ltab(T, L)) { if (dbg) dbg[2] = 5; return INF_NEED_FALLBACK; }
         }
         IPP(6)
         // ---- the block's tokens, a window at a time ----
@@ -420,7 +548,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             if (dbg) dbg[1]++;
             for (int pass = 0; pass < 67; pass++) {
                 if (dbg) dbg[0]++;
-                sg = ip_decode_segment<false>(T, L, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
+                sg = ip_decode_segment<false>(T, lenmask, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
                 uint32_t ns = wave_prev(sg.cross, 0u);
                 if (lane == 0) ns = rel0;
                 else if (lane >= nseg) ns = st;                              // (a lane without a segment has nothing to correct: left alone, or
@@ -462,7 +590,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             IpSeg wr;
             wr.nwait = 0; wr.bad = 0; wr.eob = 0; wr.eobpos = 0; wr.cross = st; wr.nout = 0;
             IPP(8)
-            if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, L, st, seg_end, obase, o, dst, wincl - w_act, w_act);
+            if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, lenmask, st, seg_end, obase, o, dst, wincl - w_act, w_act);
             IPP(9)
             if (__ballot(wr.bad != 0u)) return INF_ERR_DATA;
             if (__ballot(wr.nwait != w_act)) { if (dbg) dbg[2] = 4; return INF_NEED_FALLBACK; }   // (the two kinds of pass disagree: never seen)

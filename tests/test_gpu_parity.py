@@ -379,6 +379,38 @@ def test_decode_highly_compressible_records_retry_with_exact_slots(press, inflat
         assert g["status"] == 0 and np.array_equal(g["signal"], s)
 
 
+def test_staged_stored_blocks_behind_a_token_list_in_the_bit_buffer(press):
+    """Incompressible payloads with a few planted 4-byte runs through k_deflate_staged: the runs make general slabs whose token list (> 640
+    entries) continues inside the bit buffer, the random bytes make the block a STORED one — whose plain byte stores end inside the words the
+    list stood in.  The Adler-32 trailer (and a following block's carry) are ORed in behind them: those words have to be clean (round-5
+    advisor finding, deflate2_dev.h stored branch).  Every record must come out of stock zlib as the oracle's payload."""
+    rng = np.random.default_rng(606)
+    from slow5tools_amd import _lib
+    L = _lib.lib()
+    sigs, hdrs, auxs = [], [], []
+    for i, alen in enumerate(list(range(3000, 12500, 250)) + [15800, 16300, 16500, 20000, 33000]):
+        a = rng.integers(0, 256, alen, dtype=np.uint8)
+        for k in range(3 + i % 37):                         # planted runs, spread over the block: three or more general slabs
+            at = int(rng.integers(0, alen - 8))
+            a[at:at + 4 + k % 3] = a[at]
+        sigs.append(np.asarray([3, 4, 5, 4], dtype=np.int16))
+        hdrs.append(_hdr(press, 7000 + i))
+        auxs.append(a.tobytes())
+    _lib.check(L.s5gpu_set_option(b"fused_tier2", 0))            # one fused launch: whatever misses the named budget is staged
+    try:
+        b = press.DeviceBatch([4] * len(sigs), aux_len=[len(a) for a in auxs], lds_payload_cap=2048)
+        b.upload(sigs, hdrs, auxs)
+        b.encode()
+        recs = b.records()
+        assert int(b.ovf[0].item()) == len(sigs)                 # every read went through the staged kernel
+    finally:
+        _lib.check(L.s5gpu_set_option(b"fused_tier2", 0))
+    for i, rec in enumerate(recs):
+        payload, _ = _oracle_payload(hdrs[i], sigs[i], auxs[i], 1)
+        assert zlib.decompress(rec[8:]) == payload, "record %d (aux %d bytes)" % (i, len(auxs[i]))
+        assert len(rec) <= len(payload) + 8 + 2 + 4 + 5 * (len(payload) // 16384 + 1) + 64
+
+
 def test_very_long_read_roundtrip(press):
     """2 M samples (the reference's longest fixture read, p2solo_ulk114_dna, is 2 050 027): ~160 DEFLATE blocks
     through the staged kernels, in place in the slot"""

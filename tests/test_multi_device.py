@@ -198,16 +198,19 @@ def test_two_gloo_ranks_run_the_hip_path_on_their_shards(tmp_path):
 
 
 def test_bench_two_ranks_preflight_on_one_gpu(tmp_path):
-    """The driver's N > 1 run is `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: rehearse that very launch
+    """The driver's N > 1 run is `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (bench.py re-executes itself
+    under exactly that module when it is started bare): rehearse that launch
     with two ranks on this box's one GPU (S5BENCH_ALIAS_DEVICES=1 maps both ranks onto device 0 and swaps RCCL — which refuses two
     ranks on one device — for gloo; everything else is the production path: rendezvous, per-rank shards, barriers, MAX / SUM over
     ranks, the legs of every config).  One JSON line, n_gpus 2, both ranks seen by the all-reduce, parity true in every leg."""
     import json
 
-    port = str(29900 + os.getpid() % 1000)
     env = dict(os.environ, S5BENCH_ALIAS_DEVICES="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "20000", "--long-reads", "512", "--cpu-seconds", "0",
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    # round 6: PLAIN `python bench.py --gpus 2` — no launcher around it: bench.py makes its own ranks (torch.distributed.run, the driver's
+    # module) when WORLD_SIZE is unset, so `--gpus N` can never end as N copies' worth of one rank with `n_gpus: 1`
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "20000", "--long-reads", "512", "--cpu-seconds", "0",
            "--get-reads", "20000", "--min-leg-seconds", "0.2", "--min-leg-steps-svb", "4", "--min-leg-steps-long", "2", "--mixed-reads", "8192"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
