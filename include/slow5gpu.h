@@ -266,6 +266,21 @@ int s5gpu_recompress_batch_arena(uint32_t n, const void *const *rec, const size_
                                  int32_t *status, void **arena);
 void s5gpu_arena_release(void *arena);   /* NULL is fine */
 
+/* The two calls as SUBMIT / WAIT pairs (round 6): the reference's loop reads K records, works on them, writes them, and overlaps nothing
+ * (/root/reference/src/view.c:254-300; /root/reference/README.md:197 names the overlap as future work).  A submitted batch runs on a
+ * thread of the library's and takes one of its contexts (S5GPU_CONTEXTS, default 2): with two tickets in flight one batch's PCIe copies
+ * run under the other's kernels while the caller reads the next batch.  want_arena != 0: out[i] point into an arena that
+ * s5gpu_batch_wait hands over (release it with s5gpu_arena_release); 0: one malloc per record.  Every array named here belongs to the
+ * library until the ticket is waited for; every ticket is waited for exactly once.  NULL ticket: s5gpu_last_error() says why.
+ * s5gpu_batch_wait returns the batch call's own code, its message in the waiting thread's s5gpu_last_error(). */
+void *s5gpu_recompress_batch_submit(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                    int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                                    int32_t *status, int want_arena);
+void *s5gpu_encode_batch_submit(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                                const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                                int sig_method, void **out, size_t *out_len, int want_arena);
+int s5gpu_batch_wait(void *ticket, void **arena);
+
 /* The same worker on a CHUNK of a BLOW5 file (what bounds `view` end to end is the read and write phases around
  * work_db, /root/reference/src/view.c:265-278,296-299, not the compute).  The n records sit framed — [u64 size][bytes] — in one
  * host buffer `chunk` exactly as read from disk: rec_pos[i] = offset of record i's bytes (behind its size prefix), rec_len[i]

@@ -63,6 +63,17 @@ int slow5_gpu_hook_recompress_arena(int64_t n, char **mem, size_t *bytes, int fr
                                     void **out, size_t *out_len, void **batch);
 void slow5_gpu_hook_release(void *batch);
 
+/* ... and with the batch IN FLIGHT while the loop reads the next one (round 6): _submit returns a ticket at once (NULL: failure), the work
+ * runs on a thread of the library's; _wait(ticket, &batch) blocks until that batch is done and returns what the synchronous hook would
+ * have (0 / -1; *batch = the arena to release after the write loop).  mem[i] are freed and set NULL by the time _wait returns; mem, bytes,
+ * out, out_len (and new_read_group) must stay valid and untouched until then — use two sets of them and alternate.  Two tickets in
+ * flight keep both of the library's contexts busy: batch k + 1 uploads and decodes under batch k's encode and download.
+ * INTEGRATION.md section 2 shows the dozen lines /root/reference/src/view.c:254-300 needs. */
+void *slow5_gpu_hook_recompress_submit(int64_t n, char **mem, size_t *bytes, int from_record_method, int from_signal_method,
+                                       int to_record_method, int to_signal_method, const uint32_t *new_read_group, int drop_aux,
+                                       void **out, size_t *out_len);
+int slow5_gpu_hook_recompress_wait(void *ticket, void **batch);
+
 /* The same worker on a CHUNK of a BLOW5 file, for a loop that reads the file in large pieces instead of one record at a time
  * (examples/s5view.c; 17 GB/s of raw signal end to end against 2.9 with one fread + malloc per record): the n records sit framed
  * — [u64 size][bytes] — in `chunk` exactly as read from disk, rec_pos[i] / rec_len[i] = offset and length of record i's bytes

@@ -538,56 +538,6 @@ __device__ __forceinline__ void cl_header_wave(DeflShared &S, int hdist) {
     }
 }
 
-struct Tok { int sym; uint32_t eb, ev, mlen; };   // sym < 0: position covered by a match; mlen: bytes a match covers
-
-// Per-lane position masks: a lane owns K = ceil(len / 256) contiguous bytes; K <= 32 (blocks up to 8 KiB, the
-// case of a 4000-sample read) fits a 32-bit mask, which halves the cost of every mask operation on gfx950.
-template <typename M> struct MaskOps;
-template <> struct MaskOps<uint32_t> {
-    static constexpr int BITS = 32;
-    static __device__ __forceinline__ int msb(uint32_t m) { return 31 - __clz((int)m); }
-    static __device__ __forceinline__ int lsb(uint32_t m) { return __ffs((int)m) - 1; }
-};
-template <> struct MaskOps<uint64_t> {
-    static constexpr int BITS = 64;
-    static __device__ __forceinline__ int msb(uint64_t m) { return 63 - __clzll((long long)m); }
-    static __device__ __forceinline__ int lsb(uint64_t m) { return __ffsll((long long)m) - 1; }
-};
-
-// token at position base+j of the block for the lane that owns it
-template <typename M>
-__device__ __forceinline__ Tok token_at(const uint8_t *__restrict__ buf, int base, int j, M brk, int lastb, int nextb) {
-    using MO = MaskOps<M>;
-    const M lo = brk & (M)(((M)2 << j) - 1);
-    const int s = lo ? base + MO::msb(lo) : lastb;
-    const M hi = j < MO::BITS - 1 ? (M)(brk >> (j + 1)) : (M)0;
-    const int e = hi ? base + j + 1 + MO::lsb(hi) : nextb;
-    const int rel = base + j - s, body = e - s - 1;   // body = bytes of the run after its first one
-    Tok t;
-    t.sym = buf[base + j];
-    t.eb = 0;
-    t.ev = 0;
-    t.mlen = 0;
-    if (rel > 0 && body >= 3) {
-        const int m = rel - 1, c = m / 258, off = m - c * 258;
-        const int Lc = min(258, body - c * 258);
-        if (Lc >= 3) {
-            if (off != 0) { t.sym = -1; return t; }
-            const int l = Lc - 3;
-            t.mlen = (uint32_t)Lc;
-            if (Lc == 258) t.sym = 285;
-            else if (l < 8) t.sym = 257 + l;
-            else {
-                const int nb = 29 - __clz(l);
-                t.sym = 261 + 4 * nb + ((l >> nb) & 3);
-                t.eb = nb;
-                t.ev = l & ((1 << nb) - 1);
-            }
-        }
-    }
-    return t;
-}
-
 // Copy completed words obuf -> HBM slot and slide the partial word to obuf[0].
 // final_all: copy everything including the last partial word, no slide.
 template <int TN = NT>   // threads of the calling workgroup
@@ -620,532 +570,8 @@ __device__ __forceinline__ void flush_words(uint32_t *obuf, uint32_t *out32, ZOu
     z.flushed = full;
 }
 
-// Encode one DEFLATE block of `len` bytes at LDS `buf` into the LDS bit buffer `obuf`.
-// All NT lanes call with uniform arguments.  adA/adB: running Adler-32 halves (uniform).
-// MODE 0: B is separate LDS.  MODE 1 (fused): single-block stream whose build scratch B overlays obuf; obuf is zeroed and the
-// zlib header written here once B is dead (caller passes z.bitpos = 80, z.flushed = 0, obuf_words = size to zero).
-// MODE 2 (staged, multi-block): B overlays obuf as well; between blocks the only live word of obuf is the partial word
-// obuf[0], which travels in z.carry and is put back after the zeroing.
-// TN: threads of the calling workgroup (round 4).  The staged kernel is held to four workgroups per CU by its LDS (a 16 KiB block + its bit buffer), and
-// at 256 threads that is half the waves the fused kernel needs to cover its LDS latency: it runs 512 threads per workgroup — a lane owns 32 bytes of a
-// block, 32-bit position masks, byte loads, exactly the shape of the fused kernel on a payload of 8 KiB.
-template <int MODE, typename M = uint64_t, int TN = NT>
-__device__ __forceinline__ void deflate_block(DeflShared &S, BuildScratch &B, uint32_t *obuf, uint32_t obuf_words,
-                                              const uint8_t *__restrict__ buf, int len, bool final, ZOut &z, uint32_t &adA,
-                                              uint32_t &adB, uint32_t dbg = 0, EarlySize es = EarlySize{nullptr, 0}) {
-    using MO = MaskOps<M>;
-    const int tid = threadIdx.x;
-    constexpr bool FUSED = MODE == 1;
-    constexpr int NWV = TN / 64;
-    static_assert(TN % 64 == 0 && NWV >= 4 && NWV <= 8, "S.ws holds two words per wave");
-    static_assert(TN == NT || MODE == 2, "more than 256 threads: the staged form (its per-lane scratch lies in the bit buffer, which is dead then)");
-    if (len == 0) {
-        if (MODE != 0) {
-            for (uint32_t i = tid; i < obuf_words; i += TN) obuf[i] = 0;
-            __syncthreads();
-            if (tid == 0) { if (FUSED) put_bits(obuf, z, 64, 0x9c78u, 16); else obuf[0] = z.carry; }
-        }   // empty stream: fixed block holding only end-of-block
-        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 10);
-        z.bitpos += 10;
-        publish_size(es, z.bitpos);
-        __syncthreads();
-        return;
-    }
-    // A lane owns K contiguous bytes.  Big blocks (64-bit masks: the HBM-staged path and fused payloads over 8 KiB) run at low
-    // occupancy and are LDS-latency bound: there K is a multiple of 4 and every group of four positions is ONE aligned LDS
-    // dword (buf is 4-byte aligned) — measured +28 % on 100 k-sample reads.  Small blocks (32-bit masks, 8 workgroups per CU)
-    // are VALU bound: byte loads arrive zero-extended and save the extraction instructions — measured 3 % faster than dwords.
-    constexpr bool DW = sizeof(M) == 8;
-    const int K = DW ? (((len + TN - 1) / TN + 3) & ~3) : (len + TN - 1) / TN;
-    const int base = tid * K;
-    auto load4 = [&](int j, int &b0, int &b1, int &b2, int &b3) -> uint32_t {
-        if constexpr (DW) {
-            const uint32_t w = *reinterpret_cast<const uint32_t *>(buf + base + j);
-            b0 = w & 255u; b1 = (w >> 8) & 255u; b2 = (w >> 16) & 255u; b3 = w >> 24;
-            return w;
-        } else {
-            b0 = buf[base + j]; b1 = buf[base + j + 1]; b2 = buf[base + j + 2]; b3 = buf[base + j + 3];
-            return 0u;
-        }
-    };
-    const int kk = max(0, min(K, len - base));
-
-    for (int i = tid; i < 320; i += TN) S.freq[i] = 0;
-    if (tid < 8) S.red[tid] = 0;
-    if (tid < 20) S.clfreq[tid] = 0;
-
-    // ---- A: break mask, Adler partials; a run start is always a literal token: count it right here.  (Counting every byte
-    // and taking matched bytes out again would make the loop branch-free, but the zero runs of the svb key area then put
-    // 64 same-address LDS atomics into one instruction: measured 3.5x slower.) ----
-    M brk = 0;
-    uint32_t a_sum = 0, b_sum = 0;
-    {
-        int prev = -1;
-        if (base > 0 && kk > 0) prev = buf[base - 1];
-        // the histogram must be zero before the first atomic: the zeroing above is ordered by this barrier
-        __syncthreads();
-        // four byte loads in flight per step (the compiler will not hoist LDS loads over the LDS atomics itself)
-        int j = 0;
-        for (; j + 4 <= kk; j += 4) {
-            int b0, b1, b2, b3;
-            const uint32_t w = load4(j, b0, b1, b2, b3);
-            if (b0 != prev) { brk |= (M)1 << j; atomicAdd(&S.freq[b0], 1u); }
-            if (b1 != b0) { brk |= (M)2 << j; atomicAdd(&S.freq[b1], 1u); }
-            if (b2 != b1) { brk |= (M)4 << j; atomicAdd(&S.freq[b2], 1u); }
-            if (b3 != b2) { brk |= (M)8 << j; atomicAdd(&S.freq[b3], 1u); }
-            prev = b3;
-            if constexpr (DW) {
-                // Adler halves of four bytes with two dot products: A += b0+b1+b2+b3, B += 4 A_old + 4 b0 + 3 b1 + 2 b2 + b3
-                b_sum = __builtin_amdgcn_udot4(w, 0x01020304u, b_sum + 4u * a_sum, false);
-                a_sum = __builtin_amdgcn_udot4(w, 0x01010101u, a_sum, false);
-            } else {
-                a_sum += b0; b_sum += a_sum;   // B as a running sum of A: two adds per byte, no multiply
-                a_sum += b1; b_sum += a_sum;
-                a_sum += b2; b_sum += a_sum;
-                a_sum += b3; b_sum += a_sum;
-            }
-        }
-        for (; j < kk; j++) {
-            const int b = buf[base + j];
-            if (b != prev) { brk |= (M)1 << j; atomicAdd(&S.freq[b], 1u); }
-            prev = b;
-            a_sum += b;
-            b_sum += a_sum;
-        }
-        // b_sum = sum (kk - j) x_j so far; the bytes of later lanes each add this lane's byte sum once more
-        b_sum += a_sum * (uint32_t)max(0, len - (base + kk));
-    }
-    if (dbg == 21) { z.bitpos += (uint32_t)brk + a_sum + b_sum; return; }   // tools/stage_time.py cut-offs inside the tokeniser
-    const int local_last = brk ? base + MO::msb(brk) : -1;
-    const int local_first = brk ? base + MO::lsb(brk) : len;
-    // lastb = last break before my chunk, nextb = first break after it.  Which lanes own a break at all is a 256-bit map
-    // (one ballot per wave); inside the wave the neighbour lane comes from the ballot in registers, across waves the
-    // answer is wave-uniform.  One barrier; S.code (not yet in use) carries every lane's first | last << 16.
-    int lastb, nextb;
-    {
-        const bool has = brk != 0;
-        const uint64_t bal = __ballot(has);
-        if (lane_id() == 0) { S.ws[2 * wave_id()] = (uint32_t)bal; S.ws[2 * wave_id() + 1] = (uint32_t)(bal >> 32); }
-        uint32_t *fl = TN > 320 ? obuf : S.code;   // one word per lane: S.code (not yet in use) has 320, the bit buffer (not yet in use either) has more
-        if (has) fl[tid] = (uint32_t)local_first | ((uint32_t)local_last << 16);
-        __syncthreads();
-        int up_lane = -1, dn_lane = -1;            // wave-uniform (kept in SGPRs): nearest break-owning lane in a later / earlier wave
-        const int wv = __builtin_amdgcn_readfirstlane(wave_id());
-#pragma unroll
-        for (int w = NWV - 1; w >= 0; w--) {
-            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w]);
-            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w + 1]);
-            const uint64_t mw = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
-            if (w > wv && mw) up_lane = w * 64 + __ffsll((long long)mw) - 1;
-        }
-#pragma unroll
-        for (int w = 0; w < NWV; w++) {
-            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w]);
-            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ws[2 * w + 1]);
-            const uint64_t mw = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
-            if (w < wv && mw) dn_lane = w * 64 + 63 - __clzll((long long)mw);
-        }
-        const int lane = lane_id();
-        const uint64_t above = lane < 63 ? bal & ~((2ull << lane) - 1) : 0ull;
-        const uint64_t below = bal & ((1ull << lane) - 1);
-        const int up = above ? wave_id() * 64 + __ffsll((long long)above) - 1 : up_lane;
-        const int dn = below ? wave_id() * 64 + 63 - __clzll((long long)below) : dn_lane;
-        nextb = up >= 0 ? (int)(fl[up] & 0xFFFFu) : len;
-        lastb = dn >= 0 ? (int)(fl[dn] >> 16) : -1;
-    }   // S.ws / S.code are next written behind later barriers
-    if (dbg == 22) { z.bitpos += (uint32_t)brk + a_sum + b_sum + lastb + nextb; return; }
-
-    // Positions inside a run (no break bit) are the only ones that need the run analysis.  Most of them belong to runs of
-    // two or three equal bytes, which can never hold a match (a match needs a run of >= 4: one literal + 3 covered
-    // bytes): those positions are plain literals and are classified with mask arithmetic alone.  Only segments of
-    // >= 3 in-run positions, and segments that touch the lane's chunk boundary (their run continues in a neighbour
-    // lane), go through the per-segment analysis; there at most three positions can emit a token: the first position
-    // of each 258-byte chunk of the run body and the run's last two bytes (a chunk shorter than 3 is sent as
-    // literals) — a lane that lies entirely inside a long run (the svb key area is mostly zeros) does O(1) work.
-    // tok = positions that emit a token, mat = those that are matches; mc = the lane's first two matches, cached for
-    // the bit-count and pack passes (j | sym-257 << 6 | eb << 11 | ev << 14).
-    M tok = brk, mat = 0;
-    uint32_t nmatch = 0, nextra = 0;
-    uint32_t mc0 = 0xFFFFFFFFu, mc1 = 0xFFFFFFFFu;
-    {
-        const M valid = kk >= MO::BITS ? (M)~(M)0 : (M)(((M)1 << kk) - 1);
-        const M I = (M)~brk & valid;
-        const M L3 = I & (I >> 1) & (I >> 2);
-        const M longseg = L3 | (M)(L3 << 1) | (M)(L3 << 2);            // every position of a segment of >= 3
-        const M lowrun = I & (M)~(M)(I + 1);                            // segment that starts at my first byte
-        const M zer = (M)~I & valid;
-        const M highrun = zer ? (M)(I & (M)~(M)((((M)2 << MO::msb(zer)) - 1))) : I;   // segment that ends at my last byte
-        M slow = I & (longseg | lowrun | highrun);
-        M lits = I & (M)~slow;                                          // short interior segments: literals
-        // the two boundary segments continue in a neighbour lane; their run length follows from lastb / nextb without a
-        // loop, and nearly all of them are runs of < 4 bytes, i.e. literals too
-        if (lowrun) {
-            const M nz = (M)~I;                                         // first position after the segment
-            const int e = (nz & valid) ? base + MO::lsb(nz) : nextb;    // the run ends inside my chunk, or runs on
-            if (e - lastb - 1 < 3) { lits |= lowrun; slow &= (M)~lowrun; }
-        }
-        if (highrun && highrun != lowrun) {
-            const int s0 = base + MO::msb(zer);                         // zer != 0 here: the break in front of the segment
-            if (nextb - s0 - 1 < 3) { lits |= highrun; slow &= (M)~highrun; }
-        }
-        while (slow) {
-            const int j0 = MO::lsb(slow);
-            const M rest = (M)~(M)(slow >> j0);                         // first zero = end of this segment
-            const int seg = rest ? MO::lsb(rest) : MO::BITS - j0;
-            const int j1 = j0 + seg;                                    // segment = chunk positions [j0, j1)
-            const M segmask = seg >= MO::BITS ? (M)~(M)0 : (M)((((M)1 << seg) - 1) << j0);
-            slow &= (M)~segmask;
-            // run bounds of this segment (same for all its positions)
-            const M lo = brk & (M)(((M)1 << j0) - 1);
-            const int s = lo ? base + MO::msb(lo) : lastb;
-            const M hi = j1 < MO::BITS ? (M)(brk >> j1) : (M)0;
-            const int e = hi ? base + j1 + MO::lsb(hi) : nextb;
-            if (e - s - 1 < 3) { lits |= segmask; continue; }           // run of < 4 bytes: all literals
-            // A run of body = e-s-1 >= 3 bytes after its first one is sent as matches of up to 258 bytes (chunks starting at
-            // s+1+258c); a last chunk of 1 or 2 bytes is sent as literals.  My segment (< 258 positions) can hold at most one
-            // chunk start, and at most the run's last two positions as literals.
-            const int body = e - s - 1;
-            const int p0 = base + j0, p1 = base + j1;
-            const int c0 = ((p0 - s - 1 + 257) * 16257) >> 22;          // ceil((p0-s-1) / 258); x / 258 == x * 16257 >> 22 for x < 70000
-            const int pstart = s + 1 + 258 * c0;
-            if (pstart < p1) {
-                const int Lc = min(258, body - 258 * c0);
-                if (Lc >= 3) {
-                    const int j = pstart - base, l = Lc - 3;
-                    uint32_t sym, eb = 0, ev = 0;
-                    if (Lc == 258) sym = 285;
-                    else if (l < 8) sym = 257 + l;
-                    else {
-                        const int nb = 29 - __clz(l);
-                        sym = 261 + 4 * nb + ((l >> nb) & 3);
-                        eb = nb;
-                        ev = l & ((1 << nb) - 1);
-                    }
-                    tok |= (M)1 << j;
-                    mat |= (M)1 << j;
-                    atomicAdd(&S.freq[sym], 1u);
-                    nmatch++;
-                    nextra += eb;
-                    const uint32_t pk = (uint32_t)j | ((sym - 257) << 6) | (eb << 11) | (ev << 14);
-                    if (mc0 == 0xFFFFFFFFu) mc0 = pk; else if (mc1 == 0xFFFFFFFFu) mc1 = pk;
-                }
-            }
-            const int rem = body - 258 * ((body * 16257) >> 22);
-            if (rem == 1 || rem == 2) {                                  // the run's last rem bytes are literals
-                const int pa = e - 1, pb = e - 2;
-                if (pa >= p0 && pa < p1) lits |= (M)1 << (pa - base);
-                if (rem == 2 && pb >= p0 && pb < p1) lits |= (M)1 << (pb - base);
-            }
-        }
-        tok |= lits;
-        while (lits) {                                                  // literal tokens inside short runs
-            const int j = MO::lsb(lits);
-            lits &= lits - 1;
-            atomicAdd(&S.freq[buf[base + j]], 1u);
-        }
-    }
-    if (dbg == 23) { z.bitpos += (uint32_t)tok + (uint32_t)mat + a_sum + b_sum + nmatch + nextra + mc0 + mc1; return; }
-    // (uniform per wave) every position of every lane of this wave is a literal token — the waves that lie in the data area of an svb-zd
-    // payload, nearly always (a run of >= 4 equal data bytes is rare): the bit-count and pack passes then run their full groups of four
-    // positions without token masks (round 4: 7690 -> 7450 VALU instructions per 4000-sample read, 13.68 -> 13.43 ms per 1 M reads)
-    const bool alllit = __ballot(mat != 0 || tok != (kk >= MO::BITS ? (M)~(M)0 : (M)(((M)1 << kk) - 1))) == 0;
-    if (!alllit) {   // (no matches, no extra bits otherwise)
-        nmatch = wave_sum(nmatch);
-        nextra = wave_sum(nextra);
-    }
-    a_sum = wave_sum(a_sum);
-    b_sum = wave_sum(b_sum % 65521u);
-    if (lane_id() == 0) {
-        atomicAdd(&S.red[0], nmatch);
-        atomicAdd(&S.red[1], nextra);
-        atomicAdd(&S.red[2], a_sum);
-        atomicAdd(&S.red[3], b_sum);
-    }
-    if (tid == 0) atomicAdd(&S.freq[256], 1u);
-    __syncthreads();
-    if (dbg == 2) { z.bitpos += S.freq[tid] + S.red[0]; return; }   // tools/stage_time.py cut-off
-
-    // ---- B: codes ----
-#ifdef S5_DEFL_EXACT_HUFFMAN   // the round-based optimal construction (kept for size / speed comparisons: tools/variant.sh)
-    if (tid == 0) S.dbg = dbg;   // ordered before its first use by the barriers inside build_lengths
-    build_lengths(S, B, &B.sort, S.freq, NLIT, 15, S.lens, S.blcount, S.icount);
-    if (dbg == 3 || dbg == 31 || dbg == 32) { z.bitpos += S.lens[tid] + B.lf[tid] + B.nf[tid]; return; }
-    if (MODE != 0) {   // B is dead from here on: its storage becomes the bit buffer
-        for (uint32_t i = tid; i < obuf_words; i += TN) obuf[i] = 0;
-        __syncthreads();
-    }
-#else
-    // wave 0 assigns the code lengths (no tree, no scratch: assign_lengths_wave); the other three waves clear the bit buffer
-    if (wave_id() == 0) {
-        const bool ok = assign_lengths_wave(S.freq, NLIT, S.lens, S.blcount, S.bins);
-        if (lane_id() == 0) S.dbg = ok ? 0u : 1u;
-    } else if (MODE != 0) {
-        for (uint32_t i = tid - 64; i < obuf_words; i += TN - 64) obuf[i] = 0;
-    }
-    __syncthreads();
-    if (dbg == 3) { z.bitpos += S.lens[tid]; return; }
-#endif
-    if (MODE != 0) {
-        if (tid == 0) {
-            if (FUSED) put_bits(obuf, z, 64, 0x9c78u, 16);   // CMF/FLG 78 9c (deflate, 32K window, default level)
-            else obuf[0] = z.carry;                          // the stream's pending partial word
-        }
-    }
-    // ---- codes, code-length header and block costs: three independent jobs on different waves, wave-scope
-    // syncs only, ONE workgroup barrier at the end.  Wave 0: run-length coding of the code lengths, the 19-symbol
-    // code-length Huffman code and the header cost.  Wave 1: canonical lit/len codes.  Waves 2-3: dynamic /
-    // fixed body costs.
-    if (wave_id() == 0) {
-        // two 1-bit distance codes (complete code; only code 0 = distance 1 is ever sent)
-        if (lane_id() == 0) {
-            S.lens[DOFF] = 1; S.lens[DOFF + 1] = 1;
-            S.code[DOFF] = 0u | (1u << 16); S.code[DOFF + 1] = 1u | (1u << 16);
-        }
-        cl_header_wave(S, 2);
-    } else if (wave_id() == 1) {
-        assign_codes_wave(S.blcount, S.lens, NLIT, S.code);   // canonical lit/len codes, concurrently with wave 0
-    } else {
-        uint32_t dynb = 0, fixb = 0;
-        for (int s = tid - 128; s < NLIT; s += TN - 128) {
-            const uint32_t f = S.freq[s];
-            dynb += f * S.lens[s];
-            fixb += f * fixed_len(s);
-        }
-        dynb = wave_sum(dynb);
-        fixb = wave_sum(fixb);
-        if (lane_id() == 0) { atomicAdd(&S.red[4], dynb); atomicAdd(&S.red[5], fixb); }
-    }
-    __syncthreads();
-    if (dbg == 4 || dbg == 41) { z.bitpos += S.red[4] + S.red[6] + S.code[tid]; return; }
-    const uint32_t matches = S.red[0], extra = S.red[1];
-    const uint32_t hdr_dyn = 17 + 3 * S.hclen + S.red[6];
-    const uint32_t dyn_total = hdr_dyn + S.red[4] + extra + matches * 1;
-    const uint32_t fix_total = 3 + S.red[5] + extra + matches * 5;
-    const uint32_t sto_total = 3 + ((0u - (z.bitpos + 3)) & 7) + 32 + 8u * (uint32_t)len;
-    // Adler-32 running update (RFC 1950): B' = B + len*A + sum (len - i) x_i
-    {
-        const uint32_t nb = (uint32_t)(((uint64_t)adB + (uint64_t)len * adA + S.red[3]) % 65521u);
-        adA = (adA + S.red[2]) % 65521u;
-        adB = nb;
-    }
-
-    if (sto_total <= dyn_total && sto_total <= fix_total) {
-        // ---- stored block ----
-        const uint32_t bytepos = (z.bitpos + 3 + 7) >> 3;
-        publish_size(es, (bytepos + 4 + (uint32_t)len) * 8);
-        uint8_t *ob8 = reinterpret_cast<uint8_t *>(obuf) + (bytepos - z.flushed * 4);
-        if (tid == 0) {
-            put_bits(obuf, z, z.bitpos, final ? 1u : 0u, 3);
-            put_bits(obuf, z, bytepos * 8, (uint32_t)len | ((~(uint32_t)len) << 16), 32);
-        }
-        __syncthreads();
-        for (int i = tid; i < len; i += TN) ob8[4 + i] = buf[i];
-        z.bitpos = (bytepos + 4 + (uint32_t)len) * 8;
-        __syncthreads();
-        return;
-    }
-
-#ifdef S5_DEFL_EXACT_HUFFMAN
-    const bool use_fixed = fix_total < dyn_total;
-#else
-    const bool use_fixed = fix_total < dyn_total || S.dbg != 0;   // S.dbg: the length assignment gave up (never seen)
-#endif
-    uint32_t pos0;   // bit position of the first token
-    uint32_t dist_bits, dist_code = 0;
-    uint32_t clv[2] = {0, 0}, clnb[2] = {0, 0};   // this lane's two code-length-sequence entries (dynamic only)
-    if (use_fixed) {
-        for (int s = tid; s < 288; s += TN) S.code[s] = fixed_code(s);
-        for (int s = tid; s < 288; s += TN) S.lens[s] = (uint8_t)fixed_len(s);   // (the bit count reads the lengths as bytes)
-        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (1u << 1), 3);
-        pos0 = z.bitpos + 3;
-        dist_bits = 5;
-        __syncthreads();
-    } else {
-        // block header: BFINAL, BTYPE=10, HLIT, HDIST (2 codes), HCLEN in one 17-bit field; the HCLEN 3-bit
-        // code-length-code lengths one per lane
-        const uint32_t hclen = S.hclen;
-        if (tid == 0) put_bits(obuf, z, z.bitpos, (final ? 1u : 0u) | (2u << 1) | ((S.hlit - 257) << 3) | (1u << 8) | ((hclen - 4) << 13), 17);
-        if (tid < (int)hclen) {
-            const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-            put_bits(obuf, z, z.bitpos + 17 + 3 * tid, S.cllens[order[tid]], 3);
-        }
-        // code-length sequence: lane t owns entries 2t, 2t+1
-        const int ncl = S.ncl;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int e = 2 * tid + q;
-            if (e < ncl) {
-                const uint32_t ent = S.clseq[e];
-                const uint32_t sym = ent & 31, cc = S.clcode[sym], cl = cc >> 16;
-                const uint32_t eb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
-                clv[q] = (cc & 0xFFFF) | ((ent >> 5) << cl);
-                clnb[q] = cl + eb;
-            }
-        }
-        pos0 = z.bitpos + hdr_dyn;
-        dist_bits = 1;
-    }
-    // ---- per-lane bit totals (code-length entries and tokens share ONE prefix scan: the two sums are packed
-    // into one word, 13 bits for the <= 320 * 14 header bits, 19 for the <= 16384 * 15 token bits) ----
-    // (sym, extra bits, extra value) of the match token at chunk position j: from the lane's cache, else recomputed
-    auto match_tok = [&](int j, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
-        uint32_t pk = 0xFFFFFFFFu;
-        if (mc0 != 0xFFFFFFFFu && (mc0 & 63u) == (uint32_t)j) pk = mc0;
-        else if (mc1 != 0xFFFFFFFFu && (mc1 & 63u) == (uint32_t)j) pk = mc1;
-        if (pk != 0xFFFFFFFFu) { sym = 257 + ((pk >> 6) & 31u); eb = (pk >> 11) & 7u; ev = pk >> 14; }
-        else { const Tok tk = token_at(buf, base, j, brk, lastb, nextb); sym = (uint32_t)tk.sym; eb = tk.eb; ev = tk.ev; }
-    };
-    uint32_t mybits = 0;
-    {
-        // literal tokens: branch-free over groups of four positions (4 byte loads, then 4 code loads, in flight together)
-        M lt = tok & (M)~mat;
-        int j = 0;
-        if (alllit) {
-            for (; j + 4 <= kk; j += 4) {
-                int b0, b1, b2, b3;
-                load4(j, b0, b1, b2, b3);
-                mybits += (uint32_t)S.lens[b0] + (uint32_t)S.lens[b1] + (uint32_t)S.lens[b2] + (uint32_t)S.lens[b3];
-            }
-            lt = j >= MO::BITS ? (M)0 : (M)(lt >> j);
-        }
-        // the last group may reach up to three bytes past the lane's chunk: those positions carry no token bit and the
-        // bytes read there are in-bounds LDS (neighbour chunk / slack), so no separate tail loop is needed
-        for (; j < kk; j += 4, lt >>= 4) {
-            int b0, b1, b2, b3;
-            load4(j, b0, b1, b2, b3);
-            const uint32_t c0 = S.lens[b0], c1 = S.lens[b1], c2 = S.lens[b2], c3 = S.lens[b3];   // (bytes: no shift; the same lengths as S.code[] >> 16)
-            const uint32_t lit = (uint32_t)lt & 15u;
-            mybits += (lit & 1 ? c0 : 0) + (lit & 2 ? c1 : 0) + (lit & 4 ? c2 : 0) + (lit & 8 ? c3 : 0);
-        }
-        // match tokens: the cached ones directly, any further ones (a lane with more than two matches) by recomputation
-        M rest = mat;
-        if (mc0 != 0xFFFFFFFFu) { mybits += (S.code[257 + ((mc0 >> 6) & 31u)] >> 16) + ((mc0 >> 11) & 7u) + dist_bits; rest &= (M)~((M)1 << (mc0 & 63u)); }
-        if (mc1 != 0xFFFFFFFFu) { mybits += (S.code[257 + ((mc1 >> 6) & 31u)] >> 16) + ((mc1 >> 11) & 7u) + dist_bits; rest &= (M)~((M)1 << (mc1 & 63u)); }
-        while (rest) {
-            const int jm = MO::lsb(rest);
-            rest &= rest - 1;
-            const Tok tk = token_at(buf, base, jm, brk, lastb, nextb);
-            mybits += (S.code[tk.sym] >> 16) + tk.eb + dist_bits;
-        }
-    }
-    uint32_t packed_total;
-    const uint32_t packed = block_excl_add_w<NWV>((clnb[0] + clnb[1]) | (mybits << 13), S.ws, packed_total);
-    const uint32_t total_bits = packed_total >> 13;
-    const uint32_t start = pos0 + (packed >> 13);
-    publish_size(es, pos0 + total_bits + (S.code[256] >> 16));
-    if (!use_fixed) {
-        const uint32_t p = z.bitpos + 17 + 3 * S.hclen + (packed & 0x1FFF);
-        if (clnb[0]) put_bits(obuf, z, p, clv[0], clnb[0]);
-        if (clnb[1]) put_bits(obuf, z, p + clnb[0], clv[1], clnb[1]);
-    }
-    if (dbg == 5) { z.bitpos += start; return; }
-    {
-        // The lane's tokens go straight into the LDS bit buffer, four byte positions at a time: positions without a token
-        // contribute zero bits, the (<= 15-bit) literal codes of a group are merged into one <= 60-bit value and ORed in
-        // at its bit position — three word ORs, no accumulator, no flush test, no per-token branch.  Match tokens (rare
-        // outside the key area) take the same route one at a time.
-        uint32_t pos = start;
-        auto or_bits = [&](uint64_t v, uint32_t nb) {          // nb <= 60
-            const uint32_t w = (pos >> 5) - z.flushed, sh = pos & 31;
-            const uint64_t lo = v << sh;
-            atomicOr(&obuf[w], (uint32_t)lo);
-            atomicOr(&obuf[w + 1], (uint32_t)(lo >> 32));
-            if (sh + nb > 64) atomicOr(&obuf[w + 2], (uint32_t)(v >> (64 - sh)));   // rare: four long codes in one group
-            pos += nb;
-        };
-        auto match_bits = [&](int j, uint32_t &nb) -> uint32_t {   // code | extra | distance code, <= 15 + 5 + 5 bits
-            uint32_t sym, eb, ev;
-            match_tok(j, sym, eb, ev);
-            const uint32_t cc = S.code[sym];
-            nb = cc >> 16;
-            uint32_t v = (cc & 0xFFFF) | (ev << nb);
-            nb += eb;
-            v |= dist_code << nb;
-            nb += dist_bits;
-            return v;
-        };
-        // Lanes with only a few tokens, or with a match among not too many (the key area: long zero runs broken by the
-        // occasional non-zero key byte), walk their token bits one by one — literal and match take the same
-        // branch-free route (one code lookup, extra bits and distance code are zero-width for a literal).  Lanes full of
-        // literals (the data area) take the grouped path.  A wave that holds only one kind runs only that loop.
-        const int ntok = __popcll((unsigned long long)tok);
-        if (ntok <= 6 || (mat != 0 && ntok <= 16)) {
-            M t = tok;
-            while (t) {
-                const int j = MO::lsb(t);
-                t &= t - 1;
-                const bool ism = (mat >> j) & 1;
-                uint32_t sym = buf[base + j], eb = 0, ev = 0;
-                if (ism) {
-                    if (mc0 != 0xFFFFFFFFu && (mc0 & 63u) == (uint32_t)j) { sym = 257 + ((mc0 >> 6) & 31u); eb = (mc0 >> 11) & 7u; ev = mc0 >> 14; }
-                    else if (mc1 != 0xFFFFFFFFu && (mc1 & 63u) == (uint32_t)j) { sym = 257 + ((mc1 >> 6) & 31u); eb = (mc1 >> 11) & 7u; ev = mc1 >> 14; }
-                    else { const Tok tk = token_at(buf, base, j, brk, lastb, nextb); sym = (uint32_t)tk.sym; eb = tk.eb; ev = tk.ev; }
-                }
-                const uint32_t cc = S.code[sym];
-                uint32_t nb = cc >> 16;
-                uint32_t v = (cc & 0xFFFF) | (ev << nb);
-                nb += eb;
-                v |= (ism ? dist_code : 0u) << nb;
-                nb += ism ? dist_bits : 0u;
-                or_bits((uint64_t)v, nb);
-            }
-        } else {
-            M t = tok, mm = mat;
-            int j = 0;
-            if (alllit) {
-                for (; j + 4 <= kk; j += 4) {
-                    int b0, b1, b2, b3;
-                    load4(j, b0, b1, b2, b3);
-                    const uint32_t c0 = S.code[b0], c1 = S.code[b1], c2 = S.code[b2], c3 = S.code[b3];
-                    const uint32_t n0 = c0 >> 16, n1 = c1 >> 16, n2 = c2 >> 16, n3 = c3 >> 16;
-                    const uint32_t lo = (c0 & 0xFFFFu) | ((c1 & 0xFFFFu) << n0), nlo = n0 + n1;
-                    const uint32_t hi = (c2 & 0xFFFFu) | ((c3 & 0xFFFFu) << n2), nhi = n2 + n3;
-                    or_bits((uint64_t)lo | ((uint64_t)hi << nlo), nlo + nhi);
-                }
-                t = j >= MO::BITS ? (M)0 : (M)(t >> j);      // (mm is zero)
-            }
-            for (; j < kk; j += 4, t >>= 4, mm >>= 4) {   // the last group may overhang the chunk: no token bits there
-                int b0, b1, b2, b3;
-                load4(j, b0, b1, b2, b3);
-                const uint32_t cc[4] = {S.code[b0], S.code[b1], S.code[b2], S.code[b3]};
-                const uint32_t tt = (uint32_t)t & ~(uint32_t)mm;   // literal tokens of the group
-                uint32_t n[4], v[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    n[q] = (tt >> q) & 1u ? cc[q] >> 16 : 0u;
-                    v[q] = (tt >> q) & 1u ? cc[q] & 0xFFFFu : 0u;
-                }
-                if ((uint32_t)mm & 15u) {                          // a match in the group: patch its slot(s) in
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (((uint32_t)mm >> q) & 1u) {
-                            // tokens leave in position order: first the literals still pending in front of the match ...
-                            if (q == 1) { or_bits((uint64_t)v[0], n[0]); }
-                            else if (q == 2) { or_bits((uint64_t)(v[0] | (v[1] << n[0])), n[0] + n[1]); }
-                            else if (q == 3) { or_bits((uint64_t)(v[0] | (v[1] << n[0])) | ((uint64_t)v[2] << (n[0] + n[1])), n[0] + n[1] + n[2]); }
-#pragma unroll
-                            for (int e = 0; e < q; e++) { v[e] = 0; n[e] = 0; }
-                            // ... then the match itself (up to 25 bits)
-                            uint32_t nb;
-                            const uint32_t mv = match_bits(j + q, nb);
-                            or_bits((uint64_t)mv, nb);
-                        }
-                }
-                const uint32_t lo = v[0] | (v[1] << n[0]), nlo = n[0] + n[1];
-                const uint32_t hi = v[2] | (v[3] << n[2]), nhi = n[2] + n[3];
-                or_bits((uint64_t)lo | ((uint64_t)hi << nlo), nlo + nhi);
-            }
-        }
-        if (dbg == 6) { z.bitpos += pos; return; }
-    }
-    const uint32_t eob = S.code[256];
-    if (tid == 0) put_bits(obuf, z, pos0 + total_bits, eob & 0xFFFF, eob >> 16);
-    z.bitpos = pos0 + total_bits + (eob >> 16);
-    __syncthreads();
-}
-
 }  // namespace s5
-#include "deflate2_dev.h"   // round 5: the slab form of the block encoder (deflate_block2), the default; -DS5_DEFL_V1 keeps deflate_block above
+#include "deflate2_dev.h"   // the slab form of the block encoder (deflate_block2; round 5 — the position-per-lane encoder of rounds 1-4 is in the history, docs/history.md)
 namespace s5 {
 
 // Fused path: zlib-frame a payload of at most DEFL_BLK bytes that sits in LDS (`pay`) as ONE DEFLATE block.
@@ -1159,21 +585,15 @@ __device__ __forceinline__ uint32_t zlib_frame_fused(DeflShared &S, uint32_t *ob
     z.bitpos = 80;   // 64 bits of size prefix + 16 bits of zlib header, both written later
     z.flushed = 0;
     uint32_t adA = 1, adB = 0;
-#ifdef S5_DEFL_V1
-    deflate_block<1, M>(S, *reinterpret_cast<BuildScratch *>(obuf), obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es);
-#else
     deflate_block2<1, NT>(S, obuf, obuf_words, pay, (int)plen, true, z, adA, adB, dbg, es, gen_hint, prepared);
-#endif
     if (dbg) return 16;
     z.bitpos = (z.bitpos + 7) & ~7u;
-#ifndef S5_DEFL_V1
     if (tid == 0 && plen) {   // deflate_block2<1> leaves the block's Adler sums per wave: A = 1 + sum x_i, B = len + sum (len - i) x_i
         uint32_t a = 0, b = 0;
         for (int w = 0; w < NW; w++) { a += S.wad[w]; b += S.wad[8 + w]; }
         adB = (uint32_t)(((uint64_t)plen + b) % 65521u);
         adA = (1u + a) % 65521u;
     }
-#endif
     if (tid == 0) put_bits(obuf, z, z.bitpos, __builtin_bswap32((adB << 16) | adA), 32);
     z.bitpos += 32;
     __syncthreads();

@@ -961,6 +961,72 @@ extern "C" int s5gpu_recompress_batch_arena(uint32_t n, const void *const *rec, 
     return recompress_batch_any(n, rec, rec_len, from_rec, from_sig, to_rec, to_sig, new_read_group, drop_aux, out, out_len, status, arena);
 }
 
+// ---- the batch calls as SUBMIT / WAIT pairs (round 6) ----
+// The reference's loop is read K -> work_db -> write K with nothing overlapped (/root/reference/src/view.c:254-300; overlapping them is
+// the authors' own to-do, /root/reference/README.md:197), and a synchronous batch call keeps it that way: at K = 4096 a call is one
+// H2D -> kernels -> D2H round of 1.7 ms, latency the device spends mostly idle.  A submitted batch runs on a thread of its own and takes one
+// of the library's contexts (S5GPU_CONTEXTS, two by default) like any batch call of a caller's thread: two tickets in flight = one batch's
+// copies under the other's kernels, and the caller reads batch k + 1 from the file in the meantime.  The buffers named at submit time
+// (rec / rec_len / out / out_len / status, new_read_group) belong to the library until the ticket is waited for.  Every ticket must be
+// waited for exactly once; s5gpu_batch_wait returns the call's code and puts its message where s5gpu_last_error() of the WAITING thread
+// finds it.
+namespace {
+struct BatchTicket {
+    std::thread th;
+    int rc = S5GPU_OK;
+    std::string err;
+    void *arena = nullptr;
+};
+}  // namespace
+extern "C" void *s5gpu_recompress_batch_submit(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
+                                               int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
+                                               int32_t *status, int want_arena) {
+    BatchTicket *t = new (std::nothrow) BatchTicket();
+    if (!t) { s5gpu_set_error("s5gpu_recompress_batch_submit: out of memory"); return nullptr; }
+    try {
+        t->th = std::thread([=]() {
+            t->rc = recompress_batch_any(n, rec, rec_len, from_rec, from_sig, to_rec, to_sig, new_read_group, drop_aux, out, out_len, status,
+                                         want_arena ? &t->arena : nullptr);
+            if (t->rc != S5GPU_OK) t->err = s5gpu_last_error();
+        });
+    } catch (...) {
+        delete t;
+        s5gpu_set_error("s5gpu_recompress_batch_submit: no thread for the batch");
+        return nullptr;
+    }
+    return t;
+}
+extern "C" void *s5gpu_encode_batch_submit(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
+                                           const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
+                                           int sig_method, void **out, size_t *out_len, int want_arena) {
+    BatchTicket *t = new (std::nothrow) BatchTicket();
+    if (!t) { s5gpu_set_error("s5gpu_encode_batch_submit: out of memory"); return nullptr; }
+    try {
+        t->th = std::thread([=]() {
+            t->rc = want_arena ? s5gpu_encode_batch_arena(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len, &t->arena)
+                               : s5gpu_encode_batch(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
+            if (t->rc != S5GPU_OK) t->err = s5gpu_last_error();
+        });
+    } catch (...) {
+        delete t;
+        s5gpu_set_error("s5gpu_encode_batch_submit: no thread for the batch");
+        return nullptr;
+    }
+    return t;
+}
+extern "C" int s5gpu_batch_wait(void *ticket, void **arena) {
+    if (arena) *arena = nullptr;
+    if (!ticket) { s5gpu_set_error("s5gpu_batch_wait: NULL ticket"); return S5GPU_ERR_ARG; }
+    BatchTicket *t = static_cast<BatchTicket *>(ticket);
+    if (t->th.joinable()) t->th.join();
+    const int rc = t->rc;
+    if (rc != S5GPU_OK) s5gpu_set_error("%s", t->err.c_str());
+    if (arena) *arena = t->arena;
+    else if (t->arena) s5gpu_arena_release(t->arena);      // (submitted with want_arena, waited for without a place for it: nothing leaks)
+    delete t;
+    return rc;
+}
+
 static int recompress_encode_half(Ctx *c, uint32_t n, const std::vector<s5gpu_rec_desc_t> &rd, const std::vector<s5gpu_rec_fields_t> &ff, int to_rec, int to_sig,
                                   const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len, std::vector<uint64_t> *stream_off, s5host::Arena *ar = nullptr);
 

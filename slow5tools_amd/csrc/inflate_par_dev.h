@@ -322,6 +322,17 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
     const uint32_t group = lenmask + 1u;
     // (every trip moves every live lane by a bit at least; the trip count is bounded all the same — a scalar counter — so that no table
     // content whatsoever can hang the wave: what is left over then counts as bad data)
+    // WRITE: literals leave the lane FOUR AT A TIME, as one (unaligned) dword store — a store instruction of 64 lanes at 64 places costs the
+    // memory pipeline the same whatever its width, and the output pass is bound by exactly that (profiles/r06_inflate_phases.txt).  acc holds
+    // the acc8 / 8 literals in front of o that are not in memory yet; they go out as bytes before anything else is written or read back.
+    uint32_t acc = 0, acc8 = 0;
+    typedef uint32_t u1 __attribute__((aligned(1)));
+    auto flush_acc = [&]() {
+        if (acc8 >= 8u) dst[o - (acc8 >> 3)] = (uint8_t)acc;
+        if (acc8 >= 16u) dst[o - (acc8 >> 3) + 1u] = (uint8_t)(acc >> 8);
+        if (acc8 >= 24u) dst[o - (acc8 >> 3) + 2u] = (uint8_t)(acc >> 16);
+        acc = 0; acc8 = 0;
+    };
     for (uint32_t trips = 0; __ballot(p < lim); trips++) {
         if (trips > 8u * IP_SPAN) { if (p < lim) r.bad = 1; break; }
         uint32_t bits = 0, e = 0;
@@ -334,7 +345,15 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
             const bool lit = act && e < 0x4000u;
             held = act && !(e < 0x4000u);
             if (lit) {
-                if (WRITE) dst[o] = (uint8_t)(e >> 4);
+                if (WRITE) {
+#ifndef S5_IP_BYTE_STORES
+                    acc |= ((e >> 4) & 255u) << acc8;
+                    acc8 += 8u;
+                    if (acc8 == 32u) { *reinterpret_cast<u1 *>(dst + o - 3u) = acc; acc = 0; acc8 = 0; }
+#else
+                    dst[o] = (uint8_t)(e >> 4);
+#endif
+                }
                 lastb = WRITE ? e >> 4 : 0u;
                 p += e & 15u;
                 o += 1u;
@@ -345,6 +364,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
             uint32_t adv = len, nby = 0;
             bool stop = false;
             if (held) {
+                if (WRITE) flush_acc();
                 // an invalid code (behind the last code of an incomplete code) is a stop like a bad length symbol: sym 0x3FF
                 const uint32_t sym = e < 0x8000u ? 257u + ((e >> 4) & 31u) : (e & 0x10u) ? 0x3FFu : 256u;
                 if (sym == 256u) {
@@ -418,6 +438,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
             }
         }
     }
+    if (WRITE) flush_acc();
     r.cross = p;
     if (!r.eob) r.nout = o - obase;
     return r;

@@ -42,11 +42,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
 constexpr uint32_t S_BYTES = (sizeof(DeflShared) + 15u) & ~15u;
 constexpr uint32_t BZ_BYTES = (sizeof(BuildScratch) + 15u) & ~15u;   // deflate_block (round 1-4) and the zstd encoder overlay their build scratch on the bit buffer
-#ifdef S5_DEFL_V1
-constexpr uint32_t B_BYTES = BZ_BYTES;
-#else
 constexpr uint32_t B_BYTES = NW * 288u * 4u + 64u;                   // deflate_block2 keeps one histogram per wave in the bit buffer's tail
-#endif
 constexpr uint32_t OVF = 0xFFFFFFFFu;
 
 struct EncParams {
@@ -203,9 +199,7 @@ __global__ __launch_bounds__(NT, WPS) void k_encode_fused(EncParams p) {     // 
     uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + S_BYTES);
     uint8_t *pay = smem + S_BYTES + 4u * p.obuf_words;
     const s5gpu_read_desc_t d = p.a.desc[r];
-#ifndef S5_DEFL_V1
     deflate2_prepare<NT>(S, obuf, p.obuf_words);     // (cleared under the signal loads; ordered by the barriers of the payload's scans)
-#endif
     const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
     if (plen == OVF) {
         if (threadIdx.x == 0 && p.tier != 1) {
@@ -253,9 +247,7 @@ __global__ __launch_bounds__(NT, S5_FUSED_WG_PER_CU) void k_encode_stream(EncPar
     const uint32_t r = s_r;
 #endif
     const s5gpu_read_desc_t d = p.a.desc[r];
-#ifndef S5_DEFL_V1
     deflate2_prepare<NT>(S, obuf, p.obuf_words);     // (cleared under the signal loads; ordered by the barriers of the payload's scans)
-#endif
     const uint32_t plen = build_payload<EXZD>(p.a, d, pay, p.pay_cap, S.ws, S.red);
     uint32_t total = 0;
     if (plen == OVF) {
@@ -363,7 +355,6 @@ __global__ __launch_bounds__(NT, S5_PACK_WG) void k_pack(EncParams p, int mode, 
 #ifndef S5_STAGED_TN
 #define S5_STAGED_TN 256
 #endif
-using StagedMask = std::conditional<S5_STAGED_TN >= 512, uint32_t, uint64_t>::type;
 // the next 16 KiB block of a parked payload on its way HBM -> registers (64 bytes per lane at 256 threads)
 struct StagedPf { uint4 v[DEFL_BLK / 16 / S5_STAGED_TN]; };
 __device__ __forceinline__ void staged_fetch(StagedPf &pf, const uint8_t *src, uint32_t at, uint32_t plen) {
@@ -404,20 +395,11 @@ __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, ui
         if (!final) staged_fetch(pf, src, done + blen, plen);
         else if (next_src) staged_fetch(pf, next_src, 0, next_plen);
         __syncthreads();
-#ifdef S5_DEFL_V1
-        deflate_block<2, StagedMask, S5_STAGED_TN>(S, B, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB);
-#else
         const uint32_t front = run_heavy_front(p.a, d);
         deflate_block2<2, S5_STAGED_TN>(S, obuf, p.obuf_words, stage, (int)blen, final, z, adA, adB, 0, EarlySize{nullptr, 0},
                                         front > done ? min(front - done, blen) : 0u);
-#endif
         done += blen;
         if (!final) {
-#ifdef S5_DEFL_V1
-            flush_words<S5_STAGED_TN>(obuf, out32, z, false);
-            z.carry = obuf[0];      // uniform: every lane reads the same word (flush_words ends on a barrier)
-            __syncthreads();        // ... before the next block's scratch overwrites it
-#else
             // deflate_block2 clears the bit buffer itself and takes the pending partial word from z.carry: the completed words go out,
             // the partial one is read where it stands — one barrier instead of four and no slide
             const uint32_t full = z.bitpos >> 5;
@@ -425,7 +407,6 @@ __device__ __forceinline__ uint32_t deflate_staged_record(const EncParams &p, ui
             z.carry = obuf[full - z.flushed];      // uniform
             z.flushed = full;
             __syncthreads();        // ... before the next block's histograms overwrite the buffer's tail
-#endif
         }
     } while (done < plen);
     z.bitpos = (z.bitpos + 7) & ~7u;

@@ -382,6 +382,36 @@ int slow5_gpu_hook_recompress_arena(int64_t n, char **mem, size_t *bytes, int fr
 }
 void slow5_gpu_hook_release(void *batch) { s5gpu_arena_release(batch); }
 
+/* the same batch in flight (slow5gpu_hooks.h): the ticket remembers the input records the worker frees once the batch is through */
+struct hook_ticket { void *t; int64_t n; char **mem; };
+void *slow5_gpu_hook_recompress_submit(int64_t n, char **mem, size_t *bytes, int from_record_method, int from_signal_method, int to_record_method,
+                                       int to_signal_method, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len) {
+    if (n < 0 || n > 0xFFFFFFFFll || !hook_method_ok(from_record_method, from_signal_method) || !hook_method_ok(to_record_method, to_signal_method)) {
+        slow5_errno = SLOW5_ERR_PRESS;
+        return NULL;
+    }
+    struct hook_ticket *h = (struct hook_ticket *)calloc(1, sizeof *h);
+    if (!h) { slow5_errno = SLOW5_ERR_MEM; return NULL; }
+    h->n = n; h->mem = mem;
+    if (n) {
+        h->t = s5gpu_recompress_batch_submit((uint32_t)n, (const void *const *)mem, bytes, rec_code((enum slow5_press_method)from_record_method),
+                                             sig_code((enum slow5_press_method)from_signal_method), rec_code((enum slow5_press_method)to_record_method),
+                                             sig_code((enum slow5_press_method)to_signal_method), new_read_group, drop_aux, out, out_len, NULL, 1);
+        if (!h->t) { free(h); slow5_errno = SLOW5_ERR_MEM; return NULL; }
+    }
+    return h;
+}
+int slow5_gpu_hook_recompress_wait(void *ticket, void **batch) {
+    if (batch) *batch = NULL;
+    struct hook_ticket *h = (struct hook_ticket *)ticket;
+    if (!h) { slow5_errno = SLOW5_ERR_ARG; return -1; }
+    int ret = 0;
+    if (h->t && s5gpu_batch_wait(h->t, batch) != S5GPU_OK) { slow5_errno = SLOW5_ERR_RECPARSE; ret = -1; }
+    if (ret == 0) for (int64_t i = 0; i < h->n; i++) { free(h->mem[i]); h->mem[i] = NULL; }   /* as the synchronous worker does (src/view.c:41) */
+    free(h);
+    return ret;
+}
+
 void *slow5_gpu_hook_alloc(size_t bytes) { return s5gpu_host_alloc(bytes); }
 void slow5_gpu_hook_free(void *p) { s5gpu_host_free(p); }
 int slow5_gpu_hook_recompress_chunk(int64_t n, const void *chunk, size_t chunk_bytes, const uint64_t *rec_pos, const uint32_t *rec_len,

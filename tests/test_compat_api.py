@@ -233,6 +233,81 @@ def test_arena_form_of_the_view_hook_hands_out_the_same_bytes_with_one_release(L
     L.slow5_gpu_hook_release(None)
 
 
+def test_submit_wait_pair_keeps_two_batches_in_flight_and_equals_the_synchronous_hook(L):
+    """slow5_gpu_hook_recompress_submit / _wait (round 6): the loop of /root/reference/src/view.c:254-300 with batch k + 1 read while batch k
+    is on the device.  Six batches, two tickets in flight at any time, two alternating sets of arrays: every batch's records equal the
+    synchronous hook's byte for byte, inputs are freed by the time _wait returns, a corrupt record fails ITS ticket only (message in the
+    waiting thread), a NULL ticket is an error"""
+    hk = [C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.slow5_gpu_hook_recompress.argtypes = hk
+    L.slow5_gpu_hook_recompress_submit.argtypes = hk
+    L.slow5_gpu_hook_recompress_submit.restype = C.c_void_p
+    L.slow5_gpu_hook_recompress_wait.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.slow5_gpu_hook_release.argtypes = [C.c_void_p]
+    L.slow5_gpu_hook_error.restype = C.c_char_p
+    src = Blow5(golden("merged_expected_zlib_svb.blow5"))
+    base = src.records * 20                      # 120 records
+    n = len(base)
+    batches = [base[k:] + base[:k] for k in range(6)]          # six different orders
+
+    def arrays(recs):
+        return (C.c_void_p * n)(*[_malloc_copy(r) for r in recs]), (C.c_size_t * n)(*[len(r) for r in recs]), (C.c_void_p * n)(), (C.c_size_t * n)()
+
+    want = []
+    for recs in batches[:2]:
+        mem, nb, out, ol = arrays(recs)
+        assert L.slow5_gpu_hook_recompress(n, mem, nb, ZLIB, SVB, ZLIB, SVB, None, 0, out, ol) == 0
+        want.append([C.string_at(out[i], ol[i]) for i in range(n)])
+        for i in range(n):
+            libc.free(out[i])
+    by_first = {w[0]: w for w in want}
+
+    flight = []                                  # (ticket, arrays): at most two
+    done = 0
+    for k, recs in enumerate(batches):
+        a = arrays(recs)
+        t = L.slow5_gpu_hook_recompress_submit(n, a[0], a[1], ZLIB, SVB, ZLIB, SVB, None, 0, a[2], a[3])
+        assert t
+        flight.append((t, a, k))
+        if len(flight) == 2:
+            t0, a0, k0 = flight.pop(0)
+            h = C.c_void_p()
+            assert L.slow5_gpu_hook_recompress_wait(t0, C.byref(h)) == 0 and h.value
+            assert all(a0[0][i] is None for i in range(n))
+            got = [C.string_at(a0[2][i], a0[3][i]) for i in range(n)]
+            if k0 < 2:
+                assert got == want[k0]
+            else:                                # a rotation of batch 0: the same records in another order
+                assert sorted(got) == sorted(want[0])
+            L.slow5_gpu_hook_release(h)
+            done += 1
+    t0, a0, k0 = flight.pop(0)
+    h = C.c_void_p()
+    assert L.slow5_gpu_hook_recompress_wait(t0, C.byref(h)) == 0
+    assert sorted(C.string_at(a0[2][i], a0[3][i]) for i in range(n)) == sorted(want[0])
+    L.slow5_gpu_hook_release(h)
+    # one good and one corrupt batch in flight together
+    good = arrays(batches[0])
+    badrecs = list(batches[1])
+    b = bytearray(badrecs[7]); b[len(b) // 2] ^= 0x55; badrecs[7] = bytes(b)
+    bad = arrays(badrecs)
+    tg = L.slow5_gpu_hook_recompress_submit(n, good[0], good[1], ZLIB, SVB, ZLIB, SVB, None, 0, good[2], good[3])
+    tb = L.slow5_gpu_hook_recompress_submit(n, bad[0], bad[1], ZLIB, SVB, ZLIB, SVB, None, 0, bad[2], bad[3])
+    hb = C.c_void_p(1)
+    assert L.slow5_gpu_hook_recompress_wait(tb, C.byref(hb)) == -1 and hb.value is None
+    assert L.slow5_gpu_hook_error()              # the failing batch's message reached the waiting thread
+    hg = C.c_void_p()
+    assert L.slow5_gpu_hook_recompress_wait(tg, C.byref(hg)) == 0
+    assert [C.string_at(good[2][i], good[3][i]) for i in range(n)] == want[0]
+    L.slow5_gpu_hook_release(hg)
+    for i in range(n):
+        if bad[0][i]:
+            libc.free(bad[0][i])
+    assert L.slow5_gpu_hook_recompress_wait(None, None) == -1
+    assert L.slow5_gpu_hook_recompress_submit(n, good[0], good[1], 99, SVB, ZLIB, SVB, None, 0, good[2], good[3]) is None
+
+
 def test_arena_form_of_encode_batch_at_the_reference_batch_sizes(L):
     """s5gpu_encode_batch_arena at K = 4096 (/root/reference/src/cmd.h:8) and K = 10 000 (test/test_view_integrity.sh:62-66): the records
     of the malloc form, byte for byte"""
