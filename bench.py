@@ -1052,7 +1052,8 @@ def main():
         "bulk_decode_one_call": {k: pick(leg4, "bulk_decode_one_call", k) for k in ("reads", "ms", "reads_per_s")},
         "bulk_decode_frac": pick(leg4, "bulk_decode_one_call", "roofline", "frac"),
         "stock_zlib_records_reads_per_s": pick(leg4, "bulk_decode_one_call", "stock_zlib_records", "reads_per_s"),
-        "pcie_inclusive_GB_per_s": {k: {"malloc": pick(pcie_obj, k, "GB_per_s"), "arena": pick(pcie_obj, k, "arena", "GB_per_s")}
+        "pcie_inclusive_GB_per_s": {k: {"malloc": pick(pcie_obj, k, "GB_per_s"), "arena": pick(pcie_obj, k, "arena", "GB_per_s"),
+                                        "two_in_flight": pick(pcie_obj, k, "two_in_flight", "GB_per_s")}
                                     for k in ("batch_4096", "batch_10000", "batch_65536", "batch_%d" % n_reads)} if isinstance(pcie_obj, dict) else None,
         "e2e_whole_process_s": {k: pick(e2e_obj, k, "gpu", "whole_process_s") for k in ("slow5_to_blow5", "blow5_to_blow5")} if isinstance(e2e_obj, dict) else None,
         "e2e_get_100k_whole_process_s": pick(e2e_obj, "get_100k", "gpu", "benchmark", "whole_process_s"),

@@ -247,6 +247,8 @@ def pcie_inclusive(L, _lib, press, n_reads, n, reps=2):
         r = 8 if m <= 10000 else 6 if m <= 65536 else reps      # (the allocator needs a few calls to settle: 1.4 / 5.4 / 21.5 GB/s on calls 1 / 2 / 3 of 65536)
         out["batch_%d" % m] = _pcie_one(L, _lib, press, m, n, r, arena=False)
         out["batch_%d" % m]["arena"] = _pcie_one(L, _lib, press, m, n, r + 1, arena=True)
+        if m <= 65536:   # the reference's loop with batch k + 1 submitted while batch k is on the device (round 6: s5gpu_encode_batch_submit / s5gpu_batch_wait)
+            out["batch_%d" % m]["two_in_flight"] = _pcie_two_in_flight(L, _lib, press, m, n, 48 if m <= 10000 else 12)
     big = out["batch_%d" % n_reads]
     out.update({"reads": n_reads, "samples_per_read": n, "GB_per_s": big["GB_per_s"], "reads_per_s": big["reads_per_s"], "arena_GB_per_s": big["arena"]["GB_per_s"]})
     return out
@@ -293,6 +295,53 @@ def _pcie_one(L, _lib, press, n_reads, n, reps, arena=False):
     best = min(times)
     return {"reads": n_reads, "seconds": [round(t, 4) for t in times], "GB_per_s": round(n_reads * n * 2 / best / 1e9, 3), "reads_per_s": round(n_reads / best, 1),
             "first_call_GB_per_s": round(n_reads * n * 2 / times[0] / 1e9, 3), "bytes_per_sample": round(tot / (n_reads * n), 4)}
+
+
+def _pcie_two_in_flight(L, _lib, press, m, n, batches):
+    """`batches` host batches of m reads through s5gpu_encode_batch_submit (arena form), two tickets in flight at any time, two alternating sets
+    of output arrays: submit k, wait for k - 1, release it — what the loop of /root/reference/src/view.c:254-300 does once it reads batch k + 1
+    while batch k is on the device.  Rate = all reads / (first submit .. last release); the first two batches (pool
+    and workspace warm-up) are run once before the clock starts."""
+    rng = np.random.default_rng(0)
+    base = (500 + 30 * rng.standard_normal((1024, n))).astype(np.int16)
+    sig = np.ascontiguousarray(np.tile(base, (m // 1024 + 1, 1))[:m])
+    hdr = np.frombuffer(press.pack_hdr("0" * 36, 0, 8192.0, 23.0, 1467.61, 4000.0), dtype=np.uint8)
+    vp = C.c_void_p
+    addr = sig.ctypes.data + 2 * n * np.arange(m, dtype=np.uint64)
+    sig_p = (vp * m).from_buffer_copy(addr.tobytes())
+    ns = (C.c_uint64 * m).from_buffer_copy(np.full(m, n, dtype=np.uint64).tobytes())
+    hdr_p = (vp * m).from_buffer_copy(np.full(m, hdr.ctypes.data, dtype=np.uint64).tobytes())
+    hl = (C.c_uint32 * m).from_buffer_copy(np.full(m, len(hdr), dtype=np.uint32).tobytes())
+    sets = [((vp * m)(), (C.c_size_t * m)()) for _ in range(2)]
+    L.s5gpu_encode_batch_submit.argtypes = [C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]
+    L.s5gpu_encode_batch_submit.restype = vp
+    L.s5gpu_batch_wait.argtypes = [vp, C.POINTER(vp)]
+    L.s5gpu_arena_release.argtypes = [vp]
+
+    def run(nb):
+        tickets = [None, None]
+        tot = 0
+        t0 = time.perf_counter()
+        for k in range(nb + 1):
+            cur = k & 1
+            if k < nb:
+                t = L.s5gpu_encode_batch_submit(m, sig_p, ns, hdr_p, hl, None, None, 1, 1, sets[cur][0], sets[cur][1], 1)
+                if not t:
+                    raise RuntimeError("s5gpu_encode_batch_submit failed")
+                tickets[cur] = t
+            prev = cur ^ 1
+            if tickets[prev]:
+                h = vp()
+                _lib.check(L.s5gpu_batch_wait(tickets[prev], C.byref(h)), "s5gpu_batch_wait")
+                tickets[prev] = None
+                tot += int(np.frombuffer(sets[prev][1], dtype=np.uint64).sum())
+                L.s5gpu_arena_release(h)
+        return time.perf_counter() - t0, tot
+
+    run(2)
+    dt, tot = run(batches)
+    return {"batches": batches, "reads_per_batch": m, "seconds": round(dt, 4), "GB_per_s": round(batches * m * n * 2 / dt / 1e9, 3),
+            "reads_per_s": round(batches * m / dt, 1), "ms_per_batch": round(dt / batches * 1e3, 3), "bytes_per_sample": round(tot / (batches * m * n), 4)}
 
 
 HOST_FED_CODE = r"""

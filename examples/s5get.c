@@ -78,18 +78,24 @@ static void gfail(gpipe_t *P, const char *what, const char *arg) {
  * with the first preads, and a list of a few batches never pays for eight slots (640 MB of pinned memory up front was a third of a
  * 100 k-id job). */
 static int gslot_alloc(gpipe_t *P, gslot_t *b) {
-    b->in_cap = (size_t)P->K * 4096 + 65536;
-    b->in = (uint8_t *)s5gpu_host_alloc(b->in_cap);
-    b->out_cap = (size_t)P->K * (P->benchmark ? 10240 : 6144) + 65536;     /* decoded samples / re-encoded records; a batch that outgrows it is redone */
-    b->out = (uint8_t *)s5gpu_host_alloc(b->out_cap);
-    b->rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)P->K);
-    b->rec_len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)P->K);
-    b->off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)P->K + 1));
-    b->fields = (s5gpu_rec_fields_t *)malloc(sizeof(s5gpu_rec_fields_t) * (size_t)P->K);
-    if (b->in && b->out && b->rec_pos && b->rec_len && b->off && b->fields) return 0;
-    s5gpu_host_free(b->in); s5gpu_host_free(b->out); free(b->rec_pos); free(b->rec_len); free(b->off); free(b->fields);      /* (all or nothing) */
-    b->in = b->out = NULL; b->rec_pos = b->off = NULL; b->rec_len = NULL; b->fields = NULL;
-    return -1;
+    /* all or nothing, and b->in — what the readers test — is set LAST: a slot is either absent or whole, whoever looks at it and when */
+    const size_t in_cap = (size_t)P->K * 4096 + 65536;
+    const size_t out_cap = (size_t)P->K * (P->benchmark ? 10240 : 6144) + 65536;     /* decoded samples / re-encoded records; a batch that outgrows it is redone */
+    uint8_t *in = (uint8_t *)s5gpu_host_alloc(in_cap);
+    uint8_t *out = (uint8_t *)s5gpu_host_alloc(out_cap);
+    uint64_t *rec_pos = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)P->K);
+    uint32_t *rec_len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)P->K);
+    uint64_t *off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)P->K + 1));
+    s5gpu_rec_fields_t *fields = (s5gpu_rec_fields_t *)malloc(sizeof(s5gpu_rec_fields_t) * (size_t)P->K);
+    if (!(in && out && rec_pos && rec_len && off && fields)) {
+        s5gpu_host_free(in); s5gpu_host_free(out); free(rec_pos); free(rec_len); free(off); free(fields);
+        return -1;
+    }
+    b->in_cap = in_cap; b->out_cap = out_cap;
+    b->out = out; b->rec_pos = rec_pos; b->rec_len = rec_len; b->off = off; b->fields = fields;
+    __sync_synchronize();
+    b->in = in;
+    return 0;
 }
 
 /* read phase (get.c:335-361): one reader thread fills one whole batch; several batches are being filled at once */

@@ -544,6 +544,31 @@ static int leave(void) {
     if (e && atoi(e)) { s5gpu_shutdown(); return EXIT_SUCCESS; }
     _exit(EXIT_SUCCESS);
 }
+/* fopen(path, "wb") over an existing multi-gigabyte file gives its pages back before it returns — 0.07 s per 3.5 GB on tmpfs, on the critical
+ * path of a conversion that takes one second.  A big old output is moved aside instead, the new one is created beside it, and the old
+ * one is unlinked by a thread of its own while the pipeline runs. */
+static void *unlink_main(void *arg) {
+    char *p = (char *)arg;
+    unlink(p);
+    free(p);
+    return NULL;
+}
+static FILE *open_output(const char *path) {
+    struct stat st;
+    if (stat(path, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > (off_t)(64 << 20)) {
+        const size_t n = strlen(path) + 32;
+        char *old = (char *)malloc(n);
+        if (old) {
+            snprintf(old, n, "%s.s5old.%ld", path, (long)getpid());
+            pthread_t th;
+            if (rename(path, old) == 0) {
+                if (pthread_create(&th, NULL, unlink_main, old) == 0) pthread_detach(th);
+                else { unlink(old); free(old); }
+            } else free(old);
+        }
+    }
+    return fopen(path, "wb");
+}
 static void *early_init_main(void *arg) {
     (void)arg;
     if (s5gpu_warmup() == S5GPU_OK) s5gpu_host_free(s5gpu_host_alloc(4096));   /* (the first pinned allocation brings up its own machinery) */
@@ -593,7 +618,7 @@ int main(int argc, char **argv) {
     slow5_file_t *in = slow5_open(argv[1], "r");
     if (!in) return die("cannot open input");
     stamp("input opened, header read");
-    FILE *out = fopen(argv[2], "wb");
+    FILE *out = open_output(argv[2]);
     if (!out) return die("cannot open output");
     const size_t ol = strlen(argv[2]);
     const enum slow5_fmt fmt_out = ol > 6 && strcmp(argv[2] + ol - 6, ".slow5") == 0 ? SLOW5_FORMAT_ASCII : SLOW5_FORMAT_BINARY;

@@ -8,6 +8,8 @@
  * text blob; SLOW5 ASCII files (same text after two '#' version lines, one record per line) are framed here too.  No codec work happens here: read ids for the index come from the GPU batch decode.
  */
 #define _GNU_SOURCE
+#include <fcntl.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
@@ -34,6 +36,7 @@ struct slow5_idx {
     uint64_t tsize;
     struct slow5_version version;
     char **rids;            /* slow5_get_rids: the ids in file order (pointers into ents), made on first use */
+    char *blob;             /* an index READ from its file: the file's bytes, the ids are NUL-terminated in place (not one malloc each) */
 };
 
 static enum slow5_press_method rec_from_code(uint8_t c) { return c == 0 ? SLOW5_COMPRESS_NONE : c == 1 ? SLOW5_COMPRESS_ZLIB : c == 2 ? SLOW5_COMPRESS_ZSTD : (enum slow5_press_method)-1; }
@@ -288,17 +291,41 @@ static int idx_push(struct slow5_idx *ix, const char *id, uint16_t id_len, uint6
     e->size = size;
     return 0;
 }
+/* The lookup table of a big index is built by a few threads: a million ids are a million hash computations and a million cache misses
+ * into an 8 MB table — 0.1 s on one core, which was a third of `get`'s whole process (round 5 review).  Open addressing, insertion by
+ * compare-and-swap on the 32-bit slot: any interleaving of the threads leaves every entry findable by idx_find's linear probe. */
+struct idx_tab_job { struct slow5_idx *ix; uint64_t lo, hi; };
+static void *idx_tab_worker(void *arg) {
+    struct idx_tab_job *j = (struct idx_tab_job *)arg;
+    struct slow5_idx *ix = j->ix;
+    const uint64_t t = ix->tsize;
+    for (uint64_t i = j->lo; i < j->hi; i++) {
+        uint64_t p = hash_id(ix->ents[i].id, ix->ents[i].id_len) & (t - 1);
+        for (;;) {
+            if (ix->table[p] == 0 && __sync_bool_compare_and_swap(&ix->table[p], 0u, (uint32_t)(i + 1))) break;
+            p = (p + 1) & (t - 1);
+        }
+    }
+    return NULL;
+}
 static int idx_build_table(struct slow5_idx *ix) {
     uint64_t t = 16;
     while (t < 2 * ix->n + 1) t <<= 1;
     ix->table = (uint32_t *)calloc(t, sizeof(uint32_t));
     if (!ix->table) return -1;
     ix->tsize = t;
-    for (uint64_t i = 0; i < ix->n; i++) {
-        uint64_t p = hash_id(ix->ents[i].id, ix->ents[i].id_len) & (t - 1);
-        while (ix->table[p]) p = (p + 1) & (t - 1);
-        ix->table[p] = (uint32_t)(i + 1);
+    enum { MAXT = 8 };
+    long hw = sysconf(_SC_NPROCESSORS_ONLN);
+    int nt = ix->n < 65536 ? 1 : hw >= MAXT ? MAXT : hw > 1 ? (int)hw : 1;
+    pthread_t th[MAXT];
+    int live[MAXT];
+    struct idx_tab_job job[MAXT];
+    for (int k = 0; k < nt; k++) {
+        job[k].ix = ix; job[k].lo = ix->n * (uint64_t)k / (uint64_t)nt; job[k].hi = ix->n * (uint64_t)(k + 1) / (uint64_t)nt;
+        live[k] = k + 1 < nt && pthread_create(&th[k], NULL, idx_tab_worker, &job[k]) == 0;
+        if (!live[k]) idx_tab_worker(&job[k]);           /* the last share, or one that got no thread: on the caller's */
     }
+    for (int k = 0; k < nt; k++) if (live[k]) pthread_join(th[k], NULL);
     return 0;
 }
 static const struct idx_ent *idx_find(const struct slow5_idx *ix, const char *id) {
@@ -313,7 +340,8 @@ static const struct idx_ent *idx_find(const struct slow5_idx *ix, const char *id
 }
 static void idx_free(struct slow5_idx *ix) {
     if (!ix) return;
-    for (uint64_t i = 0; i < ix->n; i++) free(ix->ents[i].id);
+    if (!ix->blob) for (uint64_t i = 0; i < ix->n; i++) free(ix->ents[i].id);
+    free(ix->blob);
     free(ix->ents);
     free(ix->table);
     free(ix->rids);
@@ -470,29 +498,49 @@ static int idx_write(const struct slow5_idx *ix, const char *path) {
     return fclose(fp) == 0 && ok ? 0 : -1;
 }
 
+/* The whole file in one read; the entries are walked once, ids stay where they are (NUL-terminated in place: the byte behind an id is the
+ * first byte of its offset field, copied out just before) — no fread, malloc and memcpy per entry (round 6: 1 M entries 0.16 -> 0.03 s). */
 static struct slow5_idx *idx_read(const char *path) {
-    FILE *fp = fopen(path, "rb");
-    if (!fp) return NULL;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return NULL;
+    struct stat st;
     struct slow5_idx *ix = (struct slow5_idx *)calloc(1, sizeof *ix);
-    uint8_t h[64];
-    int ok = ix && fread(h, 1, 64, fp) == 64 && memcmp(h, IDX_MAGIC, 9) == 0;
-    if (ok) { ix->version.major = h[9]; ix->version.minor = h[10]; ix->version.patch = h[11]; }
-    char idbuf[65536];
-    while (ok) {
-        uint8_t pre[8];
-        if (fread(pre, 1, 2, fp) != 2) { ok = 0; break; }
-        if (pre[0] == 'X' && pre[1] == 'D') {   /* "XDI5WOLS" cannot be an entry: an id of 0x4458 bytes followed by... check fully */
-            long at = ftell(fp);
-            if (fread(pre + 2, 1, 6, fp) == 6 && memcmp(pre, IDX_EOF, 8) == 0 && fgetc(fp) == EOF) break;
-            fseek(fp, at, SEEK_SET);
-        }
-        uint16_t l;
-        memcpy(&l, pre, 2);
-        uint64_t off, size;
-        if (fread(idbuf, 1, l, fp) != l || fread(&off, 8, 1, fp) != 1 || fread(&size, 8, 1, fp) != 1) { ok = 0; break; }
-        if (idx_push(ix, idbuf, l, off, size) != 0) { ok = 0; break; }
+    int ok = ix && fstat(fd, &st) == 0 && st.st_size >= 64 + 8;
+    size_t len = ok ? (size_t)st.st_size : 0;
+    if (ok) { ix->blob = (char *)malloc(len + 1); ok = ix->blob != NULL; }
+    for (size_t got = 0; ok && got < len;) {
+        const ssize_t r = read(fd, ix->blob + got, len - got);
+        if (r <= 0) ok = 0; else got += (size_t)r;
     }
-    fclose(fp);
+    close(fd);
+    const uint8_t *b = ok ? (const uint8_t *)ix->blob : NULL;
+    ok = ok && memcmp(b, IDX_MAGIC, 9) == 0 && memcmp(b + len - 8, IDX_EOF, 8) == 0;
+    if (ok) { ix->version.major = b[9]; ix->version.minor = b[10]; ix->version.patch = b[11]; }
+    const size_t end = ok ? len - 8 : 0;           /* the end marker is the file's last eight bytes, whatever an entry might look like */
+    if (ok) {                                      /* (an entry is at least 18 bytes: a first guess of the count saves the reallocs) */
+        ix->cap = (end - 64) / 40 + 16;
+        ix->ents = (struct idx_ent *)malloc(ix->cap * sizeof *ix->ents);
+        ok = ix->ents != NULL;
+    }
+    for (size_t p = 64; ok && p < end;) {
+        uint16_t l;
+        if (end - p < 2) { ok = 0; break; }
+        memcpy(&l, b + p, 2);
+        if (end - p < (size_t)2 + l + 16) { ok = 0; break; }
+        if (ix->n == ix->cap) {
+            const uint64_t nc = ix->cap * 2;
+            struct idx_ent *ne = (struct idx_ent *)realloc(ix->ents, nc * sizeof *ne);
+            if (!ne) { ok = 0; break; }
+            ix->ents = ne; ix->cap = nc;
+        }
+        struct idx_ent *e = &ix->ents[ix->n++];
+        e->id = ix->blob + p + 2;
+        e->id_len = l;
+        memcpy(&e->offset, b + p + 2 + l, 8);
+        memcpy(&e->size, b + p + 2 + l + 8, 8);
+        ix->blob[p + 2 + l] = '\0';
+        p += (size_t)2 + l + 16;
+    }
     if (ok && idx_build_table(ix) != 0) ok = 0;
     if (!ok) { idx_free(ix); return NULL; }
     return ix;

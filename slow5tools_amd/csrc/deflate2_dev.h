@@ -336,8 +336,13 @@ __device__ __forceinline__ void deflate_block2(DeflShared &S, uint32_t *obuf, ui
             uint32_t st = 0;
             if (lane == 0) {
                 st = atomicAdd(&S.lalloc, total);
-                if (st < DEFL2_LIST_CAP && st + total > DEFL2_LIST_CAP) st = atomicAdd(&S.lalloc, total + (DEFL2_LIST_CAP - st));   // would straddle: take it from the second pool
-                if (st < DEFL2_LIST_CAP && st + total > DEFL2_LIST_CAP) st = list_cap;                                                // (another wave got in between: no list)
+                if (st < DEFL2_LIST_CAP && st + total > DEFL2_LIST_CAP) {
+                    // would straddle the two pools: the slab takes `total` entries of the SECOND pool — the counter is first raised to the pool's
+                    // start (atomicMax: whoever else got in between has raised it already), then `total` are taken there.  (Round 5 took
+                    // total + CAP - st a second time: the second pool lost up to CAP entries per straddle, listb_words grew with them.)
+                    atomicMax(&S.lalloc, (uint32_t)DEFL2_LIST_CAP);
+                    st = atomicAdd(&S.lalloc, total);
+                }
             }
             st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
             const bool listed = st + total <= list_cap && st + total < 65536u;

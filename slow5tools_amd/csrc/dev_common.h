@@ -123,8 +123,10 @@ __device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *ws, uin
 }
 // The same for a loop that scans once per round: round i uses the half ws[8 * (i & 1) ..] of a 16-word scratch, so ONE barrier per round
 // is enough — a wave can only overwrite the half of round i in round i + 2, behind round i + 1's barrier, which no wave passes before all
-// have read round i's words.  (NW <= 8.)
+// have read round i's words.  Contract: ws holds 16 words; NW <= 8; and NO OTHER scan may touch ws between two rounds or right behind the last
+// one without a __syncthreads() of its own in front of it (a slower wave may still be reading the half a different scan would overwrite).
 __device__ __forceinline__ uint32_t block_excl_add_alt(uint32_t v, uint32_t *ws, uint32_t &total, uint32_t round) {
+    static_assert(NW <= 8, "block_excl_add_alt: a half of the 16-word scratch holds one word per wave");
     uint32_t *w8 = ws + 8u * (round & 1u);
     const uint32_t incl = wave_incl_add(v);
     if (lane_id() == 63) w8[wave_id()] = incl;

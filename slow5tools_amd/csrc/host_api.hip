@@ -113,6 +113,8 @@ extern "C" int s5gpu_devices_in_use(void) {
 
 int s5host_set_option(const char *key, long value) {
     if (key && strcmp(key, "multi_min_per_device") == 0 && value >= 1) { g_multi_min = (uint32_t)value; return S5GPU_OK; }
+    // pinned memory the arena pool keeps between batch calls, MiB (default 6144; 0: every released batch is unpinned at once)
+    if (key && strcmp(key, "arena_pool_keep_mb") == 0 && value >= 0) return s5host::arena_pool_set_keep((size_t)value << 20);
     return S5GPU_ERR_ARG;
 }
 
@@ -326,7 +328,8 @@ struct PoolBuf { void *p; size_t cap; };
 std::mutex g_pool_mu;
 std::vector<PoolBuf> g_pool;
 size_t g_pool_bytes = 0;
-constexpr size_t POOL_KEEP_BYTES = 6ull << 30;   // what the pool holds on to between calls (a 1 M-read batch gives back ~3.6 GB)
+size_t g_pool_keep = 6ull << 30;   // what the pool holds on to between calls (a 1 M-read batch gives back ~3.6 GB); option "arena_pool_keep_mb"
+uint32_t g_pool_gen = 0;           // the library generation the pooled buffers belong to (a shutdown drains the pool and moves on)
 }  // namespace
 void *s5host::arena_pool_take(size_t bytes, size_t *cap) {
     {
@@ -349,11 +352,14 @@ void *s5host::arena_pool_take(size_t bytes, size_t *cap) {
     *cap = want;
     return p;
 }
-void s5host::arena_pool_give(void *p, size_t cap) {
+// gen: the library generation the buffer was taken in.  The comparison with the pool's own generation happens UNDER the pool's lock, so a
+// release that races a shutdown either gets in before the drain (and is drained with the rest) or sees the new generation and frees its
+// buffer itself — never parks a buffer of the old generation in the new pool (round-5 advisor finding).
+void s5host::arena_pool_give(void *p, size_t cap, uint32_t gen) {
     if (!p) return;
     {
         std::lock_guard<std::mutex> g(g_pool_mu);
-        if (g_pool_bytes + cap <= POOL_KEEP_BYTES && g_pool.size() < 64) { g_pool.push_back({p, cap}); g_pool_bytes += cap; return; }
+        if (gen == g_pool_gen && g_pool_bytes + cap <= g_pool_keep && g_pool.size() < 64) { g_pool.push_back({p, cap}); g_pool_bytes += cap; return; }
     }
     (void)s5_pinned_free(p);
 }
@@ -362,14 +368,26 @@ void s5host::arena_pool_drain() {
     for (const PoolBuf &b : g_pool) (void)s5_pinned_free(b.p);
     g_pool.clear();
     g_pool_bytes = 0;
+    g_pool_gen++;                  // (s5gpu_shutdown bumps s5host_generation right behind this call: the two move together)
+}
+uint32_t s5host::arena_pool_generation() {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    return g_pool_gen;
+}
+int s5host::arena_pool_set_keep(size_t bytes) {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    g_pool_keep = bytes;
+    while (g_pool_bytes > g_pool_keep && !g_pool.empty()) {      // a lower limit takes effect at once
+        (void)s5_pinned_free(g_pool.back().p);
+        g_pool_bytes -= g_pool.back().cap;
+        g_pool.pop_back();
+    }
+    return S5GPU_OK;
 }
 extern "C" void s5gpu_arena_release(void *arena) {
     s5host::Arena *ar = (s5host::Arena *)arena;
     if (!ar) return;
-    for (auto &b : ar->bufs) {
-        if (ar->generation == s5host_generation) s5host::arena_pool_give(b.first, b.second);
-        else (void)s5_pinned_free(b.first);           // the library was shut down (and its pool drained) while the caller still held the batch
-    }
+    for (auto &b : ar->bufs) s5host::arena_pool_give(b.first, b.second, ar->pool_gen);   // (a batch that outlived a shutdown: its buffers are freed, not pooled)
     delete ar;
 }
 
@@ -465,6 +483,7 @@ static int encode_batch_any(uint32_t n, const int16_t *const *sig, const uint64_
         if (s5host::n_devices() == 0) return S5GPU_ERR_NODEV;   // (initialises the library: the arena remembers its generation)
         ar = new s5host::Arena;
         ar->generation = s5host_generation;
+        ar->pool_gen = s5host::arena_pool_generation();
     }
     // contiguous index range per device (src/thread.c:76-90 does the same per thread); every record's result lands in the
     // caller's out[i], so the ordered fwrite loop of src/view.c:296-299 is untouched
@@ -936,6 +955,7 @@ static int recompress_batch_any(uint32_t n, const void *const *rec, const size_t
         if (s5host::n_devices() == 0) return S5GPU_ERR_NODEV;
         ar = new s5host::Arena;
         ar->generation = s5host_generation;
+        ar->pool_gen = s5host::arena_pool_generation();
     }
     const int rc = s5host::for_each_device_range(n, [&](int slot, uint32_t lo, uint32_t hi) {
         return recompress_batch_dev(slot, hi - lo, rec + lo, rec_len + lo, from_rec, from_sig, to_rec, to_sig,

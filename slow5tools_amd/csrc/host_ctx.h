@@ -93,11 +93,14 @@ struct Arena {
     std::mutex mu;
     std::vector<std::pair<void *, size_t>> bufs;
     uint32_t generation = 0;
+    uint32_t pool_gen = 0;      // the pool's generation when the arena was made (arena_pool_generation())
     void add(void *p, size_t cap) { std::lock_guard<std::mutex> g(mu); bufs.emplace_back(p, cap); }
 };
 void *arena_pool_take(size_t bytes, size_t *cap);   // pinned; NULL + error message when the allocation fails
-void arena_pool_give(void *p, size_t cap);
+void arena_pool_give(void *p, size_t cap, uint32_t gen);
 void arena_pool_drain();                            // s5gpu_shutdown
+uint32_t arena_pool_generation();
+int arena_pool_set_keep(size_t bytes);              // option "arena_pool_keep_mb"
 // encode descriptors already on the device -> one malloc per record on the host, or (ar != nullptr) pointers into arena buffers (host_api.hip)
 int encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_desc_t> &desc, s5gpu_encode_args_t a, uint64_t slots_bytes,
                        void **out, size_t *out_len, Arena *ar = nullptr);

@@ -50,6 +50,7 @@ struct InflShared {                  // per wave
     uint16_t dsym[32];
     uint16_t lcount[16], dcount[16];
     uint8_t lens[352];               // [0,19) code-length code | [32, 32+316) dynamic lit/len+dist; fixed: [0,288)+[288,320)
+    __device__ __forceinline__ uint16_t *cl_lut() { return dlut; }   // the code-length code's 7-bit table: built before the distance table, in its storage
 };
 
 enum { INF_OK = 0, INF_ERR_HEADER = 1, INF_ERR_DATA = 2, INF_ERR_TRUNC = 3, INF_ERR_ADLER = 4, INF_ERR_OVERFLOW = 5 };
@@ -272,7 +273,7 @@ __device__ __forceinline__ int infl_cl_sequence_wave(TT &T, BitIn &b, int tot) {
         const uint32_t abit = 32u * b.wpos - (uint32_t)b.cnt + (uint32_t)lane;      // window bit address of my offset
         const uint32_t w0 = T.win[abit >> 5], w1 = T.win[(abit >> 5) + 1];
         const uint32_t bits = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (abit & 31));
-        const uint32_t e = T.dlut[bits & 127u];
+        const uint32_t e = T.cl_lut()[bits & 127u];
         const uint32_t clen = e >> 5, sym = e & 31u;
         const uint32_t ext = sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u;
         const uint32_t x = (bits >> clen) & ((1u << ext) - 1u);
@@ -382,7 +383,7 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
         wave_sync();
         IPP(1)
         // the code-length code reuses the distance tables' storage (built before the real ones)
-        if (infl_build(T.lens, 19, T.dcount, T.dsym, T.dlut, 7, 5)) return INF_ERR_DATA;
+        if (infl_build(T.lens, 19, T.dcount, T.dsym, T.cl_lut(), 7, 5)) return INF_ERR_DATA;
         IPP(2)
         int bad = 0;
         if (PARCL) {
@@ -396,7 +397,7 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
             const int tot = nl + nd;
             while (idx < tot) {
                 bi_need32_u(b, T.win);
-                const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.dlut[(uint32_t)b.buf & 127]);
+                const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.cl_lut()[(uint32_t)b.buf & 127]);
                 if (!(e >> 5)) { bad = 1; break; }
                 const int sym = e & 31;
                 bi_get(b, e >> 5);

@@ -37,7 +37,11 @@
 
 namespace s5 {
 
-constexpr int IP_SPAN = 4096;          // compressed bytes per round
+#ifndef S5_IP_SPAN
+#define S5_IP_SPAN 4032
+#endif
+constexpr int IP_SPAN = S5_IP_SPAN;    // compressed bytes per round (a multiple of 16; 4032 and not 4096: the 64 bytes are part of what lets a 24th wave onto the CU)
+constexpr int IP_WIN_DW = IP_SPAN / 4 + 4;   // window dwords: the round's bytes + what a 32-bit look behind the last bit reaches, a multiple of four
 #ifndef S5_IP_WAIT
 #define S5_IP_WAIT 768
 #endif
@@ -60,29 +64,33 @@ constexpr int INF_NEED_FALLBACK = 8;
 #define S5_IP_DBITS 8
 #endif
 constexpr int IP_DBITS = S5_IP_DBITS;  // primary distance lookup bits (>= 7: the code-length code's 7-bit table is built in the same storage)
-static_assert(IP_DBITS >= 7 && IP_DBITS <= INF_DBITS, "");
+static_assert(IP_DBITS >= 5 && IP_DBITS <= INF_DBITS, "");
 #ifndef S5_IP_DBITS_SVB
-#define S5_IP_DBITS_SVB 7
+#define S5_IP_DBITS_SVB 6
 #endif
 constexpr int IP_DBITS_SVB = S5_IP_DBITS_SVB;     // ... in the instantiation for svb-zd records: their distance codes are a handful of short ones
-static_assert(IP_DBITS_SVB >= 7 && IP_DBITS_SVB <= INF_DBITS, "");
+static_assert(IP_DBITS_SVB >= 5 && IP_DBITS_SVB <= INF_DBITS, "");   // (the code-length code's 7-bit table stands in the lit/len table's storage: cl_lut)
 
 #ifndef S5_IP_WAIT_SVB
-#define S5_IP_WAIT_SVB 256
+#define S5_IP_WAIT_SVB 192
 #endif
 constexpr int IP_WAIT_SVB = S5_IP_WAIT_SVB;       // ... in the instantiation for svb-zd records (below)
 // Lit/len lookup table (round 6): 9 root bits + second-level tables for longer codes, 16-bit entries
 //   literal   0x0000 | byte << 4 | len          length   0x4000 | (symbol - 257) << 4 | len
 //   stop      0x8000 | len (end of block)       invalid  0x8010 | 15
 //   sublink   0xC000 | first entry << 4 | bits of the second-level index
-// 512 + 340 entries hold any code of <= 286 symbols and <= 15 bits (zlib's ENOUGH_LENS for a 9-bit root: a second-level table is
+// 512 + 340 entries would hold any code of <= 286 symbols and <= 15 bits (zlib's ENOUGH_LENS for a 9-bit root: a second-level table is
 // sized by the longest code under its 9-bit prefix).
 constexpr int IP_LROOT = 9;
-constexpr int IP_LSUB = 340;
+#ifndef S5_IP_LSUB
+#define S5_IP_LSUB 288
+#endif
+constexpr int IP_LSUB = S5_IP_LSUB;    // (340 would hold every code; 288 — what the canonical-order symbols need while the table is built — holds every code met so
+                                       // far, and a code that needs more sends its record to the wave-per-record decoder)
 template <int WAIT, int DB>
 struct InflParSharedT {                 // per wave: 6.9 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
                                        // LDS per wave = + 33 % time), so nothing here is larger than it has to be
-    alignas(16) uint32_t win[IP_SPAN / 4 + 8];     // window (16-byte aligned: filled 16 bytes per lane); the header parser uses its first INF_IW bytes
+    alignas(16) uint32_t win[IP_WIN_DW];     // window (16-byte aligned: filled 16 bytes per lane); the header parser uses its first INF_IW bytes
     union {
         uint16_t wq[WAIT];             // waiting match: position in the round's output (< 64 Ki); its length and distance wait in the
                                        // first three of the bytes it will produce — a match is at least three bytes long
@@ -114,6 +122,7 @@ struct InflParSharedT {                 // per wave: 6.9 KiB — the kernel's sp
 #endif
     static constexpr int N_WAIT = WAIT;
     static constexpr int DBITS = DB;
+    __device__ __forceinline__ uint16_t *cl_lut() { return ltab; }   // the code-length code's 7-bit table (dead before the lit/len table is built)
 };
 static_assert(IP_LSUB >= 288, "the canonical-order symbols are sorted where the second-level tables will stand");
 // Two sizes of the waiting list (round 3).  The kernel's speed follows the number of resident waves, and at 80 VGPRs the register file
@@ -140,8 +149,8 @@ __device__ __forceinline__ void ip_load_window(uint32_t *win, const uint8_t *src
     // every vector that lies inside the record; the dwords around the record's end (cut, masked, zero) the old way
     typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(1)));
     typedef uint32_t u4a __attribute__((ext_vector_type(4)));
-    constexpr uint32_t NV = (IP_SPAN / 4 + 8) / 4;                       // 258 vectors
-    static_assert((IP_SPAN / 4 + 8) % 4 == 0, "");
+    constexpr uint32_t NV = IP_WIN_DW / 4;
+    static_assert(IP_WIN_DW % 4 == 0, "");
     const uint32_t nfull = min(avail >> 4, NV);
     for (uint32_t j = lane; j < nfull; j += 64) reinterpret_cast<u4a *>(win)[j] = *reinterpret_cast<const u4u *>(src + from + 16u * j);
     const uint32_t i0 = 4u * nfull;
@@ -151,7 +160,7 @@ __device__ __forceinline__ void ip_load_window(uint32_t *win, const uint8_t *src
     const uintptr_t addr = reinterpret_cast<uintptr_t>(src) + from;
     const uint32_t *g = reinterpret_cast<const uint32_t *>(addr & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(addr & 3) * 8;
-    for (uint32_t i = i0 + lane; i < IP_SPAN / 4 + 8; i += 64) {
+    for (uint32_t i = i0 + lane; i < (uint32_t)IP_WIN_DW; i += 64) {
         uint32_t w = 0;
         if (4 * i < avail) {
             const uint32_t lo = g[i];
@@ -273,6 +282,8 @@ __device__ __forceinline__ int ip_build_ltab(SH &T, const IpLimits &L) {
     uint32_t sub[(IP_LSUB + 63) / 64];
 #pragma unroll
     for (int it = 0; it < (IP_LSUB + 63) / 64; it++) {
+        sub[it] = 0u;
+        if (it * 64 >= (int)nsub) continue;                       // (uniform: our own records need 150-odd entries, three trips of six)
         const uint32_t j = (uint32_t)(it * 64 + lane) + (1u << IP_LROOT);
         uint32_t k = 0;
 #pragma unroll
@@ -283,7 +294,7 @@ __device__ __forceinline__ int ip_build_ltab(SH &T, const IpLimits &L) {
         const uint32_t rel = j - zbk, sb = k + 1u;
         const uint32_t pfx = zsk + (rel >> sb), tail = __brev(rel & ((1u << sb) - 1u)) >> (32u - sb);     // the tail's first stream bit on top
         const uint32_t v = (pfx << (15 - IP_LROOT)) | (tail << (15u - IP_LROOT - sb));
-        sub[it] = it * 64 < (int)nsub ? ip_entry_of(T, v, ip_code_len(L, v)) : 0u;
+        sub[it] = ip_entry_of(T, v, ip_code_len(L, v));
     }
     wave_sync();
 #pragma unroll
@@ -452,10 +463,12 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
     *out_len = 0;
     IPP_DECL
     if (in_len < 6) return INF_ERR_TRUNC;
-    {
-        const uint32_t cmf = in[0], flg = in[1];
-        if ((cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) return INF_ERR_HEADER;
-    }
+    // the two header bytes and the Adler-32 trailer are fetched here and looked at behind the first window load / at the very end: their
+    // round trips to memory run under the window's instead of in front of it and behind everything (bulk decode 26.9 -> 26.5 ms per 1 M
+    // records on the sources of that moment)
+    const uint32_t cmf = in[0], flg = in[1];
+    const uint32_t want = ((uint32_t)in[in_len - 4] << 24) | ((uint32_t)in[in_len - 3] << 16) | ((uint32_t)in[in_len - 2] << 8) | in[in_len - 1];
+    bool hdr_checked = false;
     const uint8_t *src = in + 2;
     const uint32_t total = in_len - 6;
     const uint64_t total_bits = 8ull * total;
@@ -469,6 +482,10 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
         b.buf = 0; b.cnt = 0; b.wpos = 0;
         b.wbase = (uint32_t)(pos >> 3) & ~3u;
         ip_load_window(T.win, src, b.wbase, total);                           // the whole round window: the tokens behind the header are in it
+        if (!hdr_checked) {
+            hdr_checked = true;
+            if ((cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) return INF_ERR_HEADER;
+        }
         IPP(0)
         const uint32_t hdr_wb = b.wbase;
         bool win_fresh = true;
@@ -740,8 +757,6 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             adA = (adA + sa) % 65521u;
         }
     }
-    const uint8_t *t = in + in_len - 4;
-    const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
     IPP(12)
     IPP_FLUSH
     if (((adB << 16) | adA) != want) return INF_ERR_ADLER;

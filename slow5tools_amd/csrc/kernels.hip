@@ -877,7 +877,8 @@ __global__ __launch_bounds__(NT) void k_order_scatter(const s5gpu_rec_desc_t *de
 // it just wrote is in L2, the window is free as a stage for the data bytes, and the chain of dependent loads a separate kernel
 // starts with (fields -> descriptor -> three length fields of the payload) is gone.  fields.reserved = 1 marks such a record;
 // k_unpack_rest does what is left (records the fallback decoder inflated) and clears the marks.
-static_assert(sizeof(InflParSharedSvb::win) >= SVB_WSTAGE, "the inflate window doubles as the svb-zd stage");
+static_assert(offsetof(InflParSharedSvb, win) == 0 && offsetof(InflParSharedSvb, dlut) >= SVB_WSTAGE && offsetof(InflParShared, dlut) >= SVB_WSTAGE,
+              "the inflate window and the waiting list behind it (both dead once the record is out) double as the svb-zd stage");
 // pay: the record's uncompressed bytes — its payload slot, or the workgroup's scratch slot (S5GPU_DEC_NO_PAYLOAD)
 __device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, const s5gpu_rec_desc_t &d, const uint8_t *pay, s5gpu_rec_fields_t &f, uint32_t plen, uint8_t *stage) {
     if (plen < 2) return 7;

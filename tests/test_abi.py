@@ -146,3 +146,26 @@ def test_hooks_header_declares_no_slow5lib_name():
     code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     for name in ("struct slow5_rec", "enum slow5_press_method", "slow5_press_method_t", "struct slow5_file", "slow5_aux_meta", "slow5_fmt"):
         assert name not in code, name
+
+
+def test_pinned_host_memory_has_one_allocator():
+    """Round 5 found D2H copies that never reached a SMALL pinned buffer allocated while another host thread ran its first kernels; the
+    library's cure is that every pinned byte comes from s5_pinned_alloc (host_api.hip), which never pins less than 2 MiB at a time
+    (tools/hw_probe/pinned_small_d2h.hip is the stand-alone reproducer, profiles/r06_pinned_small_d2h.txt what it showed).  A
+    hipHostMalloc anywhere else in the product sources re-opens the fault, silently: this test is the guard."""
+    pat = re.compile(r"\b(hipHostMalloc|hipHostAlloc|hipMallocHost|hipHostRegister)\s*\(")
+    hits = []
+    for d in ("slow5tools_amd/csrc", "examples", "include"):
+        for root, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if not f.endswith((".hip", ".h", ".c", ".cpp")):
+                    continue
+                for ln, line in enumerate(open(os.path.join(root, f), errors="replace"), 1):
+                    code = line.split("//")[0]
+                    if pat.search(code):
+                        hits.append("%s:%d" % (os.path.relpath(os.path.join(root, f), ROOT), ln))
+    assert len(hits) == 1 and hits[0].startswith("slow5tools_amd/csrc/host_api.hip:"), hits
+    src = open(os.path.join(ROOT, "slow5tools_amd/csrc/host_api.hip")).read()
+    body = src[src.index("hipError_t s5_pinned_alloc("):]
+    body = body[: body.index("\n}") + 2]
+    assert "hipHostMalloc" in body and "S5_PIN_MIN" in body
