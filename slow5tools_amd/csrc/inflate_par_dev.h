@@ -38,9 +38,9 @@
 namespace s5 {
 
 #ifndef S5_IP_SPAN
-#define S5_IP_SPAN 4032
+#define S5_IP_SPAN 4096
 #endif
-constexpr int IP_SPAN = S5_IP_SPAN;    // compressed bytes per round (a multiple of 16; 4032 and not 4096: the 64 bytes are part of what lets a 24th wave onto the CU)
+constexpr int IP_SPAN = S5_IP_SPAN;    // compressed bytes per round (a multiple of 16)
 constexpr int IP_WIN_DW = IP_SPAN / 4 + 4;   // window dwords: the round's bytes + what a 32-bit look behind the last bit reaches, a multiple of four
 #ifndef S5_IP_WAIT
 #define S5_IP_WAIT 768
@@ -66,27 +66,29 @@ constexpr int INF_NEED_FALLBACK = 8;
 constexpr int IP_DBITS = S5_IP_DBITS;  // primary distance lookup bits (>= 7: the code-length code's 7-bit table is built in the same storage)
 static_assert(IP_DBITS >= 5 && IP_DBITS <= INF_DBITS, "");
 #ifndef S5_IP_DBITS_SVB
-#define S5_IP_DBITS_SVB 6
+#define S5_IP_DBITS_SVB 7
 #endif
 constexpr int IP_DBITS_SVB = S5_IP_DBITS_SVB;     // ... in the instantiation for svb-zd records: their distance codes are a handful of short ones
 static_assert(IP_DBITS_SVB >= 5 && IP_DBITS_SVB <= INF_DBITS, "");   // (the code-length code's 7-bit table stands in the lit/len table's storage: cl_lut)
 
 #ifndef S5_IP_WAIT_SVB
-#define S5_IP_WAIT_SVB 192
+#define S5_IP_WAIT_SVB 256
 #endif
 constexpr int IP_WAIT_SVB = S5_IP_WAIT_SVB;       // ... in the instantiation for svb-zd records (below)
 // Lit/len lookup table (round 6): 9 root bits + second-level tables for longer codes, 16-bit entries
 //   literal   0x0000 | byte << 4 | len          length   0x4000 | (symbol - 257) << 4 | len
 //   stop      0x8000 | len (end of block)       invalid  0x8010 | 15
 //   sublink   0xC000 | first entry << 4 | bits of the second-level index
-// 512 + 340 entries would hold any code of <= 286 symbols and <= 15 bits (zlib's ENOUGH_LENS for a 9-bit root: a second-level table is
+// 512 + 340 entries hold any code of <= 286 symbols and <= 15 bits (zlib's ENOUGH_LENS for a 9-bit root: a second-level table is
 // sized by the longest code under its 9-bit prefix).
 constexpr int IP_LROOT = 9;
 #ifndef S5_IP_LSUB
-#define S5_IP_LSUB 288
+#define S5_IP_LSUB 340
 #endif
-constexpr int IP_LSUB = S5_IP_LSUB;    // (340 would hold every code; 288 — what the canonical-order symbols need while the table is built — holds every code met so
-                                       // far, and a code that needs more sends its record to the wave-per-record decoder)
+constexpr int IP_LSUB = S5_IP_LSUB;    // (340 holds every code; at least 288: the canonical-order symbols stand there while the table is built.  Round 6 also
+                                       // measured the struct trimmed to 6640 bytes — 4032-byte window, 6-bit distance table, 192 waiting matches, 288 entries here —
+                                       // for a 24th wave per CU: 24.80 against 24.70 ms per 1 M of our own records, 32.4 against 31.9 M stock-zlib records/s.
+                                       // Not worth the narrower limits: profiles/r06_inflate_variants.txt)
 template <int WAIT, int DB>
 struct InflParSharedT {                 // per wave: 6.9 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
                                        // LDS per wave = + 33 % time), so nothing here is larger than it has to be

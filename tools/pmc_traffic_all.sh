@@ -22,6 +22,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   run mixed $c python bench.py --mixed --steps 2 --warmup 1 --cpu-seconds 0
   run dec4k $c python bench.py --decode --decode-batches-only --reads 200000 --cpu-seconds 0
 done
+# instruction issue of the headline encoder and the decoder (one more pass each): vector instructions per read — the ceiling that binds those kernels
+run enc SQ_INSTS_VALU python tools/stream_time.py 400000
+run decnp SQ_INSTS_VALU python tools/decode_bulk.py 1000000 4000 np 3
 python3 - <<PY
 import csv, glob, json, sys, os
 sys.path.insert(0, "$R")
@@ -51,9 +54,17 @@ for name, label, kernels, reads, n in legs:
         fetch = sum(fe.values()); write = sum(wr.values())
         b = (2 * fetch + write) * 1024 / reads
         print("%-26s %8d reads x %6s: FETCH %14.1f KiB  WRITE %14.1f KiB per launch (%s launches) -> %.1f B/read" % (label, reads, n, fetch, write, nf, b))
-        out.append({"kernel": label, "samples_per_read": n, "hbm_bytes_per_read": round(b, 1), "fetch_KiB_per_launch": round(fetch, 1), "write_KiB_per_launch": round(write, 1),
-                    "reads_per_launch": reads, "source": "tools/pmc_traffic_all.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x 2: gfx950 correction)",
-                    "csrc_sha256": sha})
+        ent = {"kernel": label, "samples_per_read": n, "hbm_bytes_per_read": round(b, 1), "fetch_KiB_per_launch": round(fetch, 1), "write_KiB_per_launch": round(write, 1),
+               "reads_per_launch": reads, "source": "tools/pmc_traffic_all.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x 2: gfx950 correction)",
+               "csrc_sha256": sha}
+        if name in ("enc", "decnp"):
+            try:
+                va, nv = per_launch(name, "SQ_INSTS_VALU", kernels)
+                ent["valu_insts_per_read"] = round(sum(va.values()) / reads, 1)      # wave-level vector instructions per read (SQ_INSTS_VALU, its own pass)
+                print("%-26s SQ_INSTS_VALU %.4g per launch -> %.1f per read" % (label, sum(va.values()), ent["valu_insts_per_read"]))
+            except Exception as e:
+                print(label, "SQ_INSTS_VALU failed:", repr(e))
+        out.append(ent)
     except Exception as e:
         print(label, "failed:", repr(e))
 json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
