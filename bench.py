@@ -481,6 +481,7 @@ def decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, want_c
     torch.cuda.synchronize()
     rec_off = b.rec_off.cpu().numpy().astype(np.int64)          # the "index": offset/size per read (Appendix A.5)
     z_total = int(rec_off[n_reads])
+    max_in_len = int(np.diff(rec_off[: n_reads + 1]).max()) - 8
     rng = np.random.default_rng(1)
     ids = rng.integers(0, n_reads, args.get_reads)
     K = args.get_batch
@@ -503,6 +504,7 @@ def decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, want_c
         a.desc, a.in_, a.sig_out, a.fields = desc_t.data_ptr(), in_ptr, sig_t.data_ptr(), fields_t.data_ptr()
         if payload_t is None:
             a.flags, a.payload, a.payload_bytes, a.max_pay_cap = _lib.DEC_NO_PAYLOAD, scratch.data_ptr(), scratch_bytes, pay_cap
+            a.max_in_len = max_in_len      # what the .idx says: the longest record of the file (records of one inflate window stay in LDS: include/slow5gpu.h)
         else:
             a.payload, a.max_pay_cap = payload_t.data_ptr(), pay_cap     # (the hint that the records are short: the kernel's 24-wave shape)
         return a
@@ -669,6 +671,7 @@ def decode_leg(args, L, _lib, shard, ob, b, n_reads, n, rank, world, dev, want_c
             d2["in_off"] = zo[idx]; d2["in_len"] = zl[idx]
             zdesc = torch.from_numpy(d2.view(np.uint8)).to(dev)
             a_z = args_for(nb, zdesc, big_sig, big_fields, zin.data_ptr())
+            a_z.max_in_len = int(zl.max())
             big_sig.zero_()
             ts = bulk_call(a_z, 3, args.min_leg_seconds / 2)
             ms2 = float(np.mean(ts[1:]))

@@ -133,7 +133,11 @@ typedef struct s5gpu_decode_args {
                                       * svb-zd / ex-zd signals runs the inflate kernel in its 24-waves-per-CU shape (a 256-entry list
                                       * of waiting matches); longer or unknown ones in the 21-wave shape with 768 entries, which long
                                       * reads written by stock zlib need in their key bytes */
-    uint32_t reserved;
+    uint32_t max_in_len;             /* largest COMPRESSED record of the batch, bytes (0 = not known; this word was `reserved`: zeroed structs keep
+                                      * their meaning).  S5GPU_DEC_NO_PAYLOAD on zlib + svb-zd records: when every record fits one 4 KiB window
+                                      * of the inflate (max_in_len <= 4000: reads of up to ~4500 samples) the uncompressed record is kept in
+                                      * LDS and never reaches HBM (round 6: k_inflate_par_np_lp; a record whose payload outgrows the 5.3 KiB
+                                      * of LDS after all is redone by the slot decoder).  A hint: any value is safe */
 } s5gpu_decode_args_t;
 /* scratch worth bringing for S5GPU_DEC_NO_PAYLOAD (one slot per workgroup the device can hold + the fallback decoder's);
  * anything from 64 + 2 * (max_pay_cap + 32) bytes up works, less only means fewer workgroups */

@@ -39,7 +39,7 @@ DEC_NO_PAYLOAD = 1
 class DecodeArgs(C.Structure):
     _fields_ = [("n_recs", C.c_uint32), ("rec_method", C.c_int32), ("sig_method", C.c_int32), ("flags", C.c_uint32),
                 ("desc", C.c_void_p), ("in_", C.c_void_p), ("payload", C.c_void_p), ("sig_out", C.c_void_p),
-                ("fields", C.c_void_p), ("payload_bytes", C.c_uint64), ("max_pay_cap", C.c_uint32), ("reserved", C.c_uint32)]
+                ("fields", C.c_void_p), ("payload_bytes", C.c_uint64), ("max_pay_cap", C.c_uint32), ("max_in_len", C.c_uint32)]
 
 
 assert C.sizeof(DecodeArgs) == 72

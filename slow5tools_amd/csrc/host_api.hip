@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/slow5gpu.h"
+#include <deque>
 #include "host_ctx.h"
 
 static thread_local char g_err[512] = "";
@@ -139,6 +140,21 @@ hipError_t s5_pinned_free(void *p) {
     return hipHostFree(p);
 }
 
+// Batches that are in flight TOGETHER (two tickets of s5gpu_*_batch_submit, the two halves of a big batch, several host threads) fall into
+// step if nothing keeps them apart: both pack at once (twice the threads on the same memory), both upload at once (half the link each),
+// both download at once — and nothing overlaps (round 6, tools/hook_trace.py: K = 4096, two in flight, 1.68 ms per batch against 1.70
+// alone).  So the two phases that share a resource take TURNS: packing into pinned staging (the host's memory system), and the upload
+// (the link's host-to-device direction), which is held until the copies have LANDED — an event behind them, waited for before the turn is
+// given up.  The batch behind then packs while this one uploads and uploads while this one computes and downloads.
+static std::mutex g_pack_turn;
+static std::mutex g_upload_turn[64];
+static int upload_landed(Ctx *c) {
+    if (!c->ev_up) HIP_TRY(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_up, c->st));
+    HIP_TRY(hipEventSynchronize(c->ev_up));
+    return S5GPU_OK;
+}
+
 int s5host::CtxHold::acquire(int want_slot) {
     if (s5host::n_devices() == 0) return S5GPU_ERR_NODEV;
     DevState *D;
@@ -153,6 +169,7 @@ int s5host::CtxHold::acquire(int want_slot) {
             want = want < 1 ? 1 : want > MAX_CTX ? MAX_CTX : want;
             for (int i = 0; i < want; i++) {
                 Ctx *c = new Ctx();
+                c->slot = want_slot;
                 if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) {
                     delete c;
                     s5gpu_set_error("hipStreamCreate failed");
@@ -206,7 +223,9 @@ using s5host::encode_and_collect;
 void s5kern_release_aux();   // kernels.hip
 void s5kern_release_order();
 
+void s5host_stop_ticket_workers();
 extern "C" void s5gpu_shutdown(void) {
+    s5host_stop_ticket_workers();
     std::lock_guard<std::mutex> lk(g_mu);
     for (int d = 0; d < g_ndev; d++) {
         DevState &D = g_dev[d];
@@ -218,6 +237,7 @@ extern "C" void s5gpu_shutdown(void) {
                 Buf *bs[] = {&c->d_sig, &c->d_hdr, &c->d_aux, &c->d_desc, &c->d_slots, &c->d_len, &c->d_ovf, &c->d_in, &c->d_pay, &c->d_fields,
                              &c->d_stream, &c->d_scan, &c->d_sig2, &c->d_desc2, &c->d_patch, &c->d_txt, &c->d_tdesc, &c->d_gather, &c->h_in, &c->h_out};
                 for (Buf *b : bs) b->release();
+                if (c->ev_up) (void)hipEventDestroy(c->ev_up);
                 if (c->st) (void)hipStreamDestroy(c->st);
             }
             delete c;
@@ -277,6 +297,7 @@ int s5host::encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_r
         HIP_TRY(hipMemcpyAsync(h, d_off, 8ull * (n + 1), hipMemcpyDeviceToHost, c->st));
         HIP_TRY(hipMemcpyAsync(h + 8ull * (n + 1), d_ctl, 16, hipMemcpyDeviceToHost, c->st));
         HIP_TRY(hipStreamSynchronize(c->st));
+        s5_trace("encode_stream_resident: uploads + kernel done, offsets back");
         const uint32_t *ctl = (const uint32_t *)(h + 8ull * (n + 1));
         if (ctl[0] == 0 && ctl[2] == 0) {
             memcpy(off.data(), h, 8ull * (n + 1));
@@ -405,6 +426,7 @@ int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_
         ar->add(buf, cap);                                  // (from here on the arena owns it, whatever happens)
         HIP_TRY(hipMemcpyAsync(buf, c->d_stream.p, produced, hipMemcpyDeviceToHost, c->st));
         HIP_TRY(hipStreamSynchronize(c->st));
+        s5_trace("encode_and_collect: records back in the arena buffer");
         for (uint32_t i = 0; i < n; i++) { out[i] = buf + off[i]; out_len[i] = (size_t)(off[i + 1] - off[i]); }
         return S5GPU_OK;
     }
@@ -518,6 +540,7 @@ static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, con
     int rc = hold.acquire(slot);
     if (rc) return rc;
     Ctx *c = hold.c;
+    s5_trace("encode_batch: context held");
     std::vector<s5gpu_read_desc_t> desc(n);
     uint64_t so = 0, ho = 0, ao = 0, oo = 0;
     uint32_t max_payload = 0;
@@ -542,22 +565,32 @@ static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, con
     if ((rc = c->h_in.reserve(in_bytes)) || (rc = c->d_sig.reserve(sig_bytes)) || (rc = c->d_hdr.reserve(ho + 64)) ||
         (rc = c->d_aux.reserve(ao + 64)) || (rc = c->d_desc.reserve(sizeof(s5gpu_read_desc_t) * n)))
         return rc;
+    s5_trace("encode_batch: descriptors made, workspaces reserved");
     // pack into pinned staging
     uint8_t *hs = (uint8_t *)c->h_in.p;
     uint8_t *hh = hs + up(sig_bytes, 64), *ha = hh + up(ho + 64, 64), *hd = ha + up(ao + 64, 64);
-    parallel_for(n, (uint64_t)so * 2, [&](uint32_t lo, uint32_t hi) {
-        for (uint32_t i = lo; i < hi; i++) {
-            const s5gpu_read_desc_t &d = desc[i];
-            if (d.n_samples) memcpy(hs + 2 * d.sig_off, sig[i], 2ull * d.n_samples);
-            memcpy(hh + d.hdr_off, hdr[i], d.hdr_len);
-            if (d.aux_len) memcpy(ha + d.aux_off, aux[i], d.aux_len);
-        }
-    });
-    memcpy(hd, desc.data(), sizeof(s5gpu_read_desc_t) * n);
-    HIP_TRY(hipMemcpyAsync(c->d_sig.p, hs, (size_t)so * 2, hipMemcpyHostToDevice, c->st));
-    HIP_TRY(hipMemcpyAsync(c->d_hdr.p, hh, ho, hipMemcpyHostToDevice, c->st));
-    if (ao) HIP_TRY(hipMemcpyAsync(c->d_aux.p, ha, ao, hipMemcpyHostToDevice, c->st));
-    HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_read_desc_t) * n, hipMemcpyHostToDevice, c->st));
+    {
+        std::lock_guard<std::mutex> turn(g_pack_turn);
+        parallel_for(n, (uint64_t)so * 2, [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t i = lo; i < hi; i++) {
+                const s5gpu_read_desc_t &d = desc[i];
+                if (d.n_samples) memcpy(hs + 2 * d.sig_off, sig[i], 2ull * d.n_samples);
+                memcpy(hh + d.hdr_off, hdr[i], d.hdr_len);
+                if (d.aux_len) memcpy(ha + d.aux_off, aux[i], d.aux_len);
+            }
+        });
+        memcpy(hd, desc.data(), sizeof(s5gpu_read_desc_t) * n);
+    }
+    s5_trace("encode_batch: packed into pinned staging");
+    {
+        std::lock_guard<std::mutex> turn(g_upload_turn[c->slot & 63]);
+        HIP_TRY(hipMemcpyAsync(c->d_sig.p, hs, (size_t)so * 2, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->d_hdr.p, hh, ho, hipMemcpyHostToDevice, c->st));
+        if (ao) HIP_TRY(hipMemcpyAsync(c->d_aux.p, ha, ao, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_read_desc_t) * n, hipMemcpyHostToDevice, c->st));
+        if ((rc = upload_landed(c))) return rc;
+    }
+    s5_trace("encode_batch: uploads landed");
     s5gpu_encode_args_t a;
     memset(&a, 0, sizeof a);
     a.n_reads = n; a.rec_method = rec_method; a.sig_method = sig_method;
@@ -906,14 +939,20 @@ static int decode_resident_impl(Ctx *c, uint32_t n, const void *const *rec, cons
             return rc;
         s5_trace("decode_resident: workspaces reserved");
         uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + (framed ? 0 : up(io + 64, 64));
-        if (!framed)
+        if (!framed) {
+            std::lock_guard<std::mutex> turn(g_pack_turn);
             parallel_for(n, io, [&](uint32_t lo, uint32_t hi_) {
                 for (uint32_t i = lo; i < hi_; i++) memcpy(hi + rd[i].in_off, rec[i], rec_len[i]);
             });
+        }
         memcpy(hd, rd.data(), sizeof(s5gpu_rec_desc_t) * n);
-        if (!framed || attempt == 0)   // a framed chunk is already on the device when overflowing records are redone
-            HIP_TRY(hipMemcpyAsync(c->d_in.p, framed ? framed->base : hi, io, hipMemcpyHostToDevice, c->st));
-        HIP_TRY(hipMemcpyAsync(c->d_desc2.p, hd, sizeof(s5gpu_rec_desc_t) * n, hipMemcpyHostToDevice, c->st));
+        {
+            std::lock_guard<std::mutex> turn(g_upload_turn[c->slot & 63]);
+            if (!framed || attempt == 0)   // a framed chunk is already on the device when overflowing records are redone
+                HIP_TRY(hipMemcpyAsync(c->d_in.p, framed ? framed->base : hi, io, hipMemcpyHostToDevice, c->st));
+            HIP_TRY(hipMemcpyAsync(c->d_desc2.p, hd, sizeof(s5gpu_rec_desc_t) * n, hipMemcpyHostToDevice, c->st));
+            if (io >= (4u << 20)) { if ((rc = upload_landed(c))) return rc; }     // (small uploads: not worth a wait)
+        }
         HIP_TRY(hipMemsetAsync(c->d_fields.p, 0, sizeof(s5gpu_rec_fields_t) * n, c->st));
         s5gpu_decode_args_t da;
         memset(&da, 0, sizeof da);
@@ -992,53 +1031,99 @@ extern "C" int s5gpu_recompress_batch_arena(uint32_t n, const void *const *rec, 
 // finds it.
 namespace {
 struct BatchTicket {
-    std::thread th;
+    std::function<int(void **)> work;     // runs the batch call; the void ** is where an arena goes (nullptr: malloc form)
+    bool want_arena = false, done = false;
     int rc = S5GPU_OK;
     std::string err;
     void *arena = nullptr;
 };
+// The submitted batches run on a few long-lived threads (as many as there can be contexts to take): a thread's first HIP call sets up the
+// runtime's per-thread state, which a thread per ticket would pay for every batch.
+struct TicketWorkers {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<BatchTicket *> q;
+    std::vector<std::thread> th;
+    bool stop = false;
+    size_t idle = 0;                      // workers waiting for a ticket
+    void run() {
+        for (;;) {
+            BatchTicket *t;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                idle++;
+                cv_work.wait(lk, [&] { return stop || !q.empty(); });
+                idle--;
+                if (q.empty()) return;
+                t = q.front();
+                q.pop_front();
+            }
+            t->rc = t->work(t->want_arena ? &t->arena : nullptr);
+            if (t->rc != S5GPU_OK) t->err = s5gpu_last_error();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                t->done = true;
+            }
+            cv_done.notify_all();
+        }
+    }
+    bool submit(BatchTicket *t) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (stop) return false;
+        if (th.size() < 4 && idle <= q.size()) {           // one more worker when none is free to take this ticket (four at most: the contexts)
+            try { th.emplace_back([this] { run(); }); } catch (...) { if (th.empty()) return false; }
+        }
+        q.push_back(t);
+        cv_work.notify_one();
+        return true;
+    }
+    void wait(BatchTicket *t) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return t->done; });
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : th) if (t.joinable()) t.join();     // (queued tickets are run to the end first: run() only returns on an empty queue)
+        std::lock_guard<std::mutex> lk(mu);
+        th.clear();
+        stop = false;
+    }
+};
+TicketWorkers g_tickets;
+void *submit_ticket(std::function<int(void **)> work, int want_arena, const char *who) {
+    BatchTicket *t = new (std::nothrow) BatchTicket();
+    if (!t) { s5gpu_set_error("%s: out of memory", who); return nullptr; }
+    t->work = std::move(work);
+    t->want_arena = want_arena != 0;
+    if (!g_tickets.submit(t)) { delete t; s5gpu_set_error("%s: no thread for the batch", who); return nullptr; }
+    return t;
+}
 }  // namespace
+void s5host_stop_ticket_workers() { g_tickets.shutdown(); }      // s5gpu_shutdown: every submitted batch is through before the contexts go
 extern "C" void *s5gpu_recompress_batch_submit(uint32_t n, const void *const *rec, const size_t *rec_len, int from_rec, int from_sig, int to_rec,
                                                int to_sig, const uint32_t *new_read_group, int drop_aux, void **out, size_t *out_len,
                                                int32_t *status, int want_arena) {
-    BatchTicket *t = new (std::nothrow) BatchTicket();
-    if (!t) { s5gpu_set_error("s5gpu_recompress_batch_submit: out of memory"); return nullptr; }
-    try {
-        t->th = std::thread([=]() {
-            t->rc = recompress_batch_any(n, rec, rec_len, from_rec, from_sig, to_rec, to_sig, new_read_group, drop_aux, out, out_len, status,
-                                         want_arena ? &t->arena : nullptr);
-            if (t->rc != S5GPU_OK) t->err = s5gpu_last_error();
-        });
-    } catch (...) {
-        delete t;
-        s5gpu_set_error("s5gpu_recompress_batch_submit: no thread for the batch");
-        return nullptr;
-    }
-    return t;
+    return submit_ticket([=](void **arena) {
+        return recompress_batch_any(n, rec, rec_len, from_rec, from_sig, to_rec, to_sig, new_read_group, drop_aux, out, out_len, status, arena);
+    }, want_arena, "s5gpu_recompress_batch_submit");
 }
 extern "C" void *s5gpu_encode_batch_submit(uint32_t n, const int16_t *const *sig, const uint64_t *n_samples, const void *const *hdr,
                                            const uint32_t *hdr_len, const void *const *aux, const uint32_t *aux_len, int rec_method,
                                            int sig_method, void **out, size_t *out_len, int want_arena) {
-    BatchTicket *t = new (std::nothrow) BatchTicket();
-    if (!t) { s5gpu_set_error("s5gpu_encode_batch_submit: out of memory"); return nullptr; }
-    try {
-        t->th = std::thread([=]() {
-            t->rc = want_arena ? s5gpu_encode_batch_arena(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len, &t->arena)
-                               : s5gpu_encode_batch(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
-            if (t->rc != S5GPU_OK) t->err = s5gpu_last_error();
-        });
-    } catch (...) {
-        delete t;
-        s5gpu_set_error("s5gpu_encode_batch_submit: no thread for the batch");
-        return nullptr;
-    }
-    return t;
+    return submit_ticket([=](void **arena) {
+        return arena ? s5gpu_encode_batch_arena(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len, arena)
+                     : s5gpu_encode_batch(n, sig, n_samples, hdr, hdr_len, aux, aux_len, rec_method, sig_method, out, out_len);
+    }, want_arena, "s5gpu_encode_batch_submit");
 }
 extern "C" int s5gpu_batch_wait(void *ticket, void **arena) {
     if (arena) *arena = nullptr;
     if (!ticket) { s5gpu_set_error("s5gpu_batch_wait: NULL ticket"); return S5GPU_ERR_ARG; }
     BatchTicket *t = static_cast<BatchTicket *>(ticket);
-    if (t->th.joinable()) t->th.join();
+    g_tickets.wait(t);
     const int rc = t->rc;
     if (rc != S5GPU_OK) s5gpu_set_error("%s", t->err.c_str());
     if (arena) *arena = t->arena;

@@ -62,6 +62,8 @@ struct Ctx {
     Buf d_txt, d_tdesc, d_gather;   // SLOW5 ASCII path (ascii_api.hip)
     Buf h_in, h_out;   // pinned staging
     hipStream_t st = nullptr;
+    hipEvent_t ev_up = nullptr;   // "this context's uploads have landed" (upload_landed, host_api.hip); made on first use
+    int slot = 0;                 // the device slot this context belongs to
     std::mutex mu;      // held by the batch call that owns this context
     Ctx() { h_in.pinned = true; h_out.pinned = true; }
 };

@@ -7,8 +7,9 @@
 // falls into step with the true code boundaries after a few codes (self-synchronisation), and that is all the parallelism
 // this decoder needs:
 //   window   up to 4 KiB of the compressed stream in LDS, cut into 64 segments of equal bit length (>= 384 bits: a lane needs a
-//            few dozen codes to fall into step), one per lane; ONE set of tables for the whole wave.  No lookup table for
-//            lit/len codes: 15 packed compares against the canonical limits (IpLimits) — every lane the same route;
+//            few dozen codes to fall into step), one per lane; ONE set of tables for the whole wave.  Lit/len codes through a
+//            two-level lookup table (round 6: 9 root bits, 852 entries, built by resolving every prefix ONCE with the 15 packed
+//            compares against the canonical limits that rounds 2-5 ran for every token) — every lane the same two reads;
 //   sync     every lane decodes the tokens that start in its segment — literal, end of block, or length + distance with
 //            their extra bits — and reports where its last token ends; that is where the next lane's segment REALLY
 //            starts.  The first pass walks only the tail of every segment (a first guess of every start), the second the whole
@@ -17,8 +18,8 @@
 //   count    the same pass counts the bytes each lane's tokens produce and the matches that will have to WAIT (source in another
 //            lane's output, or behind a match that waits itself): prefix sums give every lane its output offset and its place in
 //            the round's one list of waiting matches, in stream order;
-//   output   one more pass writes the bytes straight to HBM.  A run of a byte the lane knows goes on a list and the wave fills all
-//            runs at once afterwards; a match whose whole source the lane has written itself is copied on the spot; a waiting
+//   output   one more pass writes the bytes straight to HBM, a lane's literals four at a time as one dword store (round 6).  A run of
+//            a byte the lane knows goes on a list and the wave fills all runs at once afterwards; a match whose whole source the lane has written itself is copied on the spot; a waiting
 //            match leaves its position (16 bits) on the list and parks its length and distance in the first three bytes it will
 //            produce;
 //   waiting  64 at a time, each copied by ITS lane as soon as nothing it reads is still to come: destinations are ascending and
@@ -89,10 +90,13 @@ constexpr int IP_LSUB = S5_IP_LSUB;    // (340 holds every code; at least 288: t
                                        // measured the struct trimmed to 6640 bytes — 4032-byte window, 6-bit distance table, 192 waiting matches, 288 entries here —
                                        // for a 24th wave per CU: 24.80 against 24.70 ms per 1 M of our own records, 32.4 against 31.9 M stock-zlib records/s.
                                        // Not worth the narrower limits: profiles/r06_inflate_variants.txt)
-template <int WAIT, int DB>
+// PAYB > 0 (round 6, the no-payload decode of short records): the window's storage also takes the UNCOMPRESSED record — PAYB bytes, written
+// by the output pass, which then reads the compressed bits out of global memory (L2) instead: the record never leaves the CU
+// (zlib_inflate_par<.., LDSOUT>).
+template <int WAIT, int DB, int PAYB = 0>
 struct InflParSharedT {                 // per wave: 6.9 KiB — the kernel's speed follows the number of resident waves (measured: + 4 KiB of
                                        // LDS per wave = + 33 % time), so nothing here is larger than it has to be
-    alignas(16) uint32_t win[IP_WIN_DW];     // window (16-byte aligned: filled 16 bytes per lane); the header parser uses its first INF_IW bytes
+    alignas(16) uint32_t win[PAYB / 4 > IP_WIN_DW ? PAYB / 4 : IP_WIN_DW];     // window (16-byte aligned: filled 16 bytes per lane); the header parser uses its first INF_IW bytes
     union {
         uint16_t wq[WAIT];             // waiting match: position in the round's output (< 64 Ki); its length and distance wait in the
                                        // first three of the bytes it will produce — a match is at least three bytes long
@@ -124,6 +128,7 @@ struct InflParSharedT {                 // per wave: 6.9 KiB — the kernel's sp
 #endif
     static constexpr int N_WAIT = WAIT;
     static constexpr int DBITS = DB;
+    static constexpr uint32_t LDS_PAY = PAYB;
     __device__ __forceinline__ uint16_t *cl_lut() { return ltab; }   // the code-length code's 7-bit table (dead before the lit/len table is built)
 };
 static_assert(IP_LSUB >= 288, "the canonical-order symbols are sorted where the second-level tables will stand");
@@ -135,6 +140,13 @@ static_assert(IP_LSUB >= 288, "the canonical-order symbols are sorted where the 
 // the signal press, so svb-zd records get the small list; inflate-only calls and raw-signal records keep the large one.
 using InflParShared = InflParSharedT<IP_WAIT, IP_DBITS>;
 using InflParSharedSvb = InflParSharedT<IP_WAIT_SVB, IP_DBITS_SVB>;
+#ifndef S5_IP_LDS_PAY
+#define S5_IP_LDS_PAY 5360         // (8192 bytes of LDS per wave with the tables and a waiting list of 192: 20 waves per CU, five per SIMD — a byte more and
+                                   // the compiler plans for four, 16 per CU, which costs 14 %: profiles/r06_inflate_variants.txt)
+#endif
+using InflParSharedLp = InflParSharedT<192, IP_DBITS_SVB, S5_IP_LDS_PAY>;
+static_assert(sizeof(InflParSharedLp) <= 8192, "");
+static_assert(S5_IP_LDS_PAY % 16 == 0, "");
 static_assert(INF_IW <= IP_SPAN, "the header parser's window is the head of the round window");
 
 // 32 bits of the window starting at bit p (two aligned dwords + one alignbit)
@@ -184,18 +196,19 @@ struct IpSeg {            // what a lane learns about its segment
     uint32_t bad;         // 1: an invalid code (meaningless unless the segment was decoded from a real boundary)
     uint32_t nwait;       // matches that have to wait (source in another lane's output, or behind a match that waits itself); up to the end-of-block code
 };
-// The lit/len code is resolved WITHOUT a lookup table: with 64 lanes at 64 different places of the stream, some lane of the wave
-// meets a code longer than any affordable table in almost every step, and the wave then runs the slow path anyway.  So every
-// lane takes the same route for every code: the next 15 bits, first bit on top, are compared against the 15 left-justified
-// canonical limits — wave-uniform values, they live in scalar registers — and the code's length is the number of limits not
-// above it, plus one.  ~30 VALU instructions, no loop, no divergence; the symbol is one LDS read away.
+// Rounds 2-5 resolved EVERY token's lit/len code without a lookup table (with 64 lanes at 64 places of the stream some lane meets a code
+// longer than a one-level table in almost every step): the next 15 bits, first bit on top, compared against the 15 left-justified canonical
+// limits — wave-uniform values in scalar registers — the code's length being the number of limits not above it, plus one; ~30 VALU
+// instructions, no loop, no divergence.  Round 6 keeps that chain for the CONSTRUCTION of a two-level table (ip_build_ltab: every 9-bit
+// prefix and every second-level entry is resolved once) and the token walk reads the table: two dependent reads, the same two for every lane.
 typedef short ip_s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short ip_u2 __attribute__((ext_vector_type(2)));
 // limit of length l = (first code of length l + codes of length l) << (15 - l), left-justified in 15 bits; kept minus one, two
 // per word (lengths 2k+1 | 2k+2): eight packed 16-bit subtractions compare all fifteen, and no compare ever goes through VCC
 // (on gfx950 a VALU write of VCC needs wait states before a VALU read of it: the cmp / addc form paid a nop per limit)
-struct IpLimits { ip_s2 m1[8]; uint32_t base; int np; uint32_t end; };   // end: the code space in use, of 32768 (less: an incomplete code)   // pairs from the shortest length in use on (lengths below it always count, the
-                                                           // longest one's limit is the end of the code space and never does): np pairs matter
+struct IpLimits { ip_s2 m1[8]; uint32_t base; int np; uint32_t end; };   // pairs from the shortest length in use on (lengths below it always count, the longest one's
+                                                           // limit is the end of the code space and never does): np pairs matter; end: the code space in
+                                                           // use, of 32768 (less: an incomplete code — what lies behind it is no code)
 // (carrying the index adjustment of the code's length along in the same compare chain — a conditional move per limit instead of
 // the T.ladj read — was measured: 9 % slower; the wave is short of issue slots, not of LDS latency)
 
@@ -317,9 +330,13 @@ __device__ __forceinline__ int ip_build_ltab(SH &T, const IpLimits &L) {
 // The loop is wave-uniform (it runs while any lane has tokens left) and the length / distance part is entered only in steps in
 // which some lane stands at a length code: a lane that is done, or at a literal, rides along predicated instead of parking
 // behind nested exec masks.
-template <bool WRITE, class SH>
+// GB (with WRITE, the output pass of zlib_inflate_par<.., LDSOUT>): the window's storage is being overwritten with the output, so the bits
+// come out of GLOBAL memory — gsrc = the window's byte 0 in the record, dwords up to index gmaxw may be read — through a 64-bit buffer per
+// lane: `cnt` valid bits, refilled 32 at a time from a dword that was requested one refill earlier.
+template <bool WRITE, class SH, bool GB = false>
 __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint32_t st, uint32_t end, uint32_t obase, uint32_t o_abs0,
-                                                   uint8_t *dst, uint32_t wbase = 0, uint32_t wmax = 0) {
+                                                   uint8_t *dst, uint32_t wbase = 0, uint32_t wmax = 0, const uint8_t *gsrc = nullptr, uint32_t gmaxw = 0) {
+    static_assert(!GB || WRITE, "");
     IpSeg r;
     r.cross = st; r.nout = 0; r.eob = 0; r.eobpos = 0; r.bad = 0; r.nwait = 0;
     uint32_t p = st, o = obase;
@@ -340,6 +357,18 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
     // the acc8 / 8 literals in front of o that are not in memory yet; they go out as bytes before anything else is written or read back.
     uint32_t acc = 0, acc8 = 0;
     typedef uint32_t u1 __attribute__((aligned(1)));
+    uint64_t gbuf = 0;
+    uint32_t gcnt = 0, gnxt = 0, gw = 0;
+    auto gld = [&](uint32_t i) { return *reinterpret_cast<const u1 *>(gsrc + 4u * min(i, gmaxw)); };
+    auto refill = [&]() { if (gcnt < 32u) { gbuf |= (uint64_t)gnxt << gcnt; gcnt += 32u; gnxt = gld(gw); gw += 1u; } };
+    if (GB) {
+        const uint32_t w = st >> 5;
+        const uint32_t d0 = gld(w), d1 = gld(w + 1u);
+        gnxt = gld(w + 2u);
+        gw = w + 3u;
+        gbuf = (((uint64_t)d1 << 32) | d0) >> (st & 31u);
+        gcnt = 64u - (st & 31u);
+    }
     auto flush_acc = [&]() {
         if (acc8 >= 8u) dst[o - (acc8 >> 3)] = (uint8_t)acc;
         if (acc8 >= 16u) dst[o - (acc8 >> 3) + 1u] = (uint8_t)(acc >> 8);
@@ -351,7 +380,8 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
         uint32_t bits = 0, e = 0;
         bool held = false;
         for (uint32_t g = 0; g < group; g++) {
-            bits = ip_peek(T.win, p);                                       // (a lane that is done stands at most a token behind its limit: inside the window)
+            if (GB) { refill(); bits = (uint32_t)gbuf; }
+            else bits = ip_peek(T.win, p);                                  // (a lane that is done stands at most a token behind its limit: inside the window)
             e = T.ltab[bits & ((1u << IP_LROOT) - 1u)];
             if (e >= 0xC000u) e = T.ltab[((e >> 4) & 1023u) + __builtin_amdgcn_ubfe(bits, IP_LROOT, e & 15u)];
             const bool act = p < lim;
@@ -360,9 +390,12 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
             if (lit) {
                 if (WRITE) {
 #ifndef S5_IP_BYTE_STORES
-                    acc |= ((e >> 4) & 255u) << acc8;
-                    acc8 += 8u;
-                    if (acc8 == 32u) { *reinterpret_cast<u1 *>(dst + o - 3u) = acc; acc = 0; acc8 = 0; }
+                    if (GB) dst[o] = (uint8_t)(e >> 4);                      // (into LDS: a byte store is as good as any there)
+                    else {
+                        acc |= ((e >> 4) & 255u) << acc8;
+                        acc8 += 8u;
+                        if (acc8 == 32u) { *reinterpret_cast<u1 *>(dst + o - 3u) = acc; acc = 0; acc8 = 0; }
+                    }
 #else
                     dst[o] = (uint8_t)(e >> 4);
 #endif
@@ -370,11 +403,13 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
                 lastb = WRITE ? e >> 4 : 0u;
                 p += e & 15u;
                 o += 1u;
+                if (GB) { gbuf >>= e & 15u; gcnt -= e & 15u; }
             }
         }
         if (__ballot(held)) {
             const uint32_t len = e & 15u;
             uint32_t adv = len, nby = 0;
+            uint32_t gdone = 0;            // GB: bits of this token that have left the buffer already
             bool stop = false;
             if (held) {
                 if (WRITE) flush_acc();
@@ -392,7 +427,8 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
                     const uint32_t le = ls < 8u || ls == 28u ? 0u : (ls >> 2) - 1u;
                     const uint32_t mlen = (ls == 28u ? 258u : ls < 8u ? 3u + ls : 3u + ((4u + (ls & 3u)) << le)) + (b2 & ((1u << le) - 1u));
                     adv += le;
-                    b2 = ip_peek(T.win, p + adv);
+                    if (GB) { gbuf >>= adv; gcnt -= adv; gdone = adv; refill(); b2 = (uint32_t)gbuf; }   // (>= 32 valid bits again: a distance code with its extra bits takes 28)
+                    else b2 = ip_peek(T.win, p + adv);
                     const uint32_t de = T.dlut[b2 & ((1u << SH::DBITS) - 1)];
                     uint32_t ds, dlen = de >> 5;
                     if (dlen) ds = de & 31u;
@@ -447,6 +483,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
                 }
                 p += adv;
                 o += nby;
+                if (GB && adv > gdone) { gbuf >>= adv - gdone; gcnt -= adv - gdone; }
                 if (stop) lim = 0u;
             }
         }
@@ -458,9 +495,19 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
 }
 
 // Inflate one zlib stream with one wave.  Returns a status of inflate_dev.h or INF_NEED_FALLBACK (nothing usable was written).
-template <class SH>
+// LDSOUT (round 6; SH::LDS_PAY > 0): the output goes into the WINDOW'S OWN STORAGE (T.win, SH::LDS_PAY bytes) instead of `out`, for a caller
+// that consumes the record on the spot (the no-payload decode: parse + svb-zd unpack by the same wave) — the uncompressed record never
+// touches HBM.  Only a record whose one and only block ends inside the first window and whose output fits qualifies (every 4000-sample
+// read does); anything else — a second window, a second block, a stored block, a longer record — is declined (INF_NEED_FALLBACK) before a
+// byte is written, and the wave-per-record decoder takes it into its HBM slot.
+template <class SH, bool LDSOUT = false>
 __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap,
                                                 uint32_t *out_len, uint32_t *dbg = nullptr) {
+    static_assert(!LDSOUT || SH::LDS_PAY >= 1024u, "");
+    if (LDSOUT) {
+        out = reinterpret_cast<uint8_t *>(T.win);
+        cap = min(cap, SH::LDS_PAY - 16u);
+    }
     const int lane = lane_id();
     *out_len = 0;
     IPP_DECL
@@ -500,6 +547,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
         const int type = hdr >> 1;
         if (type == 3) return INF_ERR_DATA;
         if (type == 0) {
+            if (LDSOUT) return INF_NEED_FALLBACK;
             bi_get(b, b.cnt & 7);
             bi_need32_u(b, T.win);
             const uint32_t len = bi_get(b, 16), nlen = bi_get(b, 16);
@@ -622,6 +670,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             const uint32_t incl = lane < m ? nincl : 0u;
             const uint32_t round_out = (uint32_t)__builtin_amdgcn_readlane((int)nincl, m - 1);
             if (o + round_out > cap) { if (dbg) dbg[2] = 2; return INF_NEED_FALLBACK; }        // payload slot too small: the old decoder reports the size needed
+            if (LDSOUT && !(last && m - 1 == eob_lane && o == 0u)) return INF_NEED_FALLBACK;     // (the output is about to overwrite the window: this must be all there is)
             const uint32_t obase = incl - n_act;
             uint8_t *dst = out + o;
             // ---- output pass ----
@@ -630,7 +679,12 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             IpSeg wr;
             wr.nwait = 0; wr.bad = 0; wr.eob = 0; wr.eobpos = 0; wr.cross = st; wr.nout = 0;
             IPP(8)
-            if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, lenmask, st, seg_end, obase, o, dst, wincl - w_act, w_act);
+            if (LDSOUT) {
+                wave_sync();                                                     // (every lane has read what it needs of the window: the tables stand elsewhere)
+                const uint32_t gavail = total > wb ? total - wb : 0u;            // bytes of the record from the window's byte 0 on; 8 readable bytes follow the record (C ABI)
+                if (lane < m && st < seg_end)
+                    wr = ip_decode_segment<true, SH, true>(T, lenmask, st, seg_end, obase, o, dst, wincl - w_act, w_act, src + wb, (gavail + 4u) >> 2);
+            } else if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, lenmask, st, seg_end, obase, o, dst, wincl - w_act, w_act);
             IPP(9)
             if (__ballot(wr.bad != 0u)) return INF_ERR_DATA;
             if (__ballot(wr.nwait != w_act)) { if (dbg) dbg[2] = 4; return INF_NEED_FALLBACK; }   // (the two kinds of pass disagree: never seen)

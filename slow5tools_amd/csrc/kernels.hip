@@ -880,6 +880,7 @@ __global__ __launch_bounds__(NT) void k_order_scatter(const s5gpu_rec_desc_t *de
 static_assert(offsetof(InflParSharedSvb, win) == 0 && offsetof(InflParSharedSvb, dlut) >= SVB_WSTAGE && offsetof(InflParShared, dlut) >= SVB_WSTAGE,
               "the inflate window and the waiting list behind it (both dead once the record is out) double as the svb-zd stage");
 // pay: the record's uncompressed bytes — its payload slot, or the workgroup's scratch slot (S5GPU_DEC_NO_PAYLOAD)
+template <bool STAGED = true>     // false: pay lies in LDS already (k_inflate_par_np<.., LP>), nothing is staged
 __device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, const s5gpu_rec_desc_t &d, const uint8_t *pay, s5gpu_rec_fields_t &f, uint32_t plen, uint8_t *stage) {
     if (plen < 2) return 7;
     const uint32_t idl = (uint32_t)ld_le(pay, 2), hl = 2 + idl + 4 + 32;
@@ -896,7 +897,7 @@ __device__ __forceinline__ int unpack_svbzd_wave(const s5gpu_decode_args_t &a, c
     uint32_t total = 0;
     int carry = 0, err = 0;
     for (uint32_t t0 = 0; t0 < n; t0 += SVB_WTILE)
-        total += svb_decode_tile_wave(keys + (t0 >> 2), data + total, dend, n, t0, out, carry, err, stage);
+        total += svb_decode_tile_wave<STAGED>(keys + (t0 >> 2), data + total, dend, n, t0, out, carry, err, stage);
     if (__ballot(err != 0) || 4 + nk + total != L) return 7;
     if (lane_id() == 0) {
         f.n_samples = n;
@@ -1075,17 +1076,17 @@ __device__ __forceinline__ void np_write_fields(const s5gpu_decode_args_t &a, ui
         a.fields[r].reserved = 0;
     }
 }
-template <bool EXZD, bool SHORT = true>
-__global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode_args_t a, NpParams np) {
-    __shared__ typename std::conditional<SHORT, InflParSharedSvb, InflParShared>::type T;
-#ifdef S5_NP_LDS_PAY   // tools (a variant build, tools/variant.sh ldspay -DS5_NP_LDS_PAY=5376): the uncompressed record never leaves the CU — what that buys in
-                       // HBM traffic and what the LDS costs in resident waves (profiles/r04_np_lds_payload.txt); records larger than the array are declined
-    __shared__ __attribute__((aligned(16))) uint8_t lds_pay[S5_NP_LDS_PAY];
-    uint8_t *pay = lds_pay;
-    np.cap = np.cap < (uint32_t)S5_NP_LDS_PAY - 16u ? np.cap : (uint32_t)S5_NP_LDS_PAY - 16u;
-#else
-    uint8_t *pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
-#endif
+// LP (round 6; svb-zd records of a batch whose payloads fit SH::LDS_PAY): the record is inflated into the window's own LDS storage and unpacked
+// from there — no scratch slot, no byte of the uncompressed record in HBM (zlib_inflate_par<.., LDSOUT>).  What that inflate declines (a
+// second window or block, a stored block, a longer record) goes to the fallback kernel's slot like any other declined record.
+template <bool EXZD, bool SHORT, bool LP, class SH>
+__device__ __forceinline__ void np_records(const s5gpu_decode_args_t &a, NpParams np, SH &T) {
+    static_assert(!LP || (SHORT && !EXZD), "");
+    uint8_t *pay;
+    if constexpr (LP) pay = reinterpret_cast<uint8_t *>(T.win);
+    else pay = np.scratch + (uint64_t)blockIdx.x * np.slot;
+    // (round 6 measured the NEXT record's ticket drawn during the inflate and its descriptor fetched under the unpack: 25.34 against 24.62 ms per
+    // 1 M records — the two round trips it hides are not what the wave waits for, and the loop-carried descriptor costs registers)
     for (;;) {
         uint32_t r = blockIdx.x;
         if (np.ticket) {                               // (a batch no larger than the grid: workgroup b takes record b, no ticket)
@@ -1096,7 +1097,7 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode
         r = order_at(np.ord, r);
         const s5gpu_rec_desc_t d = a.desc[r];
         uint32_t olen = 0;
-        int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
+        int status = zlib_inflate_par<SH, LP>(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
 #ifdef S5_IP_PAD
         if (d.in_len == 0xFFFFFFFFu) T.pad[lane_id()] = 1;   // (keeps the padding alive)
 #endif
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode
                 const unsigned long long t0_ = __builtin_readcyclecounter();
 #endif
                 if (EXZD) status = unpack_exzd_wave(a, d, pay, a.fields[r], olen, *reinterpret_cast<ExzdWaveScratch *>(&T));
-                else status = unpack_svbzd_wave(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
+                else status = unpack_svbzd_wave<!LP>(a, d, pay, a.fields[r], olen, reinterpret_cast<uint8_t *>(T.win));
 #ifdef S5_IPROBE
                 if (lane_id() == 0) atomicAdd(&g_iprobe[13], (unsigned long long)__builtin_readcyclecounter() - t0_);
 #endif
@@ -1135,6 +1136,17 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode
         if (!np.ticket) return;
         wave_sync();                                   // the next record's window load overwrites the stage
     }
+}
+template <bool EXZD, bool SHORT = true>
+__global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par_np(s5gpu_decode_args_t a, NpParams np) {
+    __shared__ typename std::conditional<SHORT, InflParSharedSvb, InflParShared>::type T;
+    np_records<EXZD, SHORT, false>(a, np, T);
+}
+// (8192 bytes of LDS per wave = 20 waves per CU, five per SIMD: 96 registers.  Left to itself the compiler plans this kernel for four waves
+// per SIMD and 120 registers — 16 waves per CU, which measured 14 % slower on the slot form)
+__global__ __launch_bounds__(64, 5) void k_inflate_par_np_lp(s5gpu_decode_args_t a, NpParams np) {
+    __shared__ InflParSharedLp T;
+    np_records<false, true, true>(a, np, T);
 }
 // ... what the parallel decoder declined: the wave-per-record decoder, into its own scratch slot, and the unpack right behind it
 static_assert(offsetof(InflShared, llut) == offsetof(InflShared, ring) + INF_OW && INF_OW + sizeof(InflShared::llut) >= SVB_WSTAGE,
@@ -1995,10 +2007,12 @@ extern "C" int s5gpu_deflate_parked_dev(const s5gpu_encode_args_t *a, void *stre
 static uint32_t g_unpack_fused = 1;            // s5gpu_decode_dev, zlib + svb-zd: k_inflate_par unpacks the records it inflates (0: always k_unpack)
 static uint32_t g_inflate_par = 1;             // zlib records: the decoder that is parallel inside a record (0: the two older kernels, chosen by batch size)
 static uint32_t g_inflate_route = 1;           // big zlib batches: sort by length, long records to the wave kernel (below)
+static uint32_t g_np_lds_payload = 1;          // no-payload decode of short svb-zd records: the uncompressed record stays in LDS (option "np_lds_payload")
 static uint32_t g_inflate_simt_min = 24576;   // measured crossover on 4000-sample reads: 16384 wave 3.0 ms vs lane 4.2 ms, 32768 wave 5.8 vs lane 4.5
 extern "C" int s5gpu_set_option(const char *key, long value) {
     if (key && strcmp(key, "inflate_simt_min") == 0 && value >= 0) { g_inflate_simt_min = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "inflate_route") == 0 && (value == 0 || value == 1)) { g_inflate_route = (uint32_t)value; return S5GPU_OK; }
+    if (key && strcmp(key, "np_lds_payload") == 0 && (value == 0 || value == 1)) { g_np_lds_payload = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "fused_tier2") == 0 && value >= 0 && value <= DEFL_BLK) { g_fused_tier2 = (uint32_t)value & ~15u; return S5GPU_OK; }
     if (key && strcmp(key, "zstd_sequences") == 0 && (value == 0 || value == 1)) { g_zstd_sequences = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "unpack_fused") == 0 && (value == 0 || value == 1)) { g_unpack_fused = (uint32_t)value; return S5GPU_OK; }
@@ -2223,8 +2237,12 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         // more workgroups than the device holds at once buy nothing: they would only spread the scratch over more of L2.  The count is
         // asked for the template variant that is launched (the two waiting-list sizes differ in LDS: 24 and 21 waves per CU)
         const bool shortrec_np = a->max_pay_cap <= S5_IP_SHORT_PAY * (np_xz ? 3u : 1u);
-        const int variant = !zl ? 4 : (np_xz ? 2 : 0) + (shortrec_np ? 1 : 0);
-        static std::atomic<uint32_t> s_res[5] = {{0}, {0}, {0}, {0}, {0}};
+        // svb-zd records whose payloads all fit the window's storage: inflated into LDS, unpacked from there (k_inflate_par_np<.., LP>)
+        // (the caller names the longest compressed record: the kernel takes records of one window — IP_SPAN bytes with the block header — and
+        // declines what turns out not to fit)
+        const bool lds_pay = zl && !np_xz && g_np_lds_payload && a->max_in_len != 0 && a->max_in_len <= (uint32_t)IP_SPAN - 96u;
+        const int variant = !zl ? 4 : lds_pay ? 5 : (np_xz ? 2 : 0) + (shortrec_np ? 1 : 0);
+        static std::atomic<uint32_t> s_res[6] = {{0}, {0}, {0}, {0}, {0}, {0}};
         uint32_t res = s_res[variant].load(std::memory_order_relaxed);
         if (!res) {
             int per_cu = 0, cus = 0, dev = 0;
@@ -2235,6 +2253,7 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
             case 1: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_inflate_par_np<false, true>), 64, 0)); break;
             case 2: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_inflate_par_np<true, false>), 64, 0)); break;
             case 3: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_inflate_par_np<true, true>), 64, 0)); break;
+            case 5: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_par_np_lp, 64, 0)); break;
             default: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_zstd_inflate_np, 64, 0)); break;
             }
             res = (uint32_t)(per_cu > 0 && cus > 0 ? per_cu * cus : 4096);
@@ -2258,7 +2277,8 @@ extern "C" int s5gpu_decode_dev(const s5gpu_decode_args_t *a, void *stream_) {
         }
         if (zl) {
             const bool shortrec = shortrec_np;
-            if (np_xz) { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<true, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<true, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
+            if (lds_pay) hipLaunchKernelGGL(k_inflate_par_np_lp, dim3((uint32_t)n_main), dim3(64), 0, st, *a, np);
+            else if (np_xz) { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<true, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<true, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
             else { if (shortrec) hipLaunchKernelGGL((k_inflate_par_np<false, true>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); else hipLaunchKernelGGL((k_inflate_par_np<false, false>), dim3((uint32_t)n_main), dim3(64), 0, st, *a, np); }
             hipLaunchKernelGGL(k_inflate_fallback_np, dim3((uint32_t)n_fb), dim3(64), 0, st, *a, np);
         } else {

@@ -246,6 +246,9 @@ __device__ __forceinline__ uint32_t svb_decode_tile(const uint8_t *keys, const u
 // stage: SVB_WSTAGE bytes of LDS (the inflate window, dead by then), 16-byte aligned.
 constexpr uint32_t SVB_WTILE = 64u * 16u;
 constexpr uint32_t SVB_WSTAGE = 4u * SVB_WTILE + 16u;
+// STAGED = false (round 6): the blob already lies in LDS (the no-payload decode that inflates into the window's storage) — the lanes pick
+// their bytes where they are.
+template <bool STAGED = true>
 __device__ __forceinline__ uint32_t svb_decode_tile_wave(const uint8_t *keys, const uint8_t *data, const uint8_t *data_end, uint32_t n, uint32_t t0,
                                                          int16_t *__restrict__ out, int &carry, int &err, uint8_t *stage) {
     const int lane = lane_id();
@@ -272,7 +275,7 @@ __device__ __forceinline__ uint32_t svb_decode_tile_wave(const uint8_t *keys, co
     const uint32_t incl = wave_incl_add(nbytes);
     const uint32_t off = incl - nbytes;
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    {   // data[0 .. min(total, bytes left)) -> stage
+    if (STAGED) {   // data[0 .. min(total, bytes left)) -> stage
         const uint32_t have = (uint32_t)min((uint64_t)total, (uint64_t)(data_end - data));
         typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(1)));
         typedef uint32_t v4a __attribute__((ext_vector_type(4)));
@@ -282,7 +285,7 @@ __device__ __forceinline__ uint32_t svb_decode_tile_wave(const uint8_t *keys, co
         }
         wave_sync();
     }
-    const uint8_t *dp = stage + off;
+    const uint8_t *dp = (STAGED ? stage : data) + off;
     const bool ok = !(valid > 0 && data + off + nbytes > data_end);
     if (!ok) err = 1;
     int dlt[16];

@@ -96,7 +96,8 @@ def decode_records(records, rec_method=REC_ZLIB, sig_method=SIG_SVB_ZD, raise_on
     return out
 
 
-def decode_signals_dev(records, rec_method=REC_ZLIB, max_pay_cap=None, sig_caps=None, scratch_bytes=None, device="cuda:0", sig_method=SIG_SVB_ZD):
+def decode_signals_dev(records, rec_method=REC_ZLIB, max_pay_cap=None, sig_caps=None, scratch_bytes=None, device="cuda:0", sig_method=SIG_SVB_ZD,
+                       max_in_len=None):
     """s5gpu_decode_dev with S5GPU_DEC_NO_PAYLOAD: fields + signals only, the uncompressed records stay in reused scratch slots
     (what `get` needs of /root/reference/src/get.c:37-66 when the caller holds the read ids).  records: bytes without the u64 prefix.
     Returns (fields as a numpy REC_FIELDS array, list of int16 arrays — empty where status != 0)."""
@@ -131,6 +132,7 @@ def decode_signals_dev(records, rec_method=REC_ZLIB, max_pay_cap=None, sig_caps=
     a.n_recs, a.rec_method, a.sig_method, a.flags = n, rec_method, sig_method, _lib.DEC_NO_PAYLOAD
     a.desc, a.in_, a.payload, a.sig_out, a.fields = t_desc.data_ptr(), t_in.data_ptr(), t_scr.data_ptr(), t_sig.data_ptr(), t_fields.data_ptr()
     a.payload_bytes, a.max_pay_cap = scratch_bytes, max_pay_cap
+    a.max_in_len = int(lens.max()) if (max_in_len is None and n) else int(max_in_len or 0)   # (a hint: short records stay in LDS, include/slow5gpu.h)
     check(L.s5gpu_decode_dev(C.byref(a), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "s5gpu_decode_dev")
     torch.cuda.synchronize(dev)
     f = t_fields.cpu().numpy().view(_lib.REC_FIELDS)[:n].copy()

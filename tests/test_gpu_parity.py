@@ -694,6 +694,73 @@ def test_lz77_long_shape_is_deterministic_under_bucket_collisions(press):
             assert len(rec) <= 1.10 * ref + 64 + 48 * (len(pay) // 16384 + 1), (i, len(rec), ref)
 
 
+def test_no_payload_decode_keeps_short_records_in_lds_and_hands_the_rest_to_the_slot_decoder(press):
+    """S5GPU_DEC_NO_PAYLOAD with max_in_len naming records of one inflate window (round 6: k_inflate_par_np_lp — the record is inflated into
+    LDS, the output pass reads its bits out of global memory, the unpack reads LDS; the uncompressed record never reaches HBM).  One batch
+    with everything that kernel takes (our own records and stock zlib's at levels 1 / 6 / 9, Z_FIXED, tiny reads) and everything it has
+    to DECLINE before writing a byte — a stored block, a stream of two blocks, a record longer than a window, a payload over the cap —
+    plus damaged records: statuses and signals equal the slot form's (option np_lds_payload = 0), and every record that fits decodes."""
+    from slow5tools_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(606)
+    recs, sigs, want_ok = [], [], []
+
+    def add(sig, stream, ok=True):
+        sigs.append(sig); recs.append(stream); want_ok.append(ok)
+
+    own_n = [4000, 4000, 3999, 4001, 2000, 513, 64, 5, 1, 4100]
+    own_sig = [ob.synth_read(0x5105, 40 + i, n) for i, n in enumerate(own_n)]
+    own = press.encode_records(own_sig, [_hdr(press, 40 + i) for i in range(len(own_n))])
+    for sg, r in zip(own_sig, own):
+        add(sg, r[8:])
+    for i, level in enumerate((1, 6, 9, 6, 6)):
+        sg = ob.synth_read(0x5105, 80 + i, 4000 - 7 * i)
+        pay, _ = _oracle_payload(_hdr(press, 80 + i), sg, b"", 1)
+        add(sg, zlib.compress(pay, level))
+    sg = ob.synth_read(0x5105, 90, 3000)
+    pay, _ = _oracle_payload(_hdr(press, 90), sg, b"", 1)
+    c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+    add(sg, c.compress(pay) + c.flush())                                     # fixed codes: taken
+    add(sg, zlib.compress(pay, 0))                                           # stored block: declined -> slot decoder
+    c = zlib.compressobj(6)
+    add(sg, c.compress(pay[:1500]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(pay[1500:]) + c.flush())   # several blocks: declined
+    sg = rng.integers(-32768, 32768, 2050).astype(np.int16)                   # ~2.5 bytes per sample: 5.2 KB of payload in ~4.9 KB of stream -> two windows: declined
+    pay, _ = _oracle_payload(_hdr(press, 91), sg, b"", 1)
+    add(sg, zlib.compress(pay, 6))
+    sg = ob.synth_read(0x5105, 92, 6000)                                      # payload over the cap: status 5 (too small a slot) on both forms
+    pay, _ = _oracle_payload(_hdr(press, 92), sg, b"", 1)
+    add(sg, zlib.compress(pay, 6), ok=False)
+    bad = bytearray(own[0][8:]); bad[len(bad) // 2] ^= 0x10
+    add(own_sig[0], bytes(bad), ok=False)                                     # damaged in the middle
+    add(own_sig[1], own[1][8:-3], ok=False)                                   # truncated
+    add(own_sig[2], own[2][8:-1] + bytes([own[2][-1] ^ 1]), ok=False)         # wrong Adler-32
+    cap = 5344
+    res = {}
+    for lds in (1, 0):
+        _lib.check(L.s5gpu_set_option(b"np_lds_payload", lds))
+        try:
+            # (max_in_len is a hint: 4000 names the LDS kernel although two records of the batch are longer — they must be declined, not mangled)
+            res[lds] = press.decode_signals_dev(recs, max_pay_cap=cap, sig_caps=[max(len(s_), 8) for s_ in sigs], max_in_len=4000)
+        finally:
+            _lib.check(L.s5gpu_set_option(b"np_lds_payload", 1))
+    f1, s1 = res[1]
+    f0, s0 = res[0]
+    assert list(f1["status"]) == list(f0["status"])
+    for i, ok in enumerate(want_ok):
+        if ok:
+            assert f1["status"][i] == 0, (i, int(f1["status"][i]))
+            assert np.array_equal(s1[i], sigs[i]) and np.array_equal(s0[i], sigs[i]), i
+            assert f1["n_samples"][i] == len(sigs[i]) and f1["read_group"][i] == f0["read_group"][i] and f1["aux_len"][i] == f0["aux_len"][i]
+        else:
+            assert f1["status"][i] != 0, i
+    # a batch of a thousand copies (several records per persistent workgroup: the window's storage is reused record after record)
+    many = [recs[i % 15] for i in range(3000)]
+    f, sg_out = press.decode_signals_dev(many, max_pay_cap=cap, sig_caps=[max(len(sigs[i % 15]), 8) for i in range(3000)])
+    assert (f["status"] == 0).all()
+    for i in range(0, 3000, 7):
+        assert np.array_equal(sg_out[i], sigs[i % 15])
+
+
 def test_fused_unpack_and_the_records_it_leaves_to_the_second_kernel(press):
     """s5gpu_decode_dev on zlib + svb-zd records: the wave that inflates a record also unpacks it (k_inflate_par<true>); records the
     parallel decoder declines (periodic signals: their svb bytes are far matches for stock zlib) are inflated by the fallback

@@ -30,6 +30,7 @@ if mode == "np":
     sb = int(os.environ.get("S5_SCRATCH_BYTES", 0)) or int(L.s5gpu_decode_scratch_bytes(pay_cap))
     scr = torch.empty(sb, dtype=torch.uint8, device="cuda")
     a.flags, a.payload, a.payload_bytes, a.max_pay_cap = _lib.DEC_NO_PAYLOAD, scr.data_ptr(), sb, pay_cap
+    a.max_in_len = int(d["in_len"].max())
 else:
     pay = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device="cuda")
     a.payload, a.max_pay_cap = pay.data_ptr(), pay_cap

@@ -25,6 +25,7 @@ L.s5gpu_decode_scratch_bytes.restype = C.c_uint64; L.s5gpu_decode_scratch_bytes.
 sb = int(L.s5gpu_decode_scratch_bytes(pay_cap))
 scr = torch.empty(sb, dtype=torch.uint8, device="cuda")
 a.flags, a.payload, a.payload_bytes, a.max_pay_cap = _lib.DEC_NO_PAYLOAD, scr.data_ptr(), sb, pay_cap
+a.max_in_len = int(d["in_len"].max())
 z = (C.c_ulonglong * 20)()
 ts = []
 for i in range(3):
