@@ -340,6 +340,9 @@ int s5gpu_ascii_parse_dev(uint32_t n, const s5gpu_txt_desc_t *desc, const uint8_
 int s5gpu_ascii_format_dev(uint32_t n, const s5gpu_txt_desc_t *desc, const int16_t *sig, uint8_t *text, uint32_t *txt_len,
                            int32_t *status, void *stream);
 /* copy n byte ranges src[src_off[i] .. +len[i]) -> dst[dst_off[i] ..) on the device */
+/* dst[0, bytes) = src[0, bytes) by a kernel on `stream`: both 16-byte aligned, with room for `bytes` rounded up to 16.  dst may be pinned host
+ * memory (s5gpu_host_alloc): results then travel as the kernel's own stores, not through the copy engines every stream of the process shares. */
+int s5gpu_copy_dev(void *dst, const void *src, uint64_t bytes, void *stream);
 int s5gpu_gather_dev(uint32_t n, const uint64_t *src_off, const uint32_t *len, const uint64_t *dst_off, const uint8_t *src, uint8_t *dst,
                      void *stream);
 

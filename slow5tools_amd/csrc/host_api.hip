@@ -112,9 +112,13 @@ extern "C" int s5gpu_devices_in_use(void) {
     return g_ndev;
 }
 
+static uint32_t g_host_turns = 1;      // option "host_turns": packing and uploading of concurrent batches take turns
+static uint32_t g_d2h_kernel = 1;      // option "d2h_kernel_copy": results return to pinned host buffers by a kernel's stores, not by the copy engines
 int s5host_set_option(const char *key, long value) {
     if (key && strcmp(key, "multi_min_per_device") == 0 && value >= 1) { g_multi_min = (uint32_t)value; return S5GPU_OK; }
     // pinned memory the arena pool keeps between batch calls, MiB (default 6144; 0: every released batch is unpinned at once)
+    if (key && strcmp(key, "host_turns") == 0 && (value == 0 || value == 1)) { g_host_turns = (uint32_t)value; return S5GPU_OK; }
+    if (key && strcmp(key, "d2h_kernel_copy") == 0 && (value == 0 || value == 1)) { g_d2h_kernel = (uint32_t)value; return S5GPU_OK; }
     if (key && strcmp(key, "arena_pool_keep_mb") == 0 && value >= 0) return s5host::arena_pool_set_keep((size_t)value << 20);
     return S5GPU_ERR_ARG;
 }
@@ -146,6 +150,11 @@ hipError_t s5_pinned_free(void *p) {
 // alone).  So the two phases that share a resource take TURNS: packing into pinned staging (the host's memory system), and the upload
 // (the link's host-to-device direction), which is held until the copies have LANDED — an event behind them, waited for before the turn is
 // given up.  The batch behind then packs while this one uploads and uploads while this one computes and downloads.
+static int d2h(Ctx *c, void *dst, const void *src, size_t bytes) {      // dst: pinned, 16-byte aligned, room for bytes rounded up to 16; src: device, 16-byte aligned
+    if (g_d2h_kernel && !(((uintptr_t)dst | (uintptr_t)src) & 15)) return s5gpu_copy_dev(dst, src, bytes, c->st);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->st));
+    return S5GPU_OK;
+}
 static std::mutex g_pack_turn;
 static std::mutex g_upload_turn[64];
 static int upload_landed(Ctx *c) {
@@ -288,17 +297,16 @@ int s5host::encode_stream_resident(Ctx *c, uint32_t n, const std::vector<s5gpu_r
     if (a.rec_method == S5GPU_REC_ZLIB && a.sig_method != S5GPU_SIG_NONE && (uint64_t)a.max_payload * 100 / (a.sig_method == S5GPU_SIG_EX_ZD ? 950 : 325) <= 16384) {
         const size_t scan_bytes = 8ull * (n + 1) + 8ull * n + 16;
         if ((rc = c->d_stream.reserve(slots_bytes + 64)) || (rc = c->d_scan.reserve(scan_bytes)) ||
-            (rc = c->h_out.reserve(up(8ull * (n + 1) + 16, 64) + 64)))
+            (rc = c->h_out.reserve(up(scan_bytes, 64) + 64)))
             return rc;
         uint64_t *d_off = (uint64_t *)c->d_scan.p, *d_state = d_off + (n + 1);
         uint32_t *d_ctl = (uint32_t *)(d_state + n);
         if ((rc = s5gpu_encode_stream_dev(&a, (uint8_t *)c->d_stream.p, d_off, d_state, d_ctl, c->st))) return rc;
         uint8_t *h = (uint8_t *)c->h_out.p;
-        HIP_TRY(hipMemcpyAsync(h, d_off, 8ull * (n + 1), hipMemcpyDeviceToHost, c->st));
-        HIP_TRY(hipMemcpyAsync(h + 8ull * (n + 1), d_ctl, 16, hipMemcpyDeviceToHost, c->st));
+        if ((rc = d2h(c, h, d_off, 8ull * (n + 1) + 8ull * n + 16))) return rc;      // offsets | states | control words: one piece (d_scan's layout)
         HIP_TRY(hipStreamSynchronize(c->st));
         s5_trace("encode_stream_resident: uploads + kernel done, offsets back");
-        const uint32_t *ctl = (const uint32_t *)(h + 8ull * (n + 1));
+        const uint32_t *ctl = (const uint32_t *)(h + 8ull * (n + 1) + 8ull * n);
         if (ctl[0] == 0 && ctl[2] == 0) {
             memcpy(off.data(), h, 8ull * (n + 1));
             for (uint32_t i = 0; i < n; i++)
@@ -424,7 +432,7 @@ int s5host::encode_and_collect(Ctx *c, uint32_t n, const std::vector<s5gpu_read_
         uint8_t *buf = (uint8_t *)arena_pool_take(produced + 64, &cap);
         if (!buf) return S5GPU_ERR_NOMEM;
         ar->add(buf, cap);                                  // (from here on the arena owns it, whatever happens)
-        HIP_TRY(hipMemcpyAsync(buf, c->d_stream.p, produced, hipMemcpyDeviceToHost, c->st));
+        if ((rc = d2h(c, buf, c->d_stream.p, produced))) return rc;                  // (the pool's buffers hold produced + 64 bytes at least)
         HIP_TRY(hipStreamSynchronize(c->st));
         s5_trace("encode_and_collect: records back in the arena buffer");
         for (uint32_t i = 0; i < n; i++) { out[i] = buf + off[i]; out_len[i] = (size_t)(off[i + 1] - off[i]); }
@@ -570,7 +578,8 @@ static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, con
     uint8_t *hs = (uint8_t *)c->h_in.p;
     uint8_t *hh = hs + up(sig_bytes, 64), *ha = hh + up(ho + 64, 64), *hd = ha + up(ao + 64, 64);
     {
-        std::lock_guard<std::mutex> turn(g_pack_turn);
+        std::unique_lock<std::mutex> turn(g_pack_turn, std::defer_lock);
+        if (g_host_turns) turn.lock();
         parallel_for(n, (uint64_t)so * 2, [&](uint32_t lo, uint32_t hi) {
             for (uint32_t i = lo; i < hi; i++) {
                 const s5gpu_read_desc_t &d = desc[i];
@@ -583,12 +592,13 @@ static int encode_batch_one(int slot, uint32_t n, const int16_t *const *sig, con
     }
     s5_trace("encode_batch: packed into pinned staging");
     {
-        std::lock_guard<std::mutex> turn(g_upload_turn[c->slot & 63]);
+        std::unique_lock<std::mutex> turn(g_upload_turn[c->slot & 63], std::defer_lock);
+        if (g_host_turns) turn.lock();
         HIP_TRY(hipMemcpyAsync(c->d_sig.p, hs, (size_t)so * 2, hipMemcpyHostToDevice, c->st));
         HIP_TRY(hipMemcpyAsync(c->d_hdr.p, hh, ho, hipMemcpyHostToDevice, c->st));
         if (ao) HIP_TRY(hipMemcpyAsync(c->d_aux.p, ha, ao, hipMemcpyHostToDevice, c->st));
         HIP_TRY(hipMemcpyAsync(c->d_desc.p, hd, sizeof(s5gpu_read_desc_t) * n, hipMemcpyHostToDevice, c->st));
-        if ((rc = upload_landed(c))) return rc;
+        if (g_host_turns && (rc = upload_landed(c))) return rc;
     }
     s5_trace("encode_batch: uploads landed");
     s5gpu_encode_args_t a;
@@ -940,18 +950,20 @@ static int decode_resident_impl(Ctx *c, uint32_t n, const void *const *rec, cons
         s5_trace("decode_resident: workspaces reserved");
         uint8_t *hi = (uint8_t *)c->h_in.p, *hd = hi + (framed ? 0 : up(io + 64, 64));
         if (!framed) {
-            std::lock_guard<std::mutex> turn(g_pack_turn);
+            std::unique_lock<std::mutex> turn(g_pack_turn, std::defer_lock);
+        if (g_host_turns) turn.lock();
             parallel_for(n, io, [&](uint32_t lo, uint32_t hi_) {
                 for (uint32_t i = lo; i < hi_; i++) memcpy(hi + rd[i].in_off, rec[i], rec_len[i]);
             });
         }
         memcpy(hd, rd.data(), sizeof(s5gpu_rec_desc_t) * n);
         {
-            std::lock_guard<std::mutex> turn(g_upload_turn[c->slot & 63]);
+            std::unique_lock<std::mutex> turn(g_upload_turn[c->slot & 63], std::defer_lock);
+        if (g_host_turns) turn.lock();
             if (!framed || attempt == 0)   // a framed chunk is already on the device when overflowing records are redone
                 HIP_TRY(hipMemcpyAsync(c->d_in.p, framed ? framed->base : hi, io, hipMemcpyHostToDevice, c->st));
             HIP_TRY(hipMemcpyAsync(c->d_desc2.p, hd, sizeof(s5gpu_rec_desc_t) * n, hipMemcpyHostToDevice, c->st));
-            if (io >= (4u << 20)) { if ((rc = upload_landed(c))) return rc; }     // (small uploads: not worth a wait)
+            if (g_host_turns && io >= (4u << 20)) { if ((rc = upload_landed(c))) return rc; }     // (small uploads: not worth a wait)
         }
         HIP_TRY(hipMemsetAsync(c->d_fields.p, 0, sizeof(s5gpu_rec_fields_t) * n, c->st));
         s5gpu_decode_args_t da;
@@ -1093,7 +1105,8 @@ struct TicketWorkers {
         stop = false;
     }
 };
-TicketWorkers g_tickets;
+TicketWorkers *g_tickets_p = new TicketWorkers();      // (never destroyed: a process that exits without s5gpu_shutdown must not meet joinable threads in a static destructor)
+TicketWorkers &g_tickets = *g_tickets_p;
 void *submit_ticket(std::function<int(void **)> work, int want_arena, const char *who) {
     BatchTicket *t = new (std::nothrow) BatchTicket();
     if (!t) { s5gpu_set_error("%s: out of memory", who); return nullptr; }

@@ -1469,6 +1469,13 @@ __global__ __launch_bounds__(NT) void k_svbzd_decode(s5gpu_decode_args_t a) {
 }
 
 // read_group rewrite of the merge worker (src/merge.c:51) on decoded payloads: 4 bytes at base + off[i]
+// dst[0, bytes) = src[0, bytes), both 16-byte aligned, bytes rounded up to 16 by the caller's buffers.  What it is for: results going back to a
+// PINNED HOST buffer (device-visible under the same address) as ordinary stores of a kernel on the batch's own stream — the copy engines the
+// hipMemcpyAsync path uses are shared by every stream of the process, and a small download queued behind ANOTHER batch's 32 MB upload
+// waits for all of it (round 6, tools/hook_trace.py: 0.72 ms for 520 bytes with two batches in flight, 0.14 alone).
+__global__ __launch_bounds__(NT) void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * NT) dst[i] = src[i];
+}
 __global__ __launch_bounds__(NT) void k_patch_u32(uint8_t *base, const uint64_t *off, const uint32_t *val, uint32_t n) {
     const uint32_t i = blockIdx.x * NT + threadIdx.x;
     if (i >= n) return;
@@ -2327,6 +2334,17 @@ extern "C" int s5gpu_scatter_slots_dev(uint32_t n, const s5gpu_read_desc_t *desc
     if (n == 0) return S5GPU_OK;
     if (!desc || !slots || !len || !off || !dst) return S5GPU_ERR_ARG;
     hipLaunchKernelGGL(k_compact, dim3(n), dim3(NT), 0, (hipStream_t)stream_, desc, slots, len, off, dst);
+    HIP_TRY(hipGetLastError());
+    return S5GPU_OK;
+}
+
+// device (or device-visible pinned host) to device / pinned host, by a kernel on `stream_`: dst and src 16-byte aligned, room for bytes rounded up to 16
+extern "C" int s5gpu_copy_dev(void *dst, const void *src, uint64_t bytes, void *stream_) {
+    if (bytes == 0) return S5GPU_OK;
+    if (!dst || !src || (((uintptr_t)dst | (uintptr_t)src) & 15)) return S5GPU_ERR_ARG;
+    const uint64_t n16 = (bytes + 15) / 16;
+    const uint64_t want = (n16 + NT - 1) / NT;
+    hipLaunchKernelGGL(k_copy16, dim3((uint32_t)(want < 2048 ? want : 2048)), dim3(NT), 0, (hipStream_t)stream_, (uint4 *)dst, (const uint4 *)src, n16);
     HIP_TRY(hipGetLastError());
     return S5GPU_OK;
 }
