@@ -32,10 +32,34 @@ __global__ void k_busy(uint32_t *p, uint32_t n, uint32_t rounds) {   // thread A
     p[i] = v;
 }
 
+// Ballast (shape 4): the library's thread A does one thing the plain probe did not — its FIRST launch loads a 2 MB code object of 60 kernels
+// onto the device and sets a function attribute on 22 of them, under thread B's allocation.  64 instantiations of an unrolled kernel make a
+// code object of that size here; thread A launches one of them first and sets the attribute on all.
+template <int K>
+__global__ void k_ballast(uint32_t *p, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = p[i];
+#pragma unroll
+    for (int r = 0; r < 700; r++) v = (v ^ (uint32_t)(r * 2654435761u + K)) * (uint32_t)(2 * r + 2 * K + 1) + (v >> ((r + K) & 15));
+    p[i] = v;
+}
+template <int K>
+struct Ballast {
+    static void touch(uint32_t *d, uint32_t n, hipStream_t st, bool launch) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ballast<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (launch) k_ballast<K><<<n / 256, 256, 0, st>>>(d, n);
+        Ballast<K - 1>::touch(d, n, st, false);
+    }
+};
+template <>
+struct Ballast<0> { static void touch(uint32_t *, uint32_t, hipStream_t, bool) {} };
+
 static size_t g_small = 4900;
 static unsigned g_delay_us = 0;
 static int g_rounds = 8;
 static int g_pieces = 0;
+static int g_ballast = 0;
 static volatile int g_a_started = 0;
 
 static void *thread_a(void *) {
@@ -49,6 +73,7 @@ static void *thread_a(void *) {
     CHECK(hipMalloc(&d, 4ull * n));
     CHECK(hipHostMalloc(&h, 32u << 20, hipHostMallocPortable));
     CHECK(hipMemsetAsync(d, 1, 4ull * n, st));
+    if (g_ballast) Ballast<64>::touch(d, n, st, true);       // first launch out of a big code object + 64 attribute calls
     for (int r = 0; r < g_rounds; r++) {
         k_busy<<<n / 256, 256, 0, st>>>(d, n, 64);
         CHECK(hipMemcpyAsync(h, d, 32u << 20, hipMemcpyDeviceToHost, st));
@@ -127,6 +152,7 @@ int main(int argc, char **argv) {
     if (argc > 2) g_delay_us = (unsigned)atol(argv[2]);
     if (argc > 3) g_rounds = atoi(argv[3]);
     if (argc > 4) g_pieces = atoi(argv[4]);
+    if (argc > 5) g_ballast = atoi(argv[5]);
     if (g_small < 64) g_small = 64;
     pthread_t a, b;
     pthread_create(&a, nullptr, thread_a, nullptr);
