@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from slow5tools_amd import _lib, press
 L = _lib.lib(); _lib.check(L.s5gpu_init(0), "init")
+for kv in filter(None, os.environ.get("S5_OPTS", "").split(",")):      # library options for A/B runs, e.g. S5_OPTS=np_lds_payload=0
+    k, v = kv.split("="); _lib.check(L.s5gpu_set_option(k.encode(), int(v)), "option " + kv)
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 mode = sys.argv[3] if len(sys.argv) > 3 else "np"
