@@ -248,7 +248,10 @@ def pcie_inclusive(L, _lib, press, n_reads, n, reps=2):
         out["batch_%d" % m] = _pcie_one(L, _lib, press, m, n, r, arena=False)
         out["batch_%d" % m]["arena"] = _pcie_one(L, _lib, press, m, n, r + 1, arena=True)
         if m <= 65536:   # the reference's loop with batch k + 1 submitted while batch k is on the device (round 6: s5gpu_encode_batch_submit / s5gpu_batch_wait)
-            out["batch_%d" % m]["two_in_flight"] = _pcie_two_in_flight(L, _lib, press, m, n, 48 if m <= 10000 else 12)
+            try:
+                out["batch_%d" % m]["two_in_flight"] = _pcie_two_in_flight(L, _lib, press, m, n, 48 if m <= 10000 else 12)
+            except Exception as e:      # (never fatal for the line)
+                out["batch_%d" % m]["two_in_flight"] = {"error": repr(e)}
     big = out["batch_%d" % n_reads]
     out.update({"reads": n_reads, "samples_per_read": n, "GB_per_s": big["GB_per_s"], "reads_per_s": big["reads_per_s"], "arena_GB_per_s": big["arena"]["GB_per_s"]})
     return out
