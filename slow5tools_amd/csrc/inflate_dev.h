@@ -33,6 +33,12 @@ struct IProbe { unsigned long long t; };
 #define IPP_ARG
 #define IPP_PASS
 #endif
+// tools/par_probe.py (variant build -DS5_PAR_PROBE): cut-offs INSIDE the block header's parser, for instruction counts per step
+#ifdef S5_PAR_PROBE
+#define IPC(n) { if (cut == (n)) return INF_OK; }
+#else
+#define IPC(n)
+#endif
 
 
 constexpr int INF_LBITS = 10;      // primary lit/len lookup bits
@@ -264,17 +270,15 @@ __device__ __forceinline__ int infl_build_syms(const uint8_t *lens, int n, uint1
 // run lengths places them, and a "repeat previous" token finds the length it repeats through a ballot.  ~9 rounds per header
 // instead of ~150 dependent steps.  lens32 = T.lens + 32 must be zero (zero runs are not written).  Returns 0, or 1 bad data.
 template <class TT>
-__device__ __forceinline__ int infl_cl_sequence_wave(TT &T, BitIn &b, int tot) {
+__device__ __forceinline__ int infl_cl_sequence_wave(TT &T, BitIn &b, int tot, int idx = 0, uint32_t prev = 0xFFu) {   // prev: last length written (0xFF: none yet)
     const int lane = lane_id();
-    int idx = 0;
-    uint32_t prev = 0xFFu;                       // last length written (0xFF: none yet)
     while (idx < tot) {
         bi_need32_u(b, T.win);
         const uint32_t abit = 32u * b.wpos - (uint32_t)b.cnt + (uint32_t)lane;      // window bit address of my offset
         const uint32_t w0 = T.win[abit >> 5], w1 = T.win[(abit >> 5) + 1];
         const uint32_t bits = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (abit & 31));
         const uint32_t e = T.cl_lut()[bits & 127u];
-        const uint32_t clen = e >> 5, sym = e & 31u;
+        const uint32_t sym = e & 31u, clen = sym == 31u ? 0u : (e >> 5) & 7u;     // (the table of infl_build_cl7: the token's total bit count stands above; 31: no code)
         const uint32_t ext = sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u;
         const uint32_t x = (bits >> clen) & ((1u << ext) - 1u);
         const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + x : 3u + x;
@@ -339,10 +343,212 @@ __device__ __forceinline__ int infl_cl_sequence_wave(TT &T, BitIn &b, int tot) {
     return 0;
 }
 
+// ---- round 6, third session: the dynamic header with a quarter of the instructions ----
+// PMC cut-offs of the parallel inflate (tools/par_probe_pmc.sh, 262 144 own records): of 13.3 k vector instructions per record the block header
+// took 4.1 k, the code-length sequence alone 1.8 k — infl_cl_sequence_wave looks at 64 bit offsets per round, a fifth of which start a token,
+// and pays ~165 instructions per round for 11 rounds.  Below: the generic table builder replaced by a 19-symbol one that resolves every
+// table entry once (infl_build_cl7), and the sequence taken 1024 bits per round (infl_cl_sequence_wave2).
+
+// 7-bit lookup table of the code-length code (19 symbols, lengths 0..7): entry = symbol | code length << 5 | (code length + extra bits) << 8;
+// seven bits that start no code: "symbol 31", a token of 14 bits — the chain of infl_cl_sequence_wave2 walks over it like over any other
+// token (behind the sequence lies the block's data, garbage to this code), and only a lane that meets it INSIDE the sequence reports it.  Built by DECODING, like the lit/len table of inflate_par_dev.h: entry i is the code that starts the seven bits i, found by
+// comparing them (first bit on top) with the left-justified end of every length's codes — uniform values.  sorted: >= 19 entries of scratch,
+// adj: >= 8.  Returns 1 if the lengths are over-subscribed (an incomplete set is tolerated: its unused entries are CL7_NOCODE).
+constexpr uint32_t CL7_NOCODE = 31u | (7u << 5) | (14u << 8);
+__device__ __forceinline__ int infl_build_cl7(const uint8_t *lens19, uint16_t *lut, uint16_t *sorted, uint16_t *adj) {
+    const int lane = lane_id();
+    const uint32_t l = lane < 19 ? (uint32_t)lens19[lane] : 0u;
+    uint32_t first = 0, offs = 0, place = 0, adjv = 0;
+    uint32_t lim[8];
+    int left = 1;
+    bool over = false;
+#pragma unroll
+    for (int bb = 1; bb <= 7; bb++) {
+        const uint64_t m = __ballot(l == (uint32_t)bb);
+        const uint32_t c = (uint32_t)__popcll(m);
+        if (l == (uint32_t)bb) place = offs + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (lane == bb) adjv = offs - first;                      // index of a length's first symbol in `sorted` - its first code
+        lim[bb] = (first + c) << (7 - bb);
+        offs += c;
+        first = (first + c) << 1;
+        left = (left << 1) - (int)c;
+        if (left < 0) over = true;
+    }
+    if (over) return 1;
+    if (l) sorted[place] = (uint16_t)lane;
+    if (lane >= 1 && lane < 8) adj[lane] = (uint16_t)adjv;
+    wave_sync();
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const uint32_t i = (uint32_t)(it * 64 + lane);
+        const uint32_t v = __brev(i) >> 25;
+        uint32_t len = 1;
+#pragma unroll
+        for (int bb = 1; bb <= 7; bb++) len += v >= lim[bb] ? 1u : 0u;      // (the ends never decrease: a length without codes ends where the one below it does)
+        uint32_t ent = CL7_NOCODE;
+        if (len <= 7u) {
+            const uint32_t idx = ((uint32_t)(int)(short)adj[len] + (v >> (7u - len))) & 31u;
+            const uint32_t sym = sorted[idx];
+            const uint32_t ext = sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u;
+            ent = sym | (len << 5) | ((len + ext) << 8);
+        }
+        lut[i] = (uint16_t)ent;
+    }
+    wave_sync();
+    return 0;
+}
+
+// wave-uniform: put the reader at window bit `abit`
+__device__ __forceinline__ void bi_seek_u(BitIn &b, const uint32_t *win, uint32_t abit) {
+    const uint32_t w = abit >> 5, sh = abit & 31u;
+    const uint32_t word = __builtin_amdgcn_readfirstlane(win[w]);
+    b.buf = (uint64_t)(word >> sh);
+    b.cnt = (int)(32u - sh);
+    b.wpos = w + 1u;
+}
+
+// The code-length sequence, 1024 bits per round: lane L owns the sixteen bit offsets [16 L, 16 L + 16) behind the reader.
+//   1. every lane looks up the token that WOULD start at each of its offsets and keeps its total bit count (code + extra bits, <= 14) as a
+//      nibble: 64 bits per lane;
+//   2. where the real token chain ENTERS each lane is a serial walk over the lanes (a token never skips a lane: 15 + 14 < 32).  Every lane first
+//      folds its sixteen offsets into a FUNCTION entry offset -> exit offset (sixteen nibbles, from the last offset down); the walk is then one
+//      readlane and one scalar shift per lane.  Seven bits that start no code count as a 14-bit token (CL7_NOCODE): the chain never breaks, and
+//      whether such a place was an error is decided by where the sequence ended;
+//   3. every lane walks its own tokens from its entry — at most eight static slots (nine or more tokens in sixteen bits: the 64-offset
+//      parser above takes the header instead; only before anything was written) — and sums their run lengths; a prefix sum places them,
+//      the first token whose cumulative count reaches `tot` is the last one (beyond it: error), "repeat previous" takes the value of the
+//      nearest token in front that is not one itself (inside the lane in order, across lanes by a ballot, across rounds in `prev`);
+//   4. lengths are written (zero runs are not: T.lens + 32 was cleared), the reader is put behind the last token.
+// Our own records' sequences are ~800 bits: one round instead of eleven.  Returns 0, or 1 bad data.
+template <class TT>
+__device__ __forceinline__ int infl_cl_sequence_wave2(TT &T, BitIn &b, int tot) {
+    const int lane = lane_id();
+    const uint16_t *lut = T.cl_lut();
+    uint32_t A = 32u * b.wpos - (uint32_t)b.cnt;                    // window bit address of the round's first bit (uniform)
+    int idx = 0;
+    uint32_t prev = 0xFFu;
+    for (int round = 0; round < 4; round++) {                       // (316 lengths of at most 14 bits: three rounds)
+        const uint32_t base = A + 16u * (uint32_t)lane;
+        const uint32_t w = base >> 5, sh = base & 31u;
+        const uint32_t d0 = T.win[w], d1 = T.win[w + 1], d2 = T.win[w + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+        uint32_t tlo = 0, thi = 0;
+#pragma unroll
+        for (int o = 0; o < 16; o++) {
+            const uint32_t bits = o ? __builtin_amdgcn_alignbit(hi, lo, (uint32_t)o) : lo;
+            const uint32_t t = (uint32_t)lut[bits & 127u] >> 8;
+            if (o < 8) tlo |= t << (4 * o);
+            else thi |= t << (4 * (o - 8));
+        }
+        // where the chain leaves my sixteen offsets, for every offset it could enter at: x[o] = o + t - 16 if the token at o reaches out of
+        // them, else x[o + t] — from the last offset down, nibbles again (exits are 0 .. 13)
+        uint32_t xlo = 0, xhi = 0;
+#pragma unroll
+        for (int o = 15; o >= 0; o--) {
+            const uint32_t t = o < 8 ? __builtin_amdgcn_ubfe(tlo, 4 * o, 4) : __builtin_amdgcn_ubfe(thi, 4 * (o - 8), 4);
+            const uint32_t tgt = (uint32_t)o + t;                                         // > o
+            uint32_t x = __builtin_amdgcn_ubfe(xhi, (tgt << 2) & 31u, 4);                 // tgt in 8 .. 15
+            if (o < 7) { const uint32_t xl = __builtin_amdgcn_ubfe(xlo, (tgt << 2) & 31u, 4); x = tgt < 8u ? xl : x; }
+            x = tgt >= 16u ? tgt - 16u : x;
+            if (o < 8) xlo |= x << (4 * o);
+            else xhi |= x << (4 * (o - 8));
+        }
+        // (uniform, scalar unit) e: entry into lane L — one hop per lane: a readlane and a shift; the entries collect as nibbles, sixteen lanes to
+        // a 64-bit scalar (this compiler has no writelane builtin), and every lane picks its own.  (First form: the chain followed token by token
+        // on the scalar unit from the nibbles of step 1 — 4.6 k scalar instructions per record, serial: the kernel went from 6.9 to 9.4 ms per
+        // 262 k records.  The CU has ONE scalar unit: it issues as many instructions per cycle as the four vector units together.)
+        uint32_t e = 0;
+        uint64_t e64[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; blk++) {
+            uint64_t acc = 0;
+#pragma unroll 4
+            for (int j = 0; j < 16; j++) {
+                const int L = blk * 16 + j;
+                acc |= (uint64_t)e << (4 * j);
+                const uint32_t xw = e < 8u ? (uint32_t)__builtin_amdgcn_readlane((int)xlo, L) : (uint32_t)__builtin_amdgcn_readlane((int)xhi, L);
+                e = (xw >> (4u * (e & 7u))) & 15u;
+            }
+            e64[blk] = acc;
+        }
+        uint32_t ent;                                                 // my entry offset
+        {
+            const int q = lane >> 4;
+            const uint64_t mine = q == 0 ? e64[0] : q == 1 ? e64[1] : q == 2 ? e64[2] : e64[3];
+            ent = (uint32_t)(mine >> (4 * (lane & 15))) & 15u;
+        }
+        // my tokens: run length | symbol << 8 | offset behind the token << 16
+        uint32_t tk[8];
+        uint32_t o = ent, sum = 0, lastdef = 0;
+        bool bad = false, has_def = false;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t bits = __builtin_amdgcn_alignbit(hi, lo, o);
+            const uint32_t en = lut[bits & 127u];
+            const uint32_t sym = en & 31u, clen = (en >> 5) & 7u, t = en >> 8;
+            const uint32_t x = (bits >> clen) & ((1u << (t - clen)) - 1u);
+            const uint32_t rp = sym < 16u ? 1u : (sym == 18u ? 11u : 3u) + x;
+            const bool act = o < 16u;
+            const bool valid = act && sym != 31u;
+            if (act && sym == 31u) bad = true;
+            o = valid ? o + t : 16u;
+            tk[k] = valid ? rp | (sym << 8) | (o << 16) : 0u;
+            if (valid) sum += rp;
+            if (valid && sym != 16u) { lastdef = sym < 16u ? sym : 0u; has_def = true; }
+        }
+        if (__ballot(o < 16u)) {
+            // nine or more tokens in some lane's sixteen bits (code lengths of one and two bits): the 64-offset parser from this round's start
+            bi_seek_u(b, T.win, A);
+            return infl_cl_sequence_wave(T, b, tot, idx, prev);
+        }
+        const uint32_t incl = wave_incl_add(sum);
+        const uint64_t reach = __ballot((uint32_t)idx + incl >= (uint32_t)tot);
+        const int endlane = reach ? __ffsll((long long)reach) - 1 : 64;
+        const uint64_t badm = __ballot(bad);
+        if (badm && __ffsll((long long)badm) - 1 < endlane) return 1;             // no code at a place the sequence has to pass
+        // the value a "repeat previous" at the head of my tokens repeats
+        const uint64_t defm = __ballot(has_def);
+        const uint64_t below = defm & ((1ull << lane) - 1);
+        const int from = below ? 63 - __clzll((long long)below) : 0;
+        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)lastdef);
+        uint32_t cur = below ? got : prev;
+        uint32_t cum = (uint32_t)idx + incl - sum;                      // lengths in front of my next token
+        uint32_t endpos = 0;
+        bool err = false, isend = false;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t rp = tk[k] & 255u, sym = (tk[k] >> 8) & 31u;
+            const bool used = tk[k] != 0u && cum < (uint32_t)tot;
+            const uint32_t v = sym < 16u ? sym : sym == 16u ? cur : 0u;
+            if (used) {
+                if ((sym == 16u && cur == 0xFFu) || cum + rp > (uint32_t)tot) err = true;      // nothing to repeat; a run over the end
+                else if (sym <= 16u && v != 0u)
+                    for (uint32_t r = 0; r < rp; r++) T.lens[32u + cum + r] = (uint8_t)v;
+                cur = v;
+                cum += rp;
+                if (cum == (uint32_t)tot) { isend = true; endpos = tk[k] >> 16; }
+            }
+        }
+        if (__ballot(err)) return 1;
+        const uint64_t endm = __ballot(isend);
+        if (endm) {
+            const int el = __ffsll((long long)endm) - 1;
+            bi_seek_u(b, T.win, (uint32_t)__builtin_amdgcn_readlane((int)base, el) + (uint32_t)__builtin_amdgcn_readlane((int)endpos, el));
+            wave_sync();
+            return 0;
+        }
+        if (badm) return 1;                                             // (cannot happen: a bad token in front of the end was caught above)
+        idx += (int)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (defm) prev = (uint32_t)__builtin_amdgcn_readlane((int)lastdef, 63 - __clzll((long long)defm));
+        A += 1024u + e;
+    }
+    return 1;
+}
+
 // LITLUT = 0: no lit/len lookup table (the parallel decoder resolves those codes by comparison); PARCL: the code-length sequence by
 // the whole wave (infl_cl_sequence_wave)
 template <class TT, int LITLUT = INF_LBITS, bool PARCL = false, int DBITS = INF_DBITS>
-__device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint32_t total, uint64_t total_bits, BitIn &b, int type, int &nl, int &nd IPP_ARG) {
+__device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint32_t total, uint64_t total_bits, BitIn &b, int type, int &nl, int &nd IPP_ARG, uint32_t cut = 0) {
     const int lane = lane_id();
     // ---- code lengths ----
     if (type == 1) {
@@ -382,14 +588,21 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
         }
         wave_sync();
         IPP(1)
+        IPC(1)
         // the code-length code reuses the distance tables' storage (built before the real ones)
-        if (infl_build(T.lens, 19, T.dcount, T.dsym, T.cl_lut(), 7, 5)) return INF_ERR_DATA;
+        if (PARCL) { if (infl_build_cl7(T.lens, T.cl_lut(), T.dsym, T.dcount)) return INF_ERR_DATA; }
+        else if (infl_build(T.lens, 19, T.dcount, T.dsym, T.cl_lut(), 7, 5)) return INF_ERR_DATA;
         IPP(2)
+        IPC(2)
         int bad = 0;
         if (PARCL) {
             for (int i = lane; i < 320; i += 64) T.lens[32 + i] = 0;
             wave_sync();
+#ifndef S5_CLSEQ_V1
+            bad = infl_cl_sequence_wave2(T, b, nl + nd);
+#else
             bad = infl_cl_sequence_wave(T, b, nl + nd);
+#endif
             if (!bad && bi_consumed_bits(b) > total_bits) bad = 2;
         } else {
             uint8_t prev = 0;
@@ -421,6 +634,7 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
         if (bad) return bad == 2 ? INF_ERR_TRUNC : INF_ERR_DATA;
         wave_sync();
         IPP(3)
+        IPC(3)
     }
     // tables: dynamic lengths sit at T.lens[32 ..] (lit/len then dist); fixed at [0..288) + [288..)
     const uint8_t *ll = type == 1 ? T.lens : T.lens + 32;
@@ -429,8 +643,10 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
     if constexpr (LITLUT == 0) { if (infl_build_syms(ll, nl, T.lcount, T.lsym, reinterpret_cast<uint32_t *>(T.llut))) return INF_ERR_DATA; }   // (T.llut: >= 64 bytes of scratch)
     else { if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, LITLUT, 9)) return INF_ERR_DATA; }
     IPP(4)
+    IPC(4)
     if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, DBITS, 5)) return INF_ERR_DATA;
     IPP(5)
+    IPC(5)
     return INF_OK;
 }
 

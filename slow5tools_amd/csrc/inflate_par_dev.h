@@ -274,14 +274,17 @@ __device__ __forceinline__ int ip_build_ltab(SH &T, const IpLimits &L) {
         for (int k = 0; k < 6; k++) zb[k + 1] = zb[k] + ((zs[k + 1] - zs[k]) << (k + 1));
         if (zb[6] > (uint32_t)((1 << IP_LROOT) + IP_LSUB)) return 1;
     }
-    // root: nine stream bits i = nine code bits, first bit on top
+    // root: entry i is nine stream bits = nine code bits pfx, first bit on top.  The trips run over pfx IN CODE ORDER (the entry's index is
+    // pfx bit-reversed: a scattered 16-bit store per trip): canonical codes grow with their length, so the prefixes under which long codes
+    // stand are the LAST ones, and the forty instructions that place a link to the second level run in the one or two trips that hold such
+    // prefixes instead of in all eight (stream order mixed them into every trip)
 #pragma unroll 2
     for (int it = 0; it < (1 << IP_LROOT) / 64; it++) {
-        const uint32_t i = (uint32_t)(it * 64 + lane);
-        const uint32_t pfx = __brev(i) >> (32 - IP_LROOT), v = pfx << (15 - IP_LROOT);
+        const uint32_t pfx = (uint32_t)(it * 64 + lane), i = __brev(pfx) >> (32 - IP_LROOT);
+        const uint32_t v = pfx << (15 - IP_LROOT);
         const uint32_t len = ip_code_len(L, v);
         uint32_t e = ip_entry_of(T, v, len);
-        if (len > (uint32_t)IP_LROOT && len <= 15u) {
+        if ((uint32_t)(it * 64 + 63) >= zs[0] && len > (uint32_t)IP_LROOT && len <= 15u) {      // (zs[0]: the first prefix that holds a code of ten bits or more)
             uint32_t k = 0;
 #pragma unroll
             for (int q = 1; q < 6; q++) k += pfx >= zs[q] ? 1u : 0u;
@@ -333,18 +336,23 @@ __device__ __forceinline__ int ip_build_ltab(SH &T, const IpLimits &L) {
 // GB (with WRITE, the output pass of zlib_inflate_par<.., LDSOUT>): the window's storage is being overwritten with the output, so the bits
 // come out of GLOBAL memory — gsrc = the window's byte 0 in the record, dwords up to index gmaxw may be read — through a 64-bit buffer per
 // lane: `cnt` valid bits, refilled 32 at a time from a dword that was requested one refill earlier.
-template <bool WRITE, class SH, bool GB = false>
+// XONLY (without WRITE; round 6, third session): only `cross` is wanted — the first pass of a window, whose walk starts late in the segment and whose
+// counts a later pass replaces in any case: no byte counting, no match classification, a match costs its bit lengths only.
+template <bool WRITE, class SH, bool GB = false, bool XONLY = false>
 __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint32_t st, uint32_t end, uint32_t obase, uint32_t o_abs0,
                                                    uint8_t *dst, uint32_t wbase = 0, uint32_t wmax = 0, const uint8_t *gsrc = nullptr, uint32_t gmaxw = 0) {
     static_assert(!GB || WRITE, "");
+    static_assert(!XONLY || !WRITE, "");
     IpSeg r;
     r.cross = st; r.nout = 0; r.eob = 0; r.eobpos = 0; r.bad = 0; r.nwait = 0;
     uint32_t p = st, o = obase;
     uint32_t lim = end;            // the lane walks while p < lim (a stop clears it)
     uint32_t wait_end = obase;     // output position behind this lane's last waiting match / pending run: nothing in front of it is in memory yet
-    uint32_t lastb = 0x100u;       // the byte this lane produced last (0x100: not known — nothing yet, or a waiting match); a synchronisation
-                                   // pass only keeps track of whether it is known (0 / 0x100): which matches will have to wait is counted there,
-                                   // so that the output pass can put every lane's waiting matches at their place in ONE list in stream order
+    uint32_t lastb = 0x100u;       // WRITE: the byte this lane produced last (0x100: not known — nothing yet, or a waiting match)
+    uint32_t unk_at = obase;       // a synchronisation pass only has to know WHETHER that byte is known (which matches will have to wait is counted there, so
+                                   // that the output pass can put every lane's waiting matches at their place in ONE list in stream order): it is not exactly
+                                   // when nothing has been produced since the start or since the last waiting match, i.e. while o == unk_at — nothing to keep
+                                   // up to date per literal
     // Steps come in GROUPS of lenmask + 1 (round 6): inside a group a lane takes literals — two table reads, the same two for every lane
     // and every code (rounds 2-5: fifteen packed compares + two reads) — and a lane that meets anything else holds its position; no vote
     // is taken inside a group (a vote on a condition that is not a plain compare costs two vector instructions on this compiler).  The
@@ -384,6 +392,9 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
             else bits = ip_peek(T.win, p);                                  // (a lane that is done stands at most a token behind its limit: inside the window)
             e = T.ltab[bits & ((1u << IP_LROOT) - 1u)];
             if (e >= 0xC000u) e = T.ltab[((e >> 4) & 1023u) + __builtin_amdgcn_ubfe(bits, IP_LROOT, e & 15u)];
+            // (letting a code longer than the root's nine bits HOLD like a length code, resolved behind the group, was measured: 9 % of our own
+            // records' tokens are such codes, and what the held lanes lose in steps is what the second read costs — 13316 -> 13576 vector
+            // instructions per record, profiles/r06_inflate_variants.txt)
             const bool act = p < lim;
             const bool lit = act && e < 0x4000u;
             held = act && !(e < 0x4000u);
@@ -400,9 +411,9 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
                     dst[o] = (uint8_t)(e >> 4);
 #endif
                 }
-                lastb = WRITE ? e >> 4 : 0u;
+                if (WRITE) lastb = e >> 4;
                 p += e & 15u;
-                o += 1u;
+                if (!XONLY) o += 1u;
                 if (GB) { gbuf >>= e & 15u; gcnt -= e & 15u; }
             }
         }
@@ -416,7 +427,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
                 // an invalid code (behind the last code of an incomplete code) is a stop like a bad length symbol: sym 0x3FF
                 const uint32_t sym = e < 0x8000u ? 257u + ((e >> 4) & 31u) : (e & 0x10u) ? 0x3FFu : 256u;
                 if (sym == 256u) {
-                    if (!r.eob) { r.eob = 1; r.eobpos = p + len; r.nout = o - obase; }
+                    if (!XONLY && !r.eob) { r.eob = 1; r.eobpos = p + len; r.nout = o - obase; }
                     if (WRITE) stop = true;
                 } else if (sym - 257u >= 29u) {
                     r.bad = 1; stop = true; adv = 0;
@@ -452,8 +463,9 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
                         const uint32_t mdist = (ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx)) + (b2 & ((1u << dx) - 1u));
                         adv += dx;
                         nby = mlen;
-                        if (WRITE && mdist > o_abs0 + o) { r.bad = 1; stop = true; }                    // reaches in front of the record
-                        else if (mdist == 1 && lastb < 0x100u) {
+                        if (XONLY) { }
+                        else if (WRITE && mdist > o_abs0 + o) { r.bad = 1; stop = true; }               // reaches in front of the record
+                        else if (mdist == 1 && (WRITE ? lastb < 0x100u : o != unk_at)) {
                             // a run of the byte this lane produced last.  A lane that filled it itself would keep the other 63 waiting
                             // (the key bytes of an svb-zd record are runs of zeros, and they all sit in the first two segments): the run
                             // goes on a list and the wave fills all of them at once after the pass
@@ -467,7 +479,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
                             if (WRITE) {
                                 for (uint32_t k = 0; k < mlen; k++) dst[o + k] = dst[o + k - mdist];
                                 lastb = dst[o + mlen - 1];
-                            } else lastb = 0u;
+                            }
                         } else {                                                                      // another lane's bytes, or bytes that wait themselves
                             if (WRITE) {
                                 if (r.nwait < wmax) {
@@ -478,6 +490,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
                             } else if (!r.eob) r.nwait++;
                             wait_end = o + mlen;
                             lastb = 0x100u;
+                            unk_at = o + mlen;
                         }
                     }
                 }
@@ -561,7 +574,8 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             continue;
         }
         int nl, nd;
-        { const int rc = infl_block_tables<SH, 0, true, SH::DBITS>(T, src, total, total_bits, b, type, nl, nd IPP_PASS); if (rc != INF_OK) return rc; }
+        { const int rc = infl_block_tables<SH, 0, true, SH::DBITS>(T, src, total, total_bits, b, type, nl, nd IPP_PASS, dbg && dbg[3] >= 11 ? dbg[3] - 10 : 0u); if (rc != INF_OK) return rc; }
+        if (dbg && dbg[3] >= 11) return INF_OK;
         pos = bi_consumed_bits(b);
         if (b.wbase != hdr_wb) win_fresh = false;                             // (the header parser slid its window: never, for a window that starts at the header)
         if (dbg && dbg[3] == 1) return INF_OK;       // tools/par_probe.py cut-off: block header and tables only
@@ -604,6 +618,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             if (ip_build_ltab(T, L)) { if (dbg) dbg[2] = 5; return INF_NEED_FALLBACK; }
         }
         IPP(6)
+        if (dbg && dbg[3] == 5) return INF_OK;       // cut-off: + canonical limits and the lit/len lookup table
         // ---- the block's tokens, a window at a time ----
         for (;;) {
             if (pos >= total_bits) return INF_ERR_TRUNC;                      // no end-of-block code before the data ran out
@@ -636,12 +651,15 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             if (dbg) dbg[1]++;
             for (int pass = 0; pass < 67; pass++) {
                 if (dbg) dbg[0]++;
-                sg = ip_decode_segment<false>(T, lenmask, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
+                // (pass 0 of a window longer than the tail: lane 0 starts late as well, so it moves and another pass follows whatever happens)
+                if (pass == 0 && span > IP_TAIL) sg = ip_decode_segment<false, SH, false, true>(T, lenmask, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
+                else sg = ip_decode_segment<false>(T, lenmask, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
                 uint32_t ns = wave_prev(sg.cross, 0u);
                 if (lane == 0) ns = rel0;
                 else if (lane >= nseg) ns = st;                              // (a lane without a segment has nothing to correct: left alone, or
                 const bool moved = ns != st;                                 // a change at the last segment's end would ripple on one lane per pass)
                 st = ns;
+                if (dbg && dbg[3] == 6) return INF_OK;                       // cut-off: + window load and the first (tail) pass
                 if (!__ballot(moved)) break;
             }
             IPP(7)
@@ -686,6 +704,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                     wr = ip_decode_segment<true, SH, true>(T, lenmask, st, seg_end, obase, o, dst, wincl - w_act, w_act, src + wb, (gavail + 4u) >> 2);
             } else if (lane < m && st < seg_end) wr = ip_decode_segment<true>(T, lenmask, st, seg_end, obase, o, dst, wincl - w_act, w_act);
             IPP(9)
+            if (dbg && dbg[3] == 7) return INF_OK;   // cut-off: + output pass (without runs and waiting matches)
             if (__ballot(wr.bad != 0u)) return INF_ERR_DATA;
             if (__ballot(wr.nwait != w_act)) { if (dbg) dbg[2] = 4; return INF_NEED_FALLBACK; }   // (the two kinds of pass disagree: never seen)
             wave_sync();

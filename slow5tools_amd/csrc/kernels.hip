@@ -955,8 +955,8 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_ar
     const s5gpu_rec_desc_t d = a.desc[r];
     uint32_t olen = 0;
 #ifdef S5_PAR_PROBE   // tools/par_probe.py only (a variant build, tools/variant.sh probe -DS5_PAR_PROBE): cut-offs 91..93 and counters (99) keyed on sig_method
-    uint32_t dbg[4] = {0, 0, 0, a.sig_method >= 90 && a.sig_method < 99 ? (uint32_t)(a.sig_method - 90) : 0u};
-    int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, !UNPACK && a.sig_method >= 90 ? dbg : nullptr);
+    uint32_t dbg[4] = {0, 0, 0, a.sig_method >= 90 && a.sig_method < 99 ? (uint32_t)(a.sig_method - 90) : a.sig_method >= 81 && a.sig_method < 90 ? (uint32_t)(a.sig_method - 70) : 0u};
+    int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, !UNPACK && a.sig_method >= 81 ? dbg : nullptr);
 #else
     int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
 #endif

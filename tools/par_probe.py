@@ -35,7 +35,7 @@ for mode in (2, 1, 0):
         fields.zero_(); _lib.check(L.s5gpu_inflate_dev(C.byref(a), None), "inflate"); torch.cuda.synchronize()
         f = fields.cpu().numpy().view(_lib.REC_FIELDS)
         print("   sync passes per record: mean %.1f max %d; rounds mean %.2f; decline reasons %s" % (f["n_samples"].mean(), f["n_samples"].max(), f["read_id_len"].mean(), dict(collections.Counter(f["read_group"].tolist()))))
-        for cut, what in ((91, "block header + tables"), (92, "+ window, sync passes"), (93, "+ output pass, waiting matches"), (1, "+ Adler-32 (whole kernel)")):
+        for cut, what in ((81, "block header, 3-bit lengths"), (82, "+ code-length code tables"), (83, "+ code-length sequence"), (84, "+ lit/len symbols in canonical order"), (91, "+ distance tables (block header + tables)"), (95, "+ limits, lit/len lookup table"), (96, "+ window, first (tail) pass"), (92, "+ sync passes"), (97, "+ output pass"), (93, "+ runs, waiting matches"), (1, "+ Adler-32 (whole kernel)")):
             a.sig_method = cut
             tt = []
             for _ in range(3):
