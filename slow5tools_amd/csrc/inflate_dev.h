@@ -462,12 +462,13 @@ __device__ __forceinline__ int infl_cl_sequence_wave2(TT &T, BitIn &b, int tot) 
 #pragma unroll
         for (int blk = 0; blk < 4; blk++) {
             uint64_t acc = 0;
-#pragma unroll 4
+#pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int L = blk * 16 + j;
                 acc |= (uint64_t)e << (4 * j);
-                const uint32_t xw = e < 8u ? (uint32_t)__builtin_amdgcn_readlane((int)xlo, L) : (uint32_t)__builtin_amdgcn_readlane((int)xhi, L);
-                e = (xw >> (4u * (e & 7u))) & 15u;
+                // (both halves fetched, one 64-bit shift: choosing the half first compiled into two branches per hop — 13 scalar instructions)
+                const uint64_t xx = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)xlo, L) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)xhi, L) << 32);
+                e = (uint32_t)(xx >> (4u * e)) & 15u;
             }
             e64[blk] = acc;
         }
@@ -495,6 +496,11 @@ __device__ __forceinline__ int infl_cl_sequence_wave2(TT &T, BitIn &b, int tot) 
             tk[k] = valid ? rp | (sym << 8) | (o << 16) : 0u;
             if (valid) sum += rp;
             if (valid && sym != 16u) { lastdef = sym < 16u ? sym : 0u; has_def = true; }
+            if (k >= 3 && k < 7 && !__ballot(o < 16u)) {              // (uniform: most rounds need four or five slots)
+#pragma unroll
+                for (int q = k + 1; q < 8; q++) tk[q] = 0u;
+                break;
+            }
         }
         if (__ballot(o < 16u)) {
             // nine or more tokens in some lane's sixteen bits (code lengths of one and two bits): the 64-offset parser from this round's start
@@ -517,6 +523,7 @@ __device__ __forceinline__ int infl_cl_sequence_wave2(TT &T, BitIn &b, int tot) 
         bool err = false, isend = false;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
+            if (k >= 4 && !__ballot(tk[k] != 0u)) break;              // (uniform; slots fill from the front)
             const uint32_t rp = tk[k] & 255u, sym = (tk[k] >> 8) & 31u;
             const bool used = tk[k] != 0u && cum < (uint32_t)tot;
             const uint32_t v = sym < 16u ? sym : sym == 16u ? cur : 0u;

@@ -1097,7 +1097,14 @@ __device__ __forceinline__ void np_records(const s5gpu_decode_args_t &a, NpParam
         r = order_at(np.ord, r);
         const s5gpu_rec_desc_t d = a.desc[r];
         uint32_t olen = 0;
+#ifdef S5_PAR_PROBE   // tools/np_probe_pmc.sh (variant build): the cut-offs of tools/par_probe.py in the no-payload kernels, keyed on the top byte of a.flags
+        uint32_t dbg[4] = {0, 0, 0, a.flags >> 24};
+        int status = zlib_inflate_par<SH, LP>(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen, dbg[3] ? dbg : nullptr);
+        if (dbg[3] && dbg[3] != 9u) status = 100;         // (nothing to unpack; 9: the whole inflate, no unpack)
+        else if (dbg[3] == 9u && status == 0) status = 100;
+#else
         int status = zlib_inflate_par<SH, LP>(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
+#endif
 #ifdef S5_IP_PAD
         if (d.in_len == 0xFFFFFFFFu) T.pad[lane_id()] = 1;   // (keeps the padding alive)
 #endif

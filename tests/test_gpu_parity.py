@@ -502,6 +502,73 @@ def test_decode_fuzzed_streams_terminate_and_never_pass_wrong_data(press, inflat
     assert n_ok < len(bad) // 10          # almost every damage is caught (a flip in the unused tail of a byte may survive)
 
 
+def test_dynamic_headers_of_every_shape(press, inflate_kernel):
+    """hand-made dynamic blocks (tests/deflate_craft.py; stock zlib inflates every valid one first): what varies is the block HEADER — the
+    parallel decoder takes the code-length sequence 1024 bits per round, sixteen bit offsets per lane and at most eight tokens per lane
+    (infl_cl_sequence_wave2), so: sequences of one, two and three rounds, tokens of one bit (sixteen to a lane: the 64-offset parser
+    takes over), repeats that reach across lanes and rounds, a repeat of a ZERO length, and the headers that are wrong — a repeat with
+    nothing in front, a run over the end, seven bits that start no code in the middle of the sequence"""
+    import deflate_craft as dc
+
+    rng = np.random.default_rng(77)
+    streams, sigs, shapes = [], [], []
+
+    def add(sig, litlens, **kw):
+        payload, _ = _oracle_payload(_hdr(press, len(streams)), sig, b"", 0)
+        s, nbits = dc.zlib_stream(payload, litlens, **kw)
+        streams.append(s); sigs.append(sig); shapes.append(nbits)
+
+    # skewed bytes: lit/len lengths 5 .. 13
+    sig = np.minimum(255, rng.geometric(0.03, 6000)).astype(np.int16)
+    pay, _ = _oracle_payload(_hdr(press, 0), sig, b"", 0)
+    freq = [1] * 257
+    for x in pay:
+        freq[x] += 1
+    skew = dc.huff_lengths(freq, 15)
+    for mode in ("plain", "rle", "rep0"):
+        add(sig, skew, mode=mode)                                           # ~550 .. 770 bits: one round
+    add(sig, skew, mode="plain", cl_weights={k: 1 for k in range(19)})      # every token five bits: two rounds
+    # 286 + 30 lengths, one seven-bit token each: 2212 bits, three rounds
+    ll = [8, 9] * 60 + [8] * 166                                             # 226 x 8 + 60 x 9 bits: complete
+    assert len(ll) == 286 and sum(2 ** (15 - l) for l in ll) == 32768
+    dl = [4, 4] + [5] * 28
+    w7 = {8: 1, 9: 1, 4: 2, 5: 4, 0: 8, 1: 16, 2: 32, 3: 64}               # lengths 7 7 6 5 4 3 2 1: the two lit/len lengths cost seven bits
+    sig8 = rng.integers(-3000, 3000, 5000).astype(np.int16)
+    add(sig8, ll, mode="plain", cl_weights=w7, dlens=dl)
+    assert shapes[-1] > 2048
+    # one-bit tokens: all lit/len lengths 8 but two, "8" is the 1-bit code — sixteen tokens in a lane's sixteen bits
+    flat = [8] * 255 + [9, 9]
+    add(sig8, flat, mode="plain", cl_weights={8: 100, 9: 3, 1: 2})
+    add(sig8, flat, mode="rle", cl_weights={8: 100, 9: 3, 1: 2, 16: 50})    # 42 repeats of six in a row: two-bit codes + two extra bits
+    add(sig8, flat + [0] * 29, mode="rep0")                                   # a zero length repeated by symbol 16
+    add(sig8, flat + [0] * 29, mode="rle")
+    got = press.decode_records(streams, 1, 0)
+    for g, s_, nb in zip(got, sigs, shapes):
+        assert g["status"] == 0 and np.array_equal(g["signal"], s_), "code-length sequence of %d bits" % nb
+    # wrong headers: a status, never a hang, never status 0
+    cll = [0] * 19
+    for s_, l_ in ((0, 2), (8, 2), (16, 2), (17, 3), (18, 3)):
+        cll[s_] = l_
+    bad = [dc.raw_stream_with_sequence([(16, 0), (8, 0)] + [(8, 0)] * 300, cll, 257, 1),                       # nothing to repeat
+           dc.raw_stream_with_sequence([(18, 127), (18, 127)], cll, 257, 1),                                   # 276 lengths for 258
+           dc.raw_stream_with_sequence([(8, 0)] * 256 + [(16, 3)], cll, 257, 1)]                               # 262 for 258
+    inc = [0] * 19
+    for s_, l_ in ((0, 2), (8, 2), (18, 3)):
+        inc[s_] = l_                                                        # an incomplete code-length code: 101, 110, 111, ... start no code
+    b = dc.Bits()
+    b.put(1, 1); b.put(2, 2); b.put(0, 5); b.put(0, 5); b.put(15, 4)
+    for k in range(19):
+        b.put(inc[dc.ORDER[k]], 3)
+    clc = dc.canonical(inc)
+    for _ in range(40):
+        b.put_code(clc[8], 2)
+    b.put(0b111, 3)                                                         # no code, 40 lengths into the sequence
+    b.put(0, 700)
+    bad.append(b"\x78\x9c" + b.done() + b"\x00\x00\x00\x01")
+    for g in press.decode_records(bad, 1, 0, raise_on_error=False):
+        assert g["status"] in (2, 3)
+
+
 def test_big_host_batch_split_over_two_contexts_equals_one_context(press, monkeypatch):
     """s5gpu_encode_batch cuts batches of >= 16384 reads in two halves that run concurrently: same records, same order"""
     rng = np.random.default_rng(77)

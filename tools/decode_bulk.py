@@ -33,6 +33,7 @@ if mode == "np":
     scr = torch.empty(sb, dtype=torch.uint8, device="cuda")
     a.flags, a.payload, a.payload_bytes, a.max_pay_cap = _lib.DEC_NO_PAYLOAD, scr.data_ptr(), sb, pay_cap
     a.max_in_len = int(d["in_len"].max())
+    a.flags |= int(os.environ.get("S5_CUT", 0)) << 24      # probe build only (tools/np_probe_pmc.sh): stop every record at a cut-off of the inflate
 else:
     pay = torch.empty(n_reads * pay_cap + 64, dtype=torch.uint8, device="cuda")
     a.payload, a.max_pay_cap = pay.data_ptr(), pay_cap
