@@ -398,6 +398,55 @@ __device__ __forceinline__ int infl_build_cl7(const uint8_t *lens19, uint16_t *l
     return 0;
 }
 
+// Tables of an alphabet of at most 32 symbols and lengths up to 15 — the distance code — in the manner of infl_build_cl7 (one lane per symbol,
+// every lookup entry decoded once) instead of the generic builder's two loops over fifteen lengths and its symbol-by-symbol table fill:
+// count[1..15] and the symbols in canonical order (what the canonical walk behind a lookup miss reads), lut[1 << LB] = symbol | length << 5 for
+// codes of up to LB bits, 0 for everything longer or unused.  adj: 16 entries of scratch.  Returns 1 if over-subscribed.
+template <int LB>
+__device__ __forceinline__ int infl_build_small(const uint8_t *lens, int n, uint16_t *count, uint16_t *syms, uint16_t *lut, uint16_t *adj) {
+    const int lane = lane_id();
+    const uint32_t l = lane < n && lane < 32 ? (uint32_t)lens[lane] : 0u;
+    uint32_t first = 0, offs = 0, place = 0, adjv = 0, cntv = 0;
+    uint32_t lim[LB + 1];
+    int left = 1;
+    bool over = false;
+#pragma unroll
+    for (int bb = 1; bb <= 15; bb++) {
+        const uint64_t m = __ballot(l == (uint32_t)bb);
+        const uint32_t c = (uint32_t)__popcll(m);
+        if (m) {                                                   // (uniform: a run-length stream has two lengths' worth of work here, not fifteen)
+            if (l == (uint32_t)bb) place = offs + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (lane == bb) cntv = c;
+        }
+        if (lane == bb) adjv = offs - first;
+        if (bb <= LB) lim[bb] = (first + c) << (LB - bb);
+        offs += c;
+        first = (first + c) << 1;
+        left = (left << 1) - (int)c;
+        if (left < 0) over = true;
+    }
+    if (over) return 1;
+    if (l) syms[place] = (uint16_t)lane;
+    if (lane < 16) { count[lane] = (uint16_t)cntv; adj[lane] = (uint16_t)adjv; }
+    wave_sync();
+#pragma unroll
+    for (int it = 0; it < (1 << LB) / 64; it++) {
+        const uint32_t i = (uint32_t)(it * 64 + lane);
+        const uint32_t v = __brev(i) >> (32 - LB);
+        uint32_t len = 1;
+#pragma unroll
+        for (int bb = 1; bb <= LB; bb++) len += v >= lim[bb] ? 1u : 0u;
+        uint32_t ent = 0;
+        if (len <= (uint32_t)LB) {
+            const uint32_t idx = ((uint32_t)(int)(short)adj[len] + (v >> ((uint32_t)LB - len))) & 31u;
+            ent = (uint32_t)syms[idx] | (len << 5);
+        }
+        lut[i] = (uint16_t)ent;
+    }
+    wave_sync();
+    return 0;
+}
+
 // wave-uniform: put the reader at window bit `abit`
 __device__ __forceinline__ void bi_seek_u(BitIn &b, const uint32_t *win, uint32_t abit) {
     const uint32_t w = abit >> 5, sh = abit & 31u;
@@ -651,7 +700,8 @@ __device__ __forceinline__ int infl_block_tables(TT &T, const uint8_t *src, uint
     else { if (infl_build(ll, nl, T.lcount, T.lsym, T.llut, LITLUT, 9)) return INF_ERR_DATA; }
     IPP(4)
     IPC(4)
-    if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, DBITS, 5)) return INF_ERR_DATA;
+    if constexpr (PARCL) { if (infl_build_small<DBITS>(dl, nd, T.dcount, T.dsym, T.dlut, T.ladj)) return INF_ERR_DATA; }     // (T.ladj: scratch until the lit/len limits are set up)
+    else { if (infl_build(dl, nd, T.dcount, T.dsym, T.dlut, DBITS, 5)) return INF_ERR_DATA; }
     IPP(5)
     IPC(5)
     return INF_OK;
