@@ -517,7 +517,7 @@ __device__ __forceinline__ IpSeg ip_decode_segment(SH &T, uint32_t lenmask, uint
 // byte is written, and the wave-per-record decoder takes it into its HBM slot.
 template <class SH, bool LDSOUT = false>
 __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap,
-                                                uint32_t *out_len, uint32_t *dbg = nullptr) {
+                                                uint32_t *out_len, uint32_t *dbg = nullptr, uint32_t tail = IP_TAIL) {
     static_assert(!LDSOUT || SH::LDS_PAY >= 1024u, "");
     if (LDSOUT) {
         out = reinterpret_cast<uint8_t *>(T.win);
@@ -647,14 +647,20 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
             // step by then is caught by the next pass, like any other wrong start).  Lane 0 too, although it knows its real start: the
             // pass takes as long as its longest walk, and all this pass is for is a first guess of every other lane's start — lane 0
             // walks its whole segment in the second pass, with everybody else
+            // `tail` (uniform): IP_TAIL in a bulk launch.  In a `get` batch — one record per resident wave — the kernel's time is the SLOWEST record's,
+            // and one record in ten needs a third pass because some lane was not in step after 224 bits (two passes of 4096 records: 0.062 ms of a
+            // 0.154 ms kernel for a mean of 2.1 passes): there the first pass walks the WHOLE segment from its nominal start, after which nearly every
+            // lane's end is right and the second pass is the last
             uint32_t st = min(seg_lo, wend);
-            if (seg_end - st > IP_TAIL) st = seg_end - IP_TAIL;
+            if (nseg > 1 && seg_end - st > tail) st = seg_end - tail;
             IpSeg sg;
             if (dbg) dbg[1]++;
             for (int pass = 0; pass < 67; pass++) {
                 if (dbg) dbg[0]++;
-                // (pass 0 of a window longer than the tail: lane 0 starts late as well, so it moves and another pass follows whatever happens)
-                if (pass == 0 && span > IP_TAIL) sg = ip_decode_segment<false, SH, false, true>(T, lenmask, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
+                // (pass 0 of a window with more than one segment only guesses the other lanes' starts: it walks for its end position alone, and a
+                // counting pass follows whatever it finds)
+                const bool xo = pass == 0 && nseg > 1;
+                if (xo) sg = ip_decode_segment<false, SH, false, true>(T, lenmask, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
                 else sg = ip_decode_segment<false>(T, lenmask, st, st < seg_end ? seg_end : st, 0u, 0u, nullptr);
                 uint32_t ns = wave_prev(sg.cross, 0u);
                 if (lane == 0) ns = rel0;
@@ -662,7 +668,7 @@ __device__ __forceinline__ int zlib_inflate_par(SH &T, const uint8_t *in, uint32
                 const bool moved = ns != st;                                 // a change at the last segment's end would ripple on one lane per pass)
                 st = ns;
                 if (dbg && dbg[3] == 6) return INF_OK;                       // cut-off: + window load and the first (tail) pass
-                if (!__ballot(moved)) break;
+                if (!xo && !__ballot(moved)) break;
             }
             IPP(7)
             if (dbg && dbg[3] == 2) return INF_OK;   // cut-off: + window load and synchronisation passes

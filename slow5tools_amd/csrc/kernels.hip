@@ -944,6 +944,12 @@ __device__ __forceinline__ int unpack_exzd_wave(const s5gpu_decode_args_t &a, co
 #ifndef S5_IP_WAVES
 #define S5_IP_WAVES 6
 #endif
+// A launch of no more records than the device holds waves (a `get` batch) is as slow as its slowest record: its first pass walks whole segments
+// (inflate_par_dev.h, `tail`)
+#ifndef S5_IP_LAT_RECS
+#define S5_IP_LAT_RECS 6144u
+#endif
+__device__ __forceinline__ uint32_t ip_tail_for(uint32_t n_recs) { return n_recs <= S5_IP_LAT_RECS ? 0xFFFFu : IP_TAIL; }
 // SHORT: the caller's batch holds short records (s5gpu_decode_args.max_pay_cap <= S5_IP_SHORT_PAY): the 256-entry waiting list, 24 waves per CU
 #ifndef S5_IP_SHORT_PAY
 #define S5_IP_SHORT_PAY 32768u
@@ -956,9 +962,9 @@ __global__ __launch_bounds__(64, S5_IP_WAVES) void k_inflate_par(s5gpu_decode_ar
     uint32_t olen = 0;
 #ifdef S5_PAR_PROBE   // tools/par_probe.py only (a variant build, tools/variant.sh probe -DS5_PAR_PROBE): cut-offs 91..93 and counters (99) keyed on sig_method
     uint32_t dbg[4] = {0, 0, 0, a.sig_method >= 90 && a.sig_method < 99 ? (uint32_t)(a.sig_method - 90) : a.sig_method >= 81 && a.sig_method < 90 ? (uint32_t)(a.sig_method - 70) : 0u};
-    int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, !UNPACK && a.sig_method >= 81 ? dbg : nullptr);
+    int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, !UNPACK && a.sig_method >= 81 ? dbg : nullptr, ip_tail_for(a.n_recs));
 #else
-    int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen);
+    int status = zlib_inflate_par(T, a.in + d.in_off, d.in_len, a.payload + d.pay_off, d.pay_cap, &olen, nullptr, ip_tail_for(a.n_recs));
 #endif
     uint32_t mark = 0;
     if (UNPACK && status == 0) {
@@ -1099,11 +1105,11 @@ __device__ __forceinline__ void np_records(const s5gpu_decode_args_t &a, NpParam
         uint32_t olen = 0;
 #ifdef S5_PAR_PROBE   // tools/np_probe_pmc.sh (variant build): the cut-offs of tools/par_probe.py in the no-payload kernels, keyed on the top byte of a.flags
         uint32_t dbg[4] = {0, 0, 0, a.flags >> 24};
-        int status = zlib_inflate_par<SH, LP>(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen, dbg[3] ? dbg : nullptr);
+        int status = zlib_inflate_par<SH, LP>(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen, dbg[3] ? dbg : nullptr, np.ticket ? IP_TAIL : 0xFFFFu);
         if (dbg[3] && dbg[3] != 9u) status = 100;         // (nothing to unpack; 9: the whole inflate, no unpack)
         else if (dbg[3] == 9u && status == 0) status = 100;
 #else
-        int status = zlib_inflate_par<SH, LP>(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen);
+        int status = zlib_inflate_par<SH, LP>(T, a.in + d.in_off, d.in_len, pay, np.cap, &olen, nullptr, np.ticket ? IP_TAIL : 0xFFFFu);   // (no ticket: a batch of one record per workgroup)
 #endif
 #ifdef S5_IP_PAD
         if (d.in_len == 0xFFFFFFFFu) T.pad[lane_id()] = 1;   // (keeps the padding alive)
