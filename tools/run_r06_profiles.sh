@@ -28,5 +28,15 @@ STAGES="1 2 3 4 5 6 0" TAG=r06p_stages bash tools/stages.sh 400000 > $O/encode_s
 ( echo "# KERNEL=k_inflate_par_np tools/pmc_kernel.sh python tools/decode_bulk.py 262144 4000 np 3: totals over one launch of 262144 records"; KERNEL=k_inflate_par_np bash tools/pmc_kernel.sh python tools/decode_bulk.py 262144 4000 np 3 ) > $O/pmc_k_inflate_par_np.txt 2>&1
 for v in probe; do [ -f slow5tools_amd/_variants/libs5_$v.so ] && S5GPU_LIB=slow5tools_amd/_variants/libs5_$v.so python tools/par_probe.py 262144 4000 > $O/par_probe_262144.txt 2>&1; done
 python tools/par_decline_probe.py 2048 4000 262144 > $O/par_stock_zlib.txt 2>&1
+# instruction counts per phase of the inflate (probe build): the slot form's kernel and the product's no-payload kernel; latency-mode cut-offs of a get batch
+if [ -f slow5tools_amd/_variants/libs5_probe.so ]; then
+  ( echo "# tools/par_probe_pmc.sh 262144 4000 (k_inflate_par<0>, probe build): vector / scalar / LDS instructions per record UP TO each cut-off";
+    S5GPU_LIB=slow5tools_amd/_variants/libs5_probe.so bash tools/par_probe_pmc.sh 262144 4000 2>&1 | awk '!seen[substr($0, 8)]++';
+    echo "# tools/np_probe_pmc.sh 262144 4000 (k_inflate_par_np_lp, the product's no-payload kernel)";
+    S5GPU_LIB=slow5tools_amd/_variants/libs5_probe.so bash tools/np_probe_pmc.sh 262144 4000 2>&1;
+    echo "# tools/par_probe.py 4096 4000: one get batch — the kernel's time is the slowest record's";
+    S5GPU_LIB=slow5tools_amd/_variants/libs5_probe.so python tools/par_probe.py 4096 4000 2>&1 | grep -v amdgpu.ids | head -14 ) > $O/inflate_phase_counts.txt 2>&1
+fi
+( echo "# tools/np_lds_soak.py 24000 + tools/decode_soak.py 6000 on the final sources"; python tools/np_lds_soak.py 24000 2>&1 | grep -v amdgpu.ids; python tools/decode_soak.py 6000 2>&1 | grep -v amdgpu.ids ) > $O/decode_soak.txt 2>&1
 rm -rf gpurun_out/r06p_stages gpurun_out/pmc
 tail -9 $O/pmc_traffic.txt; tail -c 300 $O/bench_default.json
